@@ -1,0 +1,251 @@
+"""horizonator_amd - SRTM terrain panoramas rendered by hand-written HIP kernels on MI355X.
+
+Host-side mirror of the reference's Python surface (reference
+horizonator-pywrap.c): the same type name, constructor arguments, `render`
+keywords, defaults, return shapes and error behaviour, on top of the C-ABI of
+libhorizonator.so.  The reference's module is a CPython extension written in C;
+its toolchain pieces (generated docstring headers, mrbuild) are not in this
+image, so the wrapper is restated here over ctypes.  INTEGRATION.md shows how
+the reference's own horizonator-pywrap.c is built against this library instead.
+
+    h = horizonator_amd.horizonator(34.4137, -117.5621, 2000, 500, dir_dems=...,
+                                    render_radius_cells=600)
+    image, ranges = h.render(-180, 180)      # uint8[H,W,3] BGR, float32[H,W]
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RASTER_AUTO, RASTER_COLUMNS, RASTER_SCATTER, Times, View  # noqa: F401
+
+HORIZONATOR_ZNEAR_DEFAULT = 100.0
+HORIZONATOR_ZFAR_DEFAULT = 40000.0
+
+__all__ = ["horizonator", "RASTER_AUTO", "RASTER_SCATTER", "RASTER_COLUMNS"]
+
+
+def _enc(s):
+    return None if s is None else str(s).encode()
+
+
+class horizonator:
+    """SRTM terrain renderer (reference horizonator.docstring, horizonator-pywrap.c:49-125).
+
+    horizonator(lat, lon, width, height, render_texture=False, SRTM1=False,
+                dir_dems=None, dir_tiles=None, tiles_name=None, tiles_url_fmt=None,
+                allow_downloads=True, render_radius_cells=-1, render_radius_m=-1.)
+
+    The constructor loads the DEM window around (lat, lon) into HBM (slow);
+    render() calls are fast and may move the viewer inside that window.
+    """
+
+    # reference horizonator-pywrap.c:65
+    _render_radius_cells_default = 1000
+
+    def __init__(self, lat, lon, width, height,
+                 render_texture=False, SRTM1=False,
+                 dir_dems=None, dir_tiles=None,
+                 tiles_name=None, tiles_url_fmt=None,
+                 allow_downloads=True,
+                 render_radius_cells=-1, render_radius_m=-1.0):
+        self._lib = _lib.load()
+        if getattr(self, "_ctx", None) is not None and self._ctx.offscreen.inited:
+            # reference horizonator-pywrap.c:81-85
+            raise RuntimeError("Trying to init an already-inited object")
+        self._ctx = _lib.Context()
+        width, height = int(width), int(height)
+        if width < 0 or height < 0:
+            raise OverflowError("can't convert negative value to unsigned int")
+        render_radius_cells = int(render_radius_cells)
+        render_radius_m = float(render_radius_m)
+        # reference horizonator-pywrap.c:98-104
+        if render_radius_cells < 0 and render_radius_m < 0:
+            render_radius_cells = self._render_radius_cells_default
+        elif render_radius_cells > 0 and render_radius_m > 0:
+            raise RuntimeError("both render_radius_cells,render_radius_m cannot be >0")
+
+        ok = self._lib.horizonator_init(
+            C.byref(self._ctx), float(lat), float(lon), None,
+            width, height, render_radius_cells, render_radius_m,
+            True, bool(render_texture), bool(SRTM1),
+            _enc(dir_dems), _enc(dir_tiles), _enc(tiles_name), _enc(tiles_url_fmt),
+            bool(allow_downloads))
+        if not ok:
+            self._ctx = None
+            raise RuntimeError("horizonator_init() failed")
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None:
+            self._lib.horizonator_deinit(C.byref(self._ctx))
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __str__(self):
+        # reference horizonator-pywrap.c:133-156: at most 9 characters of each
+        lat = repr(float(self._ctx.viewer_lat))[:9]
+        lon = repr(float(self._ctx.viewer_lon))[:9]
+        return f"Looking out from {lat},{lon}"
+
+    # -- properties of the loaded window -----------------------------------
+    @property
+    def width(self):
+        return self._ctx.offscreen.width
+
+    @property
+    def height(self):
+        return self._ctx.offscreen.height
+
+    @property
+    def radius_cells(self):
+        return self._ctx.dems.radius_cells
+
+    @property
+    def Ntriangles(self):
+        return self._ctx.Ntriangles
+
+    @property
+    def sector(self):
+        return getattr(self, "_sector", (0, self.width))
+
+    # -- the reference's render() -------------------------------------------
+    def _prepare(self, az_deg0, az_deg1, lat, lon, az_extents_use_pixel_centers,
+                 znear, zfar, znear_color, zfar_color):
+        az_deg0, az_deg1 = float(az_deg0), float(az_deg1)
+        # reference horizonator-pywrap.c:194-195
+        if znear_color < 0.0:
+            znear_color = znear
+        if zfar_color < 0.0:
+            zfar_color = zfar
+        if az_extents_use_pixel_centers:
+            # reference horizonator-pywrap.c:204-212: the caller's azimuths are
+            # those of the first and last pixel CENTRES; widen by half a pixel
+            az_per_pixel = (az_deg1 - az_deg0) / float(self._ctx.offscreen.width - 1)
+            az_deg0 -= az_per_pixel / 2.0
+            az_deg1 += az_per_pixel / 2.0
+        ctx = C.byref(self._ctx)
+        if not self._lib.horizonator_pan_zoom(ctx, az_deg0, az_deg1):
+            raise RuntimeError("horizonator_pan_zoom() failed")
+        if lat > -1000.0:
+            if not self._lib.horizonator_move(ctx, None, float(lat), float(lon)):
+                raise RuntimeError("horizonator_move() failed")
+        if not self._lib.horizonator_set_zextents(ctx, znear, zfar, znear_color, zfar_color):
+            raise RuntimeError("horizonator_set_zextents() failed")
+
+    def render(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
+               return_image=True, return_range=True,
+               az_extents_use_pixel_centers=False,
+               znear=HORIZONATOR_ZNEAR_DEFAULT, zfar=HORIZONATOR_ZFAR_DEFAULT,
+               znear_color=-1.0, zfar_color=-1.0):
+        """render(az_deg0, az_deg1, lat=, lon=, return_image=True, return_range=True,
+                  az_extents_use_pixel_centers=False, znear=100, zfar=40000,
+                  znear_color=-1, zfar_color=-1)
+
+        reference render.docstring / horizonator-pywrap.c:158-279.  Returns
+        (image, ranges), or only one of them, or () if neither is asked for.
+        image: uint8[H,W,3] BGR; ranges: float32[H,W], < 0 where no terrain.
+        """
+        if not return_image and not return_range:
+            return ()                       # reference horizonator-pywrap.c:198-202
+        self._prepare(az_deg0, az_deg1, lat, lon, az_extents_use_pixel_centers,
+                      float(znear), float(zfar), float(znear_color), float(zfar_color))
+        c0, c1 = self.sector
+        H, W = self._ctx.offscreen.height, c1 - c0
+        image = np.empty((H, W, 3), np.uint8) if return_image else None
+        ranges = np.empty((H, W), np.float32) if return_range else None
+        ok = self._lib.horizonator_render_offscreen(
+            C.byref(self._ctx),
+            image.ctypes.data if image is not None else None,
+            ranges.ctypes.data if ranges is not None else None)
+        if not ok:
+            raise RuntimeError("horizonator_render_offscreen() failed")
+        if return_image and not return_range:
+            return image
+        if return_range and not return_image:
+            return ranges
+        return image, ranges
+
+    # -- build-side additions ------------------------------------------------
+    def render_full(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
+                    az_extents_use_pixel_centers=False,
+                    znear=HORIZONATOR_ZNEAR_DEFAULT, zfar=HORIZONATOR_ZFAR_DEFAULT,
+                    znear_color=-1.0, zfar_color=-1.0):
+        """Like render() but also returns the visible-triangle index map and the
+        raw 24-bit depth: (image, ranges, index int32[H,W], z24 uint32[H,W])."""
+        self._prepare(az_deg0, az_deg1, lat, lon, az_extents_use_pixel_centers,
+                      float(znear), float(zfar), float(znear_color), float(zfar_color))
+        c0, c1 = self.sector
+        H, W = self._ctx.offscreen.height, c1 - c0
+        image = np.empty((H, W, 3), np.uint8)
+        ranges = np.empty((H, W), np.float32)
+        index = np.empty((H, W), np.int32)
+        z24 = np.empty((H, W), np.uint32)
+        ok = self._lib.horizonator_amd_render(
+            C.byref(self._ctx), image.ctypes.data, ranges.ctypes.data,
+            index.ctypes.data, z24.ctypes.data)
+        if not ok:
+            raise RuntimeError("horizonator_amd_render() failed")
+        return image, ranges, index, z24
+
+    def render_device(self, d_image=0, d_ranges=0, d_index=0, d_z24=0):
+        """Draw with the current view into caller-owned DEVICE buffers (raw
+        pointers, 0 = skip).  Asynchronous; call sync()."""
+        ok = self._lib.horizonator_amd_render_device(
+            C.byref(self._ctx), d_image or None, d_ranges or None, d_index or None, d_z24 or None)
+        if not ok:
+            raise RuntimeError("horizonator_amd_render_device() failed")
+
+    def set_view(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
+                 znear=HORIZONATOR_ZNEAR_DEFAULT, zfar=HORIZONATOR_ZFAR_DEFAULT,
+                 znear_color=-1.0, zfar_color=-1.0):
+        self._prepare(az_deg0, az_deg1, lat, lon, False,
+                      float(znear), float(zfar), float(znear_color), float(zfar_color))
+
+    def sync(self):
+        if not self._lib.horizonator_amd_sync(C.byref(self._ctx)):
+            raise RuntimeError("horizonator_amd_sync() failed")
+
+    def set_sector(self, col0, col1):
+        if not self._lib.horizonator_amd_set_sector(C.byref(self._ctx), int(col0), int(col1)):
+            raise RuntimeError("horizonator_amd_set_sector() failed")
+        self._sector = (int(col0), int(col1))
+
+    def set_raster(self, which):
+        if not self._lib.horizonator_amd_set_raster(C.byref(self._ctx), int(which)):
+            raise RuntimeError("horizonator_amd_set_raster() failed")
+
+    def set_profiling(self, on=True):
+        self._lib.horizonator_amd_set_profiling(C.byref(self._ctx), bool(on))
+
+    def last_times(self):
+        t = Times()
+        if not self._lib.horizonator_amd_last_times(C.byref(self._ctx), C.byref(t)):
+            return None
+        return {n: getattr(t, n) for n, _ in Times._fields_}
+
+    def view(self):
+        v = View()
+        if not self._lib.horizonator_amd_get_view(C.byref(self._ctx), C.byref(v)):
+            raise RuntimeError("horizonator_amd_get_view() failed")
+        return {n: getattr(v, n) for n, _ in View._fields_}
+
+    def mosaic(self):
+        N = 2 * self.radius_cells
+        m = np.empty((N, N), np.int16)
+        if not self._lib.horizonator_amd_get_mosaic(C.byref(self._ctx), m.ctypes.data):
+            raise RuntimeError("horizonator_amd_get_mosaic() failed")
+        return m
+
+    def pick(self, x, y):
+        """(lat, lon) of the terrain under image pixel (x, y), or None for sky
+        (reference horizonator.h:145-152)."""
+        lat, lon = C.c_float(), C.c_float()
+        if not self._lib.horizonator_pick(C.byref(self._ctx), C.byref(lat), C.byref(lon), int(x), int(y)):
+            return None
+        return lat.value, lon.value

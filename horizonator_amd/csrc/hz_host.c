@@ -1,0 +1,561 @@
+/* hz_host.c - the reference's C API (include/horizonator.h) on top of the HIP
+ * render path (include/hz_hip.h).  Plain C; no HIP or GL headers here.
+ *
+ * The reference keeps its per-context values inside the GL program object as
+ * uniforms and reads them back with glGetUniformfv (reference
+ * horizonator-lib.c:966-975).  Here they live in a side record found through
+ * ctx->program, because horizonator_context_t is public, caller-allocated and
+ * has no spare pointer field.
+ */
+#define _GNU_SOURCE
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "horizonator.h"
+#include "horizonator_amd.h"
+#include "hz_dem.h"
+#include "hz_hip.h"
+#include "util.h"
+
+/* ------------------------------------------------------------------------ */
+/* side records                                                              */
+
+typedef struct
+{
+    bool         live;
+    hz_dev_t*    dev;
+    hz_view_t    view;
+    hz_tileset_t tiles;         /* tile mappings, kept for horizonator_move()      */
+    bool         tiles_owned;   /* false: aliases ctx->dems (<= 4x4 tiles)         */
+    int          N;
+    int          width, height;
+    int          col0, col1;
+    float*       tanel;         /* [height] */
+} hz_state_t;
+
+#define HZ_MAX_CONTEXTS 64
+static hz_state_t g_state[HZ_MAX_CONTEXTS];
+
+static hz_state_t* state_of(const horizonator_context_t* ctx)
+{
+    if(ctx == NULL || ctx->program == 0 || ctx->program > HZ_MAX_CONTEXTS) return NULL;
+    hz_state_t* s = &g_state[ctx->program-1];
+    return s->live ? s : NULL;
+}
+
+/* every entry point of the reference starts with this check (e.g. reference
+ * horizonator-lib.c:700-705): a destroyed context makes the call fail */
+static hz_state_t* live_state(const horizonator_context_t* ctx)
+{
+    if(ctx->use_glut && ctx->glut_window == 0) return NULL;
+    return state_of(ctx);
+}
+
+static void state_release(hz_state_t* s, horizonator_context_t* ctx)
+{
+    if(s->dev) hz_hip_destroy(s->dev);
+    if(s->tiles_owned) hz_tileset_close(&s->tiles);
+    else
+    {
+        free(s->tiles.tile); free(s->tiles.tile_bytes); free(s->tiles.tile_fd);
+        if(ctx) horizonator_dem_deinit(&ctx->dems);
+    }
+    free(s->tanel);
+    memset(s, 0, sizeof(*s));
+}
+
+/* ------------------------------------------------------------------------ */
+
+static bool load_tiles(hz_state_t* s, horizonator_context_t* ctx,
+                       float viewer_lat, float viewer_lon,
+                       int render_radius_cells, float render_radius_m,
+                       const char* dir_dems, bool SRTM1)
+{
+    hz_window_t w;
+    if(!hz_window_compute(&w, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, SRTM1))
+        return false;
+
+    if(w.ntiles[0] <= max_Ndems_ij && w.ntiles[1] <= max_Ndems_ij)
+    {
+        /* fits the public struct: load through the public API exactly as the
+         * reference does (reference horizonator-lib.c:187-197) so that callers
+         * can keep using horizonator_dem_sample(&ctx->dems, ...) */
+        if(!horizonator_dem_init(&ctx->dems, viewer_lat, viewer_lon,
+                                 render_radius_cells, render_radius_m, dir_dems, SRTM1))
+            return false;
+        const int nt = w.ntiles[0]*w.ntiles[1];
+        s->tiles.win        = w;
+        s->tiles.tile       = calloc(nt, sizeof(*s->tiles.tile));
+        s->tiles.tile_bytes = calloc(nt, sizeof(*s->tiles.tile_bytes));
+        s->tiles.tile_fd    = calloc(nt, sizeof(*s->tiles.tile_fd));
+        if(!s->tiles.tile || !s->tiles.tile_bytes || !s->tiles.tile_fd) return false;
+        for(int tj=0; tj<w.ntiles[1]; tj++)
+            for(int ti=0; ti<w.ntiles[0]; ti++)
+                s->tiles.tile[ti + tj*w.ntiles[0]] = ctx->dems.dems[ti][tj];
+        s->tiles_owned = false;
+        return true;
+    }
+
+    /* larger than the reference can load (reference dem.h:8, dem.c:173-178):
+     * own tile table; ctx->dems carries the window description only */
+    if(!hz_tileset_open(&s->tiles, &w, dir_dems)) return false;
+    s->tiles_owned = true;
+    memset(&ctx->dems, 0, sizeof(ctx->dems));
+    ctx->dems.cells_per_deg = w.cells_per_deg;
+    ctx->dems.radius_cells  = w.radius_cells;
+    for(int a=0; a<2; a++)
+    {
+        ctx->dems.origin_dem_lon_lat[a] = w.origin_tile[a];
+        ctx->dems.origin_dem_cellij [a] = w.origin_cell[a];
+        ctx->dems.Ndems_ij          [a] = w.ntiles[a];
+    }
+    return true;
+}
+
+bool horizonator_init(horizonator_context_t* ctx,
+                      float viewer_lat, float viewer_lon,
+                      float* viewer_z,
+                      int offscreen_width, int offscreen_height,
+                      int render_radius_cells, float render_radius_m,
+                      bool use_glut, bool render_texture, bool SRTM1,
+                      const char* dir_dems,
+                      const char* dir_tiles, const char* tiles_name,
+                      const char* tiles_url_fmt, bool allow_downloads)
+{
+    (void)dir_tiles; (void)tiles_name; (void)tiles_url_fmt; (void)allow_downloads;
+
+    memset(ctx, 0, sizeof(*ctx));       /* reference horizonator-lib.c:84 */
+
+    if(dir_dems == NULL)                /* reference horizonator-lib.c:94-97 */
+        dir_dems = SRTM1 ? "~/.horizonator/DEMs_SRTM1" : "~/.horizonator/DEMs_SRTM3";
+
+    if(!use_glut || offscreen_width <= 0 || offscreen_height <= 0)
+    {
+        MSG("This build renders offscreen only: horizonator_init(use_glut=true, offscreen_width,height > 0). There is no OpenGL window mode");
+        return false;
+    }
+    if(render_texture)
+    {
+        MSG("render_texture=true is not supported by this build (it needs map-tile downloads)");
+        return false;
+    }
+
+    int slot = -1;
+    for(int k=0; k<HZ_MAX_CONTEXTS; k++) if(!g_state[k].live) { slot = k; break; }
+    if(slot < 0)
+    {
+        MSG("Too many live contexts (max %d)", HZ_MAX_CONTEXTS);
+        return false;
+    }
+    hz_state_t* s = &g_state[slot];
+    memset(s, 0, sizeof(*s));
+
+    int16_t* mosaic = NULL;
+    bool     result = false;
+
+    if(!load_tiles(s, ctx, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, dir_dems, SRTM1))
+    {
+        MSG("Couldn't init DEMs. Giving up");
+        goto done;
+    }
+
+    const int R = s->tiles.win.radius_cells;
+    const int N = 2*R;
+    s->N = N;
+    s->width = offscreen_width; s->height = offscreen_height;
+    s->col0 = 0; s->col1 = offscreen_width;
+
+    int device = 0;
+    const char* env = getenv("HORIZONATOR_HIP_DEVICE");
+    if(env != NULL) device = atoi(env);
+
+    if(hz_hip_device_count() <= 0)
+    {
+        MSG("No HIP device is visible; this library has no CPU or OpenGL fallback");
+        goto done;
+    }
+    s->dev = hz_hip_create(device, N, offscreen_width, offscreen_height);
+    if(s->dev == NULL)
+    {
+        MSG("Couldn't create the device state: %s", hz_hip_last_error());
+        goto done;
+    }
+
+    /* DEM -> HBM.  Default: decode on the host into one row-major int16
+     * mosaic and upload it.  HORIZONATOR_INGEST=device uploads the raw tiles
+     * and decodes them in a kernel. */
+    const char* ingest = getenv("HORIZONATOR_INGEST");
+    if(ingest != NULL && strcmp(ingest, "device") == 0)
+    {
+        if(0 != hz_hip_ingest_tiles(s->dev, (const unsigned char* const*)s->tiles.tile,
+                                    s->tiles.win.ntiles[0], s->tiles.win.ntiles[1],
+                                    s->tiles.win.cells_per_deg,
+                                    s->tiles.win.origin_cell[0], s->tiles.win.origin_cell[1]))
+        {
+            MSG("Device-side DEM ingest failed: %s", hz_hip_last_error());
+            goto done;
+        }
+    }
+    else
+    {
+        mosaic = malloc((size_t)N*N*sizeof(int16_t));
+        if(mosaic == NULL) { MSG("out of memory for a %dx%d mosaic", N, N); goto done; }
+        hz_tileset_build_mosaic(&s->tiles, mosaic);
+        if(0 != hz_hip_upload_mosaic(s->dev, mosaic))
+        {
+            MSG("Mosaic upload failed: %s", hz_hip_last_error());
+            goto done;
+        }
+    }
+
+    s->tanel = malloc((size_t)offscreen_height*sizeof(float));
+    if(s->tanel == NULL) goto done;
+
+    /* reference horizonator-lib.c:203; the count overflows int for 11x11
+     * SRTM1 mosaics, which the reference cannot load anyway: saturate */
+    const long long ntri = 2LL*(N-1)*(N-1);
+    ctx->Ntriangles     = ntri > INT_MAX ? INT_MAX : (int)ntri;
+    ctx->render_texture = false;
+    ctx->use_glut       = true;
+    ctx->glut_window    = 1;
+    ctx->program        = (uint32_t)(slot+1);
+    s->live = true;
+
+    s->view.deg_per_cell = 1.0f / (float)s->tiles.win.cells_per_deg;        /* reference :577 */
+    s->view.aspect = (float)offscreen_width / (float)offscreen_height;     /* reference :658-659 */
+
+    if(!horizonator_move(ctx, viewer_z, viewer_lat, viewer_lon)) goto done; /* reference :611 */
+    if(!horizonator_set_zextents(ctx,
+                                 HORIZONATOR_ZNEAR_DEFAULT, HORIZONATOR_ZFAR_DEFAULT,
+                                 HORIZONATOR_ZNEAR_DEFAULT, HORIZONATOR_ZFAR_DEFAULT)) goto done;
+
+    ctx->offscreen.inited = true;
+    ctx->offscreen.width  = offscreen_width;
+    ctx->offscreen.height = offscreen_height;
+
+    if(!horizonator_pan_zoom(ctx, -45.f, 45.f)) goto done;                  /* reference :670 */
+    result = true;
+
+ done:
+    free(mosaic);
+    if(!result)
+    {
+        state_release(s, ctx);
+        memset(ctx, 0, sizeof(*ctx));
+    }
+    return result;
+}
+
+void horizonator_deinit(horizonator_context_t* ctx)
+{
+    hz_state_t* s = state_of(ctx);
+    if(s != NULL) state_release(s, ctx);
+    ctx->glut_window = 0;
+    ctx->program     = 0;
+    ctx->Ntriangles  = 0;
+    ctx->offscreen.inited = false;
+}
+
+bool horizonator_move(horizonator_context_t* ctx, float* viewer_z,
+                      float viewer_lat, float viewer_lon)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    const hz_window_t* w = &s->tiles.win;
+
+    /* reference horizonator-lib.c:765-770, float32 */
+    const float viewer_cell_i =
+        (viewer_lon - (float)w->origin_tile[0]) * (float)w->cells_per_deg - (float)w->origin_cell[0];
+    const float viewer_cell_j =
+        (viewer_lat - (float)w->origin_tile[1]) * (float)w->cells_per_deg - (float)w->origin_cell[1];
+
+    /* reference horizonator-lib.c:775-789: stand 1 m above the highest of
+     * the four samples around the viewer unless told otherwise */
+    float z;
+    if(viewer_z == NULL || *viewer_z < 0)
+    {
+        const int i0 = (int)floorf(viewer_cell_i);
+        const int j0 = (int)floorf(viewer_cell_j);
+        const float z00 = hz_tileset_sample(&s->tiles, i0,   j0  );
+        const float z10 = hz_tileset_sample(&s->tiles, i0+1, j0  );
+        const float z01 = hz_tileset_sample(&s->tiles, i0,   j0+1);
+        const float z11 = hz_tileset_sample(&s->tiles, i0+1, j0+1);
+        z = fmaxf(fmaxf(z00, z10), fmaxf(z01, z11)) + 1.0f;
+        if(viewer_z != NULL) *viewer_z = z;
+    }
+    else
+        z = *viewer_z;
+
+    s->view.viewer_cell_i  = viewer_cell_i;
+    s->view.viewer_cell_j  = viewer_cell_j;
+    s->view.viewer_z       = z;
+    /* reference horizonator-lib.c:799: the product is formed in double
+     * (M_PI is a double), rounded to float by cosf's prototype */
+    s->view.cos_viewer_lat = cosf((float)((double)viewer_lat * M_PI / 180.0));
+
+    ctx->viewer_lat = viewer_lat;
+    ctx->viewer_lon = viewer_lon;
+    return true;
+}
+
+bool horizonator_pan_zoom(const horizonator_context_t* ctx, float az_deg0, float az_deg1)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    s->view.az_deg0 = az_deg0;      /* stored raw, reference horizonator-lib.c:833-834 */
+    s->view.az_deg1 = az_deg1;
+    return true;
+}
+
+bool horizonator_resized(const horizonator_context_t* ctx, int width, int height)
+{
+    (void)width; (void)height;
+    if(live_state(ctx) == NULL) return false;
+    /* reference horizonator-lib.c:847-851 asserts here; every context of this
+     * build is offscreen */
+    MSG("Resising an offscreen window is not yet supported");
+    return false;
+}
+
+bool horizonator_set_zextents(horizonator_context_t* ctx,
+                              float znear, float zfar, float znear_color, float zfar_color)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    /* reference horizonator-lib.c:875-877 */
+    if(!(znear > 0.0f && znear_color > 0.0f && zfar > 0.0f && zfar_color > 0.0f))
+        return false;
+    s->view.znear = znear;             s->view.zfar = zfar;
+    s->view.znear_color = znear_color; s->view.zfar_color = zfar_color;
+    return true;
+}
+
+bool horizonator_redraw(const horizonator_context_t* ctx)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(0 != hz_hip_draw(s->dev, &s->view))
+    {
+        MSG("draw failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+/* tan(elevation) of every GL row (row 0 = bottom), reference
+ * horizonator-lib.c:1006-1012 and the mirrored use at :1026-1047: the lower
+ * half evaluates get_tanel(y), the upper half reuses the mirror row's value
+ * (its sign does not matter, it is squared) */
+static void fill_tanel(hz_state_t* s)
+{
+    const int   height = s->height;
+    const float aspect = (float)s->width / (float)height;
+    const float az_deg0 = s->view.az_deg0, az_deg1 = s->view.az_deg1;
+    for(int row=0; row<height; row++)
+    {
+        int y = row;
+        if(row >= height - height/2) y = height-1 - row;
+        const float el_ndc = ((float)y + 0.5f) / (float)height * 2.f - 1.f;
+        const float el     = el_ndc * (az_deg1-az_deg0) / 2.f / aspect * M_PI/180.0f;
+        s->tanel[row] = tanf(el);
+    }
+}
+
+static bool render_common(const horizonator_context_t* ctx, bool to_host,
+                          void* image, float* ranges, int32_t* index, uint32_t* z24)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(!ctx->offscreen.inited)
+    {
+        /* reference horizonator-lib.c:924-928 */
+        MSG("Prior to calling horizonator_render_offscreen(), the context must have been inited for offscreen rendering with horizonator_init(use_glut=true, offscreen_width,height > 0)");
+        return false;
+    }
+    if(!horizonator_redraw(ctx)) return false;
+    if(ranges != NULL) fill_tanel(s);
+    const int rc = to_host
+        ? hz_hip_resolve_to_host(s->dev, &s->view, s->tanel, image, ranges, index, z24)
+        : hz_hip_resolve        (s->dev, &s->view, s->tanel, image, ranges, index, z24);
+    if(rc != 0)
+    {
+        MSG("resolve failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool horizonator_render_offscreen(const horizonator_context_t* ctx, char* image, float* ranges)
+{
+    return render_common(ctx, true, image, ranges, NULL, NULL);
+}
+
+bool horizonator_pick(const horizonator_context_t* ctx, float* lat, float* lon, int x, int y)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    uint32_t zi;
+    if(0 != hz_hip_read_depth(s->dev, x, y, &zi)) return false;
+    /* reference horizonator-lib.c:1267-1273: depth as GL hands it out */
+    const float depth = (float)((double)zi * (1.0/16777215.0));
+    if(depth >= 1.0f) return false;
+    /* reference horizonator-lib.c:1285-1295 */
+    const double range_en = depth * (s->view.zfar - s->view.znear) + s->view.znear;
+    return horizonator_unproject(lat, lon, x, y, -1., range_en,
+                                 ctx->viewer_lat, s->view.cos_viewer_lat, ctx->viewer_lon,
+                                 s->view.az_deg0, s->view.az_deg1,
+                                 s->width, s->height);
+}
+
+/* ------------------------------------------------------------------------ */
+/* pure host math: reference horizonator-lib.c:1053-1213                     */
+
+static double unwrap_near_rad_d(double x, double near)
+{
+    /* reference horizonator-lib.c:1056-1060.  C round() = half away from
+     * zero, unlike the shader's round-half-even; kept as the reference has it */
+    const double d = (x - near) / (2.*M_PI);
+    return (d - round(d)) * 2.*M_PI + near;
+}
+
+bool horizonator_x_from_az(double* x, double* az_ndc_per_rad,
+                           double az_rad, double az_rad0, double az_rad1, int width)
+{
+    az_rad1 = unwrap_near_rad_d(az_rad1-az_rad0, M_PI) + az_rad0;
+    const double center = (az_rad0 + az_rad1)/2.;
+    az_rad = unwrap_near_rad_d(az_rad, center);
+    const double k = 2.0 / (az_rad1 - az_rad0);
+    const double az_ndc = (az_rad - center) * k;
+    if(!(-1. <= az_ndc && az_ndc <= 1.)) return false;
+    if(az_ndc_per_rad != NULL) *az_ndc_per_rad = k;
+    *x = (az_ndc + 1.)/2.*width - 0.5;
+    return true;
+}
+
+bool horizonator_project(double* x, double* y, double* range,
+                         double lat_viewer, double cos_lat_viewer, double lon_viewer,
+                         double ele_viewer,
+                         double lat, double lon, double ele,
+                         double az_rad0, double az_rad1, int width, int height)
+{
+    const float Rearth = 6371000.0;
+    const double dlat  = (lat - lat_viewer)*M_PI/180;
+    const double dlon  = (lon - lon_viewer)*M_PI/180;
+    const double east  = dlon * Rearth * cos_lat_viewer;
+    const double north = dlat * Rearth;
+    const double d2    = east*east + north*north;
+
+    double k;
+    if(!horizonator_x_from_az(x, &k, atan2(east, north), az_rad0, az_rad1, width))
+        return false;
+
+    const double h    = ele - ele_viewer;
+    const double d_ne = sqrt(d2);
+    *range = sqrt(d2 + h*h);
+
+    const double aspect = (double)width / (double)height;
+    const double el_ndc = atan2(h, d_ne) * aspect * k;
+    if(!(-1. <= el_ndc && el_ndc <= 1.)) return false;
+    *y = (-el_ndc + 1.)/2.*height - 0.5;
+    return true;
+}
+
+bool horizonator_unproject(float* lat, float* lon, int x, int y,
+                           double range_enh, double range_en,
+                           double lat_viewer, double cos_lat_viewer, double lon_viewer,
+                           double az_deg0, double az_deg1, int width, int height)
+{
+    if(1 != (range_enh > 0.) + (range_en > 0.)) return false;
+    const float Rearth = 6371000.0;
+
+    /* reference horizonator-lib.c:1183-1184: mixed float/double on purpose */
+    float az_ndc = ((float)x + 0.5f) / (float)width * 2.f - 1.f;
+    float az     = (az_ndc * (az_deg1-az_deg0) / 2.f + (az_deg1+az_deg0)/2.f) * M_PI/180.0f;
+
+    if(range_en <= 0)
+    {
+        double aspect = (double)width / (double)height;
+        double el_ndc = ((double)y + 0.5) / (double)height * 2. - 1.;
+        double el     = el_ndc * (az_deg1-az_deg0) / 2. / aspect * M_PI/180.0;
+        range_en = cos(el) * range_enh;
+    }
+    float e = range_en * sinf(az);
+    float n = range_en * cosf(az);
+    *lon = lon_viewer + e / Rearth / M_PI * 180. / cos_lat_viewer;
+    *lat = lat_viewer + n / Rearth / M_PI * 180.;
+    return true;
+}
+
+/* ------------------------------------------------------------------------ */
+/* build-side additions (include/horizonator_amd.h)                          */
+
+bool horizonator_amd_render(const horizonator_context_t* ctx,
+                            char* image, float* ranges, int32_t* index, uint32_t* z24)
+{
+    return render_common(ctx, true, image, ranges, index, z24);
+}
+
+bool horizonator_amd_render_device(const horizonator_context_t* ctx,
+                                   void* d_image, float* d_ranges, int32_t* d_index, uint32_t* d_z24)
+{
+    return render_common(ctx, false, d_image, d_ranges, d_index, d_z24);
+}
+
+bool horizonator_amd_sync(const horizonator_context_t* ctx)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_sync(s->dev);
+}
+
+bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(0 != hz_hip_set_sector(s->dev, col0, col1))
+    {
+        MSG("%s", hz_hip_last_error());
+        return false;
+    }
+    s->col0 = col0; s->col1 = col1;
+    return true;
+}
+
+bool horizonator_amd_set_raster(const horizonator_context_t* ctx, int which)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_set_raster(s->dev, which);
+}
+
+bool horizonator_amd_set_profiling(const horizonator_context_t* ctx, bool on)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_set_profiling(s->dev, on ? 1 : 0);
+}
+
+bool horizonator_amd_last_times(const horizonator_context_t* ctx, hz_times_t* times)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_last_times(s->dev, times);
+}
+
+bool horizonator_amd_get_view(const horizonator_context_t* ctx, hz_view_t* view)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    *view = s->view;
+    return true;
+}
+
+hz_dev_t* horizonator_amd_device(const horizonator_context_t* ctx)
+{
+    hz_state_t* s = live_state(ctx);
+    return s ? s->dev : NULL;
+}
+
+bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_download_mosaic(s->dev, mosaic);
+}

@@ -1,0 +1,166 @@
+/* hz_raster.h - triangle setup, coverage and interpolation rules of the
+ * software rasteriser (device code; also compiled on the host for unit use).
+ *
+ * These restate what the GL pipeline does between the geometry shader and the
+ * depth buffer for the state the reference sets up (reference
+ * horizonator-lib.c:183-185 depth test GL_LESS + back-face cull, :631/:646
+ * RGB8 + 24-bit depth, :657 viewport), with Mesa/llvmpipe's conventions where
+ * GL leaves a choice (8 sub-pixel bits, top-left fill rule, Z24 rounding):
+ *
+ *   window position   xw = x*W/2 + W/2,  yw = y*H/2 + H/2,  zw = z/2 + 1/2
+ *   pixel centres     at half-integers of (xw,yw); we work in f = w - 0.5 so
+ *                     that centres are integers
+ *   coverage          from positions snapped to 1/256 px, integer edge
+ *                     functions, ties owned by left and bottom edges (y up)
+ *   facing            sign of the snapped area; <= 0 is culled
+ *   depth / colour    planes through the UNSNAPPED positions, evaluated at the
+ *                     pixel centre relative to vertex 0
+ *   depth buffer      zi = rint(z * (2^24-1)), fragment dropped unless
+ *                     0 <= z <= 1, passes iff zi < stored; 0xFFFFFF = cleared
+ *
+ * The framebuffer word packs  zi<<40 | primitive<<8 | red8  so that one
+ * unsigned 64-bit min implements "GL_LESS, first drawn wins ties" regardless
+ * of the order in which triangles are processed.
+ */
+#pragma once
+
+#include "hz_num.h"
+
+#define HZ_SUBPIXEL_BITS   8
+#define HZ_SUBPIXEL_ONE    256
+#define HZ_Z24_MAX         0xFFFFFFu
+#define HZ_FB_CLEAR        0xFFFFFFFFFFFFFFFFull
+/* positions beyond this many pixels from the origin are outside the guard
+ * band: the triangle is dropped (keeps the 64-bit edge functions exact) */
+#define HZ_GUARD_PX        2097152.0f
+
+typedef struct
+{
+    /* snapped positions, 1/256 px */
+    int32_t xs[3], ys[3];
+    /* bounding box in pixels, inclusive, already clipped to the scissor */
+    int32_t px0, px1, py0, py1;
+    /* attribute planes relative to vertex 0 */
+    float fx0, fy0;
+    float z0, dzdx, dzdy;
+    float r0, drdx, drdy;
+} hz_tri_t;
+
+/* window-space vertex as the kernels keep it */
+typedef struct { float xn, fx, fy, zw, red; } hz_wvert_t;
+
+HZ_HD hz_wvert_t hz_to_window(hz_vertex_t v, float halfW, float halfH)
+{
+    hz_wvert_t w;
+    w.xn  = v.x;
+    w.fx  = (v.x*halfW + halfW) - 0.5f;
+    w.fy  = (v.y*halfH + halfH) - 0.5f;
+    w.zw  = v.z*0.5f + 0.5f;
+    w.red = v.red;
+    return w;
+}
+
+/* Returns 0 if the triangle produces no fragments inside the scissor
+ * [sx0,sx1] x [sy0,sy1] (inclusive, pixels), 1 otherwise. */
+HZ_HD int hz_tri_setup(hz_tri_t* t,
+                       hz_wvert_t a, hz_wvert_t b, hz_wvert_t c,
+                       int sx0, int sx1, int sy0, int sy1)
+{
+    /* reference geometry.glsl:21-27: wider than a quarter of the viewport
+     * (which includes everything straddling the +-180 deg seam) -> dropped */
+    const float xmax = hz_max(hz_max(a.xn, b.xn), c.xn);
+    const float xmin = hz_min(hz_min(a.xn, b.xn), c.xn);
+    if(xmax - xmin > 0.5f) return 0;
+
+    /* guard band; also rejects NaN/inf positions */
+    if(!(hz_abs(a.fx) <= HZ_GUARD_PX && hz_abs(a.fy) <= HZ_GUARD_PX &&
+         hz_abs(b.fx) <= HZ_GUARD_PX && hz_abs(b.fy) <= HZ_GUARD_PX &&
+         hz_abs(c.fx) <= HZ_GUARD_PX && hz_abs(c.fy) <= HZ_GUARD_PX))
+        return 0;
+
+    t->xs[0] = (int32_t)hz_roundeven(a.fx*256.f); t->ys[0] = (int32_t)hz_roundeven(a.fy*256.f);
+    t->xs[1] = (int32_t)hz_roundeven(b.fx*256.f); t->ys[1] = (int32_t)hz_roundeven(b.fy*256.f);
+    t->xs[2] = (int32_t)hz_roundeven(c.fx*256.f); t->ys[2] = (int32_t)hz_roundeven(c.fy*256.f);
+
+    /* back-face cull on the snapped area (counter-clockwise = front, y up) */
+    const int64_t area =
+        (int64_t)(t->xs[1]-t->xs[0])*(int64_t)(t->ys[2]-t->ys[0]) -
+        (int64_t)(t->xs[2]-t->xs[0])*(int64_t)(t->ys[1]-t->ys[0]);
+    if(area <= 0) return 0;
+
+    int32_t xlo = t->xs[0] < t->xs[1] ? t->xs[0] : t->xs[1]; xlo = xlo < t->xs[2] ? xlo : t->xs[2];
+    int32_t xhi = t->xs[0] > t->xs[1] ? t->xs[0] : t->xs[1]; xhi = xhi > t->xs[2] ? xhi : t->xs[2];
+    int32_t ylo = t->ys[0] < t->ys[1] ? t->ys[0] : t->ys[1]; ylo = ylo < t->ys[2] ? ylo : t->ys[2];
+    int32_t yhi = t->ys[0] > t->ys[1] ? t->ys[0] : t->ys[1]; yhi = yhi > t->ys[2] ? yhi : t->ys[2];
+
+    /* integer pixel centres inside the snapped box */
+    t->px0 = (xlo + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS;
+    t->px1 =  xhi                        >> HZ_SUBPIXEL_BITS;
+    t->py0 = (ylo + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS;
+    t->py1 =  yhi                        >> HZ_SUBPIXEL_BITS;
+    if(t->px0 < sx0) t->px0 = sx0;
+    if(t->px1 > sx1) t->px1 = sx1;
+    if(t->py0 < sy0) t->py0 = sy0;
+    if(t->py1 > sy1) t->py1 = sy1;
+    if(t->px0 > t->px1 || t->py0 > t->py1) return 0;
+
+    /* whole triangle in front of the near sphere or beyond the far one */
+    if((a.zw < 0.f && b.zw < 0.f && c.zw < 0.f) ||
+       (a.zw > 1.f && b.zw > 1.f && c.zw > 1.f))
+        return 0;
+
+    /* attribute planes from the unsnapped positions */
+    const float ex1 = b.fx - a.fx, ey1 = b.fy - a.fy;
+    const float ex2 = c.fx - a.fx, ey2 = c.fy - a.fy;
+    const float af  = ex1*ey2 - ex2*ey1;
+    const float dz1 = b.zw  - a.zw,  dz2 = c.zw  - a.zw;
+    const float dr1 = b.red - a.red, dr2 = c.red - a.red;
+    t->fx0 = a.fx; t->fy0 = a.fy;
+    t->z0  = a.zw;
+    t->dzdx = (dz1*ey2 - dz2*ey1) / af;
+    t->dzdy = (dz2*ex1 - dz1*ex2) / af;
+    t->r0  = a.red;
+    t->drdx = (dr1*ey2 - dr2*ey1) / af;
+    t->drdy = (dr2*ex1 - dr1*ex2) / af;
+    return 1;
+}
+
+/* coverage of pixel centre (px,py) */
+HZ_HD int hz_tri_covers(const hz_tri_t* t, int px, int py)
+{
+    const int64_t X = (int64_t)px << HZ_SUBPIXEL_BITS;
+    const int64_t Y = (int64_t)py << HZ_SUBPIXEL_BITS;
+    #pragma unroll
+    for(int m=0; m<3; m++)
+    {
+        const int a = m, b = (m == 2) ? 0 : m+1;
+        const int64_t dx = t->xs[b] - t->xs[a];
+        const int64_t dy = t->ys[b] - t->ys[a];
+        const int64_t e  = dx*(Y - t->ys[a]) - dy*(X - t->xs[a]);
+        if(e < 0) return 0;
+        if(e == 0 && !(dy < 0 || (dy == 0 && dx > 0))) return 0;
+    }
+    return 1;
+}
+
+/* depth + colour of a covered pixel; returns 0 if the fragment is clipped
+ * by the near/far spheres or cannot beat the cleared depth */
+HZ_HD int hz_tri_fragment(const hz_tri_t* t, int px, int py, uint32_t* zi, uint32_t* r8)
+{
+    const float dx = (float)px - t->fx0;
+    const float dy = (float)py - t->fy0;
+    const float z  = t->z0 + (t->dzdx*dx + t->dzdy*dy);
+    if(!(z >= 0.f && z <= 1.f)) return 0;
+    const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
+    if(q >= HZ_Z24_MAX) return 0;
+    float r = t->r0 + (t->drdx*dx + t->drdy*dy);
+    r = hz_max(hz_min(r, 1.0f), 0.0f);
+    *zi = q;
+    *r8 = (uint32_t)hz_roundeven(r * 255.f);
+    return 1;
+}
+
+HZ_HD uint64_t hz_pack(uint32_t zi, uint32_t prim, uint32_t r8)
+{
+    return ((uint64_t)zi << 40) | ((uint64_t)prim << 8) | (uint64_t)r8;
+}

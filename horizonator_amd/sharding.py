@@ -1,0 +1,52 @@
+"""Azimuth-sector sharding of one panorama across the GPUs of a node.
+
+The reference has no multi-device code; this is the multi-GPU design of this
+build (DESIGN.md "Multi-GPU").  Every rank holds the full DEM mosaic and the
+full-panorama view, and renders only image columns [col0, col1): its azimuth
+sector.  Pixels are independent given the DEM, so a sector's pixels are
+bit-identical to the same pixels of a single-GPU render, and the only exchange
+is one gather of the finished strips to rank 0 (RCCL over xGMI when the process
+group's backend is "nccl"; gloo on CPU in the tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def sector_columns(width, world_size, rank):
+    """columns [col0, col1) of `rank`: equal azimuth spans, remainder spread
+    over the first ranks.  With a viewer-centred square mosaic and a 360-degree
+    view, 2/4/8 equal sectors starting at the image edge also hold equal DEM
+    area (whole octants), so the triangle load is balanced."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank outside the world")
+    base, extra = divmod(width, world_size)
+    col0 = rank * base + min(rank, extra)
+    col1 = col0 + base + (1 if rank < extra else 0)
+    return col0, col1
+
+
+def gather_strips(strip, width, group=None, dst=0):
+    """strip: this rank's [H, SW, ...] tensor (device tensor for nccl/RCCL, CPU
+    tensor for gloo).  Returns the assembled [H, width, ...] tensor on `dst`,
+    None elsewhere.  Strips may differ in width by one column; they travel
+    padded to the widest."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return strip
+    widest = -(-width // world)
+    sw = strip.shape[1]
+    if sw < widest:
+        pad_shape = list(strip.shape)
+        pad_shape[1] = widest - sw
+        strip = torch.cat([strip, strip.new_zeros(pad_shape)], dim=1)
+    strip = strip.contiguous()
+    bins = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
+    dist.gather(strip, bins, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r, b in enumerate(bins):
+        c0, c1 = sector_columns(width, world, r)
+        parts.append(b[:, :c1 - c0])
+    return torch.cat(parts, dim=1)

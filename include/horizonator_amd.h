@@ -1,0 +1,57 @@
+/* horizonator_amd.h - build-side additions to the reference API.
+ *
+ * Nothing here exists in the reference; these calls expose what the HIP
+ * implementation has for free (the visible-primitive index map, raw depth),
+ * what multi-GPU sharding needs (azimuth sectors, device-resident outputs) and
+ * what the benchmark needs (per-kernel times).  A caller that only uses
+ * horizonator.h never needs this header.
+ */
+#pragma once
+
+#include "horizonator.h"
+#include "hz_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Like horizonator_render_offscreen() plus two more outputs, all HOST
+ * pointers, each may be NULL, all [H][sector width], top row first:
+ *   index  int32, id of the triangle that owns the pixel, -1 for sky.
+ *          id = 2*(j*(N-1)+i)+t with (i,j) the DEM cell (i east, j north,
+ *          N = 2*radius_cells) and t the triangle of the cell in the order of
+ *          the reference's index buffer (reference horizonator-lib.c:500-506),
+ *          i.e. the GL primitive id of the reference's draw call.
+ *   z24    uint32, the 24-bit depth-buffer value, 0xFFFFFF for sky */
+bool horizonator_amd_render(const horizonator_context_t* ctx,
+                            char* image, float* ranges,
+                            int32_t* index, uint32_t* z24);
+
+/* Draw + resolve into DEVICE buffers owned by the caller (e.g. torch tensors
+ * that an RCCL gather then moves); asynchronous on the context's stream,
+ * follow with horizonator_amd_sync(). */
+bool horizonator_amd_render_device(const horizonator_context_t* ctx,
+                                   void* d_image, float* d_ranges,
+                                   int32_t* d_index, uint32_t* d_z24);
+bool horizonator_amd_sync(const horizonator_context_t* ctx);
+
+/* Restrict this context to image columns [col0,col1) of the panorama: the
+ * azimuth-sector shard one GPU renders.  Outputs then have width col1-col0. */
+bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1);
+
+/* HZ_RASTER_* of hz_hip.h */
+bool horizonator_amd_set_raster(const horizonator_context_t* ctx, int which);
+
+bool horizonator_amd_set_profiling(const horizonator_context_t* ctx, bool on);
+bool horizonator_amd_last_times(const horizonator_context_t* ctx, hz_times_t* times);
+
+/* the view ("uniform") values currently in effect, and the device state */
+bool      horizonator_amd_get_view(const horizonator_context_t* ctx, hz_view_t* view);
+hz_dev_t* horizonator_amd_device  (const horizonator_context_t* ctx);
+
+/* copy of the N x N int16 mosaic as it sits in HBM (tests) */
+bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,132 @@
+/* hz_hip.h - C-ABI of the HIP side of the render path.
+ *
+ * The host library (hz_host.c, plain C) implements horizonator.h on top of
+ * these entry points; they are also what bench.py / the Python mirror bind
+ * when they need device-resident outputs (multi-GPU strips, timing).  Plain
+ * pointers and sizes only; <hip/hip_runtime.h> is included by the .hip
+ * translation unit alone.
+ *
+ * Each entry point names the reference code whose work it takes over
+ * (citations into /root/reference).
+ */
+#pragma once
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hz_dev hz_dev_t;        /* opaque device-side state */
+
+/* The "uniforms": everything a draw depends on besides the DEM.  float32, and
+ * derived on the host exactly as the reference does it:
+ *   viewer_cell_i/j, viewer_z, cos_viewer_lat  reference horizonator-lib.c:765-799
+ *   deg_per_cell                               reference horizonator-lib.c:577
+ *   az_deg0/1 (stored raw)                     reference horizonator-lib.c:833-834
+ *   aspect = (float)W/(float)H                 reference horizonator-lib.c:658-659
+ *   znear..zfar_color                          reference horizonator-lib.c:879-882 */
+typedef struct
+{
+    float viewer_cell_i, viewer_cell_j;
+    float viewer_z;
+    float cos_viewer_lat;
+    float deg_per_cell;
+    float az_deg0, az_deg1;
+    float aspect;
+    float znear, zfar;
+    float znear_color, zfar_color;
+} hz_view_t;
+
+/* which rasteriser hz_hip_draw() runs */
+enum
+{
+    HZ_RASTER_AUTO   = 0,
+    HZ_RASTER_SCATTER= 1,   /* thread per DEM cell, 64-bit atomicMin into HBM      */
+    HZ_RASTER_COLUMNS= 2    /* workgroup per image-column group, depth in LDS      */
+};
+
+/* per-draw kernel times in ms, measured with HIP events on the context's own
+ * stream (only filled while profiling is on) */
+typedef struct
+{
+    float clear_ms;
+    float raster_ms;        /* the dominant kernel */
+    float big_ms;           /* cooperative pass over large triangles (scatter path) */
+    float resolve_ms;
+    float total_ms;         /* first event to last event */
+} hz_times_t;
+
+int  hz_hip_device_count(void);
+
+/* Takes over the GL object creation of reference horizonator-lib.c:403-512
+ * (VBO/IBO) and :617-666 (FBO): allocates the N x N int16 mosaic and the
+ * W x H 64-bit depth/id/colour framebuffer on `device`.  NULL on failure. */
+hz_dev_t* hz_hip_create(int device, int N, int width, int height);
+void      hz_hip_destroy(hz_dev_t* d);
+
+/* mosaic[j*N+i], j north, i east (what reference horizonator-lib.c:435-480
+ * pushes into the VBO, minus the redundant i,j).  Host pointer. */
+int  hz_hip_upload_mosaic(hz_dev_t* d, const int16_t* mosaic);
+
+/* Alternative ingest ("next" row N3): raw big-endian .hgt tiles are copied to
+ * the device and a kernel does the byte swap, north-south flip, edge dedup and
+ * void clamp of reference dem.c:264-309.  tiles[ti + tj*ntiles_lon] is a host
+ * pointer to (cpd+1)^2 big-endian samples or NULL for sea. */
+int  hz_hip_ingest_tiles(hz_dev_t* d,
+                         const unsigned char* const* tiles,
+                         int ntiles_lon, int ntiles_lat,
+                         int cells_per_deg,
+                         int origin_cell_lon, int origin_cell_lat);
+
+/* read back the device mosaic (tests) */
+int  hz_hip_download_mosaic(hz_dev_t* d, int16_t* mosaic);
+
+/* Restrict drawing to image columns [col0, col1): the azimuth-sector shard of
+ * one GPU.  The view (centre, scale, discard rule) stays that of the full
+ * panorama, so a sector's pixels are bit-identical to the same pixels of a
+ * full draw.  Default: [0, width). */
+int  hz_hip_set_sector(hz_dev_t* d, int col0, int col1);
+
+int  hz_hip_set_raster(hz_dev_t* d, int which);
+int  hz_hip_set_profiling(hz_dev_t* d, int on);
+
+/* Takes over glClear + glDrawElements (reference horizonator-lib.c:896-897)
+ * and with it vertex.glsl / geometry.glsl / fragment.glsl and the fixed
+ * function raster + depth test.  Asynchronous on the context's stream. */
+int  hz_hip_draw(hz_dev_t* d, const hz_view_t* view);
+
+/* Takes over the two glReadPixels + flip + depth->range conversion of
+ * reference horizonator-lib.c:936-1048, on the device.  Outputs are DEVICE
+ * pointers, each may be NULL; they describe the current sector only and are
+ * laid out [height][col1-col0], top row first:
+ *   bgr    3 bytes per pixel
+ *   ranges float32, < 0 where no terrain
+ *   index  int32 primitive id (2*(j*(N-1)+i)+t), -1 where no terrain
+ *   z24    uint32 raw 24-bit depth, 0xFFFFFF where no terrain
+ * tanel is a HOST array of `height` floats: tan(elevation) of each GL row
+ * (row 0 = bottom) as the reference computes it (reference
+ * horizonator-lib.c:1007-1012). */
+int  hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                    unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
+
+/* resolve into internal device buffers, then copy to HOST pointers (each may
+ * be NULL); synchronous */
+int  hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                            unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
+
+/* 24-bit depth of image pixel (x, y), y = 0 top row, from the last draw
+ * (reference horizonator-lib.c:1268-1270) */
+int  hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24);
+
+int  hz_hip_sync(hz_dev_t* d);
+int  hz_hip_last_times(hz_dev_t* d, hz_times_t* t);
+
+/* the HIP stream the context launches on, as a void* (hipStream_t) */
+void* hz_hip_stream(hz_dev_t* d);
+
+const char* hz_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif

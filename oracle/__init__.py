@@ -1,0 +1,200 @@
+"""oracle - TEST INFRASTRUCTURE: ctypes binding of oracle/liboracle.so.
+
+CPU restatement of the reference's DEM -> panorama path (see oracle/oracle.h).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package.  Nothing under horizonator_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_DEM_PATH = os.path.join(_HERE, "_ref", "libdem_ref.so")
+GLSL_GOLDEN_PATH = os.path.join(_HERE, "_ref", "glsl_golden")
+
+
+class OrcDem(C.Structure):
+    _fields_ = [
+        ("cells_per_deg", C.c_int), ("radius_cells", C.c_int),
+        ("origin_tile", C.c_int * 2), ("origin_cell", C.c_int * 2), ("ntiles", C.c_int * 2),
+        ("tiles", C.c_void_p),
+    ]
+
+
+VIEW_FIELDS = ("viewer_cell_i", "viewer_cell_j", "viewer_z", "cos_viewer_lat", "deg_per_cell",
+               "az_deg0", "az_deg1", "aspect", "znear", "zfar", "znear_color", "zfar_color")
+
+
+class OrcView(C.Structure):
+    _fields_ = [(n, C.c_float) for n in VIEW_FIELDS]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n in VIEW_FIELDS}
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.orc_dem_open.restype = C.c_int
+    lib.orc_dem_open.argtypes = [P(OrcDem), C.c_float, C.c_float, C.c_int, C.c_float, C.c_char_p, C.c_int]
+    lib.orc_dem_close.restype = None
+    lib.orc_dem_close.argtypes = [P(OrcDem)]
+    lib.orc_dem_sample.restype = C.c_int
+    lib.orc_dem_sample.argtypes = [P(OrcDem), C.c_int, C.c_int]
+    lib.orc_dem_mosaic.restype = None
+    lib.orc_dem_mosaic.argtypes = [P(OrcDem), C.c_void_p]
+    lib.orc_view_move.restype = None
+    lib.orc_view_move.argtypes = [P(OrcView), P(OrcDem), C.c_float, C.c_float, C.c_float]
+    lib.orc_vertex.restype = None
+    lib.orc_vertex.argtypes = [P(OrcView), C.c_int, C.c_int, C.c_int, P(C.c_float * 4)]
+    lib.orc_render.restype = C.c_int
+    lib.orc_render.argtypes = [C.c_void_p, C.c_int, P(OrcView), C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_tanel.restype = None
+    lib.orc_tanel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+    _lib = lib
+    return lib
+
+
+class Dem:
+    """the oracle's view of a DEM window (restates reference dem.c)"""
+
+    def __init__(self, lat, lon, dir_dems, radius_cells=-1, radius_m=-1.0, srtm1=False):
+        self.lib = load()
+        self.d = OrcDem()
+        rc = self.lib.orc_dem_open(C.byref(self.d), lat, lon, radius_cells, radius_m,
+                                   str(dir_dems).encode(), int(srtm1))
+        if rc != 0:
+            raise RuntimeError(f"orc_dem_open failed ({rc})")
+
+    @property
+    def N(self):
+        return 2 * self.d.radius_cells
+
+    def sample(self, i, j):
+        return self.lib.orc_dem_sample(C.byref(self.d), int(i), int(j))
+
+    def mosaic(self):
+        m = np.empty((self.N, self.N), np.int16)
+        self.lib.orc_dem_mosaic(C.byref(self.d), m.ctypes.data)
+        return m
+
+    def view(self, lat, lon, W, H, az_deg0, az_deg1, viewer_z=-1.0,
+             znear=100.0, zfar=40000.0, znear_color=-1.0, zfar_color=-1.0):
+        """uniform values for a draw, derived as the reference's host code does"""
+        v = OrcView()
+        self.lib.orc_view_move(C.byref(v), C.byref(self.d), lat, lon, viewer_z)
+        v.az_deg0, v.az_deg1 = az_deg0, az_deg1
+        v.aspect = np.float32(W) / np.float32(H)          # reference horizonator-lib.c:658-659
+        v.znear, v.zfar = znear, zfar
+        v.znear_color = znear if znear_color < 0 else znear_color
+        v.zfar_color = zfar if zfar_color < 0 else zfar_color
+        return v
+
+    def close(self):
+        if self.d.tiles:
+            self.lib.orc_dem_close(C.byref(self.d))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_view(**kw):
+    v = OrcView()
+    for k, val in kw.items():
+        setattr(v, k, val)
+    return v
+
+
+def render(mosaic, view, W, H, col0=0, col1=None, nthreads=0, want=("bgr", "ranges", "index", "z24")):
+    """CPU render of image columns [col0,col1); returns a dict of arrays"""
+    lib = load()
+    mosaic = np.ascontiguousarray(mosaic, np.int16)
+    N = mosaic.shape[0]
+    if col1 is None:
+        col1 = W
+    SW = col1 - col0
+    out = {}
+    if "bgr" in want:
+        out["bgr"] = np.empty((H, SW, 3), np.uint8)
+    if "ranges" in want:
+        out["ranges"] = np.empty((H, SW), np.float32)
+    if "index" in want:
+        out["index"] = np.empty((H, SW), np.int32)
+    if "z24" in want:
+        out["z24"] = np.empty((H, SW), np.uint32)
+
+    def ptr(k):
+        return out[k].ctypes.data if k in out else None
+
+    rc = lib.orc_render(mosaic.ctypes.data, N, C.byref(view), W, H, col0, col1,
+                        ptr("bgr"), ptr("ranges"), ptr("index"), ptr("z24"), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed ({rc})")
+    return out
+
+
+def vertices(mosaic, view):
+    """gl_Position.xyz + red of every vertex: float32[N,N,4]"""
+    lib = load()
+    N = mosaic.shape[0]
+    out = np.empty((N, N, 4), np.float32)
+    buf = (C.c_float * 4)()
+    for j in range(N):
+        for i in range(N):
+            lib.orc_vertex(C.byref(view), i, j, int(mosaic[j, i]), C.byref(buf))
+            out[j, i] = buf[:]
+    return out
+
+
+def tanel(W, H, az_deg0, az_deg1):
+    lib = load()
+    t = np.empty(H, np.float32)
+    lib.orc_tanel(t.ctypes.data, W, H, az_deg0, az_deg1)
+    return t
+
+
+# ---- the reference's own dem.c, compiled in place (oracle/_ref) ---------------
+
+class _RefDemCtx(C.Structure):
+    # reference dem.h:10-29 (max_Ndems_ij = 4)
+    _fields_ = [
+        ("dems", (C.c_void_p * 4) * 4), ("mmap_sizes", (C.c_size_t * 4) * 4), ("mmap_fd", (C.c_int * 4) * 4),
+        ("origin_dem_lon_lat", C.c_int * 2), ("origin_dem_cellij", C.c_int * 2), ("Ndems_ij", C.c_int * 2),
+        ("radius_cells", C.c_int), ("cells_per_deg", C.c_int),
+    ]
+
+
+def load_ref_dem():
+    """the reference's dem.c as oracle/_ref/libdem_ref.so, or None where absent"""
+    if not os.path.exists(REF_DEM_PATH):
+        return None
+    lib = C.CDLL(REF_DEM_PATH)
+    P = C.POINTER
+    lib.horizonator_dem_init.restype = C.c_bool
+    lib.horizonator_dem_init.argtypes = [P(_RefDemCtx), C.c_float, C.c_float, C.c_int, C.c_float, C.c_char_p, C.c_bool]
+    lib.horizonator_dem_deinit.restype = None
+    lib.horizonator_dem_deinit.argtypes = [P(_RefDemCtx)]
+    lib.horizonator_dem_sample.restype = C.c_int16
+    lib.horizonator_dem_sample.argtypes = [P(_RefDemCtx), C.c_int, C.c_int]
+    lib.horizonator_dem_bounds_latlon_deg.restype = None
+    lib.horizonator_dem_bounds_latlon_deg.argtypes = [P(_RefDemCtx)] + [P(C.c_float)] * 4
+    return lib

@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE: regenerate tests/golden/*.npz from the reference itself.
+
+Runs only where /root/reference and Mesa's llvmpipe exist (the build
+container).  Two sources, both the reference's own code executed in place:
+  dem_*.npz     reference dem.c compiled as oracle/_ref/libdem_ref.so
+  vertex_*.npz  reference vertex.glsl on llvmpipe, transform-feedback capture
+  render_*.npz  reference vertex/geometry/fragment.glsl on llvmpipe, full draw
+The inputs of every fixture (DEM window, uniform values) are stored with the
+outputs, so the tests need neither the reference nor the tile generator.
+Uniform VALUES come from oracle.Dem.view(), i.e. from the restatement of the
+reference's host code (reference horizonator-lib.c:765-799): that host code
+cannot be built here, see oracle.h.
+
+    python -m oracle.make_golden
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import hzutil  # noqa: E402
+import oracle  # noqa: E402
+from oracle import glsl_run  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
+
+
+def view_arrays(v):
+    return {"u_" + k: np.float32(val) for k, val in v.as_dict().items()}
+
+
+def dem_fixtures():
+    ref = oracle.load_ref_dem()
+    cases = [  # lat, lon, radius_cells, radius_m, srtm1
+        (LAT, LON, 32, -1.0, False),
+        (LAT, LON, 600, -1.0, False),
+        (LAT, LON, 1801, -1.0, False),
+        (LAT, LON, -1, 40000.0, False),
+        (33.9, -118.2, 777, -1.0, False),
+        (LAT, LON, 300, -1.0, True),
+    ]
+    out = {}
+    for k, (lat, lon, R, Rm, srtm1) in enumerate(cases):
+        rc = 3000 if R < 0 else R
+        d = hzutil.dem_dir_for(lat, lon, rc, srtm1=srtm1)
+        ctx = oracle._RefDemCtx()
+        ok = ref.horizonator_dem_init(C.byref(ctx), lat, lon, R, Rm, d.encode(), srtm1)
+        assert ok, (lat, lon, R)
+        N = 2 * ctx.radius_cells
+        rng = np.random.default_rng(100 + k)
+        # random samples plus the window's borders and the tile seams
+        ii = np.concatenate([rng.integers(-2, N + 2, 4000), np.arange(-1, N + 1), np.arange(-1, N + 1)])
+        jj = np.concatenate([rng.integers(-2, N + 2, 4000), np.full(N + 2, 0), np.full(N + 2, N - 1)])
+        cpd = ctx.cells_per_deg
+        seam = cpd - ctx.origin_dem_cellij[0]
+        if 0 < seam < N:
+            ii = np.concatenate([ii, np.full(50, seam), np.full(50, seam - 1), np.full(50, seam + 1)])
+            jj = np.concatenate([jj, rng.integers(0, N, 150)])
+        vals = np.array([ref.horizonator_dem_sample(C.byref(ctx), int(i), int(j)) for i, j in zip(ii, jj)], np.int16)
+        b = [C.c_float() for _ in range(4)]
+        ref.horizonator_dem_bounds_latlon_deg(C.byref(ctx), *[C.byref(x) for x in b])
+        out[f"c{k}_args"] = np.array([lat, lon, R, Rm, int(srtm1)], np.float64)
+        out[f"c{k}_window"] = np.array(list(ctx.origin_dem_lon_lat) + list(ctx.origin_dem_cellij) +
+                                       list(ctx.Ndems_ij) + [ctx.radius_cells, ctx.cells_per_deg], np.int32)
+        out[f"c{k}_bounds"] = np.array([x.value for x in b], np.float32)
+        out[f"c{k}_ij"] = np.stack([ii, jj]).astype(np.int32)
+        out[f"c{k}_z"] = vals
+        ref.horizonator_dem_deinit(C.byref(ctx))
+    out["ncases"] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(OUT, "dem_samples.npz"), **out)
+    print("dem_samples.npz:", len(cases), "cases")
+
+
+def vertex_fixture(name, R, W, H, az0, az1, lat=LAT, lon=LON, **kw):
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    v = od.view(lat, lon, W, H, az0, az1, **kw)
+    gv = glsl_run.vertices(m, v)
+    np.savez_compressed(os.path.join(OUT, f"vertex_{name}.npz"), mosaic=m, W=np.int32(W), H=np.int32(H),
+                        gl_position=gv[:, :, :4], red=gv[:, :, 4], **view_arrays(v))
+    print(f"vertex_{name}.npz: {m.shape[0]}^2 vertices")
+
+
+def render_fixture(name, R, W, H, az0, az1, lat=LAT, lon=LON, keep_depth=True, **kw):
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    v = od.view(lat, lon, W, H, az0, az1, **kw)
+    g = glsl_run.render(m, v, W, H)
+    extra = {"depth": g["depth"]} if keep_depth else {}
+    np.savez_compressed(os.path.join(OUT, f"render_{name}.npz"), mosaic=m, W=np.int32(W), H=np.int32(H),
+                        bgr=g["bgr"], z24=g["z24"], **extra, **view_arrays(v))
+    print(f"render_{name}.npz: {W}x{H}, terrain fraction {(g['z24'] != 0xFFFFFF).mean():.3f}")
+
+
+def raster_probe_fixture():
+    """llvmpipe's fill rule and depth rounding on hand-made triangles (our own
+    pass-through shaders; no reference code involved)"""
+    W = H = 16
+    tris = []
+
+    def px2ndc(x, y):       # window coordinates -> clip space for a WxH viewport
+        return x / (W / 2.0) - 1.0, y / (H / 2.0) - 1.0
+
+    def tri(p0, p1, p2, z=0.0, r=0.5):
+        tris.append([[*px2ndc(*p), z, r] for p in (p0, p1, p2)])
+
+    # vertices exactly on pixel centres: which edges own their pixels?
+    tri((2.5, 2.5), (6.5, 2.5), (2.5, 6.5), z=-0.5)        # ccw right triangle
+    tri((8.5, 8.5), (12.5, 8.5), (12.5, 12.5), z=-0.25)    # ccw
+    tri((8.5, 8.5), (12.5, 12.5), (8.5, 12.5), z=-0.25)    # shares the diagonal
+    tri((2.5, 9.5), (2.5, 13.5), (6.5, 9.5), z=0.0)        # cw: culled
+    tris_a = np.array(tris, np.float32)
+    g = glsl_run.raw_triangles(tris_a, W, H)
+    np.savez_compressed(os.path.join(OUT, "raster_probe.npz"), tris=tris_a, W=np.int32(W), H=np.int32(H),
+                        bgr=g["bgr"], z24=g["z24"], depth=g["depth"])
+    print("raster_probe.npz")
+
+
+def main():
+    if not glsl_run.available() or oracle.load_ref_dem() is None:
+        sys.exit("needs /root/reference and oracle/_ref (run `make -C oracle` first)")
+    os.makedirs(OUT, exist_ok=True)
+    dem_fixtures()
+    raster_probe_fixture()
+    # vertex stage (pins reference vertex.glsl:111-162 bit for bit)
+    vertex_fixture("full360", 64, 256, 64, -180, 180)
+    vertex_fixture("partial", 64, 300, 100, -40, 100, znear_color=50.0, zfar_color=5000.0, zfar=6000.0)
+    vertex_fixture("wrapped", 64, 1000, 300, -710, -625, zfar=3000.0)
+    # full draws (G1..G5)
+    render_fixture("G1_partial", 32, 256, 64, -40, 100)
+    render_fixture("G2_full360", 32, 256, 64, -180, 180)
+    render_fixture("G3_cfg1", 600, 2000, 500, -180, 180, keep_depth=False)
+    for k, (dlat, dlon) in enumerate([(0.0, 0.0), (0.013, -0.021), (-0.02, 0.017), (0.031, 0.029)]):
+        render_fixture(f"G4_move{k}", 64, 512, 128, -180, 180, lat=LAT + dlat, lon=LON + dlon, zfar=8000.0)
+    render_fixture("G5_zextents", 64, 512, 128, 20, 200, znear=300.0, zfar=5000.0, znear_color=1000.0, zfar_color=2500.0)
+
+
+if __name__ == "__main__":
+    main()

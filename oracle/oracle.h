@@ -1,0 +1,100 @@
+/* oracle.h - CPU restatement of the reference's DEM -> panorama path.
+ *
+ * TEST INFRASTRUCTURE.  This is the checker the HIP path is compared against;
+ * it is not part of the product and nothing under horizonator_amd/ or include/
+ * may include, link or call it.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it.
+ *
+ * What it restates (citations into /root/reference):
+ *   dem.c:78-309                    window arithmetic, tile lookup, sample decode
+ *   horizonator-lib.c:765-799       viewer cell / viewer height / cos(lat)
+ *   vertex.glsl:30-38,111-162       per-vertex transform, float32
+ *   horizonator-lib.c:487-512       two triangles per cell, their order
+ *   geometry.glsl:21-27             wide / seam-crossing triangle discard
+ *   horizonator-lib.c:183-185,896   depth test LESS, back-face cull, clear
+ *   fragment.glsl:15-16             colour = (red, 0, 0)
+ *   horizonator-lib.c:936-1048      BGR readback, row flip, depth -> range
+ * The rasterisation between geometry.glsl and the depth buffer is not code of
+ * the reference: it is OpenGL's, executed for the reference by Mesa/llvmpipe.
+ * It is restated with GL's rules and llvmpipe's conventions (8 sub-pixel bits,
+ * top-left fill rule, 24-bit depth).
+ *
+ * Parity pinning: oracle_dem is checked bit-for-bit against the reference's
+ * own dem.c compiled in place (oracle/_ref/libdem_ref.so).  The render is
+ * checked against golden vectors produced by the reference's three GLSL
+ * shaders, unmodified, executed by Mesa llvmpipe (oracle/glsl_golden.c,
+ * tests/golden/); that comparison is statistical, not bit-exact, because
+ * llvmpipe's atan and interpolation differ from any restatement in the last
+ * bits (tolerance bands in tests/test_oracle_golden.py).  horizonator-lib.c
+ * itself cannot be built here (needs epoxy, freeglut and FreeImage headers the
+ * image lacks), so the host-side uniform derivation is pinned by restatement
+ * only.
+ */
+#pragma once
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- DEM ---------------------------------------------------------------- */
+
+typedef struct
+{
+    int cells_per_deg;
+    int radius_cells;
+    int origin_tile[2];         /* lon, lat */
+    int origin_cell[2];
+    int ntiles[2];
+    unsigned char** tiles;      /* [ntiles[0]*ntiles[1]], NULL = sea; whole files read into memory */
+} orc_dem_t;
+
+/* 0 on success.  No limit on the number of tiles (the reference stops at 4x4). */
+int  orc_dem_open (orc_dem_t* d, float viewer_lat, float viewer_lon,
+                   int radius_cells, float radius_m, const char* dir, int srtm1);
+void orc_dem_close(orc_dem_t* d);
+int  orc_dem_sample(const orc_dem_t* d, int i, int j);
+/* mosaic[j*N+i] = sample(i,j), N = 2*radius_cells */
+void orc_dem_mosaic(const orc_dem_t* d, int16_t* mosaic);
+
+/* ---- view ("uniforms") -------------------------------------------------- */
+
+typedef struct
+{
+    float viewer_cell_i, viewer_cell_j;
+    float viewer_z;
+    float cos_viewer_lat;
+    float deg_per_cell;
+    float az_deg0, az_deg1;
+    float aspect;
+    float znear, zfar;
+    float znear_color, zfar_color;
+} orc_view_t;
+
+/* reference horizonator-lib.c:765-799.  viewer_z < 0 -> max(4 samples)+1 */
+void orc_view_move(orc_view_t* v, const orc_dem_t* d, float viewer_lat, float viewer_lon, float viewer_z);
+
+/* ---- vertex stage ------------------------------------------------------- */
+
+/* gl_Position.xyz and rgb.r of one vertex (reference vertex.glsl:111-160) */
+void orc_vertex(const orc_view_t* v, int i, int j, int z, float out_xyzr[4]);
+
+/* ---- full render -------------------------------------------------------- */
+
+/* Renders image columns [col0,col1) of a W x H panorama.  Outputs are
+ * [H][col1-col0], top row first, each may be NULL:
+ *   bgr 3 bytes/pixel; ranges float32 (<0 = sky); index int32 primitive id
+ *   (-1 = sky); z24 uint32 (0xFFFFFF = sky).
+ * nthreads <= 0: all cores.  Returns 0 on success. */
+int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
+               int W, int H, int col0, int col1,
+               uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
+               int nthreads);
+
+/* tan(elevation) per GL row as reference horizonator-lib.c:1006-1012,1026-1047 uses it */
+void orc_tanel(float* tanel, int W, int H, float az_deg0, float az_deg1);
+
+#ifdef __cplusplus
+}
+#endif

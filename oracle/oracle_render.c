@@ -1,0 +1,375 @@
+/* oracle_render.c - TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * CPU restatement of one draw of the reference: every vertex through
+ * vertex.glsl, every triangle of the index buffer in draw order through
+ * geometry.glsl's discard, back-face cull, rasterisation and a GL_LESS depth
+ * test against a 24-bit depth buffer, then the reference's readback
+ * conversions.  float32 throughout, as on the GPU the reference runs on.
+ *
+ * Build with -ffp-contract=off: every operation below is meant to round once.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "oracle.h"
+
+/* ---- shader arithmetic -------------------------------------------------- */
+/*
+ * The vertex stage below is not a free reading of vertex.glsl: it is the
+ * operation sequence Mesa 23.2's GLSL compiler produces for that file (dump
+ * with ST_DEBUG=nir while oracle/_ref/glsl_golden runs), which is what
+ * llvmpipe then executes in IEEE float32 (fdiv, frcp = 1/x and fsqrt are
+ * exact there).  Following it operation for operation makes this function
+ * BIT-IDENTICAL to the reference's vertex shader on llvmpipe
+ * (tests/test_oracle_golden.py checks that on captured vertices).  What the
+ * compiler did to the source, and what therefore shows up below:
+ *   - Rearth*pi folded to one constant, multiplied before DEG_PER_CELL
+ *   - atan(y,x) lowered to a degree-11 polynomial with s*(1/t), not s/t
+ *   - length() as sqrt of sums in the order n*n + e*e (+ h*h first for vec3)
+ *   - unwrap_near_rad(az, c) - c and az1' - az0 simplified algebraically
+ */
+
+static const float C_REARTH_PI = 20015088.0f;       /* 0x4b98b3f8 = float(Rearth*pi) */
+static const float C_PI        = 3.14159274f;       /* 0x40490fdb */
+static const float C_TWO_PI    = 6.28318548f;       /* 0x40c90fdb */
+static const float C_HALF_PI   = 1.57079637f;       /* 0x3fc90fdb */
+static const float C_DEG2RAD   = 0.0174532924f;     /* 0x3c8efa35, radians() */
+
+/* GLSL round() on llvmpipe: to nearest, ties to even */
+static float glsl_round(float x) { return rintf(x); }
+
+/* GLSL atan(y,x) as lowered by Mesa (nir_atan2 + nir_atan) */
+static float glsl_atan2(float y, float x)
+{
+    int   flip = 0.f >= x;
+    float ax = fabsf(x);
+    float s = flip ? ax : y;
+    float t = flip ? y  : ax;
+    float scale = fabsf(t) >= 1e18f ? 0.25f : 1.0f;
+    float rcp = 1.0f / (t*scale);
+    float s_over_t = (s*scale) * rcp;
+    float tn = (ax == fabsf(y)) ? 1.0f : fabsf(s_over_t);
+
+    /* atan(tn), tn >= 0: argument reduced to [0,1] */
+    float hi = tn > 1.0f ? tn : 1.0f;
+    float lo = tn < 1.0f ? tn : 1.0f;
+    float u   = lo / hi;
+    float u2  = u*u;
+    float u3  = u2*u;
+    float u5  = u3*u2;
+    float u7  = u5*u2;
+    float u9  = u7*u2;
+    float p = u*0.9999793128310355f + u3*-0.3326756418091246f;
+    p = p + u5*0.1938924977115610f;
+    p = p + u7*-0.1173503194786851f;
+    p = p + u9*0.0536813784310406f;
+    p = p + (u9*-0.0121323213173444f)*u2;
+    float big = (1.0f < tn) ? 1.0f : 0.0f;
+    float a = big*(p*-2.0f + C_HALF_PI) + p;
+    float sign = tn > 0.f ? 1.0f : (tn < 0.f ? -1.0f : 0.0f);
+    a = a*sign;
+
+    float arc = (flip ? 1.0f : 0.0f)*C_HALF_PI + a;
+    float m = y < rcp ? y : rcp;
+    return m < 0.f ? -arc : arc;
+}
+
+typedef struct { float x, y, z, red; } ndc_t;
+
+/* reference vertex.glsl:139-150: the two per-draw constants that survive the
+ * compiler's simplification: span = az_rad1' - az_rad0 and the view centre */
+static void az_constants(const orc_view_t* v, float* az_rad_center, float* az_ndc_per_rad)
+{
+    float az_rad0 = v->az_deg0 * C_DEG2RAD;
+    float az_rad1 = v->az_deg1 * C_DEG2RAD;
+    /* unwrap_near_rad(az_rad1-az_rad0, pi), reference vertex.glsl:143 */
+    float d    = ((az_rad1 + -C_PI) + -az_rad0) / C_TWO_PI;
+    float span = C_TWO_PI*(d - glsl_round(d)) + C_PI;
+    az_rad1 = span + az_rad0;
+    *az_rad_center  = (az_rad0 + az_rad1) / 2.0f;           /* vertex.glsl:146 */
+    *az_ndc_per_rad = 2.0f / span;                          /* vertex.glsl:150 */
+}
+
+static ndc_t vertex_shader(const orc_view_t* v, float az_rad_center, float az_ndc_per_rad,
+                           float i, float j, float height)
+{
+    /* reference vertex.glsl:128-131 */
+    float e = (i - v->viewer_cell_i) * C_REARTH_PI * v->deg_per_cell / 180.0f * v->cos_viewer_lat;
+    float n = (j - v->viewer_cell_j) * C_REARTH_PI * v->deg_per_cell / 180.0f;
+    float h = height - v->viewer_z;
+
+    /* reference vertex.glsl:133-134 */
+    float nn = n*n, ee = e*e;
+    float distance_ne = sqrtf(nn + ee);
+    float az_rad = glsl_atan2(e, n);
+
+    /* reference vertex.glsl:148,152: (unwrap_near_rad(az, c) - c) * k */
+    float d = (az_rad + -az_rad_center) / C_TWO_PI;
+    ndc_t o;
+    o.x = (C_TWO_PI*(d - glsl_round(d))) * az_ndc_per_rad;
+    /* reference vertex.glsl:153 */
+    o.y = glsl_atan2(h, distance_ne) * v->aspect * az_ndc_per_rad;
+    /* reference vertex.glsl:155 */
+    o.z = (sqrtf(h*h + nn + ee) - v->znear) / (v->zfar - v->znear) * 2.0f + -1.0f;
+
+    /* reference vertex.glsl:159-160 */
+    float r = (distance_ne - v->znear_color) / (v->zfar_color - v->znear_color);
+    r = r > 0.0f ? r : 0.0f;
+    r = r < 1.0f ? r : 1.0f;
+    o.red = r;
+    return o;
+}
+
+void orc_vertex(const orc_view_t* v, int i, int j, int z, float out_xyzr[4])
+{
+    float c, k;
+    az_constants(v, &c, &k);
+    ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)z);
+    out_xyzr[0] = o.x; out_xyzr[1] = o.y; out_xyzr[2] = o.z; out_xyzr[3] = o.red;
+}
+
+/* ---- rasteriser --------------------------------------------------------- */
+
+/* a vertex after the viewport transform.  (fx,fy) are window coordinates
+ * minus one half, so pixel centres sit at integers */
+typedef struct { float xn, fx, fy, zw, red; } wvert_t;
+
+#define GUARD_PX 2097152.0f
+
+typedef struct
+{
+    uint32_t* depth;        /* [H][SW] GL row order, 24-bit values */
+    int32_t*  prim;         /* [H][SW] */
+    uint8_t*  red;          /* [H][SW] */
+    int SW, H, col0, col1;
+} target_t;
+
+static void draw_triangle(target_t* fb, int x_lo, int x_hi,
+                          const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+{
+    /* reference geometry.glsl:21-27 */
+    float xmax = A->xn > B->xn ? A->xn : B->xn; xmax = xmax > C->xn ? xmax : C->xn;
+    float xmin = A->xn < B->xn ? A->xn : B->xn; xmin = xmin < C->xn ? xmin : C->xn;
+    if(xmax - xmin > 0.5f) return;
+
+    /* guard band (also catches non-finite positions) */
+    if(!(fabsf(A->fx) <= GUARD_PX && fabsf(A->fy) <= GUARD_PX &&
+         fabsf(B->fx) <= GUARD_PX && fabsf(B->fy) <= GUARD_PX &&
+         fabsf(C->fx) <= GUARD_PX && fabsf(C->fy) <= GUARD_PX)) return;
+
+    /* positions snapped to 1/256 pixel decide coverage and facing */
+    const wvert_t* V[3] = {A,B,C};
+    int64_t X[3], Y[3];
+    for(int m=0; m<3; m++)
+    {
+        X[m] = (int64_t)rintf(V[m]->fx * 256.f);
+        Y[m] = (int64_t)rintf(V[m]->fy * 256.f);
+    }
+    /* glEnable(GL_CULL_FACE), default GL_BACK / GL_CCW (reference
+     * horizonator-lib.c:184): counter-clockwise in window space is front */
+    int64_t area = (X[1]-X[0])*(Y[2]-Y[0]) - (X[2]-X[0])*(Y[1]-Y[0]);
+    if(area <= 0) return;
+
+    int64_t bx0 = X[0], bx1 = X[0], by0 = Y[0], by1 = Y[0];
+    for(int m=1; m<3; m++)
+    {
+        if(X[m] < bx0) bx0 = X[m];
+        if(X[m] > bx1) bx1 = X[m];
+        if(Y[m] < by0) by0 = Y[m];
+        if(Y[m] > by1) by1 = Y[m];
+    }
+    /* integer pixel centres inside the box; floor division by 256 */
+    int64_t px0 = (bx0 + 255) >> 8, px1 = bx1 >> 8;
+    int64_t py0 = (by0 + 255) >> 8, py1 = by1 >> 8;
+    if(px0 < x_lo)    px0 = x_lo;
+    if(px1 > x_hi)    px1 = x_hi;
+    if(py0 < 0)       py0 = 0;
+    if(py1 > fb->H-1) py1 = fb->H-1;
+    if(px0 > px1 || py0 > py1) return;
+
+    /* primitive entirely outside the depth range [0,1] on one side */
+    if((A->zw < 0.f && B->zw < 0.f && C->zw < 0.f) ||
+       (A->zw > 1.f && B->zw > 1.f && C->zw > 1.f)) return;
+
+    /* depth and colour are planes through the unsnapped positions */
+    float ex1 = B->fx - A->fx, ey1 = B->fy - A->fy;
+    float ex2 = C->fx - A->fx, ey2 = C->fy - A->fy;
+    float af  = ex1*ey2 - ex2*ey1;
+    float dz1 = B->zw  - A->zw,  dz2 = C->zw  - A->zw;
+    float dr1 = B->red - A->red, dr2 = C->red - A->red;
+    float dzdx = (dz1*ey2 - dz2*ey1) / af;
+    float dzdy = (dz2*ex1 - dz1*ex2) / af;
+    float drdx = (dr1*ey2 - dr2*ey1) / af;
+    float drdy = (dr2*ex1 - dr1*ex2) / af;
+
+    for(int64_t py=py0; py<=py1; py++)
+        for(int64_t px=px0; px<=px1; px++)
+        {
+            /* edge functions at the pixel centre; a centre exactly on an edge
+             * belongs to the triangle if that edge is a left edge or a
+             * horizontal bottom edge (y pointing up): llvmpipe's rule for a
+             * framebuffer object, pinned by tests/golden/raster_probe.npz */
+            int inside = 1;
+            for(int m=0; m<3 && inside; m++)
+            {
+                int a = m, b = (m+1)%3;
+                int64_t dx = X[b]-X[a], dy = Y[b]-Y[a];
+                int64_t E = dx*(py*256 - Y[a]) - dy*(px*256 - X[a]);
+                if(E < 0) inside = 0;
+                else if(E == 0 && !(dy < 0 || (dy == 0 && dx > 0))) inside = 0;
+            }
+            if(!inside) continue;
+
+            float ddx = (float)px - A->fx;
+            float ddy = (float)py - A->fy;
+            float z = A->zw + (dzdx*ddx + dzdy*ddy);
+            if(!(z >= 0.f && z <= 1.f)) continue;          /* depth clip */
+            uint32_t zi = (uint32_t)rintf(z * 16777215.f); /* 24-bit unorm */
+
+            const size_t at = (size_t)py*fb->SW + (size_t)(px - fb->col0);
+            if(!(zi < fb->depth[at])) continue;             /* GL_LESS */
+
+            float r = A->red + (drdx*ddx + drdy*ddy);
+            r = r < 1.0f ? r : 1.0f;
+            r = r > 0.0f ? r : 0.0f;
+            fb->depth[at] = zi;
+            fb->prim [at] = prim;
+            fb->red  [at] = (uint8_t)rintf(r * 255.f);      /* RGB8 unorm */
+        }
+}
+
+void orc_tanel(float* tanel, int W, int H, float az_deg0, float az_deg1)
+{
+    /* reference horizonator-lib.c:1006-1012 */
+    float aspect = (float)W / (float)H;
+    for(int row=0; row<H; row++)
+    {
+        /* rows of the upper half reuse the mirrored row's value, negated
+         * (reference horizonator-lib.c:1033-1034); the sign is irrelevant to
+         * the range, so the magnitude is stored */
+        int y = row < H - H/2 ? row : H-1-row;
+        float el_ndc = ((float)y + 0.5f) / (float)H * 2.f - 1.f;
+        float el     = el_ndc * (az_deg1-az_deg0) / 2.f / aspect * M_PI/180.0f;
+        tanel[row] = tanf(el);
+    }
+}
+
+int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
+               int W, int H, int col0, int col1,
+               uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
+               int nthreads)
+{
+    if(N < 2 || W <= 0 || H <= 0 || col0 < 0 || col1 > W || col0 >= col1) return -1;
+    const int SW = col1 - col0;
+    const size_t npix = (size_t)SW*H;
+
+    target_t fb;
+    fb.SW = SW; fb.H = H; fb.col0 = col0; fb.col1 = col1;
+    fb.depth = malloc(npix*sizeof(uint32_t));
+    fb.prim  = malloc(npix*sizeof(int32_t));
+    fb.red   = malloc(npix);
+    wvert_t* vert = malloc((size_t)N*N*sizeof(wvert_t));
+    float* tanel = malloc((size_t)H*sizeof(float));
+    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel)
+    {
+        free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
+        return -1;
+    }
+
+    /* glClear: depth 1.0 -> 0xFFFFFF, colour (0,0,1) (reference horizonator-lib.c:185,896) */
+    for(size_t k=0; k<npix; k++) { fb.depth[k] = 0xFFFFFFu; fb.prim[k] = -1; fb.red[k] = 0; }
+
+#ifdef _OPENMP
+    if(nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+
+    float c, k;
+    az_constants(v, &c, &k);
+    const float halfW = (float)W*0.5f, halfH = (float)H*0.5f;
+
+    /* vertex stage + viewport transform (glViewport(0,0,W,H), reference
+     * horizonator-lib.c:657; depth range 0..1) */
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for(int j=0; j<N; j++)
+        for(int i=0; i<N; i++)
+        {
+            ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
+            wvert_t* w = &vert[(size_t)j*N + i];
+            w->xn  = o.x;
+            w->fx  = (o.x*halfW + halfW) - 0.5f;
+            w->fy  = (o.y*halfH + halfH) - 0.5f;
+            w->zw  = o.z*0.5f + 0.5f;
+            w->red = o.red;
+        }
+
+    /* triangles in index-buffer order (reference horizonator-lib.c:496-508).
+     * Threads own disjoint column strips, so within a strip the draw order,
+     * and with it the outcome of equal-depth ties, is the sequential one */
+    #pragma omp parallel num_threads(nthreads)
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+        const int tid = 0, nth = 1;
+#endif
+        const int x_lo = col0 + (int)((long long)SW*tid/nth);
+        const int x_hi = col0 + (int)((long long)SW*(tid+1)/nth) - 1;
+        if(x_lo <= x_hi)
+            for(int j=0; j<N-1; j++)
+                for(int i=0; i<N-1; i++)
+                {
+                    const wvert_t* v00 = &vert[(size_t)(j  )*N + i  ];
+                    const wvert_t* v10 = &vert[(size_t)(j  )*N + i+1];
+                    const wvert_t* v01 = &vert[(size_t)(j+1)*N + i  ];
+                    const wvert_t* v11 = &vert[(size_t)(j+1)*N + i+1];
+                    const int32_t prim = (int32_t)(((int64_t)j*(N-1) + i)*2);
+                    draw_triangle(&fb, x_lo, x_hi, v00, v11, v01, prim  );
+                    draw_triangle(&fb, x_lo, x_hi, v00, v10, v11, prim+1);
+                }
+    }
+
+    /* readback (reference horizonator-lib.c:936-1048) */
+    orc_tanel(tanel, W, H, v->az_deg0, v->az_deg1);
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for(int yo=0; yo<H; yo++)
+    {
+        const int row = H-1-yo;         /* top row first */
+        for(int x=0; x<SW; x++)
+        {
+            const size_t at = (size_t)row*SW + x, o = (size_t)yo*SW + x;
+            const uint32_t zi = fb.depth[at];
+            const int sky = zi == 0xFFFFFFu;
+            if(bgr)
+            {
+                bgr[3*o+0] = sky ? 255 : 0;
+                bgr[3*o+1] = 0;
+                bgr[3*o+2] = sky ? 0 : fb.red[at];
+            }
+            if(index) index[o] = fb.prim[at];
+            if(z24)   z24[o]   = zi;
+            if(ranges)
+            {
+                /* glReadPixels(GL_DEPTH_COMPONENT, GL_FLOAT) of a Z24 buffer */
+                float depth = (float)((double)zi * (1.0/16777215.0));
+                if(depth == 1.0f) ranges[o] = -1.0f;        /* reference :1016 */
+                else
+                {
+                    float length_en = depth * (v->zfar - v->znear) + v->znear;  /* :1018 */
+                    float zt = tanel[row] * length_en;                          /* :1023 */
+                    ranges[o] = hypotf(length_en, zt);                          /* :1024 */
+                }
+            }
+        }
+    }
+
+    free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
+    return 0;
+}

@@ -1,0 +1,92 @@
+"""shared helpers for the tests: synthetic DEM tiles, views, comparisons"""
+import os
+import tempfile
+
+import numpy as np
+
+from horizonator_amd import _lib as hzlib
+
+# the survey's generic viewpoint: not on a grid sample
+VIEW_LAT, VIEW_LON = 34.4137, -117.5621
+
+_DEM_ROOT = os.environ.get("HZ_TEST_DEM_DIR", os.path.join(tempfile.gettempdir(), "hz_synth_dems"))
+
+
+def dem_dir(lat_lo, lat_hi, lon_lo, lon_hi, srtm1=False, rough=False):
+    """directory holding synthetic tiles covering the given integer lat/lon box
+    (tiles are generated on first use and cached across test runs)"""
+    name = ("srtm1" if srtm1 else "srtm3") + ("_rough" if rough else "")
+    d = os.path.join(_DEM_ROOT, name)
+    os.makedirs(d, exist_ok=True)
+    gen = hzlib.load_demgen()
+    rc = gen.hz_demgen_write_region(d.encode(), lat_lo, lat_hi, lon_lo, lon_hi, int(srtm1), int(rough))
+    if rc < 0:
+        raise RuntimeError(f"demgen failed ({rc})")
+    return d
+
+
+def tiles_for(lat, lon, radius_cells, srtm1=False):
+    """integer lat/lon box a window of radius_cells around (lat,lon) can touch"""
+    cpd = 3600 if srtm1 else 1200
+    r = radius_cells / cpd + 0.01
+    return (int(np.floor(lat - r)), int(np.floor(lat + r)),
+            int(np.floor(lon - r)), int(np.floor(lon + r)))
+
+
+def dem_dir_for(lat, lon, radius_cells, srtm1=False, rough=False):
+    return dem_dir(*tiles_for(lat, lon, radius_cells, srtm1), srtm1=srtm1, rough=rough)
+
+
+# ---- driving the HIP path through its C-ABI (include/hz_hip.h) ---------------
+
+def hip_available():
+    try:
+        return hzlib.load().hz_hip_device_count() > 0
+    except Exception:
+        return False
+
+
+def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None):
+    """mosaic int16[N,N] + uniform values -> dict(bgr, ranges, index, z24) via
+    hz_hip_create / upload_mosaic / draw / resolve_to_host.  `view` is anything
+    with the hz_view_t field names as attributes (e.g. oracle.OrcView)."""
+    import ctypes as C
+    lib = hzlib.load()
+    mosaic = np.ascontiguousarray(mosaic, np.int16)
+    N = mosaic.shape[0]
+    if col1 is None:
+        col1 = W
+    SW = col1 - col0
+    dev = lib.hz_hip_create(0, N, W, H)
+    if not dev:
+        raise RuntimeError("hz_hip_create failed: " + lib.hz_hip_last_error().decode())
+    try:
+        assert lib.hz_hip_upload_mosaic(dev, mosaic.ctypes.data) == 0
+        assert lib.hz_hip_set_sector(dev, col0, col1) == 0
+        assert lib.hz_hip_set_raster(dev, raster) == 0
+        v = hzlib.View()
+        for name, _ in hzlib.View._fields_:
+            setattr(v, name, getattr(view, name))
+        if tanel is None:
+            # tan(elevation) per GL row exactly as hz_host.c / the reference derive it
+            import oracle
+            tanel = oracle.tanel(W, H, v.az_deg0, v.az_deg1)
+        tanel = np.ascontiguousarray(tanel, np.float32)
+        out = {"bgr": np.empty((H, SW, 3), np.uint8), "ranges": np.empty((H, SW), np.float32),
+               "index": np.empty((H, SW), np.int32), "z24": np.empty((H, SW), np.uint32)}
+        assert lib.hz_hip_draw(dev, C.byref(v)) == 0, lib.hz_hip_last_error()
+        rc = lib.hz_hip_resolve_to_host(dev, C.byref(v), tanel.ctypes.data, out["bgr"].ctypes.data,
+                                        out["ranges"].ctypes.data, out["index"].ctypes.data, out["z24"].ctypes.data)
+        assert rc == 0, lib.hz_hip_last_error()
+        return out
+    finally:
+        lib.hz_hip_destroy(dev)
+
+
+def assert_same_render(a, b, what=""):
+    for k in ("index", "z24", "bgr", "ranges"):
+        if k in a and k in b:
+            if not np.array_equal(a[k], b[k]):
+                bad = np.argwhere(a[k] != b[k])
+                raise AssertionError(f"{what}: {k} differs at {len(bad)} places, first {bad[0]}: "
+                                     f"{a[k][tuple(bad[0])]} vs {b[k][tuple(bad[0])]}")

@@ -1,0 +1,84 @@
+"""the C-ABI library loads and exports every symbol include/*.h declares (no GPU needed)"""
+import ctypes as C
+import os
+import re
+
+from horizonator_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_in_headers():
+    names = set()
+    for hdr in ("horizonator.h", "dem.h", "horizonator_amd.h", "hz_hip.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b((?:horizonator|hz_hip)_[a-z0-9_]+)\s*\(", text))
+    names.discard("horizonator_context_isvalid")      # static inline in the header
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_in_headers()
+    assert declared == set(_lib.DECLARED_SYMBOLS), declared ^ set(_lib.DECLARED_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+
+
+def test_context_layout_matches_reference_abi():
+    # numbers printed by a program compiled against the REFERENCE's own
+    # horizonator.h / dem.h (gcc 11, x86-64): sizeof(ctx), offsetof program,
+    # viewer_lat, dems, offscreen, sizeof(dem ctx) = 472 80 84 96 448 352
+    assert C.sizeof(_lib.Context) == 472
+    assert _lib.Context.program.offset == 80
+    assert _lib.Context.viewer_lat.offset == 84
+    assert _lib.Context.dems.offset == 96
+    assert _lib.Context.offscreen.offset == 448
+    assert C.sizeof(_lib.DemContext) == 352
+
+
+def test_context_layout_matches_c_compiler(tmp_path):
+    """the ctypes mirror agrees with what gcc makes of include/horizonator.h"""
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "horizonator.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(horizonator_context_t),'
+        'offsetof(horizonator_context_t,program), offsetof(horizonator_context_t,viewer_lat),'
+        'offsetof(horizonator_context_t,dems), offsetof(horizonator_context_t,offscreen),'
+        'sizeof(horizonator_dem_context_t)); return 0;}\n')
+    exe = tmp_path / "layout"
+    import subprocess
+    subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_lib.Context), _lib.Context.program.offset, _lib.Context.viewer_lat.offset,
+                   _lib.Context.dems.offset, _lib.Context.offscreen.offset, C.sizeof(_lib.DemContext)]
+
+
+def test_no_gpu_means_loud_failure():
+    """without a HIP device the product refuses to run; it never falls back to a CPU path"""
+    lib = _lib.load()
+    if lib.hz_hip_device_count() > 0:
+        return
+    import pytest
+    import horizonator_amd
+    import hzutil
+    d = hzutil.dem_dir_for(hzutil.VIEW_LAT, hzutil.VIEW_LON, 32)
+    with pytest.raises(RuntimeError):
+        horizonator_amd.horizonator(hzutil.VIEW_LAT, hzutil.VIEW_LON, 64, 16, dir_dems=d, render_radius_cells=32)
+
+
+def test_product_does_not_touch_the_oracle():
+    """nothing under horizonator_amd/ or include/ may import, include or link oracle/"""
+    bad = []
+    for base in ("horizonator_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dirpath or "__pycache__" in dirpath:
+                continue
+            for fn in files:
+                if not fn.endswith((".c", ".h", ".hip", ".py", "Makefile")):
+                    continue
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                if re.search(r"(#include\s*[\"<].*oracle|import\s+oracle|from\s+oracle|liboracle|orc_)", text):
+                    bad.append(os.path.join(dirpath, fn))
+    assert not bad, bad

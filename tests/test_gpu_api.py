@@ -1,0 +1,183 @@
+"""The reference's API surface (include/horizonator.h and the Python mirror of
+horizonator-pywrap.c) on the GPU: same behaviour, results equal to the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import hzutil
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
+
+
+@pytest.fixture(scope="module")
+def scene():
+    import horizonator_amd
+    R, W, H = 300, 1200, 300
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    yield h, od, W, H
+    h.close()
+
+
+def test_device_mosaic_is_the_dem_window(scene):
+    h, od, W, H = scene
+    assert np.array_equal(h.mosaic(), od.mosaic())
+    assert h.Ntriangles == 2 * (2 * 300 - 1) ** 2
+
+
+def test_render_returns_reference_shapes_and_matches_oracle(scene):
+    h, od, W, H = scene
+    image, ranges = h.render(-180, 180)
+    assert image.shape == (H, W, 3) and image.dtype == np.uint8
+    assert ranges.shape == (H, W) and ranges.dtype == np.float32
+    ref = oracle.render(od.mosaic(), od.view(LAT, LON, W, H, -180, 180), W, H)
+    assert np.array_equal(image, ref["bgr"]) and np.array_equal(ranges, ref["ranges"])
+    # the four return combinations of reference horizonator-pywrap.c:198-202,262-270
+    assert h.render(-180, 180, return_image=False, return_range=False) == ()
+    only_img = h.render(-180, 180, return_range=False)
+    only_rng = h.render(-180, 180, return_image=False)
+    assert np.array_equal(only_img, image) and np.array_equal(only_rng, ranges)
+    # uniforms the host code derived == the oracle's restatement of the reference's host code
+    v, ov = h.view(), od.view(LAT, LON, W, H, -180, 180).as_dict()
+    assert {k: np.float32(x) for k, x in v.items()} == {k: np.float32(x) for k, x in ov.items()}
+
+
+def test_move_zextents_and_pixel_centre_azimuths(scene):
+    h, od, W, H = scene
+    lat, lon = LAT + 0.02, LON - 0.015
+    image, ranges, index, z24 = h.render_full(-30, 80, lat=lat, lon=lon, znear=200.0, zfar=15000.0,
+                                              znear_color=500.0, zfar_color=9000.0)
+    v = od.view(lat, lon, W, H, -30, 80, znear=200.0, zfar=15000.0, znear_color=500.0, zfar_color=9000.0)
+    ref = oracle.render(od.mosaic(), v, W, H)
+    hzutil.assert_same_render(dict(bgr=image, ranges=ranges, index=index, z24=z24), ref, "moved")
+    # az_extents_use_pixel_centers (reference horizonator-pywrap.c:204-212)
+    image2, _ = h.render(-30, 80, lat=lat, lon=lon, az_extents_use_pixel_centers=True)
+    step = (80 - -30) / (W - 1)
+    v2 = od.view(lat, lon, W, H, -30 - step / 2, 80 + step / 2)
+    assert np.array_equal(image2, oracle.render(od.mosaic(), v2, W, H)["bgr"])
+    # set_zextents refuses non-positive values and leaves the view alone
+    lib = h._lib
+    before = h.view()
+    assert not lib.horizonator_set_zextents(C.byref(h._ctx), -1.0, 100.0, 1.0, 1.0)
+    assert h.view() == before
+
+
+def test_pick_inverts_the_projection(scene):
+    h, od, W, H = scene
+    _, ranges, index, z24 = h.render_full(-180, 180, lat=LAT, lon=LON)
+    ys, xs = np.nonzero(index >= 0)
+    k = len(ys) // 2
+    x, y = int(xs[k]), int(ys[k])
+    got = h.pick(x, y)
+    assert got is not None
+    # reference horizonator-lib.c:1285-1295: unproject the depth as a horizontal distance
+    lib = h._lib
+    lat, lon = C.c_float(), C.c_float()
+    v = h.view()
+    depth = np.float32(np.float64(z24[y, x]) * (1.0 / 16777215.0))
+    range_en = float(depth * np.float32(v["zfar"] - v["znear"]) + np.float32(v["znear"]))
+    assert lib.horizonator_unproject(C.byref(lat), C.byref(lon), x, y, -1.0, range_en, np.float32(LAT),
+                                     v["cos_viewer_lat"], np.float32(LON), v["az_deg0"], v["az_deg1"], W, H)
+    assert got == (lat.value, lon.value)
+    # and the picked point is the visible cell, to within a cell or two
+    cell = index[y, x] >> 1
+    N = 2 * h.radius_cells
+    j, i = divmod(int(cell), N - 1)
+    vi = h.view()
+    cell_lat = LAT + (j + 0.5 - vi["viewer_cell_j"]) / 1200.0
+    cell_lon = LON + (i + 0.5 - vi["viewer_cell_i"]) / 1200.0
+    assert abs(got[0] - cell_lat) < 3 / 1200.0 and abs(got[1] - cell_lon) < 3 / 1200.0
+    sky = np.argwhere(index < 0)[0]
+    assert h.pick(int(sky[1]), int(sky[0])) is None
+
+
+def test_sector_and_device_buffers(scene):
+    import torch
+    h, od, W, H = scene
+    h.set_view(-180, 180, lat=LAT, lon=LON)
+    image, ranges, index, _ = h.render_full(-180, 180)
+    h.set_sector(400, 700)
+    try:
+        dev = torch.device("cuda:0")
+        d_img = torch.empty((H, 300, 3), dtype=torch.uint8, device=dev)
+        d_rng = torch.empty((H, 300), dtype=torch.float32, device=dev)
+        d_idx = torch.empty((H, 300), dtype=torch.int32, device=dev)
+        h.render_device(d_img.data_ptr(), d_rng.data_ptr(), d_idx.data_ptr())
+        h.sync()
+        assert np.array_equal(d_img.cpu().numpy(), image[:, 400:700])
+        assert np.array_equal(d_rng.cpu().numpy(), ranges[:, 400:700])
+        assert np.array_equal(d_idx.cpu().numpy(), index[:, 400:700])
+    finally:
+        h.set_sector(0, W)
+
+
+def test_errors_behave_like_the_reference(tmp_path):
+    import horizonator_amd
+    d = hzutil.dem_dir_for(LAT, LON, 32)
+    # both radii (reference horizonator-pywrap.c:100-104)
+    with pytest.raises(RuntimeError):
+        horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=32, render_radius_m=1000.0)
+    # texture path and window modes are not part of this build
+    with pytest.raises(RuntimeError):
+        horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=32, render_texture=True)
+    from horizonator_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.Context()
+    assert not lib.horizonator_init(C.byref(ctx), LAT, LON, None, -1, -1, 32, -1.0, True, False, False,
+                                    d.encode(), None, None, None, True)
+    assert not lib.horizonator_init(C.byref(ctx), LAT, LON, None, 64, 16, 32, -1.0, False, False, False,
+                                    d.encode(), None, None, None, True)
+    # wrong-size tile -> init fails (reference dem.c:234-239)
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    (bad / "N34W118.hgt").write_bytes(b"\0" * 10)
+    with pytest.raises(RuntimeError):
+        horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=str(bad), render_radius_cells=32)
+    # a context that was deinit'ed refuses everything
+    h = horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=32)
+    ctxp = C.byref(h._ctx)
+    lib.horizonator_deinit(ctxp)
+    assert not lib.horizonator_pan_zoom(ctxp, 0.0, 10.0)
+    assert not lib.horizonator_render_offscreen(ctxp, None, None)
+    h._ctx = None
+    # viewer_z in/out (reference horizonator.h:90-93)
+    ctx = _lib.Context()
+    z = C.c_float(-1.0)
+    assert lib.horizonator_init(C.byref(ctx), LAT, LON, C.byref(z), 64, 16, 32, -1.0, True, False, False,
+                                d.encode(), None, None, None, True)
+    od = oracle.Dem(LAT, LON, d, radius_cells=32)
+    assert z.value == od.view(LAT, LON, 64, 16, 0, 1).viewer_z
+    assert not lib.horizonator_resized(C.byref(ctx), 10, 10)
+    lib.horizonator_deinit(C.byref(ctx))
+
+
+def test_device_side_ingest_builds_the_same_mosaic(monkeypatch):
+    import horizonator_amd
+    R = 700
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    monkeypatch.setenv("HORIZONATOR_INGEST", "device")
+    h = horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=R)
+    monkeypatch.delenv("HORIZONATOR_INGEST")
+    assert np.array_equal(h.mosaic(), oracle.Dem(LAT, LON, d, radius_cells=R).mosaic())
+    h.close()
+
+
+def test_more_tiles_than_the_reference_can_load():
+    """5x5 tiles: the reference refuses (reference dem.h:8); same semantics here"""
+    import horizonator_amd
+    R = 2100
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    h = horizonator_amd.horizonator(LAT, LON, 512, 128, dir_dems=d, render_radius_cells=R)
+    assert list(h._ctx.dems.Ndems_ij) == [5, 5]
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    assert np.array_equal(h.mosaic(), od.mosaic())
+    image, ranges, index, z24 = h.render_full(-180, 180, zfar=300000.0)
+    ref = oracle.render(od.mosaic(), od.view(LAT, LON, 512, 128, -180, 180, zfar=300000.0), 512, 128)
+    hzutil.assert_same_render(dict(bgr=image, ranges=ranges, index=index, z24=z24), ref, "5x5")
+    h.close()
