@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py - rendered-panorama throughput of the HIP render path on MI355X.
+
+One step = one full pass of the hot path over one panorama: clear + vertex
+transform + triangle emission + depth-buffered rasterisation + resolve to BGR8
+and float32 ranges, with the DEM mosaic already resident in HBM and the outputs
+left in HBM (device buffers).  On N > 1 GPUs the panorama is split into N
+azimuth sectors (image-column ranges), one per rank, and the strips are gathered
+to rank 0 over RCCL inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for what each field
+means and how `roofline` is derived.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# SURVEY.md section 8(d) / BASELINE.md section 3
+CONFIGS = {
+    "cfg1": dict(R=600, W=2000, H=500, tiles="1 SRTM3 tile window (2x2 tiles touched)"),
+    "cfg2": dict(R=1800, W=8000, H=2000, tiles="3x3 SRTM3 tile mosaic"),
+    "cfg3": dict(R=4200, W=16000, H=4000, tiles="7x7 SRTM3 tile mosaic"),
+}
+LAT, LON = 34.4137, -117.5621
+ZNEAR = 100.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--zfar", type=float, default=600000.0,
+                    help="far clip range in m; 600 km keeps every triangle of the mosaic live")
+    ap.add_argument("--raster", type=int, default=0, help="HZ_RASTER_* (0 auto, 1 scatter, 2 columns)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary zfar=40 km measurement")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build(quiet=True)
+    if world > 1:
+        dist.barrier()
+    import hzutil
+    import horizonator_amd
+    from horizonator_amd.sharding import gather_strips, sector_columns
+
+    cfg = CONFIGS[args.config]
+    R, W, H = cfg["R"], cfg["W"], cfg["H"]
+    N = 2 * R
+
+    # synthetic SRTM tiles (tools/demgen.c), generated once per node
+    if rank == 0:
+        dems = hzutil.dem_dir_for(LAT, LON, R)
+    if world > 1:
+        dist.barrier()
+    dems = hzutil.dem_dir_for(LAT, LON, R)
+
+    os.environ["HORIZONATOR_HIP_DEVICE"] = str(local_rank)
+    t0 = time.perf_counter()
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R)
+    init_s = time.perf_counter() - t0
+    h.set_raster(args.raster)
+    col0, col1 = sector_columns(W, world, rank)
+    h.set_sector(col0, col1)
+    SW = col1 - col0
+    h.set_profiling(True)
+
+    d_img = torch.empty((H, SW, 3), dtype=torch.uint8, device=dev)
+    d_rng = torch.empty((H, SW), dtype=torch.float32, device=dev)
+
+    def step():
+        h.render_device(d_img.data_ptr(), d_rng.data_ptr())
+        h.sync()
+        if world > 1:
+            # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
+            img = gather_strips(d_img, W)
+            rng = gather_strips(d_rng, W)
+            return img, rng
+        return d_img, d_rng
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(zfar, steps, warmup):
+        h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=zfar)
+        for _ in range(warmup):
+            step()
+        kern = []
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            kern.append(h.last_times())
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kern
+
+    dt, kern = timed(args.zfar, args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    value = W * H * args.steps / dt / 1e6
+
+    # dominant kernel, measured live with HIP events on the render stream
+    raster_ms = float(np.mean([k["raster_ms"] for k in kern]))
+    big_ms = float(np.mean([k["big_ms"] for k in kern]))
+    resolve_ms = float(np.mean([k["resolve_ms"] for k in kern]))
+    clear_ms = float(np.mean([k["clear_ms"] for k in kern]))
+    total_ms = float(np.mean([k["total_ms"] for k in kern]))
+    # algorithmic bytes of one render: int16 DEM read once +
+    # BGR8 and float32 range written once; a sector writes its share
+    algo_bytes = 2 * N * N + 7 * SW * H
+    achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("config") == args.config and rec.get("zfar") == args.zfar and world == 1:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    extra = {}
+    if not args.no_extra and abs(args.zfar - 40000.0) > 1:
+        dt40, k40 = timed(40000.0, max(3, args.steps // 2), 1)
+        n40 = max(3, args.steps // 2)
+        extra["zfar_40km"] = {"value": W * H * n40 / dt40 / 1e6, "unit": "Mpix/s",
+                              "ms_per_step": dt40 / n40 * 1e3,
+                              "note": "API default far clip (reference horizonator.h:10); >95% of the mosaic is beyond it"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU restatement (oracle/, test infrastructure) timed on this box's
+        # host cores on the same workload, as the checker's throughput - one render
+        import oracle
+        od = oracle.Dem(LAT, LON, dems, radius_cells=R)
+        mosaic = od.mosaic()
+        v = od.view(LAT, LON, W, H, -180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        oracle.render(mosaic, v, W, H, want=("bgr", "ranges"))
+        cdt = time.perf_counter() - t0
+        cpu = {"value": W * H / cdt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
+               "sample": f"1 full {W}x{H} render of the same workload by oracle/ (C + OpenMP, {cores} threads), {cdt:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "panorama Mpix/s (360deg, 16k-wide, 7x7 SRTM3 tiles)" if args.config == "cfg3"
+                      else f"panorama Mpix/s (360deg, {W}x{H}, {cfg['tiles']})",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
+                            f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
+                "parallelism": f"azimuth sectors x{world}" + (" + RCCL gather of BGR8/float32 strips" if world > 1 else ""),
+                "raster": {0: "auto", 1: "scatter", 2: "columns"}.get(args.raster, f"experiment {args.raster}"),
+                "outputs": "BGR8 + float32 range, device-resident",
+                "init_s": init_s,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_scatter", "kernel_ms": raster_ms,
+                "algorithmic_bytes": algo_bytes,
+                "other_kernels_ms": {"clear": clear_ms, "big_triangles": big_ms, "resolve": resolve_ms},
+                "device_ms_per_render": total_ms,
+                "achieved_whole_render": algo_bytes / (total_ms * 1e-3) / 1e9,
+            },
+            "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

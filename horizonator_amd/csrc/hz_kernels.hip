@@ -52,6 +52,7 @@ struct hz_params_t
     int   W, H;             /* full image size                          */
     int   col0, col1;       /* sector [col0,col1)                       */
     int   SW;               /* col1-col0, row stride of fb              */
+    int   dry;              /* timing experiments: 1 = compute fragments, store nothing; 2 = no read-before-atomic */
 };
 
 /* work item of the cooperative pass: one 32-row band of one large triangle */
@@ -71,6 +72,8 @@ __device__ static inline void hz_emit(unsigned long long* fb, const hz_params_t&
     if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
     const unsigned long long key = hz_pack(zi, prim, r8);
     unsigned long long* dst = &fb[(size_t)py*p.SW + (px - p.col0)];
+    if(p.dry == 1) { if(key == 0x0123456789ull) *dst = key; return; }
+    if(p.dry == 2) { atomicMin(dst, key); return; }
     /* plain read first: most fragments of far terrain lose against what is
      * already there, and a stale (larger) value only costs the atomic */
     if(key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -435,7 +438,7 @@ extern "C" int hz_hip_set_sector(hz_dev_t* d, int col0, int col1)
 
 extern "C" int hz_hip_set_raster(hz_dev_t* d, int which)
 {
-    if(which < HZ_RASTER_AUTO || which > HZ_RASTER_COLUMNS) return -1;
+    if(which < HZ_RASTER_AUTO || which > HZ_RASTER_COLUMNS+2) return -1;   /* +1,+2: timing experiments */
     d->raster = which;
     return 0;
 }
@@ -462,6 +465,7 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.halfH = (float)d->H * 0.5f;
     p.N = d->N; p.W = d->W; p.H = d->H;
     p.col0 = d->col0; p.col1 = d->col1; p.SW = d->col1 - d->col0;
+    p.dry = d->raster > HZ_RASTER_COLUMNS ? d->raster - HZ_RASTER_COLUMNS : 0;
     return p;
 }
 
