@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--zfar", type=float, default=600000.0,
                     help="far clip range in m; 600 km keeps every triangle of the mosaic live")
-    ap.add_argument("--raster", type=int, default=0, help="HZ_RASTER_* (0 auto, 1 scatter, 2 columns)")
+    ap.add_argument("--raster", type=int, default=0, help="HZ_RASTER_* (0 auto, 1 scatter, 2 march)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary zfar=40 km measurement")
     return ap.parse_args()
@@ -195,14 +195,14 @@ def main():
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
                 "parallelism": f"azimuth sectors x{world}" + (" + RCCL gather of BGR8/float32 strips" if world > 1 else ""),
-                "raster": {0: "auto", 1: "scatter", 2: "columns"}.get(args.raster, f"experiment {args.raster}"),
+                "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",
                 "init_s": init_s,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_scatter", "kernel_ms": raster_ms,
+                "kernel": "k_scatter" if args.raster == 1 else "k_march", "kernel_ms": raster_ms,
                 "algorithmic_bytes": algo_bytes,
                 "other_kernels_ms": {"clear": clear_ms, "big_triangles": big_ms, "resolve": resolve_ms},
                 "device_ms_per_render": total_ms,

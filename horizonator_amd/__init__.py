@@ -17,12 +17,12 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import RASTER_AUTO, RASTER_COLUMNS, RASTER_SCATTER, Times, View  # noqa: F401
+from ._lib import RASTER_AUTO, RASTER_MARCH, RASTER_SCATTER, Times, View  # noqa: F401
 
 HORIZONATOR_ZNEAR_DEFAULT = 100.0
 HORIZONATOR_ZFAR_DEFAULT = 40000.0
 
-__all__ = ["horizonator", "RASTER_AUTO", "RASTER_SCATTER", "RASTER_COLUMNS"]
+__all__ = ["horizonator", "RASTER_AUTO", "RASTER_SCATTER", "RASTER_MARCH"]
 
 
 def _enc(s):

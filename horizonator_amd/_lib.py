@@ -68,7 +68,7 @@ class Times(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("clear_ms", "raster_ms", "big_ms", "resolve_ms", "total_ms")]
 
 
-RASTER_AUTO, RASTER_SCATTER, RASTER_COLUMNS = 0, 1, 2
+RASTER_AUTO, RASTER_SCATTER, RASTER_MARCH = 0, 1, 2
 
 _lib = None
 

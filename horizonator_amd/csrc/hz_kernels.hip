@@ -16,6 +16,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,37 +53,71 @@ struct hz_params_t
     int   W, H;             /* full image size                          */
     int   col0, col1;       /* sector [col0,col1)                       */
     int   SW;               /* col1-col0, row stride of fb              */
-    int   dry;              /* timing experiments: 1 = compute fragments, store nothing; 2 = no read-before-atomic */
+    unsigned long long* wave_cycles;   /* diagnostics: per-wave duration of k_march, or NULL */
+    unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
 };
 
-/* work item of the cooperative pass: one 32-row band of one large triangle */
-struct hz_bigitem_t { uint32_t prim; int32_t band; };
+/* a set-up triangle as it travels between phases: through LDS inside
+ * k_scatter (stride 19 dwords = odd, conflict-free), through HBM to k_big */
+struct hz_rec_t
+{
+    int32_t  xs[3], ys[3];
+    float    fx0, fy0, z0, dzdx, dzdy, r0, drdx, drdy;
+    int32_t  px0, py0, bw;
+    float    inv_bw;
+    uint32_t prim;
+};
+struct hz_bigrec_t { hz_rec_t r; int32_t bh; };
 
-#define HZ_BIG_BAND_ROWS   32
-#define HZ_BIG_THRESHOLD   512      /* bbox pixels above which a triangle is deferred */
+/* work item of the large-triangle pass: 64 8x8-pixel tiles of one triangle */
+struct hz_bigitem_t { uint32_t rec; uint32_t chunk; };
+
+#define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
+/* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
+ * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
+#define HZ_TILE_W          64       /* k_big walks 64x1-pixel tiles (one wave per 64 tiles): near-field      */
+#define HZ_TILE_H          1        /* triangles are flat slivers, and 64 pixels of one row are 512 contiguous
+                                     * bytes of framebuffer for the atomics                                  */
 
 /* ------------------------------------------------------------------------ */
 /* device helpers                                                            */
 
-__device__ static inline void hz_emit(unsigned long long* fb, const hz_params_t& p,
-                                      const hz_tri_t& t, uint32_t prim, int px, int py)
+__device__ static inline void hz_tri_from_rec(hz_tri_t& t, const hz_rec_t& r)
+{
+    #pragma unroll
+    for(int m=0; m<3; m++) { t.xs[m] = r.xs[m]; t.ys[m] = r.ys[m]; }
+    t.fx0 = r.fx0; t.fy0 = r.fy0;
+    t.z0 = r.z0; t.dzdx = r.dzdx; t.dzdy = r.dzdy;
+    t.r0 = r.r0; t.drdx = r.drdx; t.drdy = r.drdy;
+}
+
+/* PRETEST: read the word first and skip the atomic when the fragment cannot
+ * win (a stale, larger value only costs the atomic).  It saves atomics but puts
+ * a dependent HBM round trip into the loop that calls it; callers that walk
+ * many pixels per lane in sequence do better without. */
+template<bool PRETEST>
+__device__ static inline void hz_emit_t(unsigned long long* fb, const hz_params_t& p,
+                                        const hz_tri_t& t, uint32_t prim, int px, int py)
 {
     if(!hz_tri_covers(&t, px, py)) return;
     uint32_t zi, r8;
     if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
     const unsigned long long key = hz_pack(zi, prim, r8);
     unsigned long long* dst = &fb[(size_t)py*p.SW + (px - p.col0)];
-    if(p.dry == 1) { if(key == 0x0123456789ull) *dst = key; return; }
-    if(p.dry == 2) { atomicMin(dst, key); return; }
-    /* plain read first: most fragments of far terrain lose against what is
-     * already there, and a stale (larger) value only costs the atomic */
-    if(key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if(PRETEST)
+    {
+        if(key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(dst, key);
+    }
+    else
         atomicMin(dst, key);
 }
+__device__ static inline void hz_emit(unsigned long long* fb, const hz_params_t& p,
+                                      const hz_tri_t& t, uint32_t prim, int px, int py)
+{
+    hz_emit_t<true>(fb, p, t, prim, px, py);
+}
 
-/* the three window vertices of triangle t (0|1) of cell (i,j), in the order
- * of the reference's index buffer (reference horizonator-lib.c:500-506):
- *   t=0: (j,i) (j+1,i+1) (j+1,i)      t=1: (j,i) (j,i+1) (j+1,i+1) */
 __device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int16_t* mosaic, int i, int j)
 {
     const float z = (float)mosaic[(size_t)j*p.N + i];
@@ -90,131 +125,726 @@ __device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int
 }
 
 /* ------------------------------------------------------------------------ */
-/* scatter rasteriser: one thread per DEM cell                               */
+/* scatter rasteriser                                                        */
+/*
+ * block = 64 x 4 DEM cells (one wave = one 128-byte row segment of the mosaic)
+ *   phase 0  the block's 65 x 5 vertices are transformed once into LDS (2-D
+ *            staging of the (i,j) (i+1,j) (i,j+1) (i+1,j+1) neighbourhood)
+ *   phase 1a thread = cell: the two triangles of the cell (reference
+ *            horizonator-lib.c:500-506) go through every pixel-free rejection
+ *            (discard rule, guard band, back face, empty pixel box, depth
+ *            range); ~78% of all triangles end here.  Survivors are compacted
+ *            into an LDS list with wave ballots.
+ *   phase 1b thread = surviving triangle: attribute planes; boxes above
+ *            HZ_INLINE_MAX_PIX pixels go to the HBM queue of k_big
+ *   phase 2  thread = one pixel centre of one survivor's box, found through a
+ *            block-wide prefix sum of the box sizes: every lane tests a pixel,
+ *            whatever the mix of box sizes (a per-triangle pixel loop ran at
+ *            ~15% lane utilisation here)
+ */
 
-#define SC_CX 64            /* cells per block along i (one wave = one row)  */
-#define SC_CY 4             /* cells per block along j                       */
+#define SC_CX 64
+#define SC_CY 4
 #define SC_VX (SC_CX+1)
 #define SC_VY (SC_CY+1)
+#define SC_THREADS (SC_CX*SC_CY)
+#define SC_REC_STRIDE 19
 
-__global__ __launch_bounds__(SC_CX*SC_CY)
+static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");
+
+__global__ __launch_bounds__(SC_THREADS)
 void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
-               hz_bigitem_t* __restrict__ big, unsigned int* __restrict__ big_count,
-               unsigned int big_capacity, hz_params_t p)
+               hz_bigrec_t* __restrict__ bigrec, hz_bigitem_t* __restrict__ bigitem,
+               unsigned int* __restrict__ big_counters,    /* [0] records, [1] items, [2] first invalid item */
+               unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
 {
-    /* 2-D LDS staging of the block's (SC_CX+1) x (SC_CY+1) vertices: each
-     * vertex is transformed once and shared by the up to 6 triangles around it */
-    __shared__ float s_xn [SC_VY][SC_VX];
-    __shared__ float s_fx [SC_VY][SC_VX];
-    __shared__ float s_fy [SC_VY][SC_VX];
-    __shared__ float s_zw [SC_VY][SC_VX];
-    __shared__ float s_red[SC_VY][SC_VX];
+    __shared__ float   s_xn [SC_VY][SC_VX];
+    __shared__ float   s_fx [SC_VY][SC_VX];
+    __shared__ float   s_fy [SC_VY][SC_VX];
+    __shared__ float   s_zw [SC_VY][SC_VX];
+    __shared__ float   s_red[SC_VY][SC_VX];
+    __shared__ int32_t s_xs [SC_VY][SC_VX];
+    __shared__ int32_t s_ys [SC_VY][SC_VX];
+    __shared__ unsigned short s_cand[2*SC_THREADS];
+    __shared__ uint32_t s_rec[SC_THREADS*SC_REC_STRIDE];
+    __shared__ uint32_t s_prefix[SC_THREADS+1];
+    __shared__ uint32_t s_wavesum[SC_THREADS/64];
+    __shared__ uint32_t s_ncand;
 
-    const int tid = threadIdx.x;
-    const int i0  = blockIdx.x*SC_CX;
-    const int j0  = blockIdx.y*SC_CY;
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i0   = blockIdx.x*SC_CX;
+    const int j0   = blockIdx.y*SC_CY;
 
+    /* ---- phase 0: vertices ------------------------------------------------ */
+    if(tid == 0) s_ncand = 0;
     int some_not_near = 0, some_not_far = 0;
-    for(int v = tid; v < SC_VX*SC_VY; v += SC_CX*SC_CY)
+    for(int v = tid; v < SC_VX*SC_VY; v += SC_THREADS)
     {
         const int vy = v / SC_VX, vx = v - vy*SC_VX;
         const int i = i0 + vx, j = j0 + vy;
         if(i < p.N && j < p.N)
         {
             const hz_wvert_t w = hz_vertex_at(p, mosaic, i, j);
-            s_xn [vy][vx] = w.xn;
-            s_fx [vy][vx] = w.fx;
-            s_fy [vy][vx] = w.fy;
-            s_zw [vy][vx] = w.zw;
-            s_red[vy][vx] = w.red;
+            s_xn [vy][vx] = w.xn;  s_fx [vy][vx] = w.fx;  s_fy[vy][vx] = w.fy;
+            s_zw [vy][vx] = w.zw;  s_red[vy][vx] = w.red;
+            s_xs [vy][vx] = w.xs;  s_ys [vy][vx] = w.ys;
             some_not_near |= !(w.zw < 0.f);
             some_not_far  |= !(w.zw > 1.f);
         }
     }
     /* block-wide early out: every vertex in front of the near sphere, or
-     * every vertex beyond the far one.  hz_tri_setup() drops exactly those
-     * triangles anyway; this only saves the per-triangle work (with the
-     * default zfar = 40 km most of a large mosaic goes this way). */
+     * every vertex beyond the far one.  hz_tri_cull() drops exactly those
+     * triangles anyway (with the default zfar = 40 km most of a large mosaic
+     * goes this way). */
     some_not_near = __syncthreads_or(some_not_near);
     some_not_far  = __syncthreads_or(some_not_far);
     if(!some_not_near || !some_not_far) return;
 
-    const int cx = tid & (SC_CX-1);
-    const int cy = tid / SC_CX;
-    const int i = i0 + cx, j = j0 + cy;
-    if(i >= p.N-1 || j >= p.N-1) return;
-
-    hz_wvert_t v00 = { s_xn[cy  ][cx  ], s_fx[cy  ][cx  ], s_fy[cy  ][cx  ], s_zw[cy  ][cx  ], s_red[cy  ][cx  ] };
-    hz_wvert_t v10 = { s_xn[cy  ][cx+1], s_fx[cy  ][cx+1], s_fy[cy  ][cx+1], s_zw[cy  ][cx+1], s_red[cy  ][cx+1] };
-    hz_wvert_t v01 = { s_xn[cy+1][cx  ], s_fx[cy+1][cx  ], s_fy[cy+1][cx  ], s_zw[cy+1][cx  ], s_red[cy+1][cx  ] };
-    hz_wvert_t v11 = { s_xn[cy+1][cx+1], s_fx[cy+1][cx+1], s_fy[cy+1][cx+1], s_zw[cy+1][cx+1], s_red[cy+1][cx+1] };
-
-    const uint32_t prim0 = (uint32_t)(((size_t)j*(p.N-1) + i)*2);
-
-    #pragma unroll
-    for(int t=0; t<2; t++)
+    /* ---- phase 1a: pixel-free rejection, compaction ----------------------- */
     {
-        hz_tri_t tri;
-        const int ok = (t == 0)
-            ? hz_tri_setup(&tri, v00, v11, v01, p.col0, p.col1-1, 0, p.H-1)
-            : hz_tri_setup(&tri, v00, v10, v11, p.col0, p.col1-1, 0, p.H-1);
-        if(!ok) continue;
-        const uint32_t prim = prim0 + t;
-        const int bw = tri.px1 - tri.px0 + 1;
-        const int bh = tri.py1 - tri.py0 + 1;
-        if((long long)bw*bh > HZ_BIG_THRESHOLD)
+        const int cx = lane, cy = wave;
+        const int i = i0 + cx, j = j0 + cy;
+        int keep0 = 0, keep1 = 0;
+        if(i < p.N-1 && j < p.N-1)
         {
-            /* defer: one work item per band of rows */
-            const int nbands = (bh + HZ_BIG_BAND_ROWS-1) / HZ_BIG_BAND_ROWS;
-            const unsigned int at = atomicAdd(big_count, (unsigned int)nbands);
-            if(at + nbands <= big_capacity)
-            {
-                for(int b=0; b<nbands; b++) { big[at+b].prim = prim; big[at+b].band = b; }
-                continue;
-            }
-            /* list full: fall through and rasterise inline (slow, correct) */
+            #define LDV(vy,vx) hz_wvert_t{ s_xn[vy][vx], s_fx[vy][vx], s_fy[vy][vx], s_zw[vy][vx], s_red[vy][vx], s_xs[vy][vx], s_ys[vy][vx] }
+            const hz_wvert_t v00 = LDV(cy,   cx  );
+            const hz_wvert_t v10 = LDV(cy,   cx+1);
+            const hz_wvert_t v01 = LDV(cy+1, cx  );
+            const hz_wvert_t v11 = LDV(cy+1, cx+1);
+            hz_box_t box;
+            keep0 = hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1);
+            keep1 = hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1);
         }
-        for(int py = tri.py0; py <= tri.py1; py++)
-            for(int px = tri.px0; px <= tri.px1; px++)
-                hz_emit(fb, p, tri, prim, px, py);
+        const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+        const unsigned int n0 = __popcll(m0), n1 = __popcll(m1);
+        unsigned int base = 0;
+        if(lane == 0 && n0+n1) base = atomicAdd(&s_ncand, n0+n1);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned short id = (unsigned short)((cy << 7) | (cx << 1));
+        if(keep0) s_cand[base      + __popcll(m0 & below)] = id;
+        if(keep1) s_cand[base + n0 + __popcll(m1 & below)] = id | 1;
+    }
+    __syncthreads();
+    const unsigned int ncand = s_ncand;
+
+    for(unsigned int batch = 0; batch < ncand; batch += SC_THREADS)
+    {
+        /* ---- phase 1b: attribute planes, one thread per survivor ----------- */
+        uint32_t npix = 0;
+        const unsigned int k = batch + tid;
+        if(k < ncand)
+        {
+            const unsigned int id = s_cand[k];
+            const int t = id & 1, cx = (id >> 1) & 63, cy = id >> 7;
+            const hz_wvert_t a = LDV(cy, cx);
+            const hz_wvert_t b = t == 0 ? LDV(cy+1, cx+1) : LDV(cy,   cx+1);
+            const hz_wvert_t c = t == 0 ? LDV(cy+1, cx  ) : LDV(cy+1, cx+1);
+            hz_box_t box;
+            hz_tri_cull(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);     /* known to pass: recomputes the box */
+            hz_tri_t tri;
+            hz_tri_planes(&tri, &a, &b, &c);
+            hz_rec_t r;
+            #pragma unroll
+            for(int m=0; m<3; m++) { r.xs[m] = tri.xs[m]; r.ys[m] = tri.ys[m]; }
+            r.fx0 = tri.fx0; r.fy0 = tri.fy0; r.z0 = tri.z0; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
+            r.r0 = tri.r0; r.drdx = tri.drdx; r.drdy = tri.drdy;
+            r.px0 = box.px0; r.py0 = box.py0; r.bw = box.px1 - box.px0 + 1;
+            r.inv_bw = 1.0f / (float)r.bw;
+            r.prim = (uint32_t)(((size_t)(j0+cy)*(p.N-1) + (i0+cx))*2 + t);
+            const int bh = box.py1 - box.py0 + 1;
+            const long long n = (long long)r.bw*bh;
+            if(n <= HZ_INLINE_MAX_PIX)
+            {
+                npix = (uint32_t)n;
+                uint32_t* dst = &s_rec[tid*SC_REC_STRIDE];
+                const uint32_t* src = (const uint32_t*)&r;
+                #pragma unroll
+                for(int q=0; q<SC_REC_STRIDE; q++) dst[q] = src[q];
+            }
+            else
+            {
+                /* large: hand over to k_big, 64 tiles per work item */
+                const unsigned int tiles  = (unsigned int)((r.bw + HZ_TILE_W-1)/HZ_TILE_W) * (unsigned int)((bh + HZ_TILE_H-1)/HZ_TILE_H);
+                const unsigned int chunks = (tiles + 63)/64;
+                unsigned int ri = atomicAdd(&big_counters[0], 1u), ii = 0;
+                bool queued = false;
+                if(ri < bigrec_capacity)
+                {
+                    ii = atomicAdd(&big_counters[1], chunks);
+                    if(ii + chunks <= bigitem_capacity) queued = true;
+                    else atomicMin(&big_counters[2], ii);      /* items from here on are not valid */
+                }
+                if(queued)
+                {
+                    bigrec[ri].r = r; bigrec[ri].bh = bh;
+                    for(unsigned int c2=0; c2<chunks; c2++) { bigitem[ii+c2].rec = ri; bigitem[ii+c2].chunk = c2; }
+                }
+                else
+                {
+                    /* queue full (never seen; the capacities are sized for 32k-wide
+                     * panoramas): rasterise here, slowly but correctly */
+                    for(int py = box.py0; py <= box.py1; py++)
+                        for(int px = box.px0; px <= box.px1; px++)
+                            hz_emit(fb, p, tri, r.prim, px, py);
+                }
+            }
+        }
+        #undef LDV
+
+        /* ---- exclusive prefix sum of the box sizes over the block ---------- */
+        uint32_t incl = npix;
+        #pragma unroll
+        for(int d=1; d<64; d<<=1)
+        {
+            const uint32_t up = __shfl_up(incl, d);
+            if(lane >= d) incl += up;
+        }
+        if(lane == 63) s_wavesum[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
+        #pragma unroll
+        for(int w=0; w<SC_THREADS/64; w++)
+        {
+            const uint32_t ws = s_wavesum[w];
+            if(w < wave) wave_base += ws;
+            total += ws;
+        }
+        s_prefix[tid] = wave_base + incl - npix;
+        if(tid == 0) s_prefix[SC_THREADS] = total;
+        __syncthreads();
+
+        /* ---- phase 2: one thread per pixel centre --------------------------- */
+        for(uint32_t it = tid; it < total; it += SC_THREADS)
+        {
+            /* record holding item `it`: last k with prefix[k] <= it */
+            int lo = 0, hi = SC_THREADS;
+            #pragma unroll
+            for(int step=0; step<9; step++)       /* the range [lo,hi) of 256 shrinks to empty in 9 halvings */
+            {
+                const int mid = (lo + hi) >> 1;
+                if(s_prefix[mid+1] <= it) lo = mid+1; else hi = mid;
+            }
+            const uint32_t* src = &s_rec[lo*SC_REC_STRIDE];
+            hz_rec_t r;
+            uint32_t* dst = (uint32_t*)&r;
+            #pragma unroll
+            for(int q=0; q<SC_REC_STRIDE; q++) dst[q] = src[q];
+            const uint32_t local = it - s_prefix[lo];
+            const int ry = (int)(((float)local + 0.5f) * r.inv_bw);
+            const int rx = (int)local - ry*r.bw;
+            hz_tri_t tri;
+            hz_tri_from_rec(tri, r);
+            hz_emit(fb, p, tri, r.prim, r.px0 + rx, r.py0 + ry);
+        }
+        __syncthreads();
     }
 }
 
-/* cooperative pass: a whole block walks one band of one large triangle */
+/* large triangles: one wave per work item = 64 tiles of HZ_TILE_W x HZ_TILE_H pixels.  Lane =
+ * tile for a trivial-reject test against the three edges (long thin slivers
+ * near the viewer cover a small part of their box), then lane = pixel inside
+ * every tile that survived. */
 __global__ __launch_bounds__(256)
-void k_big(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
-           const hz_bigitem_t* __restrict__ big, const unsigned int* __restrict__ big_count,
-           unsigned int big_capacity, hz_params_t p)
+void k_big(unsigned long long* __restrict__ fb,
+           const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
+           const unsigned int* __restrict__ big_counters,
+           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
 {
-    unsigned int n = *big_count;
-    if(n > big_capacity) n = big_capacity;      /* overflowed items were drawn inline */
-    for(unsigned int it = blockIdx.x; it < n; it += gridDim.x)
+    /* items at and beyond the first overflow were rasterised inline by k_scatter */
+    unsigned int nitems = min(big_counters[1], big_counters[2]);
+    (void)bigrec_capacity; (void)bigitem_capacity;
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
+    const unsigned int nwaves = gridDim.x*(blockDim.x/64);
+    /* item and record come through the scalar cache (wave-uniform addresses);
+     * the next item's are requested before the current one is rasterised, so
+     * their latency hides behind the pixel work */
+    hz_bigitem_t item_next = {};
+    hz_bigrec_t  rec_next  = {};
+    if(wave_global < nitems) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
+    for(unsigned int it = wave_global; it < nitems; it += nwaves)
     {
-        const uint32_t prim = big[it].prim;
-        const int      band = big[it].band;
-        const uint32_t cell = prim >> 1;
-        const int t = prim & 1;
-        const int j = cell / (uint32_t)(p.N-1);
-        const int i = cell - (uint32_t)j*(uint32_t)(p.N-1);
-
-        const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i,   j  );
-        const hz_wvert_t v11 = hz_vertex_at(p, mosaic, i+1, j+1);
+        const hz_bigitem_t item = item_next;
+        const hz_bigrec_t  br   = rec_next;
+        if(it + nwaves < nitems) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
         hz_tri_t tri;
-        int ok;
-        if(t == 0) ok = hz_tri_setup(&tri, v00, v11, hz_vertex_at(p, mosaic, i,   j+1), p.col0, p.col1-1, 0, p.H-1);
-        else       ok = hz_tri_setup(&tri, v00, hz_vertex_at(p, mosaic, i+1, j  ), v11, p.col0, p.col1-1, 0, p.H-1);
-        if(!ok) continue;
+        hz_tri_from_rec(tri, br.r);
+        const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;
+        const uint32_t prim = br.r.prim;
+        const int tiles_x = (bw + HZ_TILE_W-1)/HZ_TILE_W;
+        const int tiles_y = (bh + HZ_TILE_H-1)/HZ_TILE_H;
 
-        const int py_lo = tri.py0 + band*HZ_BIG_BAND_ROWS;
-        int       py_hi = py_lo + HZ_BIG_BAND_ROWS-1;
-        if(py_hi > tri.py1) py_hi = tri.py1;
-        const int bw = tri.px1 - tri.px0 + 1;
-        const int npix = bw*(py_hi - py_lo + 1);
-        for(int k = threadIdx.x; k < npix; k += blockDim.x)
+        /* lane = tile: can any pixel centre of the tile be inside? */
+        const int tile = (int)item.chunk*64 + lane;
+        int alive = 0;
+        int ox = 0, oy = 0;
+        if(tile < tiles_x*tiles_y)
         {
-            const int ry = k / bw;
-            hz_emit(fb, p, tri, prim, tri.px0 + (k - ry*bw), py_lo + ry);
+            const int ty = tile / tiles_x, tx = tile - ty*tiles_x;
+            ox = px0 + tx*HZ_TILE_W; oy = py0 + ty*HZ_TILE_H;
+            const int x1 = min(ox + HZ_TILE_W-1, px0 + bw-1), y1 = min(oy + HZ_TILE_H-1, py0 + bh-1);
+            alive = 1;
+            #pragma unroll
+            for(int m=0; m<3; m++)
+            {
+                const int a = m, b = (m == 2) ? 0 : m+1;
+                const int32_t dx = tri.xs[b] - tri.xs[a], dy = tri.ys[b] - tri.ys[a];
+                /* the edge function grows with py when dx > 0 and with px when dy < 0 */
+                const int64_t emax = hz_edge(&tri, m, dy < 0 ? x1 : ox, dx > 0 ? y1 : oy);
+                if(emax < 0 || (emax == 0 && !hz_edge_owns_zero(&tri, m))) alive = 0;
+            }
         }
+        unsigned long long live = __ballot(alive);
+        const int lx = lane % HZ_TILE_W, ly = lane / HZ_TILE_W;
+        while(live)
+        {
+            const int src = __builtin_ctzll(live);
+            live &= live - 1;
+            const int tox = __shfl(ox, src), toy = __shfl(oy, src);
+            const int px = tox + lx, py = toy + ly;
+            if(px < px0 + bw && py < py0 + bh)
+                hz_emit_t<false>(fb, p, tri, prim, px, py);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* marching rasteriser                                                       */
+/*
+ * One wave walks one strip of the DEM, 63 cells wide and 4..64 cell rows long
+ * (short near the viewer, where a cell covers many pixels and a wave would
+ * otherwise carry the whole near field; see mr_zones_t), from south to north,
+ * lane = grid column:
+ *   - the east offset e(i) is computed once per strip, the elevation of the
+ *     next row is in flight while the current row is transformed
+ *   - each vertex is transformed once (64 vertices per row for 63 cells);
+ *     a cell takes its right-hand vertices from the neighbouring lane
+ *     (cross-lane reads, no LDS staging, no workgroup barrier anywhere)
+ *   - triangles that survive every pixel-free rejection are appended to a
+ *     per-wave LDS ring (ballot compaction); whenever 64 are waiting they are
+ *     set up one per lane and their pixel centres are spread over the lanes
+ *     through a wave prefix sum, as in k_scatter
+ * Workgroup = one wave, so nothing ever waits for another wave.
+ */
+
+#define MR_COLS   63
+#define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
+#define MR_RSLOTS 8                 /* vertex rows kept in LDS (power of two)       */
+#define MR_FIELDS 6                 /* fx fy zw red xs ys                            */
+
+/* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
+ * conflict-free 256-byte store per field and row) and a ring of ids of the
+ * triangles waiting for set-up.  id = (cell row - first row of the segment)<<7
+ * | lane<<1 | t.  Only 6 + 2 LDS stores per row of 126 triangles. */
+struct mr_lds_t
+{
+    uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
+    uint32_t ids[MR_CAP];
+};
+
+__device__ static inline void mr_store_row(mr_lds_t& L, int slot, int lane, const hz_wvert_t& v)
+{
+    L.rows[slot][0][lane] = __float_as_uint(v.fx);  L.rows[slot][1][lane] = __float_as_uint(v.fy);
+    L.rows[slot][2][lane] = __float_as_uint(v.zw);  L.rows[slot][3][lane] = __float_as_uint(v.red);
+    L.rows[slot][4][lane] = (uint32_t)v.xs;         L.rows[slot][5][lane] = (uint32_t)v.ys;
+}
+__device__ static inline hz_wvert_t mr_load_vert(const mr_lds_t& L, int slot, int lane)
+{
+    hz_wvert_t v;
+    v.xn  = 0.f;
+    v.fx  = __uint_as_float(L.rows[slot][0][lane]); v.fy  = __uint_as_float(L.rows[slot][1][lane]);
+    v.zw  = __uint_as_float(L.rows[slot][2][lane]); v.red = __uint_as_float(L.rows[slot][3][lane]);
+    v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
+    return v;
+}
+
+/* The strips are cut into segments of rows; the segment length depends on the
+ * distance (in rows) from the viewer's row so that every wave gets a comparable
+ * amount of pixel work: zones south->north with 64, 16, 4, 2, 4, 16, 64 rows
+ * per segment.  Built on the host per draw (mr_make_zones).  Measured: with
+ * uniform 64-row segments the waves next to the viewer run 10-50x longer than
+ * the median and set the kernel time. */
+#define MR_NZONES 7
+struct mr_zones_t
+{
+    int row0[MR_NZONES+1];          /* first cell row of each zone; row0[MR_NZONES] = N-1 */
+    int rows[MR_NZONES];            /* cell rows per segment                              */
+    int seg0[MR_NZONES];            /* number of the zone's first segment                 */
+    int nseg[MR_NZONES];            /* segments in the zone                               */
+    int total;                      /* all segments = gridDim.y                           */
+};
+
+/* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
+ * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63
+ * gets an unspecified value; it has no cell. */
+__device__ static inline int32_t mr_from_east(int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+__device__ static inline float mr_from_east(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
+struct mr_queue_t
+{
+    hz_bigrec_t*  bigrec;
+    hz_bigitem_t* bigitem;
+    hz_rec_t*     midrec;
+    unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item [3] mid records */
+    unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity;
+};
+
+/* inclusive prefix sum over the 64 lanes */
+__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
+{
+    #pragma unroll
+    for(int d=1; d<64; d<<=1)
+    {
+        const uint32_t up = __shfl_up(v, d);
+        if(lane >= d) v += up;
+    }
+    return v;
+}
+
+/* lane k holds triangle record r with npix pixel centres in its box (0 = none):
+ * spread all those pixel centres over the 64 lanes (wave prefix sum + search),
+ * so that every lane tests one pixel per pass whatever the mix of box sizes */
+__device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
+                                     unsigned long long* fb, const hz_params_t& p)
+{
+    /* rounds in which every lane tests the next pixel of ITS OWN triangle: no
+     * cross-lane traffic, no search, short dependency chains.  Worth it while
+     * at least half the lanes still have a pixel left (boxes of similar size,
+     * the common case inside one flush) */
+    uint32_t done = 0;
+    {
+        hz_tri_t own;
+        hz_tri_from_rec(own, r);
+        for(;;)
+        {
+            const bool more = npix > done;
+            if(__popcll(__ballot(more)) < 32) break;
+            if(more)
+            {
+                const int ry = (int)(((float)done + 0.5f) * r.inv_bw);
+                const int rx = (int)done - ry*r.bw;
+                hz_emit_t<false>(fb, p, own, r.prim, r.px0 + rx, r.py0 + ry);
+                done++;
+            }
+        }
+    }
+
+    /* what is left (a few larger boxes) is spread evenly over the lanes */
+    const uint32_t rest  = npix > done ? npix - done : 0;
+    const uint32_t incl  = mr_scan(rest, lane);
+    const uint32_t excl  = incl - rest;
+    const uint32_t total = __shfl(incl, 63);
+    for(uint32_t base = 0; base < total; base += 64)
+    {
+        const uint32_t it = base + lane;
+        /* owner = last lane whose exclusive prefix is <= it */
+        int lo = 0;
+        #pragma unroll
+        for(int step=32; step>=1; step>>=1)
+        {
+            const uint32_t v = __shfl(excl, lo + step);
+            if(v <= it) lo += step;
+        }
+        hz_tri_t tri;
+        #pragma unroll
+        for(int m=0; m<3; m++) { tri.xs[m] = __shfl(r.xs[m], lo); tri.ys[m] = __shfl(r.ys[m], lo); }
+        tri.fx0 = __shfl(r.fx0, lo);  tri.fy0 = __shfl(r.fy0, lo);
+        tri.z0  = __shfl(r.z0, lo);   tri.dzdx = __shfl(r.dzdx, lo); tri.dzdy = __shfl(r.dzdy, lo);
+        tri.r0  = __shfl(r.r0, lo);   tri.drdx = __shfl(r.drdx, lo); tri.drdy = __shfl(r.drdy, lo);
+        const int      opx0 = __shfl(r.px0, lo), opy0 = __shfl(r.py0, lo), obw = __shfl(r.bw, lo);
+        const float    oinv = __shfl(r.inv_bw, lo);
+        const uint32_t oprim = __shfl(r.prim, lo);
+        const uint32_t oexcl = __shfl(excl, lo), odone = __shfl(done, lo);
+        if(it < total)
+        {
+            const uint32_t local = it - oexcl + odone;
+            const int ry = (int)(((float)local + 0.5f) * oinv);
+            const int rx = (int)local - ry*obw;
+            hz_emit_t<false>(fb, p, tri, oprim, opx0 + rx, opy0 + ry);
+        }
+    }
+}
+
+/* medium triangles queued by k_march: one wave per 64 records */
+__global__ __launch_bounds__(64)
+void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ midrec,
+           const unsigned int* __restrict__ counters, unsigned int midrec_capacity, hz_params_t p)
+{
+    const int lane = threadIdx.x;
+    const unsigned int n = min(counters[3], midrec_capacity);
+    for(unsigned int base = blockIdx.x*64u; base < n; base += gridDim.x*64u)
+    {
+        hz_rec_t r = {};
+        uint32_t npix = 0;
+        if(base + lane < n)
+        {
+            r = midrec[base + lane];
+            /* queued records carry the pixel count of the box in the inv_bw
+             * slot (the reciprocal is cheaper to redo than to store) */
+            npix = __float_as_uint(r.inv_bw);
+            r.inv_bw = 1.0f / (float)r.bw;
+        }
+        mr_distribute(r, npix, lane, fb, p);
+    }
+}
+
+/* set up and rasterise the `n` (<= 64) oldest pending triangles */
+__device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned int n, int lane,
+                                int jbeg, int i0,
+                                unsigned long long* fb, const mr_queue_t& q, const hz_params_t& p,
+                                unsigned int* dbg = nullptr)
+{
+    hz_rec_t r;
+    uint32_t npix = 0;
+    int bh = 0;
+    const bool valid = (unsigned int)lane < n;
+    if(valid)
+    {
+        const uint32_t id = L.ids[(head + lane) & (MR_CAP-1)];
+        const int t = id & 1, l = (id >> 1) & 63, rowoff = id >> 7;
+        const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
+        /* reference horizonator-lib.c:500-506 */
+        const hz_wvert_t a = mr_load_vert(L, s0, l);
+        const hz_wvert_t b = t == 0 ? mr_load_vert(L, s1, l+1) : mr_load_vert(L, s0, l+1);
+        const hz_wvert_t c = t == 0 ? mr_load_vert(L, s1, l  ) : mr_load_vert(L, s1, l+1);
+        hz_box_t box;
+        hz_tri_box(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);
+        hz_tri_t tri;
+        hz_tri_planes(&tri, &a, &b, &c);
+        #pragma unroll
+        for(int m=0; m<3; m++) { r.xs[m] = tri.xs[m]; r.ys[m] = tri.ys[m]; }
+        r.fx0 = tri.fx0; r.fy0 = tri.fy0; r.z0 = tri.z0; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
+        r.r0 = tri.r0; r.drdx = tri.drdx; r.drdy = tri.drdy;
+        r.px0 = box.px0; r.bw = box.px1 - box.px0 + 1;
+        r.py0 = box.py0; bh   = box.py1 - box.py0 + 1;
+        r.inv_bw = 1.0f / (float)r.bw;
+        r.prim = (uint32_t)(((size_t)(jbeg + rowoff)*(p.N-1) + (i0 + l))*2 + t);
+        npix = (uint32_t)r.bw*(uint32_t)bh;
+    }
+    else
+    {
+        #pragma unroll
+        for(int m=0; m<3; m++) { r.xs[m] = 0; r.ys[m] = 0; }
+        r.fx0 = r.fy0 = r.z0 = r.dzdx = r.dzdy = r.r0 = r.drdx = r.drdy = 0.f;
+        r.px0 = r.py0 = 0; r.bw = 1; r.inv_bw = 1.f; r.prim = 0;
+    }
+
+    /* large boxes go to k_big: one record, ceil(tiles/64) work items */
+    const bool is_big = valid && npix > HZ_INLINE_MAX_PIX;
+    const unsigned long long bigmask = __ballot(is_big);
+    if(dbg) { dbg[0] += 1; dbg[1] += n; dbg[2] += (unsigned int)__popcll(bigmask); }
+    if(bigmask)
+    {
+        uint32_t chunks = 0;
+        if(is_big)
+        {
+            const uint32_t tiles = (uint32_t)((r.bw + HZ_TILE_W-1)/HZ_TILE_W) * (uint32_t)((bh + HZ_TILE_H-1)/HZ_TILE_H);
+            chunks = (tiles + 63)/64;
+        }
+        const uint32_t incl  = mr_scan(chunks, lane);
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t nb    = (uint32_t)__popcll(bigmask);
+        uint32_t rbase = 0, ibase = 0, ok = 0;
+        if(lane == 0)
+        {
+            rbase = atomicAdd(&q.counters[0], nb);
+            if(rbase + nb <= q.bigrec_capacity)
+            {
+                ibase = atomicAdd(&q.counters[1], total);
+                if(ibase + total <= q.bigitem_capacity) ok = 1;
+                else atomicMin(&q.counters[2], ibase);          /* items from here on are not valid */
+            }
+        }
+        rbase = __shfl(rbase, 0); ibase = __shfl(ibase, 0); ok = __shfl(ok, 0);
+        if(is_big)
+        {
+            if(ok)
+            {
+                const uint32_t ri = rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull));
+                const uint32_t ii = ibase + incl - chunks;
+                q.bigrec[ri].r = r; q.bigrec[ri].bh = bh;
+                for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+            }
+            else
+            {
+                /* queue full (capacities are sized for 32k-wide panoramas): slow but correct */
+                hz_tri_t tri;
+                hz_tri_from_rec(tri, r);
+                for(int py = r.py0; py < r.py0 + bh; py++)
+                    for(int px = r.px0; px < r.px0 + r.bw; px++)
+                        hz_emit(fb, p, tri, r.prim, px, py);
+            }
+            npix = 0;
+        }
+    }
+
+    /* medium boxes go to k_mid, which spreads them over the whole chip: left
+     * here they make the waves next to the viewer the critical path */
+    const bool is_mid = valid && npix > p.inline_max;
+    const unsigned long long midmask = __ballot(is_mid);
+    if(dbg) { dbg[3] += (unsigned int)__popcll(midmask); }
+    if(midmask)
+    {
+        uint32_t mbase = 0;
+        if(lane == 0) mbase = atomicAdd(&q.counters[3], (uint32_t)__popcll(midmask));
+        mbase = __shfl(mbase, 0);
+        if(mbase + (uint32_t)__popcll(midmask) <= q.midrec_capacity)
+        {
+            if(is_mid)
+            {
+                hz_rec_t m = r;
+                m.inv_bw = __uint_as_float(npix);       /* see k_mid */
+                q.midrec[mbase + (uint32_t)__popcll(midmask & ((1ull << lane) - 1ull))] = m;
+                npix = 0;
+            }
+        }
+        /* else: queue full, they stay here */
+    }
+
+    if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }
+    mr_distribute(r, npix, lane, fb, p);
+}
+
+__global__ __launch_bounds__(64)
+void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
+             mr_queue_t q, mr_zones_t zn, hz_params_t p)
+{
+    __shared__ mr_lds_t L;
+    const unsigned long long t_start = p.wave_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned int dbgv[5] = {0,0,0,0,0};
+    unsigned int* dbg = p.wave_cycles ? dbgv : nullptr;
+
+    const int lane = threadIdx.x;
+    const int i0   = blockIdx.x*MR_COLS;
+    const int i    = i0 + lane;
+    int zone = 0;
+    #pragma unroll
+    for(int z=1; z<MR_NZONES; z++)
+        if((int)blockIdx.y >= zn.seg0[z] && (int)blockIdx.y < zn.seg0[z] + zn.nseg[z]) zone = z;
+    const int jbeg = zn.row0[zone] + ((int)blockIdx.y - zn.seg0[zone])*zn.rows[zone];
+    const int jend = min(jbeg + zn.rows[zone], zn.row0[zone+1]);   /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
+    const bool has_vertex = i < p.N;
+    const bool has_cell   = lane < MR_COLS && i < p.N-1;
+    const int  ic = has_vertex ? i : p.N-1;             /* clamped: idle lanes redo the last column */
+
+    /* azimuth-sector shard (multi-GPU): a segment that does not contain the
+     * viewer is a convex patch seen from outside, so its azimuth extent is that
+     * of its four corner vertices; if that lies outside this GPU's columns the
+     * whole wave has nothing to draw.  (The corners are real vertices: their x
+     * is computed exactly as the rasteriser computes it.) */
+    if(p.col0 > 0 || p.col1 < p.W)
+    {
+        const int ia = i0, ib = min(i0 + MR_COLS, p.N-1);
+        const bool viewer_inside = p.u.viewer_cell_i >= (float)(ia-1) && p.u.viewer_cell_i <= (float)(ib+1) &&
+                                   p.u.viewer_cell_j >= (float)(jbeg-1) && p.u.viewer_cell_j <= (float)(jend+1);
+        if(!viewer_inside)
+        {
+            float xlo = 2.f, xhi = -2.f;
+            #pragma unroll
+            for(int c=0; c<4; c++)
+            {
+                const hz_vertex_t v = hz_transform_en(&p.u, hz_east(&p.u, (float)((c & 1) ? ib : ia)),
+                                                      hz_north(&p.u, (float)((c & 2) ? jend : jbeg)), 0.f);
+                xlo = hz_min(xlo, v.x); xhi = hz_max(xhi, v.x);
+            }
+            if(xhi - xlo <= 1.0f)       /* not across the +-180 degree seam */
+            {
+                const float flo = (xlo*p.halfW + p.halfW) - 2.5f, fhi = (xhi*p.halfW + p.halfW) + 1.5f;
+                if(fhi < (float)p.col0 || flo > (float)p.col1) return;
+            }
+        }
+    }
+
+    const float e = hz_east(&p.u, (float)ic);
+
+    /* pending-triangle ring, wave-uniform state */
+    unsigned int head = 0, count = 0;
+    int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
+    hz_wvert_t prev = {}, east = {};
+    int16_t z_next = mosaic[(size_t)jbeg*p.N + ic];
+    for(int j = jbeg; j <= jend; j++)
+    {
+        const float z = (float)z_next;
+        if(j < jend) z_next = mosaic[(size_t)(j+1)*p.N + ic];
+        const hz_wvert_t cur = hz_to_window(hz_transform_en(&p.u, e, hz_north(&p.u, (float)j), z), p.halfW, p.halfH);
+        const int rel = j - jbeg;
+
+        /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
+         * still need it are set up now (happens where survivors are sparse) */
+        if(count && first_row <= rel - MR_RSLOTS)
+        {
+            __syncthreads();
+            mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+            __syncthreads();
+            head = (head + count) & (MR_CAP-1);
+            count = 0;
+        }
+        mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
+
+        /* cell (i, j-1): v00 = prev, v01 = cur; v11 = cur of the lane to the
+         * east (one DPP wave shift per field); v10 = that lane's prev, which
+         * is what v11 was one row ago */
+        const hz_wvert_t v10 = east;
+        east.xn = mr_from_east(cur.xn);  east.fx = mr_from_east(cur.fx);  east.fy = mr_from_east(cur.fy);
+        east.zw = mr_from_east(cur.zw);  east.red = mr_from_east(cur.red);
+        east.xs = mr_from_east(cur.xs);  east.ys = mr_from_east(cur.ys);
+        if(j > jbeg)
+        {
+            const hz_wvert_t v11 = east;
+            #pragma unroll
+            for(int t=0; t<2; t++)
+            {
+                /* reference horizonator-lib.c:500-506 */
+                const hz_wvert_t& b = t == 0 ? v11 : v10;
+                const hz_wvert_t& c = t == 0 ? cur : v11;
+                hz_box_t box;
+                const int keep = has_cell && hz_tri_cull(&box, &prev, &b, &c, p.col0, p.col1-1, 0, p.H-1);
+                const unsigned long long m = __ballot(keep);
+                if(m)
+                {
+                    if(count == 0) first_row = rel-1;
+                    if(keep)
+                    {
+                        const unsigned int at = (head + count + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & (MR_CAP-1);
+                        L.ids[at] = ((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t;
+                    }
+                    count += (unsigned int)__popcll(m);
+                    if(count >= 64)
+                    {
+                        __syncthreads();        /* one wave: orders the LDS writes before the reads */
+                        mr_flush(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
+                        head = (head + 64) & (MR_CAP-1);
+                        count -= 64;
+                        if(count) first_row = (int)(L.ids[head] >> 7);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        prev = cur;
+    }
+    if(count)
+    {
+        __syncthreads();
+        mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+    }
+    if(p.wave_cycles && lane == 0)
+    {
+        unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];
+        o[0] = __builtin_amdgcn_s_memtime() - t_start;
+        o[1] = ((unsigned long long)dbgv[0] << 32) | dbgv[1];     /* flushes, triangles set up */
+        o[2] = ((unsigned long long)dbgv[2] << 32) | dbgv[3];     /* to k_big, to k_mid        */
+        o[3] = dbgv[4];                                           /* pixel centres tested here */
     }
 }
 
@@ -276,9 +906,11 @@ struct hz_dev
     hipStream_t stream;
     int16_t*            d_mosaic;
     unsigned long long* d_fb;           /* W*H words (sector uses a prefix) */
-    hz_bigitem_t*       d_big;
-    unsigned int*       d_big_count;
-    unsigned int        big_capacity;
+    hz_bigrec_t*        d_bigrec;
+    hz_bigitem_t*       d_bigitem;
+    hz_rec_t*           d_midrec;
+    unsigned int*       d_big_counters;     /* [0] big records [1] big items [2] first invalid big item [3] mid records */
+    unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity;
     float*              d_tanel;
 
     /* internal output buffers for *_to_host */
@@ -306,8 +938,10 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     if(d->stream) (void)hipStreamSynchronize(d->stream);
     (void)hipFree(d->d_mosaic);
     (void)hipFree(d->d_fb);
-    (void)hipFree(d->d_big);
-    (void)hipFree(d->d_big_count);
+    (void)hipFree(d->d_bigrec);
+    (void)hipFree(d->d_bigitem);
+    (void)hipFree(d->d_midrec);
+    (void)hipFree(d->d_big_counters);
     (void)hipFree(d->d_tanel);
     (void)hipFree(d->d_bgr);
     (void)hipFree(d->d_ranges);
@@ -324,9 +958,15 @@ static int create_impl(hz_dev_t* d)
     HZ_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HZ_CHECK(hipMalloc(&d->d_mosaic, (size_t)d->N*d->N*sizeof(int16_t)));
     HZ_CHECK(hipMalloc(&d->d_fb, (size_t)d->W*d->H*sizeof(unsigned long long)));
-    d->big_capacity = 1u<<20;
-    HZ_CHECK(hipMalloc(&d->d_big, (size_t)d->big_capacity*sizeof(hz_bigitem_t)));
-    HZ_CHECK(hipMalloc(&d->d_big_count, sizeof(unsigned int)));
+    /* queue of triangles too large for k_scatter's in-block pass.  cfg3
+     * (16000x4000) produces ~0.3 M records and ~0.4 M items; sized for 32k-wide */
+    d->bigrec_capacity  = 1u<<21;
+    d->bigitem_capacity = 1u<<22;
+    HZ_CHECK(hipMalloc(&d->d_bigrec,  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
+    HZ_CHECK(hipMalloc(&d->d_bigitem, (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
+    d->midrec_capacity  = 1u<<21;
+    HZ_CHECK(hipMalloc(&d->d_midrec,  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
+    HZ_CHECK(hipMalloc(&d->d_big_counters, 4*sizeof(unsigned int)));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     for(int k=0; k<6; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
     return 0;
@@ -438,13 +1078,58 @@ extern "C" int hz_hip_set_sector(hz_dev_t* d, int col0, int col1)
 
 extern "C" int hz_hip_set_raster(hz_dev_t* d, int which)
 {
-    if(which < HZ_RASTER_AUTO || which > HZ_RASTER_COLUMNS+2) return -1;   /* +1,+2: timing experiments */
+    if(which < HZ_RASTER_AUTO || which > HZ_RASTER_MARCH) return -1;
     d->raster = which;
     return 0;
 }
 
 extern "C" int hz_hip_set_profiling(hz_dev_t* d, int on) { d->profiling = on; return 0; }
 extern "C" void* hz_hip_stream(hz_dev_t* d) { return (void*)d->stream; }
+
+/* segment zones of k_march for this view: a cell `r` rows away from the viewer
+ * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
+static mr_zones_t mr_make_zones(const hz_params_t& p)
+{
+    const float ppr = p.halfW * p.u.az_ndc_per_rad;
+    const int   ncr = p.N-1;                                /* cell rows */
+    const float vj  = p.u.viewer_cell_j;
+    const int r2  = (int)(ppr/16.f) + 1;                    /* cells wider than ~16 px: 2-row segments */
+    const int r4  = (int)(ppr/4.f) + 1;                     /* ~4 px: 4-row segments                   */
+    const int r16 = (int)(ppr/1.f) + 1;                     /* ~1 px: 16-row segments                  */
+    auto clampi = [&](float x) { int v = (int)floorf(x); if(v < 0) v = 0; if(v > ncr) v = ncr; return v; };
+    mr_zones_t z;
+    z.row0[0] = 0;
+    z.row0[1] = clampi(vj - (float)r16);
+    z.row0[2] = clampi(vj - (float)r4);
+    z.row0[3] = clampi(vj - (float)r2);
+    z.row0[4] = clampi(vj + (float)r2 + 1.f);
+    z.row0[5] = clampi(vj + (float)r4 + 1.f);
+    z.row0[6] = clampi(vj + (float)r16 + 1.f);
+    z.row0[7] = ncr;
+    /* a narrow azimuth sector keeps only a fraction of the waves alive: shorter
+     * segments far from the viewer then restore the parallelism (at the price
+     * of one extra vertex row per segment) */
+    int far_rows = 64*p.SW/p.W;
+    if(far_rows < 16) far_rows = 16;
+    if(far_rows > 64) far_rows = 64;
+    const int rows[MR_NZONES] = { far_rows, 16, 4, 2, 4, 16, far_rows };
+    /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
+     * zones with the longest segments first: the long far-field waves start
+     * early and the kernel ends on short ones */
+    const int order[MR_NZONES] = { 0, 6, 1, 5, 2, 4, 3 };
+    int seg = 0;
+    for(int o=0; o<MR_NZONES; o++)
+    {
+        const int k = order[o];
+        z.rows[k] = rows[k];
+        z.seg0[k] = seg;
+        const int n = z.row0[k+1] - z.row0[k];
+        z.nseg[k] = (n + rows[k]-1)/rows[k];
+        seg += z.nseg[k];
+    }
+    z.total = seg;
+    return z;
+}
 
 static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
 {
@@ -465,7 +1150,11 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.halfH = (float)d->H * 0.5f;
     p.N = d->N; p.W = d->W; p.H = d->H;
     p.col0 = d->col0; p.col1 = d->col1; p.SW = d->col1 - d->col0;
-    p.dry = d->raster > HZ_RASTER_COLUMNS ? d->raster - HZ_RASTER_COLUMNS : 0;
+    /* Whole panorama on one GPU: the marching waves keep everything up to 64
+     * pixels (cheapest in total).  One azimuth sector of several: the waves next
+     * to the viewer become the critical path, so medium boxes are handed to
+     * k_mid, which spreads them over the chip (measured: 8 sectors 0.97 -> 0.58 ms). */
+    p.inline_max = (p.SW == p.W) ? HZ_INLINE_MAX_PIX : 16;
     return p;
 }
 
@@ -478,18 +1167,62 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->stream));
     /* glClear (reference horizonator-lib.c:896): depth = 1.0 -> all-ones word */
     HZ_CHECK(hipMemsetAsync(d->d_fb, 0xFF, (size_t)p.SW*p.H*sizeof(unsigned long long), d->stream));
-    HZ_CHECK(hipMemsetAsync(d->d_big_count, 0, sizeof(unsigned int), d->stream));
+    HZ_CHECK(hipMemsetAsync(d->d_big_counters,     0x00, 2*sizeof(unsigned int), d->stream));
+    HZ_CHECK(hipMemsetAsync(d->d_big_counters + 2, 0xFF, 1*sizeof(unsigned int), d->stream));
+    HZ_CHECK(hipMemsetAsync(d->d_big_counters + 3, 0x00, 1*sizeof(unsigned int), d->stream));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->stream));
 
     {
-        dim3 grid((p.N-1 + SC_CX-1)/SC_CX, (p.N-1 + SC_CY-1)/SC_CY);
-        hipLaunchKernelGGL(k_scatter, grid, dim3(SC_CX*SC_CY), 0, d->stream,
-                           (const int16_t*)d->d_mosaic, d->d_fb, d->d_big, d->d_big_count, d->big_capacity, p);
+        if(d->raster == HZ_RASTER_SCATTER)
+        {
+            dim3 grid((p.N-1 + SC_CX-1)/SC_CX, (p.N-1 + SC_CY-1)/SC_CY);
+            hipLaunchKernelGGL(k_scatter, grid, dim3(SC_THREADS), 0, d->stream,
+                               (const int16_t*)d->d_mosaic, d->d_fb, d->d_bigrec, d->d_bigitem, d->d_big_counters,
+                               d->bigrec_capacity, d->bigitem_capacity, p);
+        }
+        else
+        {
+            mr_queue_t q = { d->d_bigrec, d->d_bigitem, d->d_midrec, d->d_big_counters,
+                             d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity };
+            const mr_zones_t zn = mr_make_zones(p);
+            dim3 grid((p.N-1 + MR_COLS-1)/MR_COLS, zn.total);
+            /* diagnostics: HZ_WAVE_TIMING=<file> dumps the duration (shader clock
+             * cycles) of every k_march wave of this draw as uint64[grid.y][grid.x] */
+            const char* timing_path = getenv("HZ_WAVE_TIMING");
+            hz_params_t pm = p;
+            unsigned long long* d_cycles = NULL;
+            if(timing_path)
+            {
+                HZ_CHECK(hipMalloc(&d_cycles, (size_t)grid.x*grid.y*4*sizeof(unsigned long long)));
+                HZ_CHECK(hipMemsetAsync(d_cycles, 0, (size_t)grid.x*grid.y*4*sizeof(unsigned long long), d->stream));
+                pm.wave_cycles = d_cycles;
+            }
+            hipLaunchKernelGGL(k_march, grid, dim3(64), 0, d->stream,
+                               (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+            if(timing_path)
+            {
+                const size_t n = (size_t)grid.x*grid.y*4;
+                unsigned long long* h = (unsigned long long*)malloc(n*sizeof(*h));
+                HZ_CHECK(hipMemcpyAsync(h, d_cycles, n*sizeof(*h), hipMemcpyDeviceToHost, d->stream));
+                HZ_CHECK(hipStreamSynchronize(d->stream));
+                FILE* f = fopen(timing_path, "wb");
+                if(f) { unsigned int hdr[2] = { grid.x, grid.y }; fwrite(hdr, 4, 2, f); fwrite(h, sizeof(*h), n, f); fclose(f); }
+                free(h);
+                (void)hipFree(d_cycles);
+            }
+        }
         HZ_CHECK(hipGetLastError());
         if(prof) HZ_CHECK(hipEventRecord(d->ev[2], d->stream));
-        hipLaunchKernelGGL(k_big, dim3(2048), dim3(256), 0, d->stream,
-                           (const int16_t*)d->d_mosaic, d->d_fb, (const hz_bigitem_t*)d->d_big,
-                           (const unsigned int*)d->d_big_count, d->big_capacity, p);
+        if(d->raster != HZ_RASTER_SCATTER)
+        {
+            hipLaunchKernelGGL(k_mid, dim3(8192), dim3(64), 0, d->stream,
+                               d->d_fb, (const hz_rec_t*)d->d_midrec, (const unsigned int*)d->d_big_counters,
+                               d->midrec_capacity, p);
+            HZ_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, d->stream,
+                           d->d_fb, (const hz_bigrec_t*)d->d_bigrec, (const hz_bigitem_t*)d->d_bigitem,
+                           (const unsigned int*)d->d_big_counters, d->bigrec_capacity, d->bigitem_capacity, p);
         HZ_CHECK(hipGetLastError());
         if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->stream));
     }

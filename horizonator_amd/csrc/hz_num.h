@@ -47,9 +47,11 @@ HZ_HD float hz_atan2(float y, float x)
     const float ax    = hz_abs(x);
     const float s     = flip ? ax : y;
     const float t     = flip ? y  : ax;
-    const float scale = (hz_abs(t) >= 1e18f) ? 0.25f : 1.0f;
-    const float rcp   = 1.0f / (t*scale);
-    const float sot   = (s*scale) * rcp;
+    /* Mesa scales huge denominators by 1/4 before the reciprocal; everywhere
+     * else the scale is 1.0 and multiplying by it changes nothing */
+    float rcp, sot;
+    if(hz_abs(t) >= 1e18f) { rcp = 1.0f / (t*0.25f); sot = (s*0.25f) * rcp; }
+    else                   { rcp = 1.0f / t;         sot = s * rcp;         }
     const float tn    = (ax == hz_abs(y)) ? 1.0f : hz_abs(sot);
 
     /* atan(tn), tn >= 0, through atan(min(tn,1)/max(tn,1)) */
@@ -64,12 +66,12 @@ HZ_HD float hz_atan2(float y, float x)
     p = p + u7*-0.1173503194786851f;
     p = p + u9*0.0536813784310406f;
     p = p + (u9*-0.0121323213173444f)*u2;
-    const float big = (1.0f < tn) ? 1.0f : 0.0f;
-    float a = big*(p*-2.0f + HZ_HALF_PI) + p;
-    const float sgn = (tn > 0.f) ? 1.0f : ((tn < 0.f) ? -1.0f : 0.0f);
-    a = a*sgn;
-
-    const float arc = (flip ? 1.0f : 0.0f)*HZ_HALF_PI + a;
+    /* Mesa: a = b2f(tn > 1)*(p*-2 + pi/2) + p, then a *= sign(tn), then
+     * arc = b2f(flip)*pi/2 + a.  With finite p >= 0 these multiplications by
+     * 0.0 / 1.0 are exact selections (and tn = 0 implies p = 0), so the
+     * selects below produce the same bits with fewer instructions. */
+    const float a   = (1.0f < tn) ? ((p*-2.0f + HZ_HALF_PI) + p) : p;
+    const float arc = flip ? (HZ_HALF_PI + a) : a;
     return (hz_min(y, rcp) < 0.f) ? -arc : arc;
 }
 
@@ -99,13 +101,22 @@ typedef struct
 
 /* fi,fj: grid indices as float; fz: elevation as float (the reference feeds
  * them as GLshort attributes, reference horizonator-lib.c:424) */
-HZ_HD hz_vertex_t hz_transform(const hz_xform_t* u, float fi, float fj, float fz)
+/* east / north offset of a grid column / row, vertex.glsl:128-130.  They
+ * depend on one index each: a kernel that walks the grid computes them once
+ * per column / row. */
+HZ_HD float hz_east(const hz_xform_t* u, float fi)
+{
+    return (fi - u->viewer_cell_i) * HZ_REARTH_PI * u->deg_per_cell / 180.0f * u->cos_viewer_lat;
+}
+HZ_HD float hz_north(const hz_xform_t* u, float fj)
+{
+    return (fj - u->viewer_cell_j) * HZ_REARTH_PI * u->deg_per_cell / 180.0f;
+}
+
+HZ_HD hz_vertex_t hz_transform_en(const hz_xform_t* u, float e, float n, float fz)
 {
     hz_vertex_t v;
-    /* vertex.glsl:128-131 */
-    const float e = (fi - u->viewer_cell_i) * HZ_REARTH_PI * u->deg_per_cell / 180.0f * u->cos_viewer_lat;
-    const float n = (fj - u->viewer_cell_j) * HZ_REARTH_PI * u->deg_per_cell / 180.0f;
-    const float h = fz - u->viewer_z;
+    const float h = fz - u->viewer_z;                       /* vertex.glsl:131 */
 
     /* vertex.glsl:133-134 */
     const float nn = n*n, ee = e*e;
@@ -122,4 +133,11 @@ HZ_HD hz_vertex_t hz_transform(const hz_xform_t* u, float fi, float fj, float fz
     const float r = (d_ne - u->znear_color) / (u->zfar_color - u->znear_color);
     v.red = hz_min(hz_max(r, 0.0f), 1.0f);
     return v;
+}
+
+/* fi,fj: grid indices as float; fz: elevation as float (the reference feeds
+ * them as GLshort attributes, reference horizonator-lib.c:424) */
+HZ_HD hz_vertex_t hz_transform(const hz_xform_t* u, float fi, float fj, float fz)
+{
+    return hz_transform_en(u, hz_east(u, fi), hz_north(u, fj), fz);
 }

@@ -5,7 +5,7 @@
  * depth buffer for the state the reference sets up (reference
  * horizonator-lib.c:183-185 depth test GL_LESS + back-face cull, :631/:646
  * RGB8 + 24-bit depth, :657 viewport), with Mesa/llvmpipe's conventions where
- * GL leaves a choice (8 sub-pixel bits, top-left fill rule, Z24 rounding):
+ * GL leaves a choice (8 sub-pixel bits, fill rule, Z24 rounding):
  *
  *   window position   xw = x*W/2 + W/2,  yw = y*H/2 + H/2,  zw = z/2 + 1/2
  *   pixel centres     at half-integers of (xw,yw); we work in f = w - 0.5 so
@@ -33,21 +33,13 @@
 /* positions beyond this many pixels from the origin are outside the guard
  * band: the triangle is dropped (keeps the 64-bit edge functions exact) */
 #define HZ_GUARD_PX        2097152.0f
+#define HZ_OUTSIDE_GUARD   INT32_MIN
 
-typedef struct
-{
-    /* snapped positions, 1/256 px */
-    int32_t xs[3], ys[3];
-    /* bounding box in pixels, inclusive, already clipped to the scissor */
-    int32_t px0, px1, py0, py1;
-    /* attribute planes relative to vertex 0 */
-    float fx0, fy0;
-    float z0, dzdx, dzdy;
-    float r0, drdx, drdy;
-} hz_tri_t;
-
-/* window-space vertex as the kernels keep it */
-typedef struct { float xn, fx, fy, zw, red; } hz_wvert_t;
+/* window-space vertex as the kernels keep it: NDC x (for the discard rule),
+ * unsnapped window position, depth, colour, and the position snapped to
+ * 1/256 px (xs = HZ_OUTSIDE_GUARD marks a vertex outside the guard band or
+ * with a non-finite position) */
+typedef struct { float xn, fx, fy, zw, red; int32_t xs, ys; } hz_wvert_t;
 
 HZ_HD hz_wvert_t hz_to_window(hz_vertex_t v, float halfW, float halfH)
 {
@@ -57,88 +49,130 @@ HZ_HD hz_wvert_t hz_to_window(hz_vertex_t v, float halfW, float halfH)
     w.fy  = (v.y*halfH + halfH) - 0.5f;
     w.zw  = v.z*0.5f + 0.5f;
     w.red = v.red;
+    if(hz_abs(w.fx) <= HZ_GUARD_PX && hz_abs(w.fy) <= HZ_GUARD_PX)
+    {
+        w.xs = (int32_t)hz_roundeven(w.fx*256.f);
+        w.ys = (int32_t)hz_roundeven(w.fy*256.f);
+    }
+    else
+    {
+        w.xs = HZ_OUTSIDE_GUARD;
+        w.ys = 0;
+    }
     return w;
 }
 
-/* Returns 0 if the triangle produces no fragments inside the scissor
- * [sx0,sx1] x [sy0,sy1] (inclusive, pixels), 1 otherwise. */
-HZ_HD int hz_tri_setup(hz_tri_t* t,
-                       hz_wvert_t a, hz_wvert_t b, hz_wvert_t c,
-                       int sx0, int sx1, int sy0, int sy1)
+/* pixel box of a triangle, inclusive, clipped to the scissor */
+typedef struct { int32_t px0, px1, py0, py1; } hz_box_t;
+
+/* pixel centres inside the snapped bounding box, clipped to the scissor;
+ * returns 0 if there is none */
+HZ_HD int hz_tri_box(hz_box_t* box,
+                     const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c,
+                     int sx0, int sx1, int sy0, int sy1)
+{
+    int32_t xlo = a->xs < b->xs ? a->xs : b->xs; xlo = xlo < c->xs ? xlo : c->xs;
+    int32_t xhi = a->xs > b->xs ? a->xs : b->xs; xhi = xhi > c->xs ? xhi : c->xs;
+    int32_t ylo = a->ys < b->ys ? a->ys : b->ys; ylo = ylo < c->ys ? ylo : c->ys;
+    int32_t yhi = a->ys > b->ys ? a->ys : b->ys; yhi = yhi > c->ys ? yhi : c->ys;
+
+    int32_t px0 = (xlo + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS;
+    int32_t px1 =  xhi                        >> HZ_SUBPIXEL_BITS;
+    int32_t py0 = (ylo + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS;
+    int32_t py1 =  yhi                        >> HZ_SUBPIXEL_BITS;
+    if(px0 < sx0) px0 = sx0;
+    if(px1 > sx1) px1 = sx1;
+    if(py0 < sy0) py0 = sy0;
+    if(py1 > sy1) py1 = sy1;
+    box->px0 = px0; box->px1 = px1; box->py0 = py0; box->py1 = py1;
+    return !(px0 > px1 || py0 > py1);
+}
+
+/* Everything that can reject a triangle without looking at a pixel.
+ * Returns 1 and the pixel box if the triangle may produce fragments inside
+ * the scissor [sx0,sx1] x [sy0,sy1] (inclusive, pixels), else 0. */
+HZ_HD int hz_tri_cull(hz_box_t* box,
+                      const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c,
+                      int sx0, int sx1, int sy0, int sy1)
 {
     /* reference geometry.glsl:21-27: wider than a quarter of the viewport
      * (which includes everything straddling the +-180 deg seam) -> dropped */
-    const float xmax = hz_max(hz_max(a.xn, b.xn), c.xn);
-    const float xmin = hz_min(hz_min(a.xn, b.xn), c.xn);
+    const float xmax = hz_max(hz_max(a->xn, b->xn), c->xn);
+    const float xmin = hz_min(hz_min(a->xn, b->xn), c->xn);
     if(xmax - xmin > 0.5f) return 0;
 
-    /* guard band; also rejects NaN/inf positions */
-    if(!(hz_abs(a.fx) <= HZ_GUARD_PX && hz_abs(a.fy) <= HZ_GUARD_PX &&
-         hz_abs(b.fx) <= HZ_GUARD_PX && hz_abs(b.fy) <= HZ_GUARD_PX &&
-         hz_abs(c.fx) <= HZ_GUARD_PX && hz_abs(c.fy) <= HZ_GUARD_PX))
-        return 0;
-
-    t->xs[0] = (int32_t)hz_roundeven(a.fx*256.f); t->ys[0] = (int32_t)hz_roundeven(a.fy*256.f);
-    t->xs[1] = (int32_t)hz_roundeven(b.fx*256.f); t->ys[1] = (int32_t)hz_roundeven(b.fy*256.f);
-    t->xs[2] = (int32_t)hz_roundeven(c.fx*256.f); t->ys[2] = (int32_t)hz_roundeven(c.fy*256.f);
+    if(a->xs == HZ_OUTSIDE_GUARD || b->xs == HZ_OUTSIDE_GUARD || c->xs == HZ_OUTSIDE_GUARD) return 0;
 
     /* back-face cull on the snapped area (counter-clockwise = front, y up) */
     const int64_t area =
-        (int64_t)(t->xs[1]-t->xs[0])*(int64_t)(t->ys[2]-t->ys[0]) -
-        (int64_t)(t->xs[2]-t->xs[0])*(int64_t)(t->ys[1]-t->ys[0]);
+        (int64_t)(b->xs - a->xs)*(int64_t)(c->ys - a->ys) -
+        (int64_t)(c->xs - a->xs)*(int64_t)(b->ys - a->ys);
     if(area <= 0) return 0;
 
-    int32_t xlo = t->xs[0] < t->xs[1] ? t->xs[0] : t->xs[1]; xlo = xlo < t->xs[2] ? xlo : t->xs[2];
-    int32_t xhi = t->xs[0] > t->xs[1] ? t->xs[0] : t->xs[1]; xhi = xhi > t->xs[2] ? xhi : t->xs[2];
-    int32_t ylo = t->ys[0] < t->ys[1] ? t->ys[0] : t->ys[1]; ylo = ylo < t->ys[2] ? ylo : t->ys[2];
-    int32_t yhi = t->ys[0] > t->ys[1] ? t->ys[0] : t->ys[1]; yhi = yhi > t->ys[2] ? yhi : t->ys[2];
-
-    /* integer pixel centres inside the snapped box */
-    t->px0 = (xlo + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS;
-    t->px1 =  xhi                        >> HZ_SUBPIXEL_BITS;
-    t->py0 = (ylo + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS;
-    t->py1 =  yhi                        >> HZ_SUBPIXEL_BITS;
-    if(t->px0 < sx0) t->px0 = sx0;
-    if(t->px1 > sx1) t->px1 = sx1;
-    if(t->py0 < sy0) t->py0 = sy0;
-    if(t->py1 > sy1) t->py1 = sy1;
-    if(t->px0 > t->px1 || t->py0 > t->py1) return 0;
+    if(!hz_tri_box(box, a, b, c, sx0, sx1, sy0, sy1)) return 0;
 
     /* whole triangle in front of the near sphere or beyond the far one */
-    if((a.zw < 0.f && b.zw < 0.f && c.zw < 0.f) ||
-       (a.zw > 1.f && b.zw > 1.f && c.zw > 1.f))
+    if((a->zw < 0.f && b->zw < 0.f && c->zw < 0.f) ||
+       (a->zw > 1.f && b->zw > 1.f && c->zw > 1.f))
         return 0;
 
+    return 1;
+}
+
+/* a triangle ready for rasterisation */
+typedef struct
+{
+    int32_t xs[3], ys[3];           /* snapped positions, 1/256 px          */
+    float fx0, fy0;                 /* attribute planes relative to vertex 0 */
+    float z0, dzdx, dzdy;
+    float r0, drdx, drdy;
+} hz_tri_t;
+
+HZ_HD void hz_tri_planes(hz_tri_t* t, const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c)
+{
+    t->xs[0] = a->xs; t->xs[1] = b->xs; t->xs[2] = c->xs;
+    t->ys[0] = a->ys; t->ys[1] = b->ys; t->ys[2] = c->ys;
     /* attribute planes from the unsnapped positions */
-    const float ex1 = b.fx - a.fx, ey1 = b.fy - a.fy;
-    const float ex2 = c.fx - a.fx, ey2 = c.fy - a.fy;
+    const float ex1 = b->fx - a->fx, ey1 = b->fy - a->fy;
+    const float ex2 = c->fx - a->fx, ey2 = c->fy - a->fy;
     const float af  = ex1*ey2 - ex2*ey1;
-    const float dz1 = b.zw  - a.zw,  dz2 = c.zw  - a.zw;
-    const float dr1 = b.red - a.red, dr2 = c.red - a.red;
-    t->fx0 = a.fx; t->fy0 = a.fy;
-    t->z0  = a.zw;
+    const float dz1 = b->zw  - a->zw,  dz2 = c->zw  - a->zw;
+    const float dr1 = b->red - a->red, dr2 = c->red - a->red;
+    t->fx0 = a->fx; t->fy0 = a->fy;
+    t->z0  = a->zw;
     t->dzdx = (dz1*ey2 - dz2*ey1) / af;
     t->dzdy = (dz2*ex1 - dz1*ex2) / af;
-    t->r0  = a.red;
+    t->r0  = a->red;
     t->drdx = (dr1*ey2 - dr2*ey1) / af;
     t->drdy = (dr2*ex1 - dr1*ex2) / af;
-    return 1;
+}
+
+/* edge function of edge m (vertex m -> m+1) at pixel centre (px,py), and
+ * whether a zero belongs to the triangle */
+HZ_HD int64_t hz_edge(const hz_tri_t* t, int m, int px, int py)
+{
+    const int a = m, b = (m == 2) ? 0 : m+1;
+    const int64_t dx = t->xs[b] - t->xs[a];
+    const int64_t dy = t->ys[b] - t->ys[a];
+    return dx*(((int64_t)py << HZ_SUBPIXEL_BITS) - t->ys[a]) - dy*(((int64_t)px << HZ_SUBPIXEL_BITS) - t->xs[a]);
+}
+HZ_HD int hz_edge_owns_zero(const hz_tri_t* t, int m)
+{
+    const int a = m, b = (m == 2) ? 0 : m+1;
+    const int32_t dx = t->xs[b] - t->xs[a];
+    const int32_t dy = t->ys[b] - t->ys[a];
+    return dy < 0 || (dy == 0 && dx > 0);
 }
 
 /* coverage of pixel centre (px,py) */
 HZ_HD int hz_tri_covers(const hz_tri_t* t, int px, int py)
 {
-    const int64_t X = (int64_t)px << HZ_SUBPIXEL_BITS;
-    const int64_t Y = (int64_t)py << HZ_SUBPIXEL_BITS;
     #pragma unroll
     for(int m=0; m<3; m++)
     {
-        const int a = m, b = (m == 2) ? 0 : m+1;
-        const int64_t dx = t->xs[b] - t->xs[a];
-        const int64_t dy = t->ys[b] - t->ys[a];
-        const int64_t e  = dx*(Y - t->ys[a]) - dy*(X - t->xs[a]);
+        const int64_t e = hz_edge(t, m, px, py);
         if(e < 0) return 0;
-        if(e == 0 && !(dy < 0 || (dy == 0 && dx > 0))) return 0;
+        if(e == 0 && !hz_edge_owns_zero(t, m)) return 0;
     }
     return 1;
 }

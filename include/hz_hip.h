@@ -42,8 +42,8 @@ typedef struct
 enum
 {
     HZ_RASTER_AUTO   = 0,
-    HZ_RASTER_SCATTER= 1,   /* thread per DEM cell, 64-bit atomicMin into HBM      */
-    HZ_RASTER_COLUMNS= 2    /* workgroup per image-column group, depth in LDS      */
+    HZ_RASTER_SCATTER= 1,   /* block per 64x4 DEM cells, vertices staged in LDS            */
+    HZ_RASTER_MARCH  = 2    /* wave per 63-cell-wide strip, marching north, no barriers   */
 };
 
 /* per-draw kernel times in ms, measured with HIP events on the context's own

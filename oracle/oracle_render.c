@@ -373,3 +373,77 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
     free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
     return 0;
 }
+
+/* ---- workload statistics (design aid, not part of any comparison) -------- */
+
+/* counts[0] triangles, [1] after geometry-shader discard, [2] after guard band,
+ * [3] front-facing, [4] non-empty pixel box, [5] inside depth range,
+ * [6] pixel centres tested (box area), [7] covered, [8] depth-clipped away,
+ * hist[k]: triangles whose box holds 2^(k-1) < n <= 2^k pixel centres (hist[0]: n = 1) */
+void orc_stats(const int16_t* mosaic, int N, const orc_view_t* v, int W, int H,
+               int64_t counts[9], int64_t hist[32])
+{
+    memset(counts, 0, 9*sizeof(int64_t));
+    memset(hist, 0, 32*sizeof(int64_t));
+    float c, k;
+    az_constants(v, &c, &k);
+    const float halfW = (float)W*0.5f, halfH = (float)H*0.5f;
+    wvert_t* row0 = malloc((size_t)N*sizeof(wvert_t));
+    wvert_t* row1 = malloc((size_t)N*sizeof(wvert_t));
+    for(int j=0; j<N; j++)
+    {
+        for(int i=0; i<N; i++)
+        {
+            ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
+            wvert_t* w = &row1[i];
+            w->xn = o.x; w->fx = (o.x*halfW + halfW) - 0.5f; w->fy = (o.y*halfH + halfH) - 0.5f;
+            w->zw = o.z*0.5f + 0.5f; w->red = o.red;
+        }
+        if(j > 0)
+            for(int i=0; i<N-1; i++)
+                for(int t=0; t<2; t++)
+                {
+                    const wvert_t* A = &row0[i];
+                    const wvert_t* B = t == 0 ? &row1[i+1] : &row0[i+1];
+                    const wvert_t* C = t == 0 ? &row1[i]   : &row1[i+1];
+                    counts[0]++;
+                    float xmax = fmaxf(fmaxf(A->xn,B->xn),C->xn), xmin = fminf(fminf(A->xn,B->xn),C->xn);
+                    if(xmax - xmin > 0.5f) continue;
+                    counts[1]++;
+                    if(!(fabsf(A->fx) <= GUARD_PX && fabsf(A->fy) <= GUARD_PX && fabsf(B->fx) <= GUARD_PX &&
+                         fabsf(B->fy) <= GUARD_PX && fabsf(C->fx) <= GUARD_PX && fabsf(C->fy) <= GUARD_PX)) continue;
+                    counts[2]++;
+                    const wvert_t* V[3] = {A,B,C};
+                    int64_t X[3], Y[3];
+                    for(int m=0; m<3; m++) { X[m] = (int64_t)rintf(V[m]->fx*256.f); Y[m] = (int64_t)rintf(V[m]->fy*256.f); }
+                    int64_t area = (X[1]-X[0])*(Y[2]-Y[0]) - (X[2]-X[0])*(Y[1]-Y[0]);
+                    if(area <= 0) continue;
+                    counts[3]++;
+                    int64_t bx0=X[0],bx1=X[0],by0=Y[0],by1=Y[0];
+                    for(int m=1;m<3;m++){ if(X[m]<bx0)bx0=X[m]; if(X[m]>bx1)bx1=X[m]; if(Y[m]<by0)by0=Y[m]; if(Y[m]>by1)by1=Y[m]; }
+                    int64_t px0=(bx0+255)>>8, px1=bx1>>8, py0=(by0+255)>>8, py1=by1>>8;
+                    if(px0<0)px0=0; if(px1>W-1)px1=W-1; if(py0<0)py0=0; if(py1>H-1)py1=H-1;
+                    if(px0>px1||py0>py1) continue;
+                    counts[4]++;
+                    if((A->zw<0.f&&B->zw<0.f&&C->zw<0.f)||(A->zw>1.f&&B->zw>1.f&&C->zw>1.f)) continue;
+                    counts[5]++;
+                    int64_t n = (px1-px0+1)*(py1-py0+1);
+                    counts[6] += n;
+                    int b = 0; while(((int64_t)1<<b) < n) b++;
+                    hist[b]++;
+                    for(int64_t py=py0;py<=py1;py++) for(int64_t px=px0;px<=px1;px++)
+                    {
+                        int inside = 1;
+                        for(int m=0;m<3&&inside;m++)
+                        {
+                            int a=m,bb=(m+1)%3; int64_t dx=X[bb]-X[a], dy=Y[bb]-Y[a];
+                            int64_t E = dx*(py*256-Y[a]) - dy*(px*256-X[a]);
+                            if(E<0) inside=0; else if(E==0 && !(dy<0||(dy==0&&dx>0))) inside=0;
+                        }
+                        counts[7] += inside;
+                    }
+                }
+        wvert_t* tmp = row0; row0 = row1; row1 = tmp;
+    }
+    free(row0); free(row1);
+}

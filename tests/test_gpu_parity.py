@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 RENDERS = sorted(os.path.basename(p)[len("render_"):-4] for p in glob.glob(os.path.join(GOLD, "render_*.npz")))
 LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
-RASTERS = [1, 2]           # HZ_RASTER_SCATTER, HZ_RASTER_COLUMNS
+RASTERS = [1, 2]           # HZ_RASTER_SCATTER, HZ_RASTER_MARCH
 
 
 def _view(g):

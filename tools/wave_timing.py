@@ -1,0 +1,34 @@
+"""diagnostics: distribution of k_march wave durations (HZ_WAVE_TIMING)"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import hzutil, horizonator_amd
+LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
+R, W, H = 4200, 16000, 4000
+h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
+h.set_view(-180, 180, zfar=600000.0)
+import torch
+img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda"); rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
+for _ in range(2):
+    h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+os.environ["HZ_WAVE_TIMING"] = "/tmp/wt.bin"
+h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+raw = open("/tmp/wt.bin", "rb").read()
+gx, gy = np.frombuffer(raw[:8], np.uint32)
+a = np.frombuffer(raw[8:], np.uint64).reshape(gy, gx, 4)
+t = a[:, :, 0].astype(np.float64) / 2400.0          # shader clock ~2.4 GHz -> us
+flushes = (a[:, :, 1] >> 32).astype(np.int64); tris = (a[:, :, 1] & 0xFFFFFFFF).astype(np.int64)
+big = (a[:, :, 2] >> 32).astype(np.int64); mid = (a[:, :, 2] & 0xFFFFFFFF).astype(np.int64)
+items = a[:, :, 3].astype(np.int64)
+print("grid", gx, gy, "waves", gx*gy)
+q = np.percentile(t, [50, 90, 99, 99.9, 100])
+print("wave duration us: p50 %.1f p90 %.1f p99 %.1f p99.9 %.1f max %.1f; sum %.1f ms" % (*q, t.sum()/1e3))
+print("totals: flushes %d tris %d big %d mid %d inline items %d" % (flushes.sum(), tris.sum(), big.sum(), mid.sum(), items.sum()))
+j, i = np.unravel_index(np.argsort(t.ravel())[-12:], t.shape)
+for y, x in zip(j[::-1], i[::-1]):
+    print("   seg %d strip %d: %.1f us flushes %d tris %d big %d mid %d items %d" % (y, x, t[y, x], flushes[y, x], tris[y, x], big[y, x], mid[y, x], items[y, x]))
+# regress time on counters
+X = np.stack([np.ones(t.size), flushes.ravel(), tris.ravel(), big.ravel(), mid.ravel(), items.ravel()], 1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(X, t.ravel(), rcond=None)
+print("least squares us: const %.2f per flush %.3f per tri %.4f per big %.3f per mid %.3f per item %.5f" % tuple(coef))
