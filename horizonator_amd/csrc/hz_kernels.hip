@@ -55,6 +55,7 @@ struct hz_params_t
     int   SW;               /* col1-col0, row stride of fb              */
     unsigned long long* wave_cycles;   /* diagnostics: per-wave duration of k_march, or NULL */
     unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
+    unsigned int big_min;              /* k_march: boxes above this many pixels go to k_big (tiles), between: k_mid  */
 };
 
 /* a set-up triangle as it travels between phases: through LDS inside
@@ -75,9 +76,21 @@ struct hz_bigitem_t { uint32_t rec; uint32_t chunk; };
 #define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
-#define HZ_TILE_W          64       /* k_big walks 64x1-pixel tiles (one wave per 64 tiles): near-field      */
-#define HZ_TILE_H          1        /* triangles are flat slivers, and 64 pixels of one row are 512 contiguous
-                                     * bytes of framebuffer for the atomics                                  */
+/* k_big walks a triangle's box in tiles of 64 pixels, one wave per 64 tiles.
+ * The tile is as wide as the box allows (64x1 for the flat slivers next to the
+ * viewer: 512 contiguous bytes of framebuffer per atomic instruction; down to
+ * 8x8 for narrow boxes, so that the 64 lanes stay busy).  Producer (queueing)
+ * and consumer (k_big) derive the tiling from the box alone. */
+struct hz_tiling_t { int tw_log2, tiles_x, tiles_y; };
+__device__ static inline hz_tiling_t hz_big_tiling(int bw, int bh)
+{
+    hz_tiling_t t;
+    t.tw_log2 = bw > 32 ? 6 : bw > 16 ? 5 : bw > 8 ? 4 : 3;
+    const int tw = 1 << t.tw_log2, th = 64 >> t.tw_log2;
+    t.tiles_x = (bw + tw-1) >> t.tw_log2;
+    t.tiles_y = (bh + th-1) / th;
+    return t;
+}
 
 /* ------------------------------------------------------------------------ */
 /* device helpers                                                            */
@@ -268,7 +281,8 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             else
             {
                 /* large: hand over to k_big, 64 tiles per work item */
-                const unsigned int tiles  = (unsigned int)((r.bw + HZ_TILE_W-1)/HZ_TILE_W) * (unsigned int)((bh + HZ_TILE_H-1)/HZ_TILE_H);
+                const hz_tiling_t tl = hz_big_tiling(r.bw, bh);
+                const unsigned int tiles  = (unsigned int)tl.tiles_x*(unsigned int)tl.tiles_y;
                 const unsigned int chunks = (tiles + 63)/64;
                 unsigned int ri = atomicAdd(&big_counters[0], 1u), ii = 0;
                 bool queued = false;
@@ -344,7 +358,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
     }
 }
 
-/* large triangles: one wave per work item = 64 tiles of HZ_TILE_W x HZ_TILE_H pixels.  Lane =
+/* large triangles: one wave per work item = 64 tiles of 64 pixels (hz_big_tiling).  Lane =
  * tile for a trivial-reject test against the three edges (long thin slivers
  * near the viewer cover a small part of their box), then lane = pixel inside
  * every tile that survived. */
@@ -375,8 +389,9 @@ void k_big(unsigned long long* __restrict__ fb,
         hz_tri_from_rec(tri, br.r);
         const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;
         const uint32_t prim = br.r.prim;
-        const int tiles_x = (bw + HZ_TILE_W-1)/HZ_TILE_W;
-        const int tiles_y = (bh + HZ_TILE_H-1)/HZ_TILE_H;
+        const hz_tiling_t tl = hz_big_tiling(bw, bh);
+        const int tiles_x = tl.tiles_x, tiles_y = tl.tiles_y;
+        const int tw = 1 << tl.tw_log2, th = 64 >> tl.tw_log2;
 
         /* lane = tile: can any pixel centre of the tile be inside? */
         const int tile = (int)item.chunk*64 + lane;
@@ -385,8 +400,8 @@ void k_big(unsigned long long* __restrict__ fb,
         if(tile < tiles_x*tiles_y)
         {
             const int ty = tile / tiles_x, tx = tile - ty*tiles_x;
-            ox = px0 + tx*HZ_TILE_W; oy = py0 + ty*HZ_TILE_H;
-            const int x1 = min(ox + HZ_TILE_W-1, px0 + bw-1), y1 = min(oy + HZ_TILE_H-1, py0 + bh-1);
+            ox = px0 + tx*tw; oy = py0 + ty*th;
+            const int x1 = min(ox + tw-1, px0 + bw-1), y1 = min(oy + th-1, py0 + bh-1);
             alive = 1;
             #pragma unroll
             for(int m=0; m<3; m++)
@@ -399,7 +414,7 @@ void k_big(unsigned long long* __restrict__ fb,
             }
         }
         unsigned long long live = __ballot(alive);
-        const int lx = lane % HZ_TILE_W, ly = lane / HZ_TILE_W;
+        const int lx = lane & (tw-1), ly = lane >> tl.tw_log2;
         while(live)
         {
             const int src = __builtin_ctzll(live);
@@ -640,7 +655,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     }
 
     /* large boxes go to k_big: one record, ceil(tiles/64) work items */
-    const bool is_big = valid && npix > HZ_INLINE_MAX_PIX;
+    const bool is_big = valid && npix > p.big_min;
     const unsigned long long bigmask = __ballot(is_big);
     if(dbg) { dbg[0] += 1; dbg[1] += n; dbg[2] += (unsigned int)__popcll(bigmask); }
     if(bigmask)
@@ -648,7 +663,8 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         uint32_t chunks = 0;
         if(is_big)
         {
-            const uint32_t tiles = (uint32_t)((r.bw + HZ_TILE_W-1)/HZ_TILE_W) * (uint32_t)((bh + HZ_TILE_H-1)/HZ_TILE_H);
+            const hz_tiling_t tl = hz_big_tiling(r.bw, bh);
+            const uint32_t tiles = (uint32_t)tl.tiles_x*(uint32_t)tl.tiles_y;
             chunks = (tiles + 63)/64;
         }
         const uint32_t incl  = mr_scan(chunks, lane);
@@ -962,9 +978,15 @@ static int create_impl(hz_dev_t* d)
      * (16000x4000) produces ~0.3 M records and ~0.4 M items; sized for 32k-wide */
     d->bigrec_capacity  = 1u<<21;
     d->bigitem_capacity = 1u<<22;
+    d->midrec_capacity  = 1u<<21;
+    {
+        /* tests shrink the queues to exercise the overflow paths */
+        const char* cap = getenv("HZ_QUEUE_CAPACITY");
+        if(cap && atoi(cap) > 0)
+            d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = (unsigned int)atoi(cap);
+    }
     HZ_CHECK(hipMalloc(&d->d_bigrec,  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
     HZ_CHECK(hipMalloc(&d->d_bigitem, (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
-    d->midrec_capacity  = 1u<<21;
     HZ_CHECK(hipMalloc(&d->d_midrec,  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
     HZ_CHECK(hipMalloc(&d->d_big_counters, 4*sizeof(unsigned int)));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
@@ -1155,6 +1177,9 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
      * to the viewer become the critical path, so medium boxes are handed to
      * k_mid, which spreads them over the chip (measured: 8 sectors 0.97 -> 0.58 ms). */
     p.inline_max = (p.SW == p.W) ? HZ_INLINE_MAX_PIX : 16;
+    p.big_min    = HZ_INLINE_MAX_PIX;
+    { const char* a = getenv("HZ_T_INLINE"); if(a) p.inline_max = (unsigned int)atoi(a); }
+    { const char* a = getenv("HZ_T_BIG");    if(a) p.big_min    = (unsigned int)atoi(a); }
     return p;
 }
 

@@ -112,3 +112,18 @@ def test_oracle_spot_check_at_cfg2_size():
     hip = hzutil.hip_render(mosaic, v, W, H, 2500, 3000)
     orc = oracle.render(mosaic, v, W, H, 2500, 3000)
     hzutil.assert_same_render(hip, orc, "cfg2 sector")
+
+
+@pytest.mark.parametrize("raster", RASTERS)
+@pytest.mark.parametrize("capacity", [1, 50, 3000])
+def test_full_triangle_queues_fall_back_correctly(raster, capacity, monkeypatch):
+    """the HBM queues for medium/large triangles overflow: the kernels must
+    rasterise the overflow in place and still match the oracle bit for bit"""
+    monkeypatch.setenv("HZ_QUEUE_CAPACITY", str(capacity))
+    mosaic, v = _scene(200, 1000, 250, -180, 180, zfar=30000.0)
+    hip = hzutil.hip_render(mosaic, v, 1000, 250, raster=raster)
+    sect = hzutil.hip_render(mosaic, v, 1000, 250, 300, 425, raster=raster)     # sector: medium queue in use
+    orc = oracle.render(mosaic, v, 1000, 250)
+    hzutil.assert_same_render(hip, orc, f"capacity {capacity}")
+    for k in sect:
+        assert np.array_equal(sect[k], orc[k][:, 300:425]), k

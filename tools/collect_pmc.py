@@ -1,0 +1,37 @@
+"""Aggregate rocprofv3 --pmc runs of bench.py into profiles/pmc_<tag>.json.
+
+Run on the GPU box (see tools/collect_pmc.sh), FETCH_SIZE and WRITE_SIZE in
+separate passes as MI355X_MICROARCH.md prescribes.  On gfx950 FETCH_SIZE counts
+half the bytes of a streaming read; the factor is checked in the same run on
+k_resolve, whose traffic is known exactly (reads 8 B/pixel, writes 7 B/pixel)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+indir, outpath, config, zfar, W, H = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(indir + "/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+res = mean.get("k_resolve", {})
+read_factor = None
+if "FETCH_SIZE" in res:
+    read_factor = (8.0 * W * H) / (res["FETCH_SIZE"] * 1024.0)
+out = {"config": config, "zfar": zfar, "W": W, "H": H, "fetch_size_read_factor_measured_on_k_resolve": read_factor,
+       "write_size_check_on_k_resolve": (res.get("WRITE_SIZE", 0) * 1024.0) / (7.0 * W * H) if res else None, "kernels": {}}
+for k, cs in mean.items():
+    if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
+        continue
+    out["kernels"][k] = {"FETCH_SIZE_KB": cs["FETCH_SIZE"], "WRITE_SIZE_KB": cs["WRITE_SIZE"],
+                         "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024.0,
+                         **{c: v for c, v in cs.items() if c not in ("FETCH_SIZE", "WRITE_SIZE")}}
+dom = "k_march" if "k_march" in out["kernels"] else "k_scatter"
+out["kernel"] = dom
+out["hbm_bytes_per_launch"] = out["kernels"][dom]["hbm_bytes_per_launch"]
+json.dump(out, open(outpath, "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
+for k, v in out["kernels"].items():
+    print(k, {a: round(b) for a, b in v.items()})
