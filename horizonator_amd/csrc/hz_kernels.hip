@@ -56,6 +56,7 @@ struct hz_params_t
     unsigned long long* wave_cycles;   /* diagnostics: per-wave duration of k_march, or NULL */
     unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
     unsigned int big_min;              /* k_march: boxes above this many pixels go to k_big (tiles), between: k_mid  */
+    float far_dd;                      /* k_march: squared horizontal distance beyond which a vertex is surely past zfar */
 };
 
 /* a set-up triangle as it travels between phases: through LDS inside
@@ -788,11 +789,26 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
     hz_wvert_t prev = {}, east = {};
     int16_t z_next = mosaic[(size_t)jbeg*p.N + ic];
+    /* rows whose 64 vertices all lie safely beyond zfar (by horizontal distance
+     * alone, 0.1% margin): their triangles can only be far-clipped, so a vertex
+     * row is transformed only if it or a neighbouring row is not such a row.
+     * With the default zfar = 40 km this is most of a large mosaic. */
+    float n_cur = hz_north(&p.u, (float)jbeg);
+    bool far_prev = true;
+    bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
     for(int j = jbeg; j <= jend; j++)
     {
         const float z = (float)z_next;
         if(j < jend) z_next = mosaic[(size_t)(j+1)*p.N + ic];
-        const hz_wvert_t cur = hz_to_window(hz_transform_en(&p.u, e, hz_north(&p.u, (float)j), z), p.halfW, p.halfH);
+        const float n_next   = hz_north(&p.u, (float)(j+1));
+        const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
+        const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
+        const bool  skip_cells = far_prev && far_cur;               /* cell row j-1 entirely clipped */
+        const float n = n_cur;
+        n_cur = n_next; far_prev = far_cur; far_cur = far_next;
+        if(skip_row) continue;
+
+        const hz_wvert_t cur = hz_to_window(hz_transform_en(&p.u, e, n, z), p.halfW, p.halfH);
         const int rel = j - jbeg;
 
         /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
@@ -814,7 +830,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         east.xn = mr_from_east(cur.xn);  east.fx = mr_from_east(cur.fx);  east.fy = mr_from_east(cur.fy);
         east.zw = mr_from_east(cur.zw);  east.red = mr_from_east(cur.red);
         east.xs = mr_from_east(cur.xs);  east.ys = mr_from_east(cur.ys);
-        if(j > jbeg)
+        if(j > jbeg && !skip_cells)
         {
             const hz_wvert_t v11 = east;
             #pragma unroll
@@ -1177,6 +1193,7 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
      * to the viewer become the critical path, so medium boxes are handed to
      * k_mid, which spreads them over the chip (measured: 8 sectors 0.97 -> 0.58 ms). */
     p.inline_max = (p.SW == p.W) ? HZ_INLINE_MAX_PIX : 16;
+    p.far_dd = (v->zfar*1.001f)*(v->zfar*1.001f);
     p.big_min    = HZ_INLINE_MAX_PIX;
     { const char* a = getenv("HZ_T_INLINE"); if(a) p.inline_max = (unsigned int)atoi(a); }
     { const char* a = getenv("HZ_T_BIG");    if(a) p.big_min    = (unsigned int)atoi(a); }
