@@ -64,7 +64,7 @@ struct hz_params_t
 struct hz_rec_t
 {
     int32_t  xs[3], ys[3];
-    float    fx0, fy0, z0, dzdx, dzdy, r0, drdx, drdy;
+    float    z_org, dzdx, dzdy, r_org, drdx, drdy;
     int32_t  px0, py0, bw;
     float    inv_bw;
     uint32_t prim;
@@ -100,9 +100,8 @@ __device__ static inline void hz_tri_from_rec(hz_tri_t& t, const hz_rec_t& r)
 {
     #pragma unroll
     for(int m=0; m<3; m++) { t.xs[m] = r.xs[m]; t.ys[m] = r.ys[m]; }
-    t.fx0 = r.fx0; t.fy0 = r.fy0;
-    t.z0 = r.z0; t.dzdx = r.dzdx; t.dzdy = r.dzdy;
-    t.r0 = r.r0; t.drdx = r.drdx; t.drdy = r.drdy;
+    t.z_org = r.z_org; t.dzdx = r.dzdx; t.dzdy = r.dzdy;
+    t.r_org = r.r_org; t.drdx = r.drdx; t.drdy = r.drdy;
 }
 
 /* PRETEST: read the word first and skip the atomic when the fragment cannot
@@ -162,7 +161,7 @@ __device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int
 #define SC_VX (SC_CX+1)
 #define SC_VY (SC_CY+1)
 #define SC_THREADS (SC_CX*SC_CY)
-#define SC_REC_STRIDE 19
+#define SC_REC_STRIDE 17
 
 static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");
 
@@ -201,7 +200,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
         if(i < p.N && j < p.N)
         {
             const hz_wvert_t w = hz_vertex_at(p, mosaic, i, j);
-            s_xn [vy][vx] = w.xn;  s_fx [vy][vx] = w.fx;  s_fy[vy][vx] = w.fy;
+            s_xn [vy][vx] = w.xn;  s_fx [vy][vx] = w.wx;  s_fy[vy][vx] = w.wy;
             s_zw [vy][vx] = w.zw;  s_red[vy][vx] = w.red;
             s_xs [vy][vx] = w.xs;  s_ys [vy][vx] = w.ys;
             some_not_near |= !(w.zw < 0.f);
@@ -264,8 +263,8 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             hz_rec_t r;
             #pragma unroll
             for(int m=0; m<3; m++) { r.xs[m] = tri.xs[m]; r.ys[m] = tri.ys[m]; }
-            r.fx0 = tri.fx0; r.fy0 = tri.fy0; r.z0 = tri.z0; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
-            r.r0 = tri.r0; r.drdx = tri.drdx; r.drdy = tri.drdy;
+            r.z_org = tri.z_org; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
+            r.r_org = tri.r_org; r.drdx = tri.drdx; r.drdy = tri.drdy;
             r.px0 = box.px0; r.py0 = box.py0; r.bw = box.px1 - box.px0 + 1;
             r.inv_bw = 1.0f / (float)r.bw;
             r.prim = (uint32_t)(((size_t)(j0+cy)*(p.N-1) + (i0+cx))*2 + t);
@@ -450,7 +449,7 @@ void k_big(unsigned long long* __restrict__ fb,
 #define MR_COLS   63
 #define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
 #define MR_RSLOTS 8                 /* vertex rows kept in LDS (power of two)       */
-#define MR_FIELDS 6                 /* fx fy zw red xs ys                            */
+#define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the
@@ -464,7 +463,7 @@ struct mr_lds_t
 
 __device__ static inline void mr_store_row(mr_lds_t& L, int slot, int lane, const hz_wvert_t& v)
 {
-    L.rows[slot][0][lane] = __float_as_uint(v.fx);  L.rows[slot][1][lane] = __float_as_uint(v.fy);
+    L.rows[slot][0][lane] = __float_as_uint(v.wx);  L.rows[slot][1][lane] = __float_as_uint(v.wy);
     L.rows[slot][2][lane] = __float_as_uint(v.zw);  L.rows[slot][3][lane] = __float_as_uint(v.red);
     L.rows[slot][4][lane] = (uint32_t)v.xs;         L.rows[slot][5][lane] = (uint32_t)v.ys;
 }
@@ -472,7 +471,7 @@ __device__ static inline hz_wvert_t mr_load_vert(const mr_lds_t& L, int slot, in
 {
     hz_wvert_t v;
     v.xn  = 0.f;
-    v.fx  = __uint_as_float(L.rows[slot][0][lane]); v.fy  = __uint_as_float(L.rows[slot][1][lane]);
+    v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
     v.zw  = __uint_as_float(L.rows[slot][2][lane]); v.red = __uint_as_float(L.rows[slot][3][lane]);
     v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
     return v;
@@ -574,9 +573,8 @@ __device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
         hz_tri_t tri;
         #pragma unroll
         for(int m=0; m<3; m++) { tri.xs[m] = __shfl(r.xs[m], lo); tri.ys[m] = __shfl(r.ys[m], lo); }
-        tri.fx0 = __shfl(r.fx0, lo);  tri.fy0 = __shfl(r.fy0, lo);
-        tri.z0  = __shfl(r.z0, lo);   tri.dzdx = __shfl(r.dzdx, lo); tri.dzdy = __shfl(r.dzdy, lo);
-        tri.r0  = __shfl(r.r0, lo);   tri.drdx = __shfl(r.drdx, lo); tri.drdy = __shfl(r.drdy, lo);
+        tri.z_org = __shfl(r.z_org, lo); tri.dzdx = __shfl(r.dzdx, lo); tri.dzdy = __shfl(r.dzdy, lo);
+        tri.r_org = __shfl(r.r_org, lo); tri.drdx = __shfl(r.drdx, lo); tri.drdy = __shfl(r.drdy, lo);
         const int      opx0 = __shfl(r.px0, lo), opy0 = __shfl(r.py0, lo), obw = __shfl(r.bw, lo);
         const float    oinv = __shfl(r.inv_bw, lo);
         const uint32_t oprim = __shfl(r.prim, lo);
@@ -639,8 +637,8 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         hz_tri_planes(&tri, &a, &b, &c);
         #pragma unroll
         for(int m=0; m<3; m++) { r.xs[m] = tri.xs[m]; r.ys[m] = tri.ys[m]; }
-        r.fx0 = tri.fx0; r.fy0 = tri.fy0; r.z0 = tri.z0; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
-        r.r0 = tri.r0; r.drdx = tri.drdx; r.drdy = tri.drdy;
+        r.z_org = tri.z_org; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
+        r.r_org = tri.r_org; r.drdx = tri.drdx; r.drdy = tri.drdy;
         r.px0 = box.px0; r.bw = box.px1 - box.px0 + 1;
         r.py0 = box.py0; bh   = box.py1 - box.py0 + 1;
         r.inv_bw = 1.0f / (float)r.bw;
@@ -651,7 +649,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     {
         #pragma unroll
         for(int m=0; m<3; m++) { r.xs[m] = 0; r.ys[m] = 0; }
-        r.fx0 = r.fy0 = r.z0 = r.dzdx = r.dzdy = r.r0 = r.drdx = r.drdy = 0.f;
+        r.z_org = r.dzdx = r.dzdy = r.r_org = r.drdx = r.drdy = 0.f;
         r.px0 = r.py0 = 0; r.bw = 1; r.inv_bw = 1.f; r.prim = 0;
     }
 
@@ -827,7 +825,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
          * east (one DPP wave shift per field); v10 = that lane's prev, which
          * is what v11 was one row ago */
         const hz_wvert_t v10 = east;
-        east.xn = mr_from_east(cur.xn);  east.fx = mr_from_east(cur.fx);  east.fy = mr_from_east(cur.fy);
+        east.xn = mr_from_east(cur.xn);  east.wx = mr_from_east(cur.wx);  east.wy = mr_from_east(cur.wy);
         east.zw = mr_from_east(cur.zw);  east.red = mr_from_east(cur.red);
         east.xs = mr_from_east(cur.xs);  east.ys = mr_from_east(cur.ys);
         if(j > jbeg && !skip_cells)

@@ -13,8 +13,8 @@
  *   coverage          from positions snapped to 1/256 px, integer edge
  *                     functions, ties owned by left and bottom edges (y up)
  *   facing            sign of the snapped area; <= 0 is culled
- *   depth / colour    planes through the UNSNAPPED positions, evaluated at the
- *                     pixel centre relative to vertex 0
+ *   depth / colour    planes through the UNSNAPPED positions, set up and
+ *                     evaluated with llvmpipe's arithmetic (hz_tri_planes)
  *   depth buffer      zi = rint(z * (2^24-1)), fragment dropped unless
  *                     0 <= z <= 1, passes iff zi < stored; 0xFFFFFF = cleared
  *
@@ -36,23 +36,25 @@
 #define HZ_OUTSIDE_GUARD   INT32_MIN
 
 /* window-space vertex as the kernels keep it: NDC x (for the discard rule),
- * unsnapped window position, depth, colour, and the position snapped to
- * 1/256 px (xs = HZ_OUTSIDE_GUARD marks a vertex outside the guard band or
- * with a non-finite position) */
-typedef struct { float xn, fx, fy, zw, red; int32_t xs, ys; } hz_wvert_t;
+ * unsnapped window position (pixel centres at half-integers), depth, colour,
+ * and the position relative to the pixel-centre grid snapped to 1/256 px
+ * (xs = HZ_OUTSIDE_GUARD marks a vertex outside the guard band or with a
+ * non-finite position) */
+typedef struct { float xn, wx, wy, zw, red; int32_t xs, ys; } hz_wvert_t;
 
 HZ_HD hz_wvert_t hz_to_window(hz_vertex_t v, float halfW, float halfH)
 {
     hz_wvert_t w;
     w.xn  = v.x;
-    w.fx  = (v.x*halfW + halfW) - 0.5f;
-    w.fy  = (v.y*halfH + halfH) - 0.5f;
+    w.wx  = v.x*halfW + halfW;
+    w.wy  = v.y*halfH + halfH;
     w.zw  = v.z*0.5f + 0.5f;
     w.red = v.red;
-    if(hz_abs(w.fx) <= HZ_GUARD_PX && hz_abs(w.fy) <= HZ_GUARD_PX)
+    const float fx = w.wx - 0.5f, fy = w.wy - 0.5f;     /* pixel centres at integers */
+    if(hz_abs(fx) <= HZ_GUARD_PX && hz_abs(fy) <= HZ_GUARD_PX)
     {
-        w.xs = (int32_t)hz_roundeven(w.fx*256.f);
-        w.ys = (int32_t)hz_roundeven(w.fy*256.f);
+        w.xs = (int32_t)hz_roundeven(fx*256.f);
+        w.ys = (int32_t)hz_roundeven(fy*256.f);
     }
     else
     {
@@ -122,29 +124,37 @@ HZ_HD int hz_tri_cull(hz_box_t* box,
 /* a triangle ready for rasterisation */
 typedef struct
 {
-    int32_t xs[3], ys[3];           /* snapped positions, 1/256 px          */
-    float fx0, fy0;                 /* attribute planes relative to vertex 0 */
-    float z0, dzdx, dzdy;
-    float r0, drdx, drdy;
+    int32_t xs[3], ys[3];           /* snapped positions, 1/256 px                       */
+    float z_org, dzdx, dzdy;        /* depth  = fma(dzdy, py, fma(dzdx, px, z_org))      */
+    float r_org, drdx, drdy;        /* colour likewise                                   */
 } hz_tri_t;
 
+/* Attribute planes with the arithmetic of llvmpipe's triangle setup and
+ * fragment interpolation.  Pinned on the reference's draws (tests/golden):
+ * with exactly these operations the depth of every triangle llvmpipe does not
+ * clip comes out bit-identical.
+ *   - llvmpipe sees the front faces of an FBO draw as clockwise and swaps the
+ *     first two vertices: its v0 is the SECOND vertex (b) of the draw call
+ *   - gradients via ooa = 1/area and four pre-multiplied edge deltas
+ *   - value at the window origin, then two fused multiply-adds per pixel */
 HZ_HD void hz_tri_planes(hz_tri_t* t, const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c)
 {
     t->xs[0] = a->xs; t->xs[1] = b->xs; t->xs[2] = c->xs;
     t->ys[0] = a->ys; t->ys[1] = b->ys; t->ys[2] = c->ys;
-    /* attribute planes from the unsnapped positions */
-    const float ex1 = b->fx - a->fx, ey1 = b->fy - a->fy;
-    const float ex2 = c->fx - a->fx, ey2 = c->fy - a->fy;
-    const float af  = ex1*ey2 - ex2*ey1;
-    const float dz1 = b->zw  - a->zw,  dz2 = c->zw  - a->zw;
-    const float dr1 = b->red - a->red, dr2 = c->red - a->red;
-    t->fx0 = a->fx; t->fy0 = a->fy;
-    t->z0  = a->zw;
-    t->dzdx = (dz1*ey2 - dz2*ey1) / af;
-    t->dzdy = (dz2*ex1 - dz1*ex2) / af;
-    t->r0  = a->red;
-    t->drdx = (dr1*ey2 - dr2*ey1) / af;
-    t->drdy = (dr2*ex1 - dr1*ex2) / af;
+    const hz_wvert_t *v0 = b, *v1 = a, *v2 = c;
+    const float dx01 = v0->wx - v1->wx, dy01 = v0->wy - v1->wy;
+    const float dx20 = v2->wx - v0->wx, dy20 = v2->wy - v0->wy;
+    const float ooa  = 1.0f / (dx01*dy20 - dx20*dy01);
+    const float dy20_ooa = dy20*ooa, dy01_ooa = dy01*ooa, dx20_ooa = dx20*ooa, dx01_ooa = dx01*ooa;
+    const float x0c = v0->wx - 0.5f, y0c = v0->wy - 0.5f;
+    const float dz01 = v0->zw  - v1->zw,  dz20 = v2->zw  - v0->zw;
+    const float dr01 = v0->red - v1->red, dr20 = v2->red - v0->red;
+    t->dzdx  = dz01*dy20_ooa - dz20*dy01_ooa;
+    t->dzdy  = dz20*dx01_ooa - dz01*dx20_ooa;
+    t->z_org = v0->zw  - (t->dzdx*x0c + t->dzdy*y0c);
+    t->drdx  = dr01*dy20_ooa - dr20*dy01_ooa;
+    t->drdy  = dr20*dx01_ooa - dr01*dx20_ooa;
+    t->r_org = v0->red - (t->drdx*x0c + t->drdy*y0c);
 }
 
 /* edge function of edge m (vertex m -> m+1) at pixel centre (px,py), and
@@ -181,13 +191,12 @@ HZ_HD int hz_tri_covers(const hz_tri_t* t, int px, int py)
  * by the near/far spheres or cannot beat the cleared depth */
 HZ_HD int hz_tri_fragment(const hz_tri_t* t, int px, int py, uint32_t* zi, uint32_t* r8)
 {
-    const float dx = (float)px - t->fx0;
-    const float dy = (float)py - t->fy0;
-    const float z  = t->z0 + (t->dzdx*dx + t->dzdy*dy);
+    const float fpx = (float)px, fpy = (float)py;
+    const float z = __builtin_fmaf(t->dzdy, fpy, __builtin_fmaf(t->dzdx, fpx, t->z_org));
     if(!(z >= 0.f && z <= 1.f)) return 0;
     const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
     if(q >= HZ_Z24_MAX) return 0;
-    float r = t->r0 + (t->drdx*dx + t->drdy*dy);
+    float r = __builtin_fmaf(t->drdy, fpy, __builtin_fmaf(t->drdx, fpx, t->r_org));
     r = hz_max(hz_min(r, 1.0f), 0.0f);
     *zi = q;
     *r8 = (uint32_t)hz_roundeven(r * 255.f);

@@ -136,9 +136,9 @@ void orc_vertex(const orc_view_t* v, int i, int j, int z, float out_xyzr[4])
 
 /* ---- rasteriser --------------------------------------------------------- */
 
-/* a vertex after the viewport transform.  (fx,fy) are window coordinates
- * minus one half, so pixel centres sit at integers */
-typedef struct { float xn, fx, fy, zw, red; } wvert_t;
+/* a vertex after the viewport transform: window coordinates (pixel centres at
+ * half-integers), depth in [0,1], colour */
+typedef struct { float xn, wx, wy, zw, red; } wvert_t;
 
 #define GUARD_PX 2097152.0f
 
@@ -158,18 +158,22 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
     float xmin = A->xn < B->xn ? A->xn : B->xn; xmin = xmin < C->xn ? xmin : C->xn;
     if(xmax - xmin > 0.5f) return;
 
+    /* positions relative to the pixel-centre grid (llvmpipe's "pixel offset"):
+     * centres at integers */
+    const wvert_t* V[3] = {A,B,C};
+    float fx[3], fy[3];
+    for(int m=0; m<3; m++) { fx[m] = V[m]->wx - 0.5f; fy[m] = V[m]->wy - 0.5f; }
+
     /* guard band (also catches non-finite positions) */
-    if(!(fabsf(A->fx) <= GUARD_PX && fabsf(A->fy) <= GUARD_PX &&
-         fabsf(B->fx) <= GUARD_PX && fabsf(B->fy) <= GUARD_PX &&
-         fabsf(C->fx) <= GUARD_PX && fabsf(C->fy) <= GUARD_PX)) return;
+    for(int m=0; m<3; m++)
+        if(!(fabsf(fx[m]) <= GUARD_PX && fabsf(fy[m]) <= GUARD_PX)) return;
 
     /* positions snapped to 1/256 pixel decide coverage and facing */
-    const wvert_t* V[3] = {A,B,C};
     int64_t X[3], Y[3];
     for(int m=0; m<3; m++)
     {
-        X[m] = (int64_t)rintf(V[m]->fx * 256.f);
-        Y[m] = (int64_t)rintf(V[m]->fy * 256.f);
+        X[m] = (int64_t)rintf(fx[m] * 256.f);
+        Y[m] = (int64_t)rintf(fy[m] * 256.f);
     }
     /* glEnable(GL_CULL_FACE), default GL_BACK / GL_CCW (reference
      * horizonator-lib.c:184): counter-clockwise in window space is front */
@@ -197,16 +201,27 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
     if((A->zw < 0.f && B->zw < 0.f && C->zw < 0.f) ||
        (A->zw > 1.f && B->zw > 1.f && C->zw > 1.f)) return;
 
-    /* depth and colour are planes through the unsnapped positions */
-    float ex1 = B->fx - A->fx, ey1 = B->fy - A->fy;
-    float ex2 = C->fx - A->fx, ey2 = C->fy - A->fy;
-    float af  = ex1*ey2 - ex2*ey1;
-    float dz1 = B->zw  - A->zw,  dz2 = C->zw  - A->zw;
-    float dr1 = B->red - A->red, dr2 = C->red - A->red;
-    float dzdx = (dz1*ey2 - dz2*ey1) / af;
-    float dzdy = (dz2*ex1 - dz1*ex2) / af;
-    float drdx = (dr1*ey2 - dr2*ey1) / af;
-    float drdy = (dr2*ex1 - dr1*ex2) / af;
+    /* Depth and colour are planes through the unsnapped positions, set up and
+     * evaluated the way llvmpipe does it (pinned on the golden draws: with this
+     * arithmetic the depth of every unclipped triangle comes out bit-identical):
+     *   - llvmpipe sees the front faces of an FBO draw as clockwise and swaps
+     *     the first two vertices: its v0 is the SECOND vertex of the draw call
+     *   - gradients through ooa = 1/area and four pre-multiplied edge deltas
+     *   - a0 = value at the window origin, value(px,py) = fma(dady,py, fma(dadx,px,a0)) */
+    const wvert_t *v0 = B, *v1 = A, *v2 = C;
+    float dx01 = v0->wx - v1->wx, dy01 = v0->wy - v1->wy;
+    float dx20 = v2->wx - v0->wx, dy20 = v2->wy - v0->wy;
+    float ooa  = 1.0f / (dx01*dy20 - dx20*dy01);
+    float dy20_ooa = dy20*ooa, dy01_ooa = dy01*ooa, dx20_ooa = dx20*ooa, dx01_ooa = dx01*ooa;
+    float x0_center = v0->wx - 0.5f, y0_center = v0->wy - 0.5f;
+    float dz01 = v0->zw  - v1->zw,  dz20 = v2->zw  - v0->zw;
+    float dr01 = v0->red - v1->red, dr20 = v2->red - v0->red;
+    float dzdx = dz01*dy20_ooa - dz20*dy01_ooa;
+    float dzdy = dz20*dx01_ooa - dz01*dx20_ooa;
+    float z_org = v0->zw  - (dzdx*x0_center + dzdy*y0_center);
+    float drdx = dr01*dy20_ooa - dr20*dy01_ooa;
+    float drdy = dr20*dx01_ooa - dr01*dx20_ooa;
+    float r_org = v0->red - (drdx*x0_center + drdy*y0_center);
 
     for(int64_t py=py0; py<=py1; py++)
         for(int64_t px=px0; px<=px1; px++)
@@ -226,16 +241,14 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
             }
             if(!inside) continue;
 
-            float ddx = (float)px - A->fx;
-            float ddy = (float)py - A->fy;
-            float z = A->zw + (dzdx*ddx + dzdy*ddy);
+            float z = fmaf(dzdy, (float)py, fmaf(dzdx, (float)px, z_org));
             if(!(z >= 0.f && z <= 1.f)) continue;          /* depth clip */
             uint32_t zi = (uint32_t)rintf(z * 16777215.f); /* 24-bit unorm */
 
             const size_t at = (size_t)py*fb->SW + (size_t)(px - fb->col0);
             if(!(zi < fb->depth[at])) continue;             /* GL_LESS */
 
-            float r = A->red + (drdx*ddx + drdy*ddy);
+            float r = fmaf(drdy, (float)py, fmaf(drdx, (float)px, r_org));
             r = r < 1.0f ? r : 1.0f;
             r = r > 0.0f ? r : 0.0f;
             fb->depth[at] = zi;
@@ -304,8 +317,8 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
             ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
             wvert_t* w = &vert[(size_t)j*N + i];
             w->xn  = o.x;
-            w->fx  = (o.x*halfW + halfW) - 0.5f;
-            w->fy  = (o.y*halfH + halfH) - 0.5f;
+            w->wx  = o.x*halfW + halfW;
+            w->wy  = o.y*halfH + halfH;
             w->zw  = o.z*0.5f + 0.5f;
             w->red = o.red;
         }
@@ -396,7 +409,7 @@ void orc_stats(const int16_t* mosaic, int N, const orc_view_t* v, int W, int H,
         {
             ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
             wvert_t* w = &row1[i];
-            w->xn = o.x; w->fx = (o.x*halfW + halfW) - 0.5f; w->fy = (o.y*halfH + halfH) - 0.5f;
+            w->xn = o.x; w->wx = o.x*halfW + halfW; w->wy = o.y*halfH + halfH;
             w->zw = o.z*0.5f + 0.5f; w->red = o.red;
         }
         if(j > 0)
@@ -410,12 +423,14 @@ void orc_stats(const int16_t* mosaic, int N, const orc_view_t* v, int W, int H,
                     float xmax = fmaxf(fmaxf(A->xn,B->xn),C->xn), xmin = fminf(fminf(A->xn,B->xn),C->xn);
                     if(xmax - xmin > 0.5f) continue;
                     counts[1]++;
-                    if(!(fabsf(A->fx) <= GUARD_PX && fabsf(A->fy) <= GUARD_PX && fabsf(B->fx) <= GUARD_PX &&
-                         fabsf(B->fy) <= GUARD_PX && fabsf(C->fx) <= GUARD_PX && fabsf(C->fy) <= GUARD_PX)) continue;
-                    counts[2]++;
                     const wvert_t* V[3] = {A,B,C};
+                    int guard_ok = 1;
+                    for(int m=0; m<3; m++)
+                        if(!(fabsf(V[m]->wx - 0.5f) <= GUARD_PX && fabsf(V[m]->wy - 0.5f) <= GUARD_PX)) guard_ok = 0;
+                    if(!guard_ok) continue;
+                    counts[2]++;
                     int64_t X[3], Y[3];
-                    for(int m=0; m<3; m++) { X[m] = (int64_t)rintf(V[m]->fx*256.f); Y[m] = (int64_t)rintf(V[m]->fy*256.f); }
+                    for(int m=0; m<3; m++) { X[m] = (int64_t)rintf((V[m]->wx - 0.5f)*256.f); Y[m] = (int64_t)rintf((V[m]->wy - 0.5f)*256.f); }
                     int64_t area = (X[1]-X[0])*(Y[2]-Y[0]) - (X[2]-X[0])*(Y[1]-Y[0]);
                     if(area <= 0) continue;
                     counts[3]++;
