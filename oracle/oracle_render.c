@@ -245,8 +245,10 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
             if(!(z >= 0.f && z <= 1.f)) continue;          /* depth clip */
             uint32_t zi = (uint32_t)rintf(z * 16777215.f); /* 24-bit unorm */
 
+            /* GL_LESS against what was drawn before; among equal depths the
+             * triangle drawn first (lowest primitive id) stays */
             const size_t at = (size_t)py*fb->SW + (size_t)(px - fb->col0);
-            if(!(zi < fb->depth[at])) continue;             /* GL_LESS */
+            if(!(zi < fb->depth[at] || (zi == fb->depth[at] && zi != 0xFFFFFFu && prim < fb->prim[at]))) continue;
 
             float r = fmaf(drdy, (float)py, fmaf(drdx, (float)px, r_org));
             r = r < 1.0f ? r : 1.0f;
@@ -323,9 +325,42 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
             w->red = o.red;
         }
 
-    /* triangles in index-buffer order (reference horizonator-lib.c:496-508).
-     * Threads own disjoint column strips, so within a strip the draw order,
-     * and with it the outcome of equal-depth ties, is the sequential one */
+    /* Triangles of the index buffer (reference horizonator-lib.c:496-508).
+     * GL draws them in order and keeps the first of equal depths (GL_LESS);
+     * draw_triangle() implements that as "lower depth wins, then lower
+     * primitive id", which does not depend on the order of processing.  So the
+     * grid can be walked in blocks of 32x32 cells, threads owning disjoint
+     * column strips of the image and skipping the blocks whose window x-range
+     * (from their 33x33 vertices) misses their strip. */
+    enum { BLK = 32 };
+    const int nb = (N-1 + BLK-1)/BLK;
+    int* blk_lo = malloc((size_t)nb*nb*sizeof(int));
+    int* blk_hi = malloc((size_t)nb*nb*sizeof(int));
+    if(!blk_lo || !blk_hi)
+    {
+        free(blk_lo); free(blk_hi);
+        free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
+        return -1;
+    }
+    #pragma omp parallel for schedule(dynamic,8) num_threads(nthreads)
+    for(int b=0; b<nb*nb; b++)
+    {
+        const int jb = (b/nb)*BLK, ib = (b%nb)*BLK;
+        float lo = INFINITY, hi = -INFINITY, nlo = INFINITY, nhi = -INFINITY;
+        for(int j=jb; j<=jb+BLK && j<N; j++)
+            for(int i=ib; i<=ib+BLK && i<N; i++)
+            {
+                const wvert_t* w = &vert[(size_t)j*N + i];
+                if(!(w->wx >= lo)) lo = w->wx;      /* NaN-proof: a NaN widens the range */
+                if(!(w->wx <= hi)) hi = w->wx;
+                if(w->xn < nlo) nlo = w->xn;
+                if(w->xn > nhi) nhi = w->xn;
+            }
+        /* a block that reaches across the +-180 degree seam (or holds the
+         * viewer) spans the image: keep it for every strip */
+        if(!(lo == lo) || !(hi == hi) || nhi - nlo > 0.5f) { blk_lo[b] = INT32_MIN; blk_hi[b] = INT32_MAX; }
+        else { blk_lo[b] = (int)floorf(fmaxf(lo, -1e9f)) - 2; blk_hi[b] = (int)ceilf(fminf(hi, 1e9f)) + 2; }
+    }
     #pragma omp parallel num_threads(nthreads)
     {
 #ifdef _OPENMP
@@ -336,18 +371,24 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
         const int x_lo = col0 + (int)((long long)SW*tid/nth);
         const int x_hi = col0 + (int)((long long)SW*(tid+1)/nth) - 1;
         if(x_lo <= x_hi)
-            for(int j=0; j<N-1; j++)
-                for(int i=0; i<N-1; i++)
-                {
-                    const wvert_t* v00 = &vert[(size_t)(j  )*N + i  ];
-                    const wvert_t* v10 = &vert[(size_t)(j  )*N + i+1];
-                    const wvert_t* v01 = &vert[(size_t)(j+1)*N + i  ];
-                    const wvert_t* v11 = &vert[(size_t)(j+1)*N + i+1];
-                    const int32_t prim = (int32_t)(((int64_t)j*(N-1) + i)*2);
-                    draw_triangle(&fb, x_lo, x_hi, v00, v11, v01, prim  );
-                    draw_triangle(&fb, x_lo, x_hi, v00, v10, v11, prim+1);
-                }
+            for(int b=0; b<nb*nb; b++)
+            {
+                if(blk_hi[b] < x_lo || blk_lo[b] > x_hi) continue;
+                const int jb = (b/nb)*BLK, ib = (b%nb)*BLK;
+                for(int j=jb; j<jb+BLK && j<N-1; j++)
+                    for(int i=ib; i<ib+BLK && i<N-1; i++)
+                    {
+                        const wvert_t* v00 = &vert[(size_t)(j  )*N + i  ];
+                        const wvert_t* v10 = &vert[(size_t)(j  )*N + i+1];
+                        const wvert_t* v01 = &vert[(size_t)(j+1)*N + i  ];
+                        const wvert_t* v11 = &vert[(size_t)(j+1)*N + i+1];
+                        const int32_t prim = (int32_t)(((int64_t)j*(N-1) + i)*2);
+                        draw_triangle(&fb, x_lo, x_hi, v00, v11, v01, prim  );
+                        draw_triangle(&fb, x_lo, x_hi, v00, v10, v11, prim+1);
+                    }
+            }
     }
+    free(blk_lo); free(blk_hi);
 
     /* readback (reference horizonator-lib.c:936-1048) */
     orc_tanel(tanel, W, H, v->az_deg0, v->az_deg1);
