@@ -448,7 +448,7 @@ void k_big(unsigned long long* __restrict__ fb,
 
 #define MR_COLS   63
 #define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
-#define MR_RSLOTS 8                 /* vertex rows kept in LDS (power of two)       */
+#define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one

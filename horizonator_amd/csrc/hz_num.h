@@ -47,11 +47,11 @@ HZ_HD float hz_atan2(float y, float x)
     const float ax    = hz_abs(x);
     const float s     = flip ? ax : y;
     const float t     = flip ? y  : ax;
-    /* Mesa scales huge denominators by 1/4 before the reciprocal; everywhere
-     * else the scale is 1.0 and multiplying by it changes nothing */
-    float rcp, sot;
-    if(hz_abs(t) >= 1e18f) { rcp = 1.0f / (t*0.25f); sot = (s*0.25f) * rcp; }
-    else                   { rcp = 1.0f / t;         sot = s * rcp;         }
+    /* Mesa scales huge denominators by 1/4 before the reciprocal (kept as a
+     * multiplication by a selected constant: branch-free) */
+    const float scale = (hz_abs(t) >= 1e18f) ? 0.25f : 1.0f;
+    const float rcp   = 1.0f / (t*scale);
+    const float sot   = (s*scale) * rcp;
     const float tn    = (ax == hz_abs(y)) ? 1.0f : hz_abs(sot);
 
     /* atan(tn), tn >= 0, through atan(min(tn,1)/max(tn,1)) */
