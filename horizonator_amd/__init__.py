@@ -242,6 +242,39 @@ class horizonator:
             raise RuntimeError("horizonator_amd_get_mosaic() failed")
         return m
 
+    def link_cells(self, cell_width=14, cell_height=14, cut_off_bottom_px=0):
+        """lat/lon under the centre of every cell of the last render that shows
+        terrain (what the reference's annotator turns into map links, reference
+        annotator.c:228-264), computed on the device: (lat, lon) float32[ny,nx],
+        NaN where the cell shows sky."""
+        nx, ny = C.c_int(), C.c_int()
+        ctx = C.byref(self._ctx)
+        if not self._lib.horizonator_amd_link_cells_size(ctx, cell_width, cell_height, cut_off_bottom_px,
+                                                         C.byref(nx), C.byref(ny)):
+            raise RuntimeError("horizonator_amd_link_cells_size() failed")
+        lat = np.full((ny.value, nx.value), np.nan, np.float32)
+        lon = np.full((ny.value, nx.value), np.nan, np.float32)
+        if nx.value and ny.value:
+            if not self._lib.horizonator_amd_link_cells(ctx, cell_width, cell_height, cut_off_bottom_px,
+                                                        lat.ctypes.data, lon.ctypes.data):
+                raise RuntimeError("horizonator_amd_link_cells() failed")
+        return lat, lon
+
+    def poi_visibility(self, pois, cut_off_bottom_px=0):
+        """pois: float32[n,3] = lat, lon, elevation (m).  Which of them show in
+        the last render and where their label crosshair goes (reference
+        annotator.c:280-348), computed on the device: (visible uint8[n],
+        x float32[n], y float32[n])."""
+        pois = np.ascontiguousarray(pois, np.float32).reshape(-1, 3)
+        n = pois.shape[0]
+        vis = np.zeros(n, np.uint8)
+        x = np.zeros(n, np.float32)
+        y = np.zeros(n, np.float32)
+        if not self._lib.horizonator_amd_poi_visibility(C.byref(self._ctx), cut_off_bottom_px, pois.ctypes.data, n,
+                                                        vis.ctypes.data, x.ctypes.data, y.ctypes.data):
+            raise RuntimeError("horizonator_amd_poi_visibility() failed")
+        return vis, x, y
+
     def pick(self, x, y):
         """(lat, lon) of the terrain under image pixel (x, y), or None for sky
         (reference horizonator.h:145-152)."""

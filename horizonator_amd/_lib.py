@@ -123,6 +123,9 @@ def load():
     sig("horizonator_amd_get_view", b, ctxp, P(View))
     sig("horizonator_amd_device", vp, ctxp)
     sig("horizonator_amd_get_mosaic", b, ctxp, vp)
+    sig("horizonator_amd_link_cells_size", b, ctxp, i, i, i, P(i), P(i))
+    sig("horizonator_amd_link_cells", b, ctxp, i, i, i, vp, vp)
+    sig("horizonator_amd_poi_visibility", b, ctxp, i, vp, i, vp, vp, vp)
 
     sig("hz_hip_device_count", i)
     sig("hz_hip_create", vp, i, i, i, i)
@@ -137,6 +140,8 @@ def load():
     sig("hz_hip_resolve", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_resolve_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_read_depth", i, vp, i, i, P(C.c_uint32))
+    sig("hz_hip_link_cells", i, vp, P(View), vp, d, d, i, i, i, i, i, vp, vp)
+    sig("hz_hip_poi_visibility", i, vp, P(View), vp, d, d, d, i, vp, i, vp, vp, vp)
     sig("hz_hip_sync", i, vp)
     sig("hz_hip_last_times", i, vp, P(Times))
     sig("hz_hip_stream", vp, vp)
@@ -159,12 +164,13 @@ DECLARED_SYMBOLS = [
     "horizonator_amd_render", "horizonator_amd_render_device", "horizonator_amd_sync",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
-    "horizonator_amd_get_mosaic",
+    "horizonator_amd_get_mosaic", "horizonator_amd_link_cells_size", "horizonator_amd_link_cells",
+    "horizonator_amd_poi_visibility",
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
     "hz_hip_set_profiling", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
-    "hz_hip_read_depth", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_last_error",
+    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_last_error",
 ]
 
 

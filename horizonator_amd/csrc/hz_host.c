@@ -554,6 +554,55 @@ hz_dev_t* horizonator_amd_device(const horizonator_context_t* ctx)
     return s ? s->dev : NULL;
 }
 
+bool horizonator_amd_link_cells_size(const horizonator_context_t* ctx, int cell_width, int cell_height,
+                                     int cut_off_bottom_px, int* nx, int* ny)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || cell_width <= 0 || cell_height <= 0) return false;
+    /* the loops of reference annotator.c:230-232 */
+    const int height_out = s->height - cut_off_bottom_px;
+    int cx = 0, cy = 0;
+    for(int x=0; x<s->width-cell_width; x += cell_width) cx++;
+    for(int y=0; y<height_out-cell_height; y += cell_height) cy++;
+    *nx = cx; *ny = cy;
+    return true;
+}
+
+bool horizonator_amd_link_cells(const horizonator_context_t* ctx, int cell_width, int cell_height,
+                                int cut_off_bottom_px, float* lat, float* lon)
+{
+    hz_state_t* s = live_state(ctx);
+    int nx, ny;
+    if(s == NULL || !horizonator_amd_link_cells_size(ctx, cell_width, cell_height, cut_off_bottom_px, &nx, &ny))
+        return false;
+    if(nx == 0 || ny == 0) return true;
+    fill_tanel(s);
+    if(0 != hz_hip_link_cells(s->dev, &s->view, s->tanel, (double)ctx->viewer_lat, (double)ctx->viewer_lon,
+                              cell_width, cell_height, cut_off_bottom_px, nx, ny, lat, lon))
+    {
+        MSG("%s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool horizonator_amd_poi_visibility(const horizonator_context_t* ctx, int cut_off_bottom_px,
+                                    const hz_poi_t* pois, int npois,
+                                    unsigned char* visible, float* label_x, float* label_y)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    fill_tanel(s);
+    if(0 != hz_hip_poi_visibility(s->dev, &s->view, s->tanel,
+                                  (double)ctx->viewer_lat, (double)ctx->viewer_lon, (double)s->view.viewer_z,
+                                  cut_off_bottom_px, pois, npois, visible, label_x, label_y))
+    {
+        MSG("%s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
 bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic)
 {
     hz_state_t* s = live_state(ctx);

@@ -1345,6 +1345,203 @@ extern "C" int hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24)
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* consumers of the range image (annotator passes)                           */
+
+/* range of framebuffer word `key` in GL row `row`, as k_resolve computes it */
+__device__ static inline float hz_range_of(unsigned long long key, float tanel_row, float znear, float zfar)
+{
+    const uint32_t zi = (uint32_t)(key >> 40);
+    if(zi == HZ_Z24_MAX) return -1.0f;
+    const float depth = (float)((double)zi * (1.0/16777215.0));
+    const float len   = depth * (zfar-znear) + znear;
+    const float zt    = tanel_row * len;
+    return (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
+}
+
+/* reference horizonator_unproject (horizonator-lib.c:1157-1213), range_enh given */
+__device__ static inline void hz_unproject_enh(float* lat, float* lon, int x, int y, double range_enh,
+                                               double lat_viewer, double cos_lat_viewer, double lon_viewer,
+                                               double az_deg0, double az_deg1, int width, int height)
+{
+    const float Rearth = 6371000.0;
+    float az_ndc = ((float)x + 0.5f) / (float)width * 2.f - 1.f;
+    float az     = (az_ndc * (az_deg1-az_deg0) / 2.f + (az_deg1+az_deg0)/2.f) * M_PI/180.0f;
+    double aspect = (double)width / (double)height;
+    double el_ndc = ((double)y + 0.5) / (double)height * 2. - 1.;
+    double el     = el_ndc * (az_deg1-az_deg0) / 2. / aspect * M_PI/180.0;
+    double range_en = cos(el) * range_enh;
+    float e = range_en * sinf(az);
+    float n = range_en * cosf(az);
+    *lon = lon_viewer + e / Rearth / M_PI * 180. / cos_lat_viewer;
+    *lat = lat_viewer + n / Rearth / M_PI * 180.;
+}
+
+__global__ __launch_bounds__(256)
+void k_link_cells(const unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
+                  float* __restrict__ lat, float* __restrict__ lon,
+                  int W, int H, int cell_w, int cell_h, int nx, int ny,
+                  float znear, float zfar, double viewer_lat, double cos_viewer_lat, double viewer_lon,
+                  double az_deg0, double az_deg1)
+{
+    const int c = blockIdx.x*blockDim.x + threadIdx.x;
+    if(c >= nx*ny) return;
+    const int cy = c / nx, cx = c - cy*nx;
+    const int x = cx*cell_w, y = cy*cell_h;            /* image pixel, y = 0 top */
+    const int row = H-1-y;
+    const float range = hz_range_of(fb[(size_t)row*W + x], tanel[row], znear, zfar);
+    float la = __builtin_nanf(""), lo = __builtin_nanf("");
+    if(range > 0.0f)                                    /* reference annotator.c:236-238 */
+        hz_unproject_enh(&la, &lo, x + cell_w/2, y + cell_h/2, (double)range,
+                         viewer_lat, cos_viewer_lat, viewer_lon, az_deg0, az_deg1, W, H);
+    lat[c] = la; lon[c] = lo;
+}
+
+/* reference horizonator-lib.c:1053-1095 */
+__device__ static inline double hz_unwrap_d(double x, double near)
+{
+    const double d = (x - near) / (2.*M_PI);
+    return (d - round(d)) * 2.*M_PI + near;
+}
+
+__global__ __launch_bounds__(256)
+void k_poi(const unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
+           const hz_poi_t* __restrict__ pois, int npois,
+           unsigned char* __restrict__ visible, float* __restrict__ label_x, float* __restrict__ label_y,
+           int W, int H, int height_out, float znear, float zfar,
+           double lat_viewer, double cos_lat_viewer, double lon_viewer, double ele_viewer,
+           double az_rad0, double az_rad1)
+{
+    const int k = blockIdx.x*blockDim.x + threadIdx.x;
+    if(k >= npois) return;
+    visible[k] = 0; label_x[k] = 0.f; label_y[k] = 0.f;
+
+    /* reference horizonator_project (horizonator-lib.c:1097-1155) */
+    const float Rearth = 6371000.0;
+    const double dlat = ((double)pois[k].lat - lat_viewer)*M_PI/180;
+    const double dlon = ((double)pois[k].lon - lon_viewer)*M_PI/180;
+    const double east  = dlon * Rearth * cos_lat_viewer;
+    const double north = dlat * Rearth;
+    const double d2    = east*east + north*north;
+    double a1 = hz_unwrap_d(az_rad1-az_rad0, M_PI) + az_rad0;
+    const double center = (az_rad0 + a1)/2.;
+    const double az = hz_unwrap_d(atan2(east, north), center);
+    const double kk = 2.0 / (a1 - az_rad0);
+    const double az_ndc = (az - center) * kk;
+    if(!(-1. <= az_ndc && az_ndc <= 1.)) return;
+    const double cx = (az_ndc + 1.)/2.*W - 0.5;
+    const double h = (double)pois[k].ele_m - ele_viewer;
+    const double d_ne = sqrt(d2);
+    const double range_have = sqrt(d2 + h*h);
+    const double aspect = (double)W / (double)H;
+    const double el_ndc = atan2(h, d_ne) * aspect * kk;
+    if(!(-1. <= el_ndc && el_ndc <= 1.)) return;
+    const double cy = (-el_ndc + 1.)/2.*H - 0.5;
+
+    /* reference annotator.c:297-347 */
+    if(range_have < 500.0 || range_have > 100000.0) return;
+    int    fuzz_nearest = 0;
+    double err_nearest  = 1.7976931348623157e308;
+    const int xi = (int)round(cx), yi = (int)round(cy);
+    for(int fuzz = -6; fuzz < 6; fuzz++)
+    {
+        if(cy + (double)fuzz < 0) continue;
+        if(cy + (double)fuzz >= height_out) break;
+        const int y = yi + fuzz;
+        if(y < 0 || y >= H || xi < 0 || xi >= W) continue;   /* the reference reads out of bounds here */
+        const int row = H-1-y;
+        const float range = hz_range_of(fb[(size_t)row*W + xi], tanel[row], znear, zfar);
+        if(range <= 0.0f) continue;
+        const double err = fabs(range_have - (double)range);
+        if(err < err_nearest) { err_nearest = err; fuzz_nearest = fuzz; }
+        else break;
+    }
+    if(err_nearest < 500.)
+    {
+        visible[k] = 1;
+        label_x[k] = (float)cx;
+        label_y[k] = (float)(cy + (float)fuzz_nearest);
+    }
+}
+
+static int upload_tanel(hz_dev_t* d, const float* tanel)
+{
+    if(!tanel) { snprintf(g_last_error, sizeof(g_last_error), "a tanel table is required"); return -1; }
+    HZ_CHECK(hipMemcpyAsync(d->d_tanel, tanel, (size_t)d->H*sizeof(float), hipMemcpyHostToDevice, d->stream));
+    return 0;
+}
+
+extern "C" int hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                                 double viewer_lat, double viewer_lon,
+                                 int cell_w, int cell_h, int cut_off_bottom_px,
+                                 int nx, int ny, float* lat, float* lon)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    if(d->col0 != 0 || d->col1 != d->W || cell_w <= 0 || cell_h <= 0 || nx <= 0 || ny <= 0)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells: needs a full-width context and positive sizes");
+        return -1;
+    }
+    (void)cut_off_bottom_px;
+    if(upload_tanel(d, tanel) != 0) return -1;
+    float *d_lat = NULL, *d_lon = NULL;
+    const size_t n = (size_t)nx*ny;
+    HZ_CHECK(hipMalloc(&d_lat, n*sizeof(float)));
+    HZ_CHECK(hipMalloc(&d_lon, n*sizeof(float)));
+    hipLaunchKernelGGL(k_link_cells, dim3((unsigned)((n + 255)/256)), dim3(256), 0, d->stream,
+                       (const unsigned long long*)d->d_fb, (const float*)d->d_tanel, d_lat, d_lon,
+                       d->W, d->H, cell_w, cell_h, nx, ny, view->znear, view->zfar,
+                       viewer_lat, cos(viewer_lat * M_PI/180.), viewer_lon,
+                       (double)view->az_deg0, (double)view->az_deg1);
+    int rc = hipGetLastError() == hipSuccess ? 0 : -1;
+    if(rc == 0 && hipMemcpyAsync(lat, d_lat, n*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0 && hipMemcpyAsync(lon, d_lon, n*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
+    if(hipStreamSynchronize(d->stream) != hipSuccess) rc = -1;
+    (void)hipFree(d_lat); (void)hipFree(d_lon);
+    if(rc != 0) snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells failed");
+    return rc;
+}
+
+extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                                     double viewer_lat, double viewer_lon, double viewer_ele_m,
+                                     int cut_off_bottom_px,
+                                     const hz_poi_t* pois, int npois,
+                                     unsigned char* visible, float* label_x, float* label_y)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    if(d->col0 != 0 || d->col1 != d->W || npois < 0)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_poi_visibility: needs a full-width context");
+        return -1;
+    }
+    if(npois == 0) return 0;
+    if(upload_tanel(d, tanel) != 0) return -1;
+    hz_poi_t* d_pois = NULL; unsigned char* d_vis = NULL; float *d_x = NULL, *d_y = NULL;
+    HZ_CHECK(hipMalloc(&d_pois, (size_t)npois*sizeof(hz_poi_t)));
+    HZ_CHECK(hipMalloc(&d_vis, (size_t)npois));
+    HZ_CHECK(hipMalloc(&d_x, (size_t)npois*sizeof(float)));
+    HZ_CHECK(hipMalloc(&d_y, (size_t)npois*sizeof(float)));
+    int rc = 0;
+    if(hipMemcpyAsync(d_pois, pois, (size_t)npois*sizeof(hz_poi_t), hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0)
+    {
+        hipLaunchKernelGGL(k_poi, dim3((unsigned)((npois + 255)/256)), dim3(256), 0, d->stream,
+                           (const unsigned long long*)d->d_fb, (const float*)d->d_tanel,
+                           (const hz_poi_t*)d_pois, npois, d_vis, d_x, d_y,
+                           d->W, d->H, d->H - cut_off_bottom_px, view->znear, view->zfar,
+                           viewer_lat, cos(viewer_lat * M_PI/180.), viewer_lon, viewer_ele_m,
+                           (double)view->az_deg0 * M_PI/180., (double)view->az_deg1 * M_PI/180.);
+        if(hipGetLastError() != hipSuccess) rc = -1;
+    }
+    if(rc == 0 && hipMemcpyAsync(visible, d_vis, (size_t)npois, hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0 && hipMemcpyAsync(label_x, d_x, (size_t)npois*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0 && hipMemcpyAsync(label_y, d_y, (size_t)npois*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
+    if(hipStreamSynchronize(d->stream) != hipSuccess) rc = -1;
+    (void)hipFree(d_pois); (void)hipFree(d_vis); (void)hipFree(d_x); (void)hipFree(d_y);
+    if(rc != 0) snprintf(g_last_error, sizeof(g_last_error), "hz_hip_poi_visibility failed");
+    return rc;
+}
+
 extern "C" int hz_hip_sync(hz_dev_t* d)
 {
     HZ_CHECK(hipSetDevice(d->device));

@@ -49,6 +49,17 @@ bool horizonator_amd_last_times(const horizonator_context_t* ctx, hz_times_t* ti
 bool      horizonator_amd_get_view(const horizonator_context_t* ctx, hz_view_t* view);
 hz_dev_t* horizonator_amd_device  (const horizonator_context_t* ctx);
 
+/* Annotator passes over the range image of the last draw, on the device
+ * (see hz_hip.h: hz_hip_link_cells, hz_hip_poi_visibility).  Viewer position,
+ * height and azimuth extents are those of the context. */
+bool horizonator_amd_link_cells_size(const horizonator_context_t* ctx, int cell_width, int cell_height,
+                                     int cut_off_bottom_px, int* nx, int* ny);
+bool horizonator_amd_link_cells(const horizonator_context_t* ctx, int cell_width, int cell_height,
+                                int cut_off_bottom_px, float* lat, float* lon);
+bool horizonator_amd_poi_visibility(const horizonator_context_t* ctx, int cut_off_bottom_px,
+                                    const hz_poi_t* pois, int npois,
+                                    unsigned char* visible, float* label_x, float* label_y);
+
 /* copy of the N x N int16 mosaic as it sits in HBM (tests) */
 bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic);
 

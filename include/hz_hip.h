@@ -119,6 +119,36 @@ int  hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tan
  * (reference horizonator-lib.c:1268-1270) */
 int  hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24);
 
+/* ---- consumers of the range image ("next" row N2) ---------------------------
+ * The two passes the reference's annotator makes over the range image
+ * (reference annotator.c:228-264 and :280-348), on the device, reading the
+ * framebuffer of the last draw: the full-size range image never has to leave
+ * the GPU for them. */
+
+/* For every cell of cell_w x cell_h pixels (x = 0, cell_w, ... < W-cell_w;
+ * y likewise below height_out = H - cut_off_bottom_px) whose top-left pixel
+ * shows terrain: latitude/longitude under the cell centre (reference
+ * horizonator_unproject with range_enh = range of that pixel).  lat/lon are
+ * HOST arrays [ny][nx]; NaN where the cell has no terrain.  Full-width
+ * contexts only (sector = whole image). */
+int  hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                       double viewer_lat, double viewer_lon,
+                       int cell_w, int cell_h, int cut_off_bottom_px,
+                       int nx, int ny, float* lat, float* lon);
+
+typedef struct { float lat, lon, ele_m; } hz_poi_t;
+
+/* For every point of interest: is it visible in the last draw, and where does
+ * its label crosshair go (reference annotator.c:280-348: project, distance
+ * window 500 m .. 100 km, vertical search of +-6 pixels in the range image for
+ * the range closest to the expected one, accepted within 500 m).  Outputs are
+ * HOST arrays of npois: visible (0/1), label_x, label_y (pixels). */
+int  hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                           double viewer_lat, double viewer_lon, double viewer_ele_m,
+                           int cut_off_bottom_px,
+                           const hz_poi_t* pois, int npois,
+                           unsigned char* visible, float* label_x, float* label_y);
+
 int  hz_hip_sync(hz_dev_t* d);
 int  hz_hip_last_times(hz_dev_t* d, hz_times_t* t);
 

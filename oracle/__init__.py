@@ -65,6 +65,16 @@ def load():
     lib.orc_render.restype = C.c_int
     lib.orc_render.argtypes = [C.c_void_p, C.c_int, P(OrcView), C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    d = C.c_double
+    lib.orc_project.restype = C.c_int
+    lib.orc_project.argtypes = [P(d), P(d), P(d), d, d, d, d, d, d, d, d, d, C.c_int, C.c_int]
+    lib.orc_unproject.restype = C.c_int
+    lib.orc_unproject.argtypes = [P(C.c_float), P(C.c_float), C.c_int, C.c_int, d, d, d, d, d, d, d, C.c_int, C.c_int]
+    lib.orc_link_cells.restype = C.c_int
+    lib.orc_link_cells.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, d, d, d, d, C.c_void_p, C.c_void_p]
+    lib.orc_poi_visibility.restype = None
+    lib.orc_poi_visibility.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, d, d, d, d, d,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_tanel.restype = None
     lib.orc_tanel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
     _lib = lib
@@ -163,6 +173,36 @@ def vertices(mosaic, view):
             lib.orc_vertex(C.byref(view), i, j, int(mosaic[j, i]), C.byref(buf))
             out[j, i] = buf[:]
     return out
+
+
+def link_cells(ranges, cell_w, cell_h, cut_off_bottom_px, lat, lon, az_deg0, az_deg1):
+    """reference annotator.c:228-264 on a range image; returns (lat, lon) float32[ny,nx]"""
+    lib = load()
+    ranges = np.ascontiguousarray(ranges, np.float32)
+    H, W = ranges.shape
+    nx = len(range(0, W - cell_w, cell_w))
+    ny = len(range(0, H - cut_off_bottom_px - cell_h, cell_h))
+    la = np.full((ny, nx), np.nan, np.float32)
+    lo = np.full((ny, nx), np.nan, np.float32)
+    if nx and ny:
+        lib.orc_link_cells(ranges.ctypes.data, W, H, cut_off_bottom_px, cell_w, cell_h, lat, lon, az_deg0, az_deg1,
+                           la.ctypes.data, lo.ctypes.data)
+    return la, lo
+
+
+def poi_visibility(ranges, pois, cut_off_bottom_px, lat, lon, az_deg0, az_deg1, ele_m):
+    """reference annotator.c:280-348; pois float32[n,3] = lat, lon, ele_m"""
+    lib = load()
+    ranges = np.ascontiguousarray(ranges, np.float32)
+    pois = np.ascontiguousarray(pois, np.float32)
+    H, W = ranges.shape
+    n = pois.shape[0]
+    vis = np.zeros(n, np.uint8)
+    x = np.zeros(n, np.float32)
+    y = np.zeros(n, np.float32)
+    lib.orc_poi_visibility(ranges.ctypes.data, W, H, cut_off_bottom_px, pois.ctypes.data, n, lat, lon, az_deg0, az_deg1,
+                           ele_m, vis.ctypes.data, x.ctypes.data, y.ctypes.data)
+    return vis, x, y
 
 
 def tanel(W, H, az_deg0, az_deg1):

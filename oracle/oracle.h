@@ -14,21 +14,23 @@
  *   horizonator-lib.c:183-185,896   depth test LESS, back-face cull, clear
  *   fragment.glsl:15-16             colour = (red, 0, 0)
  *   horizonator-lib.c:936-1048      BGR readback, row flip, depth -> range
+ *   horizonator-lib.c:1053-1213     x_from_az / project / unproject (host math)
+ *   annotator.c:228-264, 280-348    link cells and label visibility from the range image
  * The rasterisation between geometry.glsl and the depth buffer is not code of
  * the reference: it is OpenGL's, executed for the reference by Mesa/llvmpipe.
  * It is restated with GL's rules and llvmpipe's conventions (8 sub-pixel bits,
- * top-left fill rule, 24-bit depth).
+ * left/bottom fill rule, 24-bit depth, llvmpipe's plane set-up arithmetic).
  *
  * Parity pinning: oracle_dem is checked bit-for-bit against the reference's
  * own dem.c compiled in place (oracle/_ref/libdem_ref.so).  The render is
  * checked against golden vectors produced by the reference's three GLSL
  * shaders, unmodified, executed by Mesa llvmpipe (oracle/glsl_golden.c,
- * tests/golden/); that comparison is statistical, not bit-exact, because
- * llvmpipe's atan and interpolation differ from any restatement in the last
- * bits (tolerance bands in tests/test_oracle_golden.py).  horizonator-lib.c
- * itself cannot be built here (needs epoxy, freeglut and FreeImage headers the
- * image lacks), so the host-side uniform derivation is pinned by restatement
- * only.
+ * tests/golden/): the vertex stage bit-exact, coverage exact, depth bit-exact
+ * except in triangles llvmpipe clips (bands in tests/test_oracle_golden.py).
+ * horizonator-lib.c and annotator.c themselves cannot be built here (they need
+ * epoxy, freeglut, FreeImage, cairo and swscale headers the image lacks), so
+ * the host-side uniform derivation, the readback conversion and the annotator
+ * passes are pinned by restatement only.
  */
 #pragma once
 
@@ -91,6 +93,29 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
                int W, int H, int col0, int col1,
                uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
                int nthreads);
+
+/* ---- annotator passes over the range image ("next" row N2) ----------------- */
+
+/* reference horizonator-lib.c:1097-1155 / :1157-1213; return 1 on success */
+int orc_project(double* x, double* y, double* range,
+                double lat_viewer, double cos_lat_viewer, double lon_viewer, double ele_viewer,
+                double lat, double lon, double ele,
+                double az_rad0, double az_rad1, int width, int height);
+int orc_unproject(float* lat, float* lon, int x, int y, double range_enh, double range_en,
+                  double lat_viewer, double cos_lat_viewer, double lon_viewer,
+                  double az_deg0, double az_deg1, int width, int height);
+
+/* reference annotator.c:228-264; out arrays [ny][nx], NaN where no terrain; returns nx*ny */
+int orc_link_cells(const float* range_image, int width, int height, int cut_off_bottom_px,
+                   int cell_width, int cell_height,
+                   double lat, double lon, double az_deg0, double az_deg1,
+                   float* out_lat, float* out_lon);
+
+/* reference annotator.c:280-348; pois = (lat, lon, ele_m) float triples */
+void orc_poi_visibility(const float* range_image, int width, int height, int cut_off_bottom_px,
+                        const float* pois, int Npois,
+                        double lat, double lon, double az_deg0, double az_deg1, double ele_m,
+                        uint8_t* visible, float* label_x, float* label_y);
 
 /* tan(elevation) per GL row as reference horizonator-lib.c:1006-1012,1026-1047 uses it */
 void orc_tanel(float* tanel, int W, int H, float az_deg0, float az_deg1);
