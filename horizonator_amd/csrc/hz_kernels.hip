@@ -71,8 +71,35 @@ struct hz_rec_t
 };
 struct hz_bigrec_t { hz_rec_t r; int32_t bh; };
 
-/* work item of the large-triangle pass: 64 8x8-pixel tiles of one triangle */
+/* work item of the large-triangle pass: 64 tiles of one triangle */
 struct hz_bigitem_t { uint32_t rec; uint32_t chunk; };
+
+/* the HBM queues between the kernels of one draw */
+struct mr_queue_t
+{
+    hz_bigrec_t*  bigrec;           /* set-up triangles for k_big                                */
+    hz_bigitem_t* bigitem;          /* ... and their work items                                  */
+    hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
+    uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
+    unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item
+                                     * [3] mid records [4] clip ids                              */
+    unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
+};
+
+/* triangles that cross a plane of the view volume: their ids go to k_clip.
+ * One atomic per wave.  Ids that do not fit are not stored, but still counted:
+ * counters[4] > capacity makes k_clip_rescan redo the job without the queue. */
+__device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint32_t prim, int lane)
+{
+    const unsigned long long m = __ballot(want);
+    if(!m) return;
+    uint32_t base = 0;
+    if(lane == (int)__builtin_ctzll(m)) base = atomicAdd(&q.counters[4], (uint32_t)__popcll(m));
+    base = __shfl(base, (int)__builtin_ctzll(m));
+    if(!want) return;
+    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if(at < q.clip_capacity) q.clip[at] = prim;
+}
 
 #define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
@@ -137,6 +164,94 @@ __device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int
     return hz_to_window(hz_transform(&p.u, (float)i, (float)j, z), p.halfW, p.halfH);
 }
 
+/* clip one triangle of the grid (by id) and hand its pieces on: to the k_big
+ * queue, or - `inline_ok` and no room - straight into the framebuffer */
+__device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long long* fb, const mr_queue_t& q,
+                                        const hz_params_t& p, uint32_t prim, bool inline_ok)
+{
+    const uint32_t cell = prim >> 1;
+    const int t = prim & 1;
+    const int j = cell / (uint32_t)(p.N-1);
+    const int i = cell - (uint32_t)j*(uint32_t)(p.N-1);
+    /* reference horizonator-lib.c:500-506 */
+    const int ib = i+1,           jb = t == 0 ? j+1 : j;
+    const int ic = t == 0 ? i : i+1, jc = j+1;
+    const hz_cvert_t a = hz_cvert(hz_transform(&p.u, (float)i,  (float)j,  (float)mosaic[(size_t)j *p.N + i ]), p.halfW, p.halfH);
+    const hz_cvert_t b = hz_cvert(hz_transform(&p.u, (float)ib, (float)jb, (float)mosaic[(size_t)jb*p.N + ib]), p.halfW, p.halfH);
+    const hz_cvert_t c = hz_cvert(hz_transform(&p.u, (float)ic, (float)jc, (float)mosaic[(size_t)jc*p.N + ic]), p.halfW, p.halfH);
+
+    hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1], *poly;
+    const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
+    /* fan that keeps vertex 0 last (GL provoking-vertex convention) */
+    for(int k=2; k<n; k++)
+    {
+        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
+        hz_box_t box;
+        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
+        hz_tri_t tri;
+        hz_tri_planes(&tri, &va, &vb, &vc);
+        hz_bigrec_t br;
+        #pragma unroll
+        for(int m=0; m<3; m++) { br.r.xs[m] = tri.xs[m]; br.r.ys[m] = tri.ys[m]; }
+        br.r.z_org = tri.z_org; br.r.dzdx = tri.dzdx; br.r.dzdy = tri.dzdy;
+        br.r.r_org = tri.r_org; br.r.drdx = tri.drdx; br.r.drdy = tri.drdy;
+        br.r.px0 = box.px0; br.r.py0 = box.py0; br.r.bw = box.px1 - box.px0 + 1;
+        br.r.inv_bw = 1.0f / (float)br.r.bw;
+        br.r.prim = prim;
+        br.bh = box.py1 - box.py0 + 1;
+        const hz_tiling_t tl = hz_big_tiling(br.r.bw, br.bh);
+        const uint32_t chunks = ((uint32_t)tl.tiles_x*(uint32_t)tl.tiles_y + 63)/64;
+        bool queued = false;
+        const uint32_t ri = atomicAdd(&q.counters[0], 1u);
+        if(ri < q.bigrec_capacity)
+        {
+            const uint32_t ii = atomicAdd(&q.counters[1], chunks);
+            if(ii + chunks <= q.bigitem_capacity)
+            {
+                q.bigrec[ri] = br;
+                for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+                queued = true;
+            }
+            else atomicMin(&q.counters[2], ii);
+        }
+        if(!queued && inline_ok)
+            for(int py = box.py0; py <= box.py1; py++)
+                for(int px = box.px0; px <= box.px1; px++)
+                    hz_emit(fb, p, tri, prim, px, py);
+    }
+}
+
+/* one thread per queued triangle id */
+__global__ __launch_bounds__(64)
+void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
+{
+    const unsigned int n = q.counters[4];
+    if(n > q.clip_capacity) return;                 /* overflow: k_clip_rescan does it all */
+    for(unsigned int k = blockIdx.x*blockDim.x + threadIdx.x; k < n; k += gridDim.x*blockDim.x)
+        hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true);
+}
+
+/* Only when the id queue overflowed (never with the default capacity): find
+ * the triangles that need the clipper again, one thread per cell, and clip them
+ * on the spot.  Slow, correct, and out of the way of the fast kernels. */
+__global__ __launch_bounds__(256)
+void k_clip_rescan(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
+{
+    if(q.counters[4] <= q.clip_capacity) return;
+    const size_t ncells = (size_t)(p.N-1)*(p.N-1);
+    for(size_t cell = (size_t)blockIdx.x*blockDim.x + threadIdx.x; cell < ncells; cell += (size_t)gridDim.x*blockDim.x)
+    {
+        const int j = (int)(cell / (size_t)(p.N-1)), i = (int)(cell - (size_t)j*(p.N-1));
+        const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i, j),   v10 = hz_vertex_at(p, mosaic, i+1, j);
+        const hz_wvert_t v01 = hz_vertex_at(p, mosaic, i, j+1), v11 = hz_vertex_at(p, mosaic, i+1, j+1);
+        hz_box_t box;
+        if(hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true);
+        if(hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true);
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* scatter rasteriser                                                        */
 /*
@@ -167,10 +282,12 @@ static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");
 
 __global__ __launch_bounds__(SC_THREADS)
 void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
-               hz_bigrec_t* __restrict__ bigrec, hz_bigitem_t* __restrict__ bigitem,
-               unsigned int* __restrict__ big_counters,    /* [0] records, [1] items, [2] first invalid item */
-               unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
+               mr_queue_t q, hz_params_t p)
 {
+    hz_bigrec_t* const bigrec = q.bigrec;
+    hz_bigitem_t* const bigitem = q.bigitem;
+    unsigned int* const big_counters = q.counters;
+    const unsigned int bigrec_capacity = q.bigrec_capacity, bigitem_capacity = q.bigitem_capacity;
     __shared__ float   s_xn [SC_VY][SC_VX];
     __shared__ float   s_fx [SC_VY][SC_VX];
     __shared__ float   s_fy [SC_VY][SC_VX];
@@ -178,6 +295,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
     __shared__ float   s_red[SC_VY][SC_VX];
     __shared__ int32_t s_xs [SC_VY][SC_VX];
     __shared__ int32_t s_ys [SC_VY][SC_VX];
+    __shared__ uint32_t s_cm[SC_VY][SC_VX];
     __shared__ unsigned short s_cand[2*SC_THREADS];
     __shared__ uint32_t s_rec[SC_THREADS*SC_REC_STRIDE];
     __shared__ uint32_t s_prefix[SC_THREADS+1];
@@ -202,7 +320,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             const hz_wvert_t w = hz_vertex_at(p, mosaic, i, j);
             s_xn [vy][vx] = w.xn;  s_fx [vy][vx] = w.wx;  s_fy[vy][vx] = w.wy;
             s_zw [vy][vx] = w.zw;  s_red[vy][vx] = w.red;
-            s_xs [vy][vx] = w.xs;  s_ys [vy][vx] = w.ys;
+            s_xs [vy][vx] = w.xs;  s_ys [vy][vx] = w.ys;  s_cm[vy][vx] = w.cmask;
             some_not_near |= !(w.zw < 0.f);
             some_not_far  |= !(w.zw > 1.f);
         }
@@ -222,7 +340,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
         int keep0 = 0, keep1 = 0;
         if(i < p.N-1 && j < p.N-1)
         {
-            #define LDV(vy,vx) hz_wvert_t{ s_xn[vy][vx], s_fx[vy][vx], s_fy[vy][vx], s_zw[vy][vx], s_red[vy][vx], s_xs[vy][vx], s_ys[vy][vx] }
+            #define LDV(vy,vx) hz_wvert_t{ s_xn[vy][vx], s_fx[vy][vx], s_fy[vy][vx], s_zw[vy][vx], s_red[vy][vx], s_xs[vy][vx], s_ys[vy][vx], s_cm[vy][vx] }
             const hz_wvert_t v00 = LDV(cy,   cx  );
             const hz_wvert_t v10 = LDV(cy,   cx+1);
             const hz_wvert_t v01 = LDV(cy+1, cx  );
@@ -230,6 +348,13 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             hz_box_t box;
             keep0 = hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1);
             keep1 = hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1);
+        }
+        /* triangles that cross the view volume's planes go through k_clip */
+        {
+            const uint32_t prim0 = (uint32_t)(((size_t)j*(p.N-1) + i)*2);
+            hz_queue_clip(q, keep0 == HZ_TRI_CLIP, prim0,   lane);
+            hz_queue_clip(q, keep1 == HZ_TRI_CLIP, prim0+1, lane);
+            keep0 = keep0 == HZ_TRI_DRAW; keep1 = keep1 == HZ_TRI_DRAW;
         }
         const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
         const unsigned int n0 = __popcll(m0), n1 = __popcll(m1);
@@ -257,7 +382,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             const hz_wvert_t b = t == 0 ? LDV(cy+1, cx+1) : LDV(cy,   cx+1);
             const hz_wvert_t c = t == 0 ? LDV(cy+1, cx  ) : LDV(cy+1, cx+1);
             hz_box_t box;
-            hz_tri_cull(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);     /* known to pass: recomputes the box */
+            hz_tri_cull_window(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);     /* known to pass: recomputes the box */
             hz_tri_t tri;
             hz_tri_planes(&tri, &a, &b, &c);
             hz_rec_t r;
@@ -474,6 +599,7 @@ __device__ static inline hz_wvert_t mr_load_vert(const mr_lds_t& L, int slot, in
     v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
     v.zw  = __uint_as_float(L.rows[slot][2][lane]); v.red = __uint_as_float(L.rows[slot][3][lane]);
     v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
+    v.cmask = 0;
     return v;
 }
 
@@ -505,14 +631,7 @@ __device__ static inline float mr_from_east(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
-struct mr_queue_t
-{
-    hz_bigrec_t*  bigrec;
-    hz_bigitem_t* bigitem;
-    hz_rec_t*     midrec;
-    unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item [3] mid records */
-    unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity;
-};
+
 
 /* inclusive prefix sum over the 64 lanes */
 __device__ static inline uint32_t mr_scan(uint32_t v, int lane)
@@ -828,6 +947,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         east.xn = mr_from_east(cur.xn);  east.wx = mr_from_east(cur.wx);  east.wy = mr_from_east(cur.wy);
         east.zw = mr_from_east(cur.zw);  east.red = mr_from_east(cur.red);
         east.xs = mr_from_east(cur.xs);  east.ys = mr_from_east(cur.ys);
+        east.cmask = (uint32_t)mr_from_east((int32_t)cur.cmask);
         if(j > jbeg && !skip_cells)
         {
             const hz_wvert_t v11 = east;
@@ -838,7 +958,13 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                 const hz_wvert_t& b = t == 0 ? v11 : v10;
                 const hz_wvert_t& c = t == 0 ? cur : v11;
                 hz_box_t box;
-                const int keep = has_cell && hz_tri_cull(&box, &prev, &b, &c, p.col0, p.col1-1, 0, p.H-1);
+                const int verdict = has_cell ? hz_tri_cull(&box, &prev, &b, &c, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
+                /* crossing the image border or the near/far sphere: k_clip */
+                {
+                    const uint32_t prim = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2 + t);
+                    hz_queue_clip(q, verdict == HZ_TRI_CLIP, prim, lane);
+                }
+                const int keep = verdict == HZ_TRI_DRAW;
                 const unsigned long long m = __ballot(keep);
                 if(m)
                 {
@@ -939,8 +1065,9 @@ struct hz_dev
     hz_bigrec_t*        d_bigrec;
     hz_bigitem_t*       d_bigitem;
     hz_rec_t*           d_midrec;
+    uint32_t*           d_clip;
     unsigned int*       d_big_counters;     /* [0] big records [1] big items [2] first invalid big item [3] mid records */
-    unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity;
+    unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
     float*              d_tanel;
 
     /* internal output buffers for *_to_host */
@@ -971,6 +1098,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_bigrec);
     (void)hipFree(d->d_bigitem);
     (void)hipFree(d->d_midrec);
+    (void)hipFree(d->d_clip);
     (void)hipFree(d->d_big_counters);
     (void)hipFree(d->d_tanel);
     (void)hipFree(d->d_bgr);
@@ -993,16 +1121,18 @@ static int create_impl(hz_dev_t* d)
     d->bigrec_capacity  = 1u<<21;
     d->bigitem_capacity = 1u<<22;
     d->midrec_capacity  = 1u<<21;
+    d->clip_capacity    = 1u<<21;
     {
         /* tests shrink the queues to exercise the overflow paths */
         const char* cap = getenv("HZ_QUEUE_CAPACITY");
         if(cap && atoi(cap) > 0)
-            d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = (unsigned int)atoi(cap);
+            d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = d->clip_capacity = (unsigned int)atoi(cap);
     }
     HZ_CHECK(hipMalloc(&d->d_bigrec,  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
     HZ_CHECK(hipMalloc(&d->d_bigitem, (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
     HZ_CHECK(hipMalloc(&d->d_midrec,  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
-    HZ_CHECK(hipMalloc(&d->d_big_counters, 4*sizeof(unsigned int)));
+    HZ_CHECK(hipMalloc(&d->d_clip,    (size_t)d->clip_capacity*sizeof(uint32_t)));
+    HZ_CHECK(hipMalloc(&d->d_big_counters, 5*sizeof(unsigned int)));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     for(int k=0; k<6; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
     return 0;
@@ -1209,21 +1339,20 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     HZ_CHECK(hipMemsetAsync(d->d_fb, 0xFF, (size_t)p.SW*p.H*sizeof(unsigned long long), d->stream));
     HZ_CHECK(hipMemsetAsync(d->d_big_counters,     0x00, 2*sizeof(unsigned int), d->stream));
     HZ_CHECK(hipMemsetAsync(d->d_big_counters + 2, 0xFF, 1*sizeof(unsigned int), d->stream));
-    HZ_CHECK(hipMemsetAsync(d->d_big_counters + 3, 0x00, 1*sizeof(unsigned int), d->stream));
+    HZ_CHECK(hipMemsetAsync(d->d_big_counters + 3, 0x00, 2*sizeof(unsigned int), d->stream));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->stream));
 
     {
+        mr_queue_t q = { d->d_bigrec, d->d_bigitem, d->d_midrec, d->d_clip, d->d_big_counters,
+                         d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity, d->clip_capacity };
         if(d->raster == HZ_RASTER_SCATTER)
         {
             dim3 grid((p.N-1 + SC_CX-1)/SC_CX, (p.N-1 + SC_CY-1)/SC_CY);
             hipLaunchKernelGGL(k_scatter, grid, dim3(SC_THREADS), 0, d->stream,
-                               (const int16_t*)d->d_mosaic, d->d_fb, d->d_bigrec, d->d_bigitem, d->d_big_counters,
-                               d->bigrec_capacity, d->bigitem_capacity, p);
+                               (const int16_t*)d->d_mosaic, d->d_fb, q, p);
         }
         else
         {
-            mr_queue_t q = { d->d_bigrec, d->d_bigitem, d->d_midrec, d->d_big_counters,
-                             d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity };
             const mr_zones_t zn = mr_make_zones(p);
             dim3 grid((p.N-1 + MR_COLS-1)/MR_COLS, zn.total);
             /* diagnostics: HZ_WAVE_TIMING=<file> dumps the duration (shader clock
@@ -1253,6 +1382,12 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         }
         HZ_CHECK(hipGetLastError());
         if(prof) HZ_CHECK(hipEventRecord(d->ev[2], d->stream));
+        hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, d->stream,
+                           (const int16_t*)d->d_mosaic, d->d_fb, q, p);
+        HZ_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_clip_rescan, dim3(2048), dim3(256), 0, d->stream,
+                           (const int16_t*)d->d_mosaic, d->d_fb, q, p);
+        HZ_CHECK(hipGetLastError());
         if(d->raster != HZ_RASTER_SCATTER)
         {
             hipLaunchKernelGGL(k_mid, dim3(8192), dim3(64), 0, d->stream,

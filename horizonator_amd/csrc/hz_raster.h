@@ -40,7 +40,22 @@
  * and the position relative to the pixel-centre grid snapped to 1/256 px
  * (xs = HZ_OUTSIDE_GUARD marks a vertex outside the guard band or with a
  * non-finite position) */
-typedef struct { float xn, wx, wy, zw, red; int32_t xs, ys; } hz_wvert_t;
+typedef struct { float xn, wx, wy, zw, red; int32_t xs, ys; uint32_t cmask; } hz_wvert_t;
+
+/* GL clips against the view volume -1 <= x,y,z <= 1 (w = 1 here): which of the
+ * six planes a vertex lies beyond, bit order as in Mesa (x>1, x<-1, y>1, y<-1,
+ * z<-1, z>1) */
+HZ_HD uint32_t hz_clip_mask(float xn, float yn, float zn)
+{
+    uint32_t m = 0;
+    if(xn > 1.0f)        m |= 1;
+    if(xn + 1.0f < 0.f)  m |= 2;
+    if(yn > 1.0f)        m |= 4;
+    if(yn + 1.0f < 0.f)  m |= 8;
+    if(zn + 1.0f < 0.f)  m |= 16;
+    if(zn > 1.0f)        m |= 32;
+    return m;
+}
 
 HZ_HD hz_wvert_t hz_to_window(hz_vertex_t v, float halfW, float halfH)
 {
@@ -50,6 +65,7 @@ HZ_HD hz_wvert_t hz_to_window(hz_vertex_t v, float halfW, float halfH)
     w.wy  = v.y*halfH + halfH;
     w.zw  = v.z*0.5f + 0.5f;
     w.red = v.red;
+    w.cmask = hz_clip_mask(v.x, v.y, v.z);
     const float fx = w.wx - 0.5f, fy = w.wy - 0.5f;     /* pixel centres at integers */
     if(hz_abs(fx) <= HZ_GUARD_PX && hz_abs(fy) <= HZ_GUARD_PX)
     {
@@ -90,19 +106,11 @@ HZ_HD int hz_tri_box(hz_box_t* box,
     return !(px0 > px1 || py0 > py1);
 }
 
-/* Everything that can reject a triangle without looking at a pixel.
- * Returns 1 and the pixel box if the triangle may produce fragments inside
- * the scissor [sx0,sx1] x [sy0,sy1] (inclusive, pixels), else 0. */
-HZ_HD int hz_tri_cull(hz_box_t* box,
-                      const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c,
-                      int sx0, int sx1, int sy0, int sy1)
+/* the window-space rejections: guard band, back face, empty pixel box */
+HZ_HD int hz_tri_cull_window(hz_box_t* box,
+                             const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c,
+                             int sx0, int sx1, int sy0, int sy1)
 {
-    /* reference geometry.glsl:21-27: wider than a quarter of the viewport
-     * (which includes everything straddling the +-180 deg seam) -> dropped */
-    const float xmax = hz_max(hz_max(a->xn, b->xn), c->xn);
-    const float xmin = hz_min(hz_min(a->xn, b->xn), c->xn);
-    if(xmax - xmin > 0.5f) return 0;
-
     if(a->xs == HZ_OUTSIDE_GUARD || b->xs == HZ_OUTSIDE_GUARD || c->xs == HZ_OUTSIDE_GUARD) return 0;
 
     /* back-face cull on the snapped area (counter-clockwise = front, y up) */
@@ -111,14 +119,32 @@ HZ_HD int hz_tri_cull(hz_box_t* box,
         (int64_t)(c->xs - a->xs)*(int64_t)(b->ys - a->ys);
     if(area <= 0) return 0;
 
-    if(!hz_tri_box(box, a, b, c, sx0, sx1, sy0, sy1)) return 0;
+    return hz_tri_box(box, a, b, c, sx0, sx1, sy0, sy1);
+}
 
-    /* whole triangle in front of the near sphere or beyond the far one */
-    if((a->zw < 0.f && b->zw < 0.f && c->zw < 0.f) ||
-       (a->zw > 1.f && b->zw > 1.f && c->zw > 1.f))
-        return 0;
+/* Everything that can be decided about a triangle without looking at a pixel.
+ * Returns HZ_TRI_DROP, HZ_TRI_DRAW (with the pixel box, clipped to the scissor
+ * [sx0,sx1] x [sy0,sy1], inclusive), or HZ_TRI_CLIP: the triangle crosses a
+ * plane of the view volume and has to go through the clipper first. */
+#define HZ_TRI_DROP 0
+#define HZ_TRI_DRAW 1
+#define HZ_TRI_CLIP 2
+HZ_HD int hz_tri_cull(hz_box_t* box,
+                      const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c,
+                      int sx0, int sx1, int sy0, int sy1)
+{
+    /* reference geometry.glsl:21-27: wider than a quarter of the viewport
+     * (which includes everything straddling the +-180 deg seam) -> dropped */
+    const float xmax = hz_max(hz_max(a->xn, b->xn), c->xn);
+    const float xmin = hz_min(hz_min(a->xn, b->xn), c->xn);
+    if(xmax - xmin > 0.5f) return HZ_TRI_DROP;
 
-    return 1;
+    /* wholly beyond one plane of the view volume (image border, near sphere,
+     * far sphere) */
+    if(a->cmask & b->cmask & c->cmask) return HZ_TRI_DROP;
+    if(a->cmask | b->cmask | c->cmask) return HZ_TRI_CLIP;
+
+    return hz_tri_cull_window(box, a, b, c, sx0, sx1, sy0, sy1) ? HZ_TRI_DRAW : HZ_TRI_DROP;
 }
 
 /* a triangle ready for rasterisation */
@@ -187,13 +213,16 @@ HZ_HD int hz_tri_covers(const hz_tri_t* t, int px, int py)
     return 1;
 }
 
-/* depth + colour of a covered pixel; returns 0 if the fragment is clipped
- * by the near/far spheres or cannot beat the cleared depth */
+/* depth + colour of a covered pixel; returns 0 if the fragment cannot beat the
+ * cleared depth */
 HZ_HD int hz_tri_fragment(const hz_tri_t* t, int px, int py, uint32_t* zi, uint32_t* r8)
 {
     const float fpx = (float)px, fpy = (float)py;
-    const float z = __builtin_fmaf(t->dzdy, fpy, __builtin_fmaf(t->dzdx, fpx, t->z_org));
-    if(!(z >= 0.f && z <= 1.f)) return 0;
+    /* all vertices are inside the depth range by now (clipper); what rounding
+     * leaves outside is clamped, as llvmpipe does */
+    float z = __builtin_fmaf(t->dzdy, fpy, __builtin_fmaf(t->dzdx, fpx, t->z_org));
+    if(!(z == z)) return 0;
+    z = hz_min(hz_max(z, 0.f), 1.f);
     const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
     if(q >= HZ_Z24_MAX) return 0;
     float r = __builtin_fmaf(t->drdy, fpy, __builtin_fmaf(t->drdx, fpx, t->r_org));
@@ -201,6 +230,124 @@ HZ_HD int hz_tri_fragment(const hz_tri_t* t, int px, int py, uint32_t* zi, uint3
     *zi = q;
     *r8 = (uint32_t)hz_roundeven(r * 255.f);
     return 1;
+}
+
+/* ---- clipper -----------------------------------------------------------------
+ * Mesa's polygon clipper (draw_pipe_clip.c) restated operation for operation:
+ * Sutherland-Hodgman against the planes in hz_clip_mask() order, new vertices
+ * interpolated in clip space from the inside vertex towards the outside one and
+ * sent through the viewport transform again, the polygon rasterised as a fan
+ * that keeps vertex 0 last.  The visible pixels do not change, but depth and
+ * colour are interpolated over the pieces: with this the depth of triangles
+ * that cross the image border or the near/far sphere matches the reference's
+ * draw on llvmpipe bit for bit as well. */
+#define HZ_MAX_CLIPPED 12
+
+typedef struct { float xn, yn, zn, wx, wy, zw, red; } hz_cvert_t;
+
+HZ_HD hz_cvert_t hz_cvert(hz_vertex_t v, float halfW, float halfH)
+{
+    hz_cvert_t c;
+    c.xn = v.x; c.yn = v.y; c.zn = v.z; c.red = v.red;
+    c.wx = v.x*halfW + halfW; c.wy = v.y*halfH + halfH; c.zw = v.z*0.5f + 0.5f;
+    return c;
+}
+
+HZ_HD float hz_clip_dist(const hz_cvert_t* v, int p)
+{
+    /* dot4(position, plane) evaluated left to right, w = 1 */
+    const float px = (p == 0) ? -1.f : (p == 1) ? 1.f : 0.f;
+    const float py = (p == 2) ? -1.f : (p == 3) ? 1.f : 0.f;
+    const float pz = (p == 4) ?  1.f : (p == 5) ? -1.f : 0.f;
+    return px*v->xn + py*v->yn + pz*v->zn + 1.0f*1.0f;
+}
+
+HZ_HD hz_cvert_t hz_clip_interp(float t, const hz_cvert_t* out, const hz_cvert_t* in, float halfW, float halfH)
+{
+    hz_cvert_t d;
+    d.xn  = out->xn  + t*(in->xn  - out->xn);
+    d.yn  = out->yn  + t*(in->yn  - out->yn);
+    d.zn  = out->zn  + t*(in->zn  - out->zn);
+    const float w   = 1.0f + t*(1.0f - 1.0f);
+    const float oow = 1.0f / w;
+    d.wx  = d.xn*oow*halfW + halfW;
+    d.wy  = d.yn*oow*halfH + halfH;
+    d.zw  = d.zn*oow*0.5f  + 0.5f;
+    d.red = out->red + t*(in->red - out->red);
+    return d;
+}
+
+/* clips triangle (a,b,c); the result lands in bufa or bufb, *poly points at it;
+ * returns the vertex count (< 3: nothing left) */
+HZ_HD int hz_clip_triangle(hz_cvert_t* bufa, hz_cvert_t* bufb, hz_cvert_t** poly,
+                           const hz_cvert_t* a, const hz_cvert_t* b, const hz_cvert_t* c,
+                           float halfW, float halfH)
+{
+    uint32_t todo = hz_clip_mask(a->xn, a->yn, a->zn) | hz_clip_mask(b->xn, b->yn, b->zn) | hz_clip_mask(c->xn, c->yn, c->zn);
+    hz_cvert_t *in = bufa, *out = bufb;
+    in[0] = *a; in[1] = *b; in[2] = *c;
+    int n = 3;
+    while(todo && n >= 3)
+    {
+        const int p = __builtin_ctz(todo);
+        todo &= ~(1u << p);
+        int outcount = 0;
+        in[n] = in[0];
+        const hz_cvert_t* vert_prev = &in[0];
+        float dp_prev = hz_clip_dist(vert_prev, p);
+        if(!(hz_abs(dp_prev) <= 3.0e38f)) return 0;                 /* NaN or infinite */
+        for(int i=1; i<=n; i++)
+        {
+            const hz_cvert_t* vert = &in[i];
+            const float dp = hz_clip_dist(vert, p);
+            if(!(hz_abs(dp) <= 3.0e38f)) return 0;
+            int different_sign;
+            if(dp_prev >= 0.0f)
+            {
+                if(outcount >= HZ_MAX_CLIPPED) return 0;
+                out[outcount++] = *vert_prev;
+                different_sign = dp < 0.0f;
+            }
+            else
+                different_sign = !(dp < 0.0f);
+            if(different_sign)
+            {
+                if(outcount >= HZ_MAX_CLIPPED) return 0;
+                const float denom = dp - dp_prev;
+                if(dp < 0.0f)
+                {
+                    if(-dp < dp_prev) out[outcount++] = hz_clip_interp(dp / denom,       vert,      vert_prev, halfW, halfH);
+                    else              out[outcount++] = hz_clip_interp(-dp_prev / denom, vert_prev, vert,      halfW, halfH);
+                }
+                else
+                {
+                    if(-dp_prev < dp) out[outcount++] = hz_clip_interp(-dp_prev / denom, vert_prev, vert,      halfW, halfH);
+                    else              out[outcount++] = hz_clip_interp(dp / denom,       vert,      vert_prev, halfW, halfH);
+                }
+            }
+            vert_prev = vert;
+            dp_prev   = dp;
+        }
+        hz_cvert_t* tmp = in; in = out; out = tmp;
+        n = outcount;
+    }
+    *poly = in;
+    return n;
+}
+
+/* a clipper vertex as the rasteriser wants it */
+HZ_HD hz_wvert_t hz_wvert_of(const hz_cvert_t* c)
+{
+    hz_wvert_t w;
+    w.xn = c->xn; w.wx = c->wx; w.wy = c->wy; w.zw = c->zw; w.red = c->red; w.cmask = 0;
+    const float fx = w.wx - 0.5f, fy = w.wy - 0.5f;
+    if(hz_abs(fx) <= HZ_GUARD_PX && hz_abs(fy) <= HZ_GUARD_PX)
+    {
+        w.xs = (int32_t)hz_roundeven(fx*256.f);
+        w.ys = (int32_t)hz_roundeven(fy*256.f);
+    }
+    else { w.xs = HZ_OUTSIDE_GUARD; w.ys = 0; }
+    return w;
 }
 
 HZ_HD uint64_t hz_pack(uint32_t zi, uint32_t prim, uint32_t r8)

@@ -136,9 +136,10 @@ void orc_vertex(const orc_view_t* v, int i, int j, int z, float out_xyzr[4])
 
 /* ---- rasteriser --------------------------------------------------------- */
 
-/* a vertex after the viewport transform: window coordinates (pixel centres at
- * half-integers), depth in [0,1], colour */
-typedef struct { float xn, wx, wy, zw, red; } wvert_t;
+/* a vertex as it leaves the vertex stage: clip-space position (w = 1), its
+ * viewport transform (window coordinates with pixel centres at half-integers,
+ * depth in [0,1]) and colour */
+typedef struct { float xn, yn, zn, wx, wy, zw, red; } wvert_t;
 
 #define GUARD_PX 2097152.0f
 
@@ -150,14 +151,10 @@ typedef struct
     int SW, H, col0, col1;
 } target_t;
 
-static void draw_triangle(target_t* fb, int x_lo, int x_hi,
-                          const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+/* rasterise one window-space triangle (a whole one, or a piece the clipper made) */
+static void raster_triangle(target_t* fb, int x_lo, int x_hi,
+                            const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
 {
-    /* reference geometry.glsl:21-27 */
-    float xmax = A->xn > B->xn ? A->xn : B->xn; xmax = xmax > C->xn ? xmax : C->xn;
-    float xmin = A->xn < B->xn ? A->xn : B->xn; xmin = xmin < C->xn ? xmin : C->xn;
-    if(xmax - xmin > 0.5f) return;
-
     /* positions relative to the pixel-centre grid (llvmpipe's "pixel offset"):
      * centres at integers */
     const wvert_t* V[3] = {A,B,C};
@@ -196,10 +193,6 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
     if(py0 < 0)       py0 = 0;
     if(py1 > fb->H-1) py1 = fb->H-1;
     if(px0 > px1 || py0 > py1) return;
-
-    /* primitive entirely outside the depth range [0,1] on one side */
-    if((A->zw < 0.f && B->zw < 0.f && C->zw < 0.f) ||
-       (A->zw > 1.f && B->zw > 1.f && C->zw > 1.f)) return;
 
     /* Depth and colour are planes through the unsnapped positions, set up and
      * evaluated the way llvmpipe does it (pinned on the golden draws: with this
@@ -241,8 +234,11 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
             }
             if(!inside) continue;
 
+            /* every vertex lies inside the depth range by now (clipper); what
+             * interpolation rounding leaves outside is clamped, as llvmpipe does */
             float z = fmaf(dzdy, (float)py, fmaf(dzdx, (float)px, z_org));
-            if(!(z >= 0.f && z <= 1.f)) continue;          /* depth clip */
+            if(!(z == z)) continue;
+            z = z < 0.f ? 0.f : (z > 1.f ? 1.f : z);
             uint32_t zi = (uint32_t)rintf(z * 16777215.f); /* 24-bit unorm */
 
             /* GL_LESS against what was drawn before; among equal depths the
@@ -257,6 +253,123 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi,
             fb->prim [at] = prim;
             fb->red  [at] = (uint8_t)rintf(r * 255.f);      /* RGB8 unorm */
         }
+}
+
+/* ---- clipping --------------------------------------------------------------
+ * Between the geometry shader and the rasteriser GL clips every primitive
+ * against the view volume -1 <= x,y,z <= 1 (w = 1 here).  For the reference
+ * that concerns the triangles that cross the image border, the near sphere
+ * (range = znear) or the far sphere (range = zfar).  The visible pixels are the
+ * same with or without it, but the clipper cuts such a triangle into a fan of
+ * smaller ones with NEW vertices, and depth/colour are then interpolated over
+ * those.  This is Mesa's clipper (draw_pipe_clip.c) restated operation for
+ * operation; with it the depth of clipped triangles matches llvmpipe bit for
+ * bit too (probe: 6 769 pixels of random triangles cut by the y, z and y+z
+ * planes: all equal).
+ */
+#define MAX_CLIPPED 12
+
+static unsigned clip_mask(const wvert_t* v)
+{
+    unsigned m = 0;
+    if(v->xn > 1.0f)        m |= 1;
+    if(v->xn + 1.0f < 0.f)  m |= 2;
+    if(v->yn > 1.0f)        m |= 4;
+    if(v->yn + 1.0f < 0.f)  m |= 8;
+    if(v->zn + 1.0f < 0.f)  m |= 16;
+    if(v->zn > 1.0f)        m |= 32;
+    return m;
+}
+
+/* signed distance to clip plane p (w = 1): dot4 with the plane, left to right */
+static float clip_dist(const wvert_t* v, int p)
+{
+    static const float plane[6][4] = { {-1,0,0,1}, {1,0,0,1}, {0,-1,0,1}, {0,1,0,1}, {0,0,1,1}, {0,0,-1,1} };
+    return plane[p][0]*v->xn + plane[p][1]*v->yn + plane[p][2]*v->zn + plane[p][3]*1.0f;
+}
+
+/* new vertex at parameter t on the way from `out` to `in` */
+static wvert_t clip_interp(float t, const wvert_t* out, const wvert_t* in, float halfW, float halfH)
+{
+    wvert_t d;
+    d.xn  = out->xn  + t*(in->xn  - out->xn);
+    d.yn  = out->yn  + t*(in->yn  - out->yn);
+    d.zn  = out->zn  + t*(in->zn  - out->zn);
+    const float w   = 1.0f + t*(1.0f - 1.0f);
+    const float oow = 1.0f / w;
+    d.wx  = d.xn*oow*halfW + halfW;
+    d.wy  = d.yn*oow*halfH + halfH;
+    d.zw  = d.zn*oow*0.5f  + 0.5f;
+    d.red = out->red + t*(in->red - out->red);
+    return d;
+}
+
+static void draw_triangle(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
+                          const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+{
+    /* reference geometry.glsl:21-27 */
+    float xmax = A->xn > B->xn ? A->xn : B->xn; xmax = xmax > C->xn ? xmax : C->xn;
+    float xmin = A->xn < B->xn ? A->xn : B->xn; xmin = xmin < C->xn ? xmin : C->xn;
+    if(xmax - xmin > 0.5f) return;
+
+    const unsigned ma = clip_mask(A), mb = clip_mask(B), mc = clip_mask(C);
+    if(ma & mb & mc) return;                        /* wholly outside one plane */
+    unsigned todo = ma | mb | mc;
+    if(!todo) { raster_triangle(fb, x_lo, x_hi, A, B, C, prim); return; }
+
+    /* Sutherland-Hodgman, one plane after the other in Mesa's order */
+    wvert_t bufa[MAX_CLIPPED+1], bufb[MAX_CLIPPED+1];
+    wvert_t *in = bufa, *out = bufb;
+    in[0] = *A; in[1] = *B; in[2] = *C;
+    int n = 3;
+    while(todo && n >= 3)
+    {
+        const int p = __builtin_ctz(todo);
+        todo &= ~(1u << p);
+        int outcount = 0;
+        in[n] = in[0];
+        const wvert_t* vert_prev = &in[0];
+        float dp_prev = clip_dist(vert_prev, p);
+        if(!(dp_prev == dp_prev) || isinf(dp_prev)) return;
+        for(int i=1; i<=n; i++)
+        {
+            const wvert_t* vert = &in[i];
+            const float dp = clip_dist(vert, p);
+            if(!(dp == dp) || isinf(dp)) return;
+            int different_sign;
+            if(dp_prev >= 0.0f)
+            {
+                if(outcount >= MAX_CLIPPED) return;
+                out[outcount++] = *vert_prev;
+                different_sign = dp < 0.0f;
+            }
+            else
+                different_sign = !(dp < 0.0f);
+            if(different_sign)
+            {
+                if(outcount >= MAX_CLIPPED) return;
+                const float denom = dp - dp_prev;
+                /* always interpolate from the inside vertex towards the outside one */
+                if(dp < 0.0f)
+                {
+                    if(-dp < dp_prev) out[outcount++] = clip_interp(dp / denom,       vert,      vert_prev, halfW, halfH);
+                    else              out[outcount++] = clip_interp(-dp_prev / denom, vert_prev, vert,      halfW, halfH);
+                }
+                else
+                {
+                    if(-dp_prev < dp) out[outcount++] = clip_interp(-dp_prev / denom, vert_prev, vert,      halfW, halfH);
+                    else              out[outcount++] = clip_interp(dp / denom,       vert,      vert_prev, halfW, halfH);
+                }
+            }
+            vert_prev = vert;
+            dp_prev   = dp;
+        }
+        wvert_t* tmp = in; in = out; out = tmp;
+        n = outcount;
+    }
+    /* the polygon goes on as a fan that keeps vertex 0 last (GL provoking vertex) */
+    for(int i=2; i<n; i++)
+        raster_triangle(fb, x_lo, x_hi, &in[i-1], &in[i], &in[0], prim);
 }
 
 void orc_tanel(float* tanel, int W, int H, float az_deg0, float az_deg1)
@@ -318,7 +431,7 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
         {
             ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
             wvert_t* w = &vert[(size_t)j*N + i];
-            w->xn  = o.x;
+            w->xn  = o.x; w->yn = o.y; w->zn = o.z;
             w->wx  = o.x*halfW + halfW;
             w->wy  = o.y*halfH + halfH;
             w->zw  = o.z*0.5f + 0.5f;
@@ -383,8 +496,8 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
                         const wvert_t* v01 = &vert[(size_t)(j+1)*N + i  ];
                         const wvert_t* v11 = &vert[(size_t)(j+1)*N + i+1];
                         const int32_t prim = (int32_t)(((int64_t)j*(N-1) + i)*2);
-                        draw_triangle(&fb, x_lo, x_hi, v00, v11, v01, prim  );
-                        draw_triangle(&fb, x_lo, x_hi, v00, v10, v11, prim+1);
+                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, v00, v11, v01, prim  );
+                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, v00, v10, v11, prim+1);
                     }
             }
     }
@@ -450,7 +563,7 @@ void orc_stats(const int16_t* mosaic, int N, const orc_view_t* v, int W, int H,
         {
             ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
             wvert_t* w = &row1[i];
-            w->xn = o.x; w->wx = o.x*halfW + halfW; w->wy = o.y*halfH + halfH;
+            w->xn = o.x; w->yn = o.y; w->zn = o.z; w->wx = o.x*halfW + halfW; w->wy = o.y*halfH + halfH;
             w->zw = o.z*0.5f + 0.5f; w->red = o.red;
         }
         if(j > 0)

@@ -24,21 +24,15 @@ def _view(g):
 
 @pytest.mark.parametrize("raster", RASTERS)
 @pytest.mark.parametrize("name", RENDERS)
-def test_golden_scenes_bit_exact_vs_oracle_and_in_band_vs_reference(name, raster):
+def test_golden_scenes_bit_exact_vs_oracle_and_vs_reference(name, raster):
     g = np.load(os.path.join(GOLD, f"render_{name}.npz"))
     W, H, v = int(g["W"]), int(g["H"]), _view(g)
     hip = hzutil.hip_render(g["mosaic"], v, W, H, raster=raster)
     orc = oracle.render(g["mosaic"], v, W, H)
     hzutil.assert_same_render(hip, orc, name)
-    # and against what the reference's shaders drew on llvmpipe
-    gsky, hsky = g["z24"] == 0xFFFFFF, hip["z24"] == 0xFFFFFF
-    assert (gsky != hsky).sum() <= max(1, W * H // 100000)
-    both = ~gsky & ~hsky
-    dz = np.abs(g["z24"].astype(np.int64) - hip["z24"].astype(np.int64))[both]
-    dr = np.abs(g["bgr"][:, :, 2].astype(int) - hip["bgr"][:, :, 2].astype(int))[both]
-    assert (dr == 0).mean() >= 0.9999
-    assert (dz == 0).mean() >= 0.95 and (dz <= 1).mean() >= 0.995 and (dz <= 64).mean() >= 0.9999
-    assert np.array_equal(hip["bgr"][hsky], np.broadcast_to(np.uint8([255, 0, 0]), hip["bgr"][hsky].shape))
+    # and against what the reference's shaders drew on llvmpipe: identical
+    assert np.array_equal(hip["bgr"], g["bgr"])
+    assert np.array_equal(hip["z24"], g["z24"])
 
 
 def _scene(R, W, H, az0, az1, lat=LAT, lon=LON, rough=False, **kw):
