@@ -89,8 +89,8 @@ def vertex_fixture(name, R, W, H, az0, az1, lat=LAT, lon=LON, **kw):
     print(f"vertex_{name}.npz: {m.shape[0]}^2 vertices")
 
 
-def render_fixture(name, R, W, H, az0, az1, lat=LAT, lon=LON, keep_depth=True, **kw):
-    d = hzutil.dem_dir_for(LAT, LON, R)
+def render_fixture(name, R, W, H, az0, az1, lat=LAT, lon=LON, keep_depth=True, rough=False, **kw):
+    d = hzutil.dem_dir_for(LAT, LON, R, rough=rough)
     od = oracle.Dem(LAT, LON, d, radius_cells=R)
     m = od.mosaic()
     v = od.view(lat, lon, W, H, az0, az1, **kw)
@@ -99,6 +99,32 @@ def render_fixture(name, R, W, H, az0, az1, lat=LAT, lon=LON, keep_depth=True, *
     np.savez_compressed(os.path.join(OUT, f"render_{name}.npz"), mosaic=m, W=np.int32(W), H=np.int32(H),
                         bgr=g["bgr"], z24=g["z24"], **extra, **view_arrays(v))
     print(f"render_{name}.npz: {W}x{H}, terrain fraction {(g['z24'] != 0xFFFFFF).mean():.3f}")
+
+
+def checksum_fixtures():
+    """full-size scenes, too large to commit as images: the SHA-256 of what the
+    reference's shaders drew on llvmpipe (BGR bytes, 24-bit depth), next to the
+    hash of the DEM window and the uniform values that went in"""
+    import hashlib
+    import json
+    out = {}
+    for name, R, W, H, zfar in [("cfg2_3x3_8000x2000", 1800, 8000, 2000, 600000.0),
+                                ("cfg3_7x7_16000x4000", 4200, 16000, 4000, 600000.0),
+                                ("cfg3_7x7_16000x4000_zfar40km", 4200, 16000, 4000, 40000.0)]:
+        d = hzutil.dem_dir_for(LAT, LON, R)
+        od = oracle.Dem(LAT, LON, d, radius_cells=R)
+        m = od.mosaic()
+        v = od.view(LAT, LON, W, H, -180.0, 180.0, zfar=zfar)
+        g = glsl_run.render(m, v, W, H)
+        out[name] = {"R": R, "W": W, "H": H, "lat": LAT, "lon": LON, "az_deg0": -180.0, "az_deg1": 180.0,
+                     "znear": 100.0, "zfar": zfar,
+                     "view": {k: float(np.float32(x)) for k, x in v.as_dict().items()},
+                     "mosaic_sha256": hashlib.sha256(m.tobytes()).hexdigest(),
+                     "bgr_sha256": hashlib.sha256(g["bgr"].tobytes()).hexdigest(),
+                     "z24_sha256": hashlib.sha256(g["z24"].tobytes()).hexdigest(),
+                     "terrain_fraction": float((g["z24"] != 0xFFFFFF).mean())}
+        print(f"checksum {name}: terrain fraction {out[name]['terrain_fraction']:.3f}")
+    json.dump(out, open(os.path.join(OUT, "render_checksums.json"), "w"), indent=1)
 
 
 def raster_probe_fixture():
@@ -142,6 +168,10 @@ def main():
     for k, (dlat, dlon) in enumerate([(0.0, 0.0), (0.013, -0.021), (-0.02, 0.017), (0.031, 0.029)]):
         render_fixture(f"G4_move{k}", 64, 512, 128, -180, 180, lat=LAT + dlat, lon=LON + dlon, zfar=8000.0)
     render_fixture("G5_zextents", 64, 512, 128, 20, 200, znear=300.0, zfar=5000.0, znear_color=1000.0, zfar_color=2500.0)
+    render_fixture("G6_rough", 150, 900, 240, -180, 180, zfar=60000.0, rough=True)
+    render_fixture("G7_zoom", 200, 600, 450, 40, 52, zfar=30000.0)
+    render_fixture("G8_on_vertex", 64, 512, 128, -180, 180, lat=34.0 + 500 / 1200.0, lon=-118.0 + 500 / 1200.0)
+    checksum_fixtures()
 
 
 if __name__ == "__main__":

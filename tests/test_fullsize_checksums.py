@@ -1,0 +1,62 @@
+"""Full-size scenes against the reference: tests/golden/render_checksums.json
+holds the SHA-256 of what the reference's own shaders drew on Mesa llvmpipe for
+BASELINE's 3x3-tile / 8000x2000 and 7x7-tile / 16000x4000 panoramas (made by
+oracle/make_golden.py; the images themselves are too large to commit).  Equal
+hashes = every byte of the BGR image and of the 24-bit depth is the reference's."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hzutil
+import oracle
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "render_checksums.json")))
+
+
+def _inputs(c):
+    d = hzutil.dem_dir_for(c["lat"], c["lon"], c["R"])
+    od = oracle.Dem(c["lat"], c["lon"], d, radius_cells=c["R"])
+    m = od.mosaic()
+    if hashlib.sha256(m.tobytes()).hexdigest() != c["mosaic_sha256"]:
+        pytest.skip("the synthetic DEM generator produced different tiles on this machine (libm?)")
+    v = od.view(c["lat"], c["lon"], c["W"], c["H"], c["az_deg0"], c["az_deg1"], znear=c["znear"], zfar=c["zfar"])
+    assert {k: float(np.float32(x)) for k, x in v.as_dict().items()} == c["view"]
+    return m, v
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_oracle_cfg2_is_the_reference_render():
+    c = GOLD["cfg2_3x3_8000x2000"]
+    m, v = _inputs(c)
+    o = oracle.render(m, v, c["W"], c["H"], want=("bgr", "z24"))
+    assert _sha(o["bgr"]) == c["bgr_sha256"]
+    assert _sha(o["z24"]) == c["z24_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_hip_full_size_is_the_reference_render(name):
+    """the benchmark workload itself: HIP output == reference-on-llvmpipe, byte for byte"""
+    c = GOLD[name]
+    m, v = _inputs(c)
+    hip = hzutil.hip_render(m, v, c["W"], c["H"])
+    assert _sha(hip["bgr"]) == c["bgr_sha256"]
+    assert _sha(hip["z24"]) == c["z24_sha256"]
+    assert abs(float((hip["index"] >= 0).mean()) - c["terrain_fraction"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_hip_cfg3_equals_oracle_on_every_output():
+    """16000x4000 over the 7x7 mosaic: index map and ranges too (the reference
+    has no index map; ranges are its CPU conversion of the depth)"""
+    c = GOLD["cfg3_7x7_16000x4000"]
+    m, v = _inputs(c)
+    hip = hzutil.hip_render(m, v, c["W"], c["H"])
+    orc = oracle.render(m, v, c["W"], c["H"])
+    hzutil.assert_same_render(hip, orc, "cfg3 full size")
