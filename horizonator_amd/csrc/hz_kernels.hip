@@ -1323,8 +1323,6 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.inline_max = (p.SW == p.W) ? HZ_INLINE_MAX_PIX : 16;
     p.far_dd = (v->zfar*1.001f)*(v->zfar*1.001f);
     p.big_min    = HZ_INLINE_MAX_PIX;
-    { const char* a = getenv("HZ_T_INLINE"); if(a) p.inline_max = (unsigned int)atoi(a); }
-    { const char* a = getenv("HZ_T_BIG");    if(a) p.big_min    = (unsigned int)atoi(a); }
     return p;
 }
 
