@@ -78,7 +78,7 @@ def main():
         dist.barrier()
     import hzutil
     import horizonator_amd
-    from horizonator_amd.sharding import gather_strips, sector_columns
+    from horizonator_amd.sharding import gather_strips_async, sector_columns
 
     cfg = CONFIGS[args.config]
     R, W, H = cfg["R"], cfg["W"], cfg["H"]
@@ -101,18 +101,35 @@ def main():
     SW = col1 - col0
     h.set_profiling(True)
 
-    d_img = torch.empty((H, SW, 3), dtype=torch.uint8, device=dev)
-    d_rng = torch.empty((H, SW), dtype=torch.float32, device=dev)
+    # two sets of strip buffers: while RCCL moves the strips of panorama k to
+    # rank 0, panorama k+1 is already being rendered into the other set
+    NBUF = 2 if world > 1 else 1
+    d_img = [torch.empty((H, SW, 3), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    d_rng = [torch.empty((H, SW), dtype=torch.float32, device=dev) for _ in range(NBUF)]
+    pending = [[] for _ in range(NBUF)]
+    state = {"k": 0, "last": None}
+
+    def finish(slot):
+        """complete the exchange that still reads buffer set `slot`"""
+        for hnd in pending[slot]:
+            state["last"] = hnd.result()         # rank 0: the assembled [H, W, ...] tensor
+        if pending[slot]:
+            torch.cuda.current_stream().synchronize()
+        pending[slot] = []
 
     def step():
-        h.render_device(d_img.data_ptr(), d_rng.data_ptr())
+        slot = state["k"] % NBUF
+        state["k"] += 1
+        finish(slot)
+        h.render_device(d_img[slot].data_ptr(), d_rng[slot].data_ptr())
         h.sync()
         if world > 1:
             # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
-            img = gather_strips(d_img, W)
-            rng = gather_strips(d_rng, W)
-            return img, rng
-        return d_img, d_rng
+            pending[slot] = [gather_strips_async(d_img[slot], W), gather_strips_async(d_rng[slot], W)]
+
+    def drain():
+        for slot in range(NBUF):
+            finish(slot)
 
     def fence():
         torch.cuda.synchronize()
@@ -124,13 +141,15 @@ def main():
         h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=zfar)
         for _ in range(warmup):
             step()
+        drain()
         kern = []
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
             kern.append(h.last_times())
-        fence()
+        drain()                 # every one of the K panoramas is assembled on rank 0 ...
+        fence()                 # ... before the clock stops
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -195,7 +214,7 @@ def main():
             "config": {
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
-                "parallelism": f"azimuth sectors x{world}" + (" + RCCL gather of BGR8/float32 strips" if world > 1 else ""),
+                "parallelism": f"azimuth sectors x{world}" + (" + RCCL gather of BGR8/float32 strips to rank 0, overlapped with the next render" if world > 1 else ""),
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",
                 "init_s": init_s,

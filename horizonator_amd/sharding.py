@@ -50,3 +50,47 @@ def gather_strips(strip, width, group=None, dst=0):
         c0, c1 = sector_columns(width, world, r)
         parts.append(b[:, :c1 - c0])
     return torch.cat(parts, dim=1)
+
+
+class PendingGather:
+    """a gather of strips that is in flight (see gather_strips_async)"""
+
+    def __init__(self, work, bins, width, world, strip):
+        self._work, self._bins, self._width, self._world = work, bins, width, world
+        self._strip = strip                 # keeps the send buffer alive until the exchange is over
+
+    def result(self):
+        """wait for the exchange; the assembled [H, width, ...] tensor on the
+        destination rank, None elsewhere"""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self._bins is None:
+            return None
+        parts = []
+        for r, b in enumerate(self._bins):
+            c0, c1 = sector_columns(self._width, self._world, r)
+            parts.append(b[:, :c1 - c0])
+        return torch.cat(parts, dim=1)
+
+
+def gather_strips_async(strip, width, group=None, dst=0):
+    """gather_strips() without waiting: the exchange of panorama k runs (on
+    RCCL's stream) while the caller renders panorama k+1 into another buffer.
+    Call .result() on the returned handle before the strip's buffer is reused."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        done = PendingGather(None, None, width, world, strip)
+        done.result = lambda: strip
+        return done
+    widest = -(-width // world)
+    sw = strip.shape[1]
+    if sw < widest:
+        pad_shape = list(strip.shape)
+        pad_shape[1] = widest - sw
+        strip = torch.cat([strip, strip.new_zeros(pad_shape)], dim=1)
+    strip = strip.contiguous()
+    bins = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
+    work = dist.gather(strip, bins, dst=dst, group=group, async_op=True)
+    return PendingGather(work, bins, width, world, strip)

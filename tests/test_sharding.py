@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import gather_strips, sector_columns
+from horizonator_amd.sharding import gather_strips, gather_strips_async, sector_columns
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -52,13 +52,19 @@ def _worker(rank, world, port, q):
         img = gather_strips(torch.from_numpy(mine["bgr"]), W)
         rng = gather_strips(torch.from_numpy(mine["ranges"]), W)
         idx = gather_strips(torch.from_numpy(mine["index"]), W)
+        # the pipelined form bench.py uses: two exchanges in flight, finished later
+        h1 = gather_strips_async(torch.from_numpy(mine["z24"].astype(np.int64)), W)
+        h2 = gather_strips_async(torch.from_numpy(mine["ranges"]), W)
+        z_async, rng_async = h1.result(), h2.result()
         if rank == 0:
             full = oracle.render(g["mosaic"], v, W, H, nthreads=1)
+            assert np.array_equal(z_async.numpy(), full["z24"].astype(np.int64))
+            assert np.array_equal(rng_async.numpy(), full["ranges"])
             ok = (np.array_equal(img.numpy(), full["bgr"]) and np.array_equal(rng.numpy(), full["ranges"])
                   and np.array_equal(idx.numpy(), full["index"]))
             q.put(bool(ok))
         else:
-            assert img is None and rng is None
+            assert img is None and rng is None and z_async is None and rng_async is None
     finally:
         dist.destroy_process_group()
 
