@@ -201,6 +201,25 @@ class horizonator:
         if not ok:
             raise RuntimeError("horizonator_amd_render_device() failed")
 
+    def render_batch(self, lats, lons, d_images=0, d_ranges=0, viewer_z=None):
+        """One render per viewpoint (lats[v], lons[v]) with the current azimuth
+        and z extents, into caller-owned DEVICE buffers laid out [n][H][SW][3]
+        (BGR) and [n][H][SW] (float32); raw pointers, 0 = skip.  The whole batch
+        is queued without waiting; call sync().  Returns the viewer heights used
+        (float32[n]): viewer_z, or 1 m above the terrain where that is None/<0."""
+        lats = np.ascontiguousarray(lats, np.float32)
+        lons = np.ascontiguousarray(lons, np.float32)
+        if lats.shape != lons.shape or lats.ndim != 1:
+            raise ValueError("lats and lons must be 1-D and of equal length")
+        z = np.full(lats.shape, -1.0, np.float32) if viewer_z is None else \
+            np.array(np.broadcast_to(np.asarray(viewer_z, np.float32), lats.shape))
+        ok = self._lib.horizonator_amd_render_batch(
+            C.byref(self._ctx), int(lats.size), lats.ctypes.data, lons.ctypes.data, z.ctypes.data,
+            d_images or None, d_ranges or None)
+        if not ok:
+            raise RuntimeError("horizonator_amd_render_batch() failed")
+        return z
+
     def set_view(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
                  znear=HORIZONATOR_ZNEAR_DEFAULT, zfar=HORIZONATOR_ZFAR_DEFAULT,
                  znear_color=-1.0, zfar_color=-1.0):

@@ -115,6 +115,7 @@ def load():
 
     sig("horizonator_amd_render", b, ctxp, vp, vp, vp, vp)
     sig("horizonator_amd_render_device", b, ctxp, vp, vp, vp, vp)
+    sig("horizonator_amd_render_batch", b, ctxp, i, vp, vp, vp, vp, vp)
     sig("horizonator_amd_sync", b, ctxp)
     sig("horizonator_amd_set_sector", b, ctxp, i, i)
     sig("horizonator_amd_set_raster", b, ctxp, i)
@@ -161,7 +162,8 @@ DECLARED_SYMBOLS = [
     "horizonator_dem_init", "horizonator_dem_deinit", "horizonator_dem_sample",
     "horizonator_dem_bounds_latlon_deg",
     # include/horizonator_amd.h
-    "horizonator_amd_render", "horizonator_amd_render_device", "horizonator_amd_sync",
+    "horizonator_amd_render", "horizonator_amd_render_device", "horizonator_amd_render_batch",
+    "horizonator_amd_sync",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
     "horizonator_amd_get_mosaic", "horizonator_amd_link_cells_size", "horizonator_amd_link_cells",

@@ -33,6 +33,8 @@ typedef struct
     int          width, height;
     int          col0, col1;
     float*       tanel;         /* [height] */
+    bool         tanel_valid;   /* ... computed for these azimuth extents: */
+    float        tanel_az0, tanel_az1;
 } hz_state_t;
 
 #define HZ_MAX_CONTEXTS 64
@@ -353,6 +355,8 @@ static void fill_tanel(hz_state_t* s)
     const int   height = s->height;
     const float aspect = (float)s->width / (float)height;
     const float az_deg0 = s->view.az_deg0, az_deg1 = s->view.az_deg1;
+    if(s->tanel_valid && s->tanel_az0 == az_deg0 && s->tanel_az1 == az_deg1) return;
+    s->tanel_valid = true; s->tanel_az0 = az_deg0; s->tanel_az1 = az_deg1;
     for(int row=0; row<height; row++)
     {
         int y = row;
@@ -501,6 +505,27 @@ bool horizonator_amd_render_device(const horizonator_context_t* ctx,
                                    void* d_image, float* d_ranges, int32_t* d_index, uint32_t* d_z24)
 {
     return render_common(ctx, false, d_image, d_ranges, d_index, d_z24);
+}
+
+bool horizonator_amd_render_batch(horizonator_context_t* ctx, int n,
+                                  const float* viewer_lat, const float* viewer_lon, float* viewer_z,
+                                  void* d_images, float* d_ranges)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || n < 0 || viewer_lat == NULL || viewer_lon == NULL) return false;
+    const size_t npix = (size_t)(s->col1 - s->col0) * (size_t)s->height;
+    for(int v=0; v<n; v++)
+    {
+        /* exactly what a caller of the reference does per viewpoint
+         * (horizonator-pywrap.c:219-233: move, then render) */
+        if(!horizonator_move(ctx, viewer_z ? &viewer_z[v] : NULL, viewer_lat[v], viewer_lon[v]))
+            return false;
+        if(!render_common(ctx, false,
+                          d_images ? (char*)d_images + (size_t)v*npix*3 : NULL,
+                          d_ranges ? d_ranges + (size_t)v*npix : NULL, NULL, NULL))
+            return false;
+    }
+    return true;
 }
 
 bool horizonator_amd_sync(const horizonator_context_t* ctx)

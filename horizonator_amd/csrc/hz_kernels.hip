@@ -1069,6 +1069,8 @@ struct hz_dev
     unsigned int*       d_big_counters;     /* [0] big records [1] big items [2] first invalid big item [3] mid records */
     unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
     float*              d_tanel;
+    float*              h_tanel;        /* the table d_tanel holds (or is about to, in stream order) */
+    int                 tanel_resident;
 
     /* internal output buffers for *_to_host */
     unsigned char* d_bgr;
@@ -1101,6 +1103,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_clip);
     (void)hipFree(d->d_big_counters);
     (void)hipFree(d->d_tanel);
+    free(d->h_tanel);
     (void)hipFree(d->d_bgr);
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
@@ -1134,6 +1137,8 @@ static int create_impl(hz_dev_t* d)
     HZ_CHECK(hipMalloc(&d->d_clip,    (size_t)d->clip_capacity*sizeof(uint32_t)));
     HZ_CHECK(hipMalloc(&d->d_big_counters, 5*sizeof(unsigned int)));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
+    d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
+    d->tanel_resident = 0;
     for(int k=0; k<6; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
     return 0;
 }
@@ -1403,6 +1408,20 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     return 0;
 }
 
+/* The per-row tan(elevation) table only changes with the azimuth extents: a
+ * table equal to the resident one is not sent again (a host->device copy from
+ * pageable memory would otherwise stall the host on the stream once per render) */
+static int upload_tanel(hz_dev_t* d, const float* tanel)
+{
+    if(!tanel) { snprintf(g_last_error, sizeof(g_last_error), "a tanel table is required"); return -1; }
+    const size_t bytes = (size_t)d->H*sizeof(float);
+    if(d->tanel_resident && memcmp(d->h_tanel, tanel, bytes) == 0) return 0;
+    memcpy(d->h_tanel, tanel, bytes);
+    HZ_CHECK(hipMemcpyAsync(d->d_tanel, d->h_tanel, bytes, hipMemcpyHostToDevice, d->stream));
+    d->tanel_resident = 1;
+    return 0;
+}
+
 extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                               unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
@@ -1416,7 +1435,7 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
             snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve: ranges requested without a tanel table");
             return -1;
         }
-        HZ_CHECK(hipMemcpyAsync(d->d_tanel, tanel, (size_t)d->H*sizeof(float), hipMemcpyHostToDevice, d->stream));
+        if(upload_tanel(d, tanel) != 0) return -1;
     }
     if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->stream));
     const size_t npix = (size_t)SW*d->H;
@@ -1595,13 +1614,6 @@ void k_poi(const unsigned long long* __restrict__ fb, const float* __restrict__ 
         label_x[k] = (float)cx;
         label_y[k] = (float)(cy + (float)fuzz_nearest);
     }
-}
-
-static int upload_tanel(hz_dev_t* d, const float* tanel)
-{
-    if(!tanel) { snprintf(g_last_error, sizeof(g_last_error), "a tanel table is required"); return -1; }
-    HZ_CHECK(hipMemcpyAsync(d->d_tanel, tanel, (size_t)d->H*sizeof(float), hipMemcpyHostToDevice, d->stream));
-    return 0;
 }
 
 extern "C" int hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float* tanel,

@@ -1,4 +1,5 @@
-"""Azimuth-sector sharding of one panorama across the GPUs of a node.
+"""Sharding across the GPUs of a node: one panorama by azimuth sector, or a
+batch of viewpoints by viewpoint.
 
 The reference has no multi-device code; this is the multi-GPU design of this
 build (DESIGN.md "Multi-GPU").  Every rank holds the full DEM mosaic and the
@@ -10,6 +11,14 @@ group's backend is "nccl"; gloo on CPU in the tests).
 """
 import torch
 import torch.distributed as dist
+
+
+def _world_and_rank(group):
+    """(1, 0) in a process that runs alone (no process group), so that the same
+    caller code serves one GPU and many"""
+    if not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
 
 
 def sector_columns(width, world_size, rank):
@@ -30,8 +39,7 @@ def gather_strips(strip, width, group=None, dst=0):
     tensor for gloo).  Returns the assembled [H, width, ...] tensor on `dst`,
     None elsewhere.  Strips may differ in width by one column; they travel
     padded to the widest."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world_and_rank(group)
     if world == 1:
         return strip
     widest = -(-width // world)
@@ -78,8 +86,7 @@ def gather_strips_async(strip, width, group=None, dst=0):
     """gather_strips() without waiting: the exchange of panorama k runs (on
     RCCL's stream) while the caller renders panorama k+1 into another buffer.
     Call .result() on the returned handle before the strip's buffer is reused."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world_and_rank(group)
     if world == 1:
         done = PendingGather(None, None, width, world, strip)
         done.result = lambda: strip
@@ -94,3 +101,36 @@ def gather_strips_async(strip, width, group=None, dst=0):
     bins = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
     work = dist.gather(strip, bins, dst=dst, group=group, async_op=True)
     return PendingGather(work, bins, width, world, strip)
+
+
+# ---- a batch of viewpoints (BASELINE.json configs[3]) --------------------------
+
+def viewpoint_slice(n, world_size, rank):
+    """viewpoints [v0, v1) of `rank`: every rank holds the whole DEM mosaic and
+    renders a contiguous block of the batch; renders are independent, so the
+    only exchange is the gather of the finished images"""
+    return sector_columns(n, world_size, rank)
+
+
+def gather_viewpoints(images, n, group=None, dst=0):
+    """images: this rank's [n_local, ...] tensor of finished panoramas.
+    Returns the [n, ...] batch on `dst` (viewpoint order), None elsewhere.
+    Blocks may differ in length by one; they travel padded to the longest."""
+    world, rank = _world_and_rank(group)
+    if world == 1:
+        return images
+    longest = -(-n // world)
+    if images.shape[0] < longest:
+        pad_shape = list(images.shape)
+        pad_shape[0] = longest - images.shape[0]
+        images = torch.cat([images, images.new_zeros(pad_shape)], dim=0)
+    images = images.contiguous()
+    bins = [torch.empty_like(images) for _ in range(world)] if rank == dst else None
+    dist.gather(images, bins, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r, b in enumerate(bins):
+        v0, v1 = viewpoint_slice(n, world, r)
+        parts.append(b[:v1 - v0])
+    return torch.cat(parts, dim=0)

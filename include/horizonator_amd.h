@@ -35,6 +35,19 @@ bool horizonator_amd_render_device(const horizonator_context_t* ctx,
                                    int32_t* d_index, uint32_t* d_z24);
 bool horizonator_amd_sync(const horizonator_context_t* ctx);
 
+/* A batch of viewpoints over the context's DEM window (BASELINE.json configs[3]):
+ * for v in [0,n): horizonator_move(viewer_lat[v], viewer_lon[v]) followed by a
+ * render into DEVICE buffers d_images[v] ([H][sector width][3] BGR) and
+ * d_ranges[v] ([H][sector width] float32); either base pointer may be NULL.
+ * viewer_z: NULL = stand 1 m above the terrain at every viewpoint; otherwise n
+ * in/out values with the meaning of horizonator_move()'s argument.  Nothing is
+ * synchronised between viewpoints: the whole batch is queued on the context's
+ * stream; follow with horizonator_amd_sync().  The context is left at the last
+ * viewpoint. */
+bool horizonator_amd_render_batch(horizonator_context_t* ctx, int n,
+                                  const float* viewer_lat, const float* viewer_lon, float* viewer_z,
+                                  void* d_images, float* d_ranges);
+
 /* Restrict this context to image columns [col0,col1) of the panorama: the
  * azimuth-sector shard one GPU renders.  Outputs then have width col1-col0. */
 bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1);

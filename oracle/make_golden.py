@@ -127,6 +127,32 @@ def checksum_fixtures():
     json.dump(out, open(os.path.join(OUT, "render_checksums.json"), "w"), indent=1)
 
 
+def batch_checksum_fixtures():
+    """BASELINE.json configs[3]: viewpoints of the 16x16 lattice over one 5x5-tile
+    window, 8000x2000 each - the SHA-256 of the reference's draw for a few of them"""
+    import hashlib
+    import json
+    R, W, H, zfar = 3000, 8000, 2000, 600000.0
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    lats, lons = hzutil.viewpoint_lattice(LAT, LON)
+    out = {"R": R, "W": W, "H": H, "lat": LAT, "lon": LON, "az_deg0": -180.0, "az_deg1": 180.0,
+           "znear": 100.0, "zfar": zfar, "mosaic_sha256": hashlib.sha256(m.tobytes()).hexdigest(),
+           "viewpoints": {}}
+    for vp in (0, 37, 136, 255):
+        v = od.view(float(lats[vp]), float(lons[vp]), W, H, -180.0, 180.0, zfar=zfar)
+        g = glsl_run.render(m, v, W, H)
+        out["viewpoints"][str(vp)] = {
+            "lat": float(lats[vp]), "lon": float(lons[vp]),
+            "view": {k: float(np.float32(x)) for k, x in v.as_dict().items()},
+            "bgr_sha256": hashlib.sha256(g["bgr"].tobytes()).hexdigest(),
+            "z24_sha256": hashlib.sha256(g["z24"].tobytes()).hexdigest(),
+            "terrain_fraction": float((g["z24"] != 0xFFFFFF).mean())}
+        print(f"batch checksum viewpoint {vp}: terrain fraction {out['viewpoints'][str(vp)]['terrain_fraction']:.3f}")
+    json.dump(out, open(os.path.join(OUT, "batch_checksums.json"), "w"), indent=1)
+
+
 def raster_probe_fixture():
     """llvmpipe's fill rule and depth rounding on hand-made triangles (our own
     pass-through shaders; no reference code involved)"""
@@ -155,6 +181,9 @@ def main():
     if not glsl_run.available() or oracle.load_ref_dem() is None:
         sys.exit("needs /root/reference and oracle/_ref (run `make -C oracle` first)")
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["batch"]:               # only tests/golden/batch_checksums.json
+        batch_checksum_fixtures()
+        return
     dem_fixtures()
     raster_probe_fixture()
     # vertex stage (pins reference vertex.glsl:111-162 bit for bit)
@@ -172,6 +201,7 @@ def main():
     render_fixture("G7_zoom", 200, 600, 450, 40, 52, zfar=30000.0)
     render_fixture("G8_on_vertex", 64, 512, 128, -180, 180, lat=34.0 + 500 / 1200.0, lon=-118.0 + 500 / 1200.0)
     checksum_fixtures()
+    batch_checksum_fixtures()
 
 
 if __name__ == "__main__":

@@ -37,6 +37,16 @@ def dem_dir_for(lat, lon, radius_cells, srtm1=False, rough=False):
     return dem_dir(*tiles_for(lat, lon, radius_cells, srtm1), srtm1=srtm1, rough=rough)
 
 
+def viewpoint_lattice(lat=VIEW_LAT, lon=VIEW_LON, side=16, half_span_deg=0.2):
+    """the batch of side*side viewpoints of BASELINE.json configs[3],
+    a lattice of +-half_span_deg around (lat,lon); viewpoint v = row*side + column,
+    rows south to north, columns west to east; float32 as the API takes them"""
+    off = (np.arange(side, dtype=np.float64) / (side - 1) - 0.5) * 2.0 * half_span_deg
+    lats = np.repeat(lat + off, side).astype(np.float32)
+    lons = np.tile(lon + off, side).astype(np.float32)
+    return lats, lons
+
+
 # ---- driving the HIP path through its C-ABI (include/hz_hip.h) ---------------
 
 def hip_available():

@@ -14,6 +14,8 @@ import hzutil
 import oracle
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "render_checksums.json")))
+# BASELINE.json configs[3]: four of the 256 viewpoints over the 5x5-tile window, same provenance
+BATCH = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "batch_checksums.json")))
 
 
 def _inputs(c):
@@ -60,3 +62,57 @@ def test_hip_cfg3_equals_oracle_on_every_output():
     hip = hzutil.hip_render(m, v, c["W"], c["H"])
     orc = oracle.render(m, v, c["W"], c["H"])
     hzutil.assert_same_render(hip, orc, "cfg3 full size")
+
+
+def _batch_inputs():
+    c = BATCH
+    d = hzutil.dem_dir_for(c["lat"], c["lon"], c["R"])
+    od = oracle.Dem(c["lat"], c["lon"], d, radius_cells=c["R"])
+    if hashlib.sha256(od.mosaic().tobytes()).hexdigest() != c["mosaic_sha256"]:
+        pytest.skip("the synthetic DEM generator produced different tiles on this machine (libm?)")
+    return d, od
+
+
+def test_oracle_batch_viewpoint_is_the_reference_render():
+    """a moved viewpoint inside the 5x5-tile window (pins the host-side derivation of
+    the viewer cell / height for viewpoints other than the window's centre)"""
+    c = BATCH
+    d, od = _batch_inputs()
+    g = c["viewpoints"]["37"]
+    v = od.view(g["lat"], g["lon"], c["W"], c["H"], c["az_deg0"], c["az_deg1"], znear=c["znear"], zfar=c["zfar"])
+    assert {k: float(np.float32(x)) for k, x in v.as_dict().items()} == g["view"]
+    o = oracle.render(od.mosaic(), v, c["W"], c["H"], want=("bgr", "z24"))
+    assert _sha(o["bgr"]) == g["bgr_sha256"] and _sha(o["z24"]) == g["z24_sha256"]
+
+
+@pytest.mark.gpu
+def test_hip_viewpoint_batch_is_the_reference_render():
+    """BASELINE.json configs[3] at full size through the product API: one context over the
+    5x5-tile window, horizonator_amd_render_batch() over lattice viewpoints; every byte of
+    every image is what the reference's shaders drew on llvmpipe for that viewpoint"""
+    import torch
+    import horizonator_amd
+    c = BATCH
+    d, od = _batch_inputs()
+    W, H = c["W"], c["H"]
+    lats, lons = hzutil.viewpoint_lattice(c["lat"], c["lon"])
+    pick = sorted(int(k) for k in c["viewpoints"])
+    h = horizonator_amd.horizonator(c["lat"], c["lon"], W, H, dir_dems=d, render_radius_cells=c["R"])
+    try:
+        h.set_view(c["az_deg0"], c["az_deg1"], znear=c["znear"], zfar=c["zfar"])
+        d_img = torch.empty((len(pick), H, W, 3), dtype=torch.uint8, device="cuda:0")
+        z = h.render_batch(lats[pick], lons[pick], d_img.data_ptr(), 0)
+        h.sync()
+        img = d_img.cpu().numpy()
+        for k, vp in enumerate(pick):
+            g = c["viewpoints"][str(vp)]
+            assert np.float32(g["view"]["viewer_z"]) == z[k]
+            assert _sha(img[k]) == g["bgr_sha256"], vp
+        # depth of one of them through the one-at-a-time API
+        g = c["viewpoints"][str(pick[-1])]
+        _, _, index, z24 = h.render_full(c["az_deg0"], c["az_deg1"], lat=g["lat"], lon=g["lon"],
+                                         znear=c["znear"], zfar=c["zfar"])
+        assert _sha(z24) == g["z24_sha256"]
+        assert abs(float((index >= 0).mean()) - g["terrain_fraction"]) < 1e-12
+    finally:
+        h.close()

@@ -181,3 +181,34 @@ def test_more_tiles_than_the_reference_can_load():
     ref = oracle.render(od.mosaic(), od.view(LAT, LON, 512, 128, -180, 180, zfar=300000.0), 512, 128)
     hzutil.assert_same_render(dict(bgr=image, ranges=ranges, index=index, z24=z24), ref, "5x5")
     h.close()
+
+
+def test_viewpoint_batch_equals_one_render_per_viewpoint(scene):
+    """BASELINE.json configs[3] in small: horizonator_amd_render_batch() == move + render
+    per viewpoint == the oracle, and reports the viewer heights it stood at"""
+    import torch
+    h, od, W, H = scene
+    n = 9
+    lats = np.array([LAT + 0.03 * (v // 3 - 1) for v in range(n)], np.float32)
+    lons = np.array([LON + 0.04 * (v % 3 - 1) for v in range(n)], np.float32)
+    h.set_view(-180, 180, zfar=30000.0)
+    d_img = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda:0")
+    d_rng = torch.empty((n, H, W), dtype=torch.float32, device="cuda:0")
+    z = h.render_batch(lats, lons, d_img.data_ptr(), d_rng.data_ptr())
+    h.sync()
+    img, rng = d_img.cpu().numpy(), d_rng.cpu().numpy()
+    mosaic = od.mosaic()
+    for v in range(n):
+        ov = od.view(float(lats[v]), float(lons[v]), W, H, -180, 180, zfar=30000.0)
+        assert np.float32(ov.viewer_z) == z[v]
+        ref = oracle.render(mosaic, ov, W, H, want=("bgr", "ranges"))
+        assert np.array_equal(img[v], ref["bgr"]) and np.array_equal(rng[v], ref["ranges"]), v
+    # ... and equals the one-at-a-time API of the reference
+    one_img, one_rng = h.render(-180, 180, lat=float(lats[4]), lon=float(lons[4]), zfar=30000.0)
+    assert np.array_equal(one_img, img[4]) and np.array_equal(one_rng, rng[4])
+    # explicit viewer heights are taken as given
+    z2 = h.render_batch(lats[:2], lons[:2], d_img.data_ptr(), 0, viewer_z=[2500.0, 2600.0])
+    h.sync()
+    assert list(z2) == [2500.0, 2600.0]
+    ov = od.view(float(lats[1]), float(lons[1]), W, H, -180, 180, viewer_z=2600.0, zfar=30000.0)
+    assert np.array_equal(d_img[1].cpu().numpy(), oracle.render(mosaic, ov, W, H, want=("bgr",))["bgr"])

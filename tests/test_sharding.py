@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import gather_strips, gather_strips_async, sector_columns
+from horizonator_amd.sharding import (gather_strips, gather_strips_async, gather_viewpoints, sector_columns,
+                                      viewpoint_slice)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -78,5 +79,69 @@ def test_two_rank_gloo_gather_reassembles_the_panorama():
         p.start()
     for p in procs:
         p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
+
+
+# ---- batch of viewpoints, sharded by viewpoint (BASELINE.json configs[3]) -------
+
+def _batch_views(g, n):
+    """n viewpoints around the fixture's: the viewer cell moves, everything else stays"""
+    import oracle
+    base = {k: float(g["u_" + k]) for k in oracle.VIEW_FIELDS}
+    views = []
+    for v in range(n):
+        u = dict(base)
+        u["viewer_cell_i"] = base["viewer_cell_i"] + 1.75 * (v % 3 - 1)
+        u["viewer_cell_j"] = base["viewer_cell_j"] - 1.25 * (v // 3 - 1)
+        views.append(oracle.make_view(**u))
+    return views
+
+
+def _batch_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = np.load(os.path.join(GOLD, "render_G4_move2.npz"))
+        W, H, n = int(g["W"]), int(g["H"]), 7            # 7 over 2 ranks: blocks of 4 and 3
+        views = _batch_views(g, n)
+        v0, v1 = viewpoint_slice(n, world, rank)
+        mine = np.stack([oracle.render(g["mosaic"], views[v], W, H, nthreads=1, want=("bgr",))["bgr"]
+                         for v in range(v0, v1)])
+        batch = gather_viewpoints(torch.from_numpy(mine), n)
+        if rank == 0:
+            assert batch.shape == (n, H, W, 3)
+            ok = all(np.array_equal(batch[v].numpy(),
+                                    oracle.render(g["mosaic"], views[v], W, H, nthreads=1, want=("bgr",))["bgr"])
+                     for v in range(n))
+            distinct = len({batch[v].numpy().tobytes() for v in range(n)}) == n
+            q.put(bool(ok and distinct))
+        else:
+            assert batch is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_viewpoint_slices_partition_the_batch():
+    for n, world in [(256, 8), (256, 3), (7, 2), (3, 8)]:
+        sl = [viewpoint_slice(n, world, r) for r in range(world)]
+        assert sl[0][0] == 0 and sl[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+
+
+def test_two_rank_gloo_gather_of_a_viewpoint_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) is True
