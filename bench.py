@@ -166,6 +166,7 @@ def main():
     big_ms = float(np.mean([k["big_ms"] for k in kern]))
     resolve_ms = float(np.mean([k["resolve_ms"] for k in kern]))
     clear_ms = float(np.mean([k["clear_ms"] for k in kern]))
+    near_ms = float(np.mean([k["near_ms"] for k in kern]))
     total_ms = float(np.mean([k["total_ms"] for k in kern]))
     # algorithmic bytes of one render: int16 DEM read once +
     # BGR8 and float32 range written once; a sector writes its share
@@ -224,7 +225,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "k_scatter" if args.raster == 1 else "k_march", "kernel_ms": raster_ms,
                 "algorithmic_bytes": algo_bytes,
-                "other_kernels_ms": {"clear": clear_ms, "big_triangles": big_ms, "resolve": resolve_ms},
+                "other_kernels_ms": {"clear": clear_ms, "round1_near_viewer": near_ms, "queues_after": big_ms, "resolve": resolve_ms},
                 "device_ms_per_render": total_ms,
                 "achieved_whole_render": algo_bytes / (total_ms * 1e-3) / 1e9,
             },

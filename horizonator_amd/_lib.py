@@ -65,7 +65,7 @@ class View(C.Structure):
 
 class Times(C.Structure):
     """hz_times_t (include/hz_hip.h)"""
-    _fields_ = [(n, C.c_float) for n in ("clear_ms", "raster_ms", "big_ms", "resolve_ms", "total_ms")]
+    _fields_ = [(n, C.c_float) for n in ("clear_ms", "raster_ms", "big_ms", "resolve_ms", "total_ms", "near_ms")]
 
 
 RASTER_AUTO, RASTER_SCATTER, RASTER_MARCH = 0, 1, 2

@@ -183,6 +183,43 @@ HZ_HD void hz_tri_planes(hz_tri_t* t, const hz_wvert_t* a, const hz_wvert_t* b, 
     t->r_org = v0->red - (t->drdx*x0c + t->drdy*y0c);
 }
 
+/* Early depth rejection: a depth value that no fragment of triangle (a,b,c)
+ * can fall below, as a 24-bit integer.  If every pixel centre of the triangle's
+ * box already holds a SMALLER depth, none of its fragments can pass GL_LESS and
+ * the triangle may be skipped without changing a single byte of the result
+ * (stored depths only ever decrease during a draw).
+ *
+ * Why min(vertex depth) alone is not such a value: coverage is decided on
+ * positions snapped to 1/256 px, the depth plane goes through the unsnapped
+ * ones.  A covered pixel centre p lies in the snapped triangle, i.e. within
+ * 1/512 px (per axis) of a point q of the unsnapped one; depth(q) is a convex
+ * combination of the vertex depths, depth(p) = depth(q) + grad . (p-q).  For
+ * slivers grad is huge (1/area) and depth(p) undershoots the vertex depths -
+ * the oracle counts ~1800 such fragments in the 16000x4000 benchmark scene.
+ * So: floor = min vertex depth - G*(1/512 + rounding) with G >= |dz/dx|+|dz/dy|
+ * bounded from the very expressions hz_tri_planes() evaluates (same `area`,
+ * bit for bit), and the float rounding of the plane set-up and evaluation
+ * (z_org and two fmas on coordinates up to max(W,H)) bounded by
+ * 2^-22*max(W,H)*G + 3*2^-24.  `guard` = 1/500 + max(W,H)*2^-22 is passed in.
+ * Returns 0 when no useful floor exists (degenerate set-up, floor <= 0). */
+HZ_HD int hz_tri_depth_floor(const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c,
+                             float guard, uint32_t* zfloor)
+{
+    const hz_wvert_t *v0 = b, *v1 = a, *v2 = c;             /* as hz_tri_planes */
+    const float dx01 = v0->wx - v1->wx, dy01 = v0->wy - v1->wy;
+    const float dx20 = v2->wx - v0->wx, dy20 = v2->wy - v0->wy;
+    const float area = dx01*dy20 - dx20*dy01;
+    const float dz01 = hz_abs(v0->zw - v1->zw), dz20 = hz_abs(v2->zw - v0->zw);
+    /* |dzdx| <= (|dz01||dy20| + |dz20||dy01|)/|area|, |dzdy| likewise */
+    const float num  = dz01*(hz_abs(dy20) + hz_abs(dx20)) + dz20*(hz_abs(dy01) + hz_abs(dx01));
+    const float G    = num / hz_abs(area) * 1.01f;          /* 1%: rounding of this bound and of the set-up */
+    const float zmin = hz_min(v0->zw, hz_min(v1->zw, v2->zw));
+    const float zf   = zmin*16777215.f - (G*guard*16777215.f + 8.f);
+    if(!(zf >= 1.0f)) return 0;                             /* also catches NaN/inf from area == 0 */
+    *zfloor = (uint32_t)zf;                                 /* truncation: rounds down */
+    return 1;
+}
+
 /* edge function of edge m (vertex m -> m+1) at pixel centre (px,py), and
  * whether a zero belongs to the triangle */
 HZ_HD int64_t hz_edge(const hz_tri_t* t, int m, int px, int py)

@@ -51,10 +51,12 @@ enum
 typedef struct
 {
     float clear_ms;
-    float raster_ms;        /* the dominant kernel */
-    float big_ms;           /* cooperative pass over large triangles (scatter path) */
+    float raster_ms;        /* the dominant kernel: k_scatter, or k_march over everything but the strips
+                             * next to the viewer (round 2 of the draw) */
+    float big_ms;           /* the queue kernels after it: clipped, medium and large triangles */
     float resolve_ms;
     float total_ms;         /* first event to last event */
+    float near_ms;          /* round 1 of the draw: k_march next to the viewer + its queue kernels */
 } hz_times_t;
 
 int  hz_hip_device_count(void);

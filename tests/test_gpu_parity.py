@@ -121,3 +121,22 @@ def test_full_triangle_queues_fall_back_correctly(raster, capacity, monkeypatch)
     hzutil.assert_same_render(hip, orc, f"capacity {capacity}")
     for k in sect:
         assert np.array_equal(sect[k], orc[k][:, 300:425]), k
+
+
+def test_two_round_draw_with_early_depth_test_changes_nothing(monkeypatch):
+    """HZ_TWO_PASS=1: strips next to the viewer first, then everything else with the early
+    depth test of mr_flush (hz_tri_depth_floor) - byte-identical to the one-round draw and to
+    the oracle, on a scene where most of the far field is hidden and on one where none is"""
+    R, W, H = 700, 4000, 1000
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    for viewer_z in (-1.0, 6000.0):
+        v = od.view(LAT, LON, W, H, -180, 180, viewer_z=viewer_z, zfar=200000.0)
+        monkeypatch.delenv("HZ_TWO_PASS", raising=False)
+        one = hzutil.hip_render(m, v, W, H, raster=2)
+        monkeypatch.setenv("HZ_TWO_PASS", "1")
+        monkeypatch.setenv("HZ_NEAR_CELLS", "96")
+        two = hzutil.hip_render(m, v, W, H, raster=2)
+        hzutil.assert_same_render(two, one, f"two rounds vs one, viewer_z {viewer_z}")
+        hzutil.assert_same_render(two, oracle.render(m, v, W, H), f"two rounds vs oracle, viewer_z {viewer_z}")

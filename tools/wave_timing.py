@@ -20,11 +20,11 @@ a = np.frombuffer(raw[8:], np.uint64).reshape(gy, gx, 4)
 t = a[:, :, 0].astype(np.float64) / 2400.0          # shader clock ~2.4 GHz -> us
 flushes = (a[:, :, 1] >> 32).astype(np.int64); tris = (a[:, :, 1] & 0xFFFFFFFF).astype(np.int64)
 big = (a[:, :, 2] >> 32).astype(np.int64); mid = (a[:, :, 2] & 0xFFFFFFFF).astype(np.int64)
-items = a[:, :, 3].astype(np.int64)
+items = (a[:, :, 3] & 0xFFFFFFFF).astype(np.int64); hidden = (a[:, :, 3] >> 32).astype(np.int64)
 print("grid", gx, gy, "waves", gx*gy)
 q = np.percentile(t, [50, 90, 99, 99.9, 100])
 print("wave duration us: p50 %.1f p90 %.1f p99 %.1f p99.9 %.1f max %.1f; sum %.1f ms" % (*q, t.sum()/1e3))
-print("totals: flushes %d tris %d big %d mid %d inline items %d" % (flushes.sum(), tris.sum(), big.sum(), mid.sum(), items.sum()))
+print("totals: flushes %d tris %d big %d mid %d inline items %d hidden by early-Z %d" % (flushes.sum(), tris.sum(), big.sum(), mid.sum(), items.sum(), hidden.sum()))
 j, i = np.unravel_index(np.argsort(t.ravel())[-12:], t.shape)
 for y, x in zip(j[::-1], i[::-1]):
     print("   seg %d strip %d: %.1f us flushes %d tris %d big %d mid %d items %d" % (y, x, t[y, x], flushes[y, x], tris[y, x], big[y, x], mid[y, x], items[y, x]))
