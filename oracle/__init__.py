@@ -35,6 +35,21 @@ class OrcView(C.Structure):
         return {n: getattr(self, n) for n in VIEW_FIELDS}
 
 
+class OrcTex(C.Structure):
+    _fields_ = [("viewer_lat_rad", C.c_float), ("origin_cell_lon_deg", C.c_float), ("origin_cell_lat_deg", C.c_float),
+                ("lon0", C.c_float), ("lon1", C.c_float), ("dlat0", C.c_float), ("dlat1", C.c_float), ("dlat2", C.c_float),
+                ("ntiles_x", C.c_int), ("ntiles_y", C.c_int), ("lowest_x", C.c_int), ("lowest_y", C.c_int),
+                ("tex_w", C.c_int), ("tex_h", C.c_int), ("texels", C.c_void_p)]
+
+    def as_glsl_job(self):
+        """the dict oracle/glsl_run.py's texture functions take"""
+        return dict(viewer_lat_rad=self.viewer_lat_rad, origin_cell_lon_deg=self.origin_cell_lon_deg,
+                    origin_cell_lat_deg=self.origin_cell_lat_deg, texturemap_lon0=self.lon0, texturemap_lon1=self.lon1,
+                    texturemap_dlat0=self.dlat0, texturemap_dlat1=self.dlat1, texturemap_dlat2=self.dlat2,
+                    NtilesX=self.ntiles_x, NtilesY=self.ntiles_y, osmtile_lowestX=self.lowest_x,
+                    osmtile_lowestY=self.lowest_y)
+
+
 _lib = None
 
 
@@ -75,6 +90,17 @@ def load():
     lib.orc_poi_visibility.restype = None
     lib.orc_poi_visibility.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, d, d, d, d, d,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_osm_tile_id.restype = None
+    lib.orc_osm_tile_id.argtypes = [P(C.c_int), P(C.c_int), C.c_float, C.c_float]
+    lib.orc_tex_setup.restype = None
+    lib.orc_tex_setup.argtypes = [P(OrcTex), P(OrcDem), C.c_float, C.c_float, C.c_float]
+    lib.orc_vertex_tex.restype = None
+    lib.orc_vertex_tex.argtypes = [P(OrcTex), C.c_float, C.c_int, C.c_int, P(C.c_float * 2)]
+    lib.orc_tex_sample.restype = None
+    lib.orc_tex_sample.argtypes = [P(OrcTex), C.c_float, C.c_float, P(C.c_uint8 * 3)]
+    lib.orc_render_tex.restype = C.c_int
+    lib.orc_render_tex.argtypes = [C.c_void_p, C.c_int, P(OrcView), P(OrcTex), C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_tanel.restype = None
     lib.orc_tanel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
     _lib = lib
@@ -116,6 +142,15 @@ class Dem:
         v.zfar_color = zfar if zfar_color < 0 else zfar_color
         return v
 
+    def texture(self, init_lat, init_lon, viewer_lat=None):
+        """uniforms and size of the texture mosaic for a context initialised at (init_lat, init_lon)
+        whose viewer now stands at latitude viewer_lat (reference horizonator-lib.c:372-389,577-588,
+        707-759,801-809); texels are attached by render()"""
+        t = OrcTex()
+        self.lib.orc_tex_setup(C.byref(t), C.byref(self.d), init_lat, init_lon,
+                               init_lat if viewer_lat is None else viewer_lat)
+        return t
+
     def close(self):
         if self.d.tiles:
             self.lib.orc_dem_close(C.byref(self.d))
@@ -134,8 +169,10 @@ def make_view(**kw):
     return v
 
 
-def render(mosaic, view, W, H, col0=0, col1=None, nthreads=0, want=("bgr", "ranges", "index", "z24")):
-    """CPU render of image columns [col0,col1); returns a dict of arrays"""
+def render(mosaic, view, W, H, col0=0, col1=None, nthreads=0, want=("bgr", "ranges", "index", "z24"),
+           tex=None, texels=None):
+    """CPU render of image columns [col0,col1); returns a dict of arrays.
+    tex (OrcTex) + texels uint8[tex_h,tex_w,3] (B,G,R; row 0 = south): the textured draw"""
     lib = load()
     mosaic = np.ascontiguousarray(mosaic, np.int16)
     N = mosaic.shape[0]
@@ -155,8 +192,14 @@ def render(mosaic, view, W, H, col0=0, col1=None, nthreads=0, want=("bgr", "rang
     def ptr(k):
         return out[k].ctypes.data if k in out else None
 
-    rc = lib.orc_render(mosaic.ctypes.data, N, C.byref(view), W, H, col0, col1,
-                        ptr("bgr"), ptr("ranges"), ptr("index"), ptr("z24"), nthreads)
+    if tex is not None:
+        texels = np.ascontiguousarray(texels, np.uint8)
+        if texels.shape != (tex.tex_h, tex.tex_w, 3):
+            raise ValueError(f"texels must be uint8[{tex.tex_h},{tex.tex_w},3]")
+        tex.texels = texels.ctypes.data
+    rc = lib.orc_render_tex(mosaic.ctypes.data, N, C.byref(view), C.byref(tex) if tex is not None else None,
+                            W, H, col0, col1,
+                            ptr("bgr"), ptr("ranges"), ptr("index"), ptr("z24"), nthreads)
     if rc != 0:
         raise RuntimeError(f"orc_render failed ({rc})")
     return out

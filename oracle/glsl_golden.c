@@ -33,10 +33,22 @@
  *                         znear, zfar, znear_color, zfar_color
  *   mode 0,1: int16 z[N*N]          elevation, j-major (row j = constant latitude)
  *   mode 2:   int32 ntri; float32 v[ntri*3*4]   clip-space x,y,z,red per vertex
+ *   modes 3,4,5 (the texture path, reference vertex.glsl:41-61,116-126,
+ *   fragment.glsl:17-22, horizonator-lib.c:247-266,361-366,577-588,801-809):
+ *             float32 t[8]  viewer_lat (radians), origin_cell_lon_deg, origin_cell_lat_deg,
+ *                           texturemap_lon0, lon1, dlat0, dlat1, dlat2
+ *             int32 ti[6]   NtilesX, NtilesY, osmtile_lowestX, osmtile_lowestY, texW, texH
+ *             uint8 texels[texH*texW*3]   as handed to glTexSubImage2D(GL_BGR): row 0 first
+ *     3 = textured render, 4 = vertex capture including `tex`: then int16 z[N*N]
+ *     5 = raw triangles through the reference's FRAGMENT shader (our pass-through
+ *         vertex stage): int32 ntri; float32 v[ntri*3*6]  clip x,y,z, red, s, t
+ *     6 = as 5 with a fragment shader of ours that outputs texture() itself (probes
+ *         Mesa's sampler; no reference code)
  * Result file:
- *   mode 0,2: uint8 bgr[H*W*3] (GL row order, bottom first), float32 depth[H*W],
+ *   mode 0,2,3,5: uint8 bgr[H*W*3] (GL row order, bottom first), float32 depth[H*W],
  *             uint32 z24[H*W]
  *   mode 1:   float32 out[N*N*5]    gl_Position.xyzw, rgb.r
+ *   mode 4:   float32 out[N*N*7]    gl_Position.xyzw, rgb.r, tex.xy
  *
  * usage: glsl_golden SHADER_DIR JOB RESULT
  */
@@ -83,7 +95,10 @@
     X(PFNGLBINDBUFFERBASEPROC, glBindBufferBase) \
     X(PFNGLBEGINTRANSFORMFEEDBACKPROC, glBeginTransformFeedback) \
     X(PFNGLENDTRANSFORMFEEDBACKPROC, glEndTransformFeedback) \
-    X(PFNGLGETBUFFERSUBDATAPROC, glGetBufferSubData)
+    X(PFNGLGETBUFFERSUBDATAPROC, glGetBufferSubData) \
+    X(PFNGLGENTEXTURESPROC, glGenTextures) X(PFNGLACTIVETEXTUREPROC, glActiveTexture) \
+    X(PFNGLBINDTEXTUREPROC, glBindTexture) X(PFNGLTEXPARAMETERIPROC, glTexParameteri) \
+    X(PFNGLTEXIMAGE2DPROC, glTexImage2D) X(PFNGLTEXSUBIMAGE2DPROC, glTexSubImage2D)
 
 #define X(type, name) static type p_##name;
 GLFUNCS(X)
@@ -226,6 +241,52 @@ static void set_reference_uniforms(GLuint prog, const float* u)
     set1i(prog, "osmtile_lowestX", 0); set1i(prog, "osmtile_lowestY", 0);
 }
 
+/* the texture half of the uniforms and the texture object itself, made with the
+ * calls the reference makes (horizonator-lib.c:247-266 initOSMtexture, :361-366
+ * one glTexSubImage2D per tile - here the whole mosaic at once) */
+static void set_texture(GLuint prog, const float* t, const int32_t* ti, const unsigned char* texels)
+{
+    set1f(prog, "viewer_lat", t[0]);
+    set1f(prog, "origin_cell_lon_deg", t[1]); set1f(prog, "origin_cell_lat_deg", t[2]);
+    set1f(prog, "texturemap_lon0", t[3]);  set1f(prog, "texturemap_lon1", t[4]);
+    set1f(prog, "texturemap_dlat0", t[5]); set1f(prog, "texturemap_dlat1", t[6]); set1f(prog, "texturemap_dlat2", t[7]);
+    set1i(prog, "NtilesX", ti[0]); set1i(prog, "NtilesY", ti[1]);
+    set1i(prog, "osmtile_lowestX", ti[2]); set1i(prog, "osmtile_lowestY", ti[3]);
+    GLuint tex;
+    p_glGenTextures(1, &tex);
+    p_glActiveTexture(GL_TEXTURE0);
+    p_glBindTexture(GL_TEXTURE_2D, tex);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_REPEAT);
+    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_REPEAT);
+    p_glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+    p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGB, ti[4], ti[5], 0, GL_BGR, GL_UNSIGNED_BYTE, NULL);
+    p_glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, ti[4], ti[5], GL_BGR, GL_UNSIGNED_BYTE, texels);
+    set1i(prog, "tex", 0);
+    GLCHECK("texture");
+}
+
+/* vertex stage of the texture probe: position, shade and texture coordinate
+ * straight from the attributes, under the names the reference's fragment
+ * shader reads */
+static const char* texprobe_vs =
+    "#version 420\n"
+    "layout (location = 0) in vec4 v;\n"
+    "layout (location = 1) in vec2 t;\n"
+    "out vec3 rgb_fragment;\n"
+    "out vec2 tex_fragment;\n"
+    "void main(void) { gl_Position = vec4(v.xyz, 1.0); rgb_fragment = vec3(v.w, 0., 0.); tex_fragment = t; }\n";
+
+/* fragment stage that shows the sampler's result unscaled (mode 6) */
+static const char* texprobe_fs =
+    "#version 420\n"
+    "layout(location = 0) out vec4 frag_color;\n"
+    "in vec3 rgb_fragment;\n"
+    "in vec2 tex_fragment;\n"
+    "uniform sampler2D tex;\n"
+    "void main(void) { frag_color = texture(tex, tex_fragment.xy) + 0.*vec4(rgb_fragment, 0.); }\n";
+
 static const char* passthrough_vs =
     "#version 420\n"
     "layout (location = 0) in vec4 v;\n"
@@ -284,6 +345,14 @@ int main(int argc, char** argv)
     int32_t hdr[4]; float u[12];
     if(fread(hdr, 4, 4, job) != 4 || fread(u, 4, 12, job) != 12) DIE("short job header");
     const int mode = hdr[0], N = hdr[1], W = hdr[2], H = hdr[3];
+    float t[8] = {0}; int32_t ti[6] = {0}; unsigned char* texels = NULL;
+    if(mode >= 3)
+    {
+        if(fread(t, 4, 8, job) != 8 || fread(ti, 4, 6, job) != 6) DIE("short texture header");
+        const size_t nb = (size_t)ti[4]*ti[5]*3;
+        texels = malloc(nb);
+        if(fread(texels, 1, nb, job) != nb) DIE("short texture body");
+    }
 
     make_context();
     fprintf(stderr, "glsl_golden: %s / %s\n", (const char*)p_glGetString(GL_VERSION), (const char*)p_glGetString(GL_RENDERER));
@@ -303,7 +372,7 @@ int main(int argc, char** argv)
     GLuint vbo; p_glGenBuffers(1, &vbo);      p_glBindBuffer(GL_ARRAY_BUFFER, vbo);
     p_glEnableVertexAttribArray(0);
 
-    if(mode == 0 || mode == 1)
+    if(mode == 0 || mode == 1 || mode == 3 || mode == 4)
     {
         int16_t* z = malloc((size_t)N*N*sizeof(int16_t));
         if(fread(z, 2, (size_t)N*N, job) != (size_t)N*N) DIE("short job body");
@@ -318,13 +387,14 @@ int main(int argc, char** argv)
         char* vs_src = read_text(argv[1], "vertex.glsl");
         GLuint prog = p_glCreateProgram();
         p_glAttachShader(prog, compile(GL_VERTEX_SHADER, vs_src, "vertex"));
-        if(mode == 0)
+        if(mode == 0 || mode == 3)
         {
             p_glAttachShader(prog, compile(GL_FRAGMENT_SHADER, read_text(argv[1], "fragment.glsl"), "fragment"));
             p_glAttachShader(prog, compile(GL_GEOMETRY_SHADER, read_text(argv[1], "geometry.glsl"), "geometry"));
             link_program(prog);
             p_glUseProgram(prog);
             set_reference_uniforms(prog, u);
+            if(mode == 3) set_texture(prog, t, ti, texels);
             GLCHECK("uniforms");
 
             /* reference horizonator-lib.c:492-508 */
@@ -351,15 +421,17 @@ int main(int argc, char** argv)
         {
             /* vertex stage only: capture gl_Position and rgb of every vertex */
             p_glAttachShader(prog, compile(GL_FRAGMENT_SHADER, dummy_fs, "dummy fragment"));
-            const char* varyings[] = { "gl_Position", "rgb" };
-            p_glTransformFeedbackVaryings(prog, 2, varyings, GL_INTERLEAVED_ATTRIBS);
+            const char* varyings[] = { "gl_Position", "rgb", "tex" };
+            const int nvar = mode == 4 ? 3 : 2, stride = mode == 4 ? 9 : 7;
+            p_glTransformFeedbackVaryings(prog, nvar, varyings, GL_INTERLEAVED_ATTRIBS);
             link_program(prog);
             p_glUseProgram(prog);
             set_reference_uniforms(prog, u);
+            if(mode == 4) set_texture(prog, t, ti, texels);
             const size_t nv = (size_t)N*N;
             GLuint tfb; p_glGenBuffers(1, &tfb);
             p_glBindBuffer(GL_TRANSFORM_FEEDBACK_BUFFER, tfb);
-            p_glBufferData(GL_TRANSFORM_FEEDBACK_BUFFER, nv*7*sizeof(float), NULL, GL_STATIC_READ);
+            p_glBufferData(GL_TRANSFORM_FEEDBACK_BUFFER, nv*stride*sizeof(float), NULL, GL_STATIC_READ);
             p_glBindBufferBase(GL_TRANSFORM_FEEDBACK_BUFFER, 0, tfb);
             p_glEnable(GL_RASTERIZER_DISCARD);
             p_glBeginTransformFeedback(GL_POINTS);
@@ -367,9 +439,13 @@ int main(int argc, char** argv)
             p_glEndTransformFeedback();
             p_glFinish();
             GLCHECK("transform feedback");
-            float* cap = malloc(nv*7*sizeof(float));
-            p_glGetBufferSubData(GL_TRANSFORM_FEEDBACK_BUFFER, 0, nv*7*sizeof(float), cap);
-            for(size_t k=0; k<nv; k++) fwrite(&cap[k*7], sizeof(float), 5, out);   /* xyzw + r */
+            float* cap = malloc(nv*stride*sizeof(float));
+            p_glGetBufferSubData(GL_TRANSFORM_FEEDBACK_BUFFER, 0, nv*stride*sizeof(float), cap);
+            for(size_t k=0; k<nv; k++)
+            {
+                fwrite(&cap[k*stride], sizeof(float), 5, out);                       /* xyzw + r */
+                if(mode == 4) fwrite(&cap[k*stride + 7], sizeof(float), 2, out);     /* tex.xy   */
+            }
             free(cap);
         }
     }
@@ -387,6 +463,30 @@ int main(int argc, char** argv)
         p_glAttachShader(prog, compile(GL_FRAGMENT_SHADER, passthrough_fs, "passthrough fragment"));
         link_program(prog);
         p_glUseProgram(prog);
+        setup_fbo(W, H);
+        p_glClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT);
+        p_glDrawArrays(GL_TRIANGLES, 0, ntri*3);
+        GLCHECK("draw");
+        readback(out, W, H);
+    }
+    else if(mode == 5 || mode == 6)
+    {
+        int32_t ntri;
+        if(fread(&ntri, 4, 1, job) != 1) DIE("short job");
+        float* v = malloc((size_t)ntri*18*sizeof(float));
+        if(fread(v, 4, (size_t)ntri*18, job) != (size_t)ntri*18) DIE("short job body");
+        p_glBufferData(GL_ARRAY_BUFFER, (size_t)ntri*18*sizeof(float), v, GL_STATIC_DRAW);
+        p_glVertexAttribPointer(0, 4, GL_FLOAT, GL_FALSE, 6*sizeof(float), NULL);
+        p_glEnableVertexAttribArray(1);
+        p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 6*sizeof(float), (const void*)(4*sizeof(float)));
+        free(v);
+        GLuint prog = p_glCreateProgram();
+        p_glAttachShader(prog, compile(GL_VERTEX_SHADER, texprobe_vs, "texture probe vertex"));
+        p_glAttachShader(prog, mode == 5 ? compile(GL_FRAGMENT_SHADER, read_text(argv[1], "fragment.glsl"), "fragment")
+                                         : compile(GL_FRAGMENT_SHADER, texprobe_fs, "texture probe fragment"));
+        link_program(prog);
+        p_glUseProgram(prog);
+        set_texture(prog, t, ti, texels);
         setup_fbo(W, H);
         p_glClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT);
         p_glDrawArrays(GL_TRIANGLES, 0, ntri*3);

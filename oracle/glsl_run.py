@@ -77,3 +77,54 @@ def raw_triangles(tris, W, H):
         setattr(v, n, 0.0)
     raw, log = _run(2, 0, W, H, v, struct.pack("<i", tris.shape[0]) + tris.tobytes())
     return _split_frame(raw, W, H)
+
+
+# ---- the texture path (reference vertex.glsl:41-61,116-126, fragment.glsl:17-22) ----
+
+TEX_FLOATS = ("viewer_lat_rad", "origin_cell_lon_deg", "origin_cell_lat_deg",
+              "texturemap_lon0", "texturemap_lon1", "texturemap_dlat0", "texturemap_dlat1", "texturemap_dlat2")
+TEX_INTS = ("NtilesX", "NtilesY", "osmtile_lowestX", "osmtile_lowestY")
+
+
+def _tex_block(tex, texels):
+    """tex: dict with TEX_FLOATS and TEX_INTS; texels uint8[texH,texW,3] exactly as the
+    reference hands them to glTexSubImage2D(GL_BGR): row 0 first (GL: bottom), B,G,R"""
+    texels = np.ascontiguousarray(texels, np.uint8)
+    th, tw, _ = texels.shape
+    return (np.array([tex[k] for k in TEX_FLOATS], np.float32).tobytes()
+            + struct.pack("<6i", *[int(tex[k]) for k in TEX_INTS], tw, th) + texels.tobytes())
+
+
+def render_textured(mosaic, view, W, H, tex, texels, threads=None):
+    mosaic = np.ascontiguousarray(mosaic, np.int16)
+    raw, log = _run(3, mosaic.shape[0], W, H, view, _tex_block(tex, texels) + mosaic.tobytes(), threads)
+    out = _split_frame(raw, W, H)
+    out["log"] = log
+    return out
+
+
+def vertices_textured(mosaic, view, tex, texels=None):
+    """float32[N,N,7] = gl_Position.xyzw, rgb.r, tex.xy"""
+    mosaic = np.ascontiguousarray(mosaic, np.int16)
+    N = mosaic.shape[0]
+    if texels is None:
+        texels = np.zeros((2, 2, 3), np.uint8)
+    raw, _ = _run(4, N, 4, 4, view, _tex_block(tex, texels) + mosaic.tobytes())
+    return raw.view(np.float32).reshape(N, N, 7)
+
+
+def textured_triangles(tris, W, H, texels, NtilesX=1, NtilesY=1, sampler_only=False):
+    """probe of llvmpipe's texture sampling through the reference's fragment shader:
+    tris float32[n,3,6] = clip x,y,z, red, s, t per vertex"""
+    tris = np.ascontiguousarray(tris, np.float32)
+
+    class _V:
+        pass
+    v = _V()
+    for n in VIEW_FIELDS:
+        setattr(v, n, 0.0)
+    tex = {k: 0.0 for k in TEX_FLOATS}
+    tex.update(NtilesX=NtilesX, NtilesY=NtilesY, osmtile_lowestX=0, osmtile_lowestY=0)
+    raw, log = _run(6 if sampler_only else 5, 0, W, H, v,
+                    _tex_block(tex, texels) + struct.pack("<i", tris.shape[0]) + tris.tobytes())
+    return _split_frame(raw, W, H)

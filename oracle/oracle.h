@@ -31,6 +31,15 @@
  * epoxy, freeglut, FreeImage, cairo and swscale headers the image lacks), so
  * the host-side uniform derivation, the readback conversion and the annotator
  * passes are pinned by restatement only.
+ *
+ * The texture path ("next" row N4: vertex.glsl:41-61,116-126, fragment.glsl:17-22,
+ * horizonator-lib.c:225-246,372-389,577-588,707-759,801-809) is restated the same
+ * way: texture coordinates follow the compiler's operation order (bit-exact on
+ * captured vertices), and the GL_LINEAR / GL_REPEAT sampling of the RGB8 texture
+ * is llvmpipe's, pinned on 7 M probe samples: coordinates in 24.8 fixed point
+ * (round to nearest even of s*size*256, minus 128), two 8-bit lerps in x then one
+ * in y, each (w*(b-a)+128)>>8, result byte*(1/255); then 0.7*tex + 0.3*shade in
+ * float32 and round(x*255) into the RGB8 target.
  */
 #pragma once
 
@@ -93,6 +102,42 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
                int W, int H, int col0, int col1,
                uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
                int nthreads);
+
+/* ---- texture path ("next" row N4) ----------------------------------------------- */
+
+typedef struct
+{
+    /* uniforms of the texture half of vertex.glsl */
+    float viewer_lat_rad;
+    float origin_cell_lon_deg, origin_cell_lat_deg;
+    float lon0, lon1, dlat0, dlat1, dlat2;
+    int   ntiles_x, ntiles_y, lowest_x, lowest_y;
+    /* the texture as glTexSubImage2D(GL_BGR) receives it: [tex_h][tex_w][3],
+     * B,G,R, row 0 = texture coordinate t = 0 = southern edge of the mosaic */
+    int   tex_w, tex_h;
+    const uint8_t* texels;
+} orc_tex_t;
+
+#define ORC_OSM_ZOOM      12
+#define ORC_OSM_TILE_PX   256
+
+/* reference horizonator-lib.c:225-246: slippy-map tile that holds (E,N), degrees */
+void orc_osm_tile_id(int* x, int* y, float E, float N);
+/* everything but the texels: tile range from the DEM window around the INIT
+ * viewpoint (reference :372-389, fixed for the life of a context), origin of
+ * the grid (:577-582), and the coefficients of the current viewpoint (:707-759,
+ * :801-809; they change with every horizonator_move) */
+void orc_tex_setup(orc_tex_t* t, const orc_dem_t* d,
+                   float init_lat, float init_lon, float viewer_lat);
+/* texture coordinate of one vertex (reference vertex.glsl:116-126) */
+void orc_vertex_tex(const orc_tex_t* t, float deg_per_cell, int i, int j, float out_st[2]);
+/* the sampler alone: B,G,R bytes of texture(tex, (s,t)) */
+void orc_tex_sample(const orc_tex_t* t, float s, float tt, uint8_t out_bgr[3]);
+/* orc_render() with render_texture = true; tex == NULL is orc_render() */
+int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_tex_t* tex,
+                   int W, int H, int col0, int col1,
+                   uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
+                   int nthreads);
 
 /* ---- annotator passes over the range image ("next" row N2) ----------------- */
 

@@ -134,12 +134,131 @@ void orc_vertex(const orc_view_t* v, int i, int j, int z, float out_xyzr[4])
     out_xyzr[0] = o.x; out_xyzr[1] = o.y; out_xyzr[2] = o.z; out_xyzr[3] = o.red;
 }
 
+/* ---- texture path: host side and vertex stage ------------------------------- */
+
+void orc_osm_tile_id(int* x, int* y, float E, float N)
+{
+    /* reference horizonator-lib.c:225-246 */
+    float n = (float)(1 << ORC_OSM_ZOOM);
+    E *= (float)M_PI/180.0f;
+    N *= (float)M_PI/180.0f;
+    float lon0 = n / 2.0f;
+    float lon1 = n / ((float)M_PI * 2.0f);
+    *x = (int)( fminf( n, fmaxf( 0.0f, E*lon1 + lon0 )));
+    *y = (int)( n/2.0f * (1.0f - logf( (sinf(N) + 1.0f)/cosf(N) ) / (float)M_PI) );
+}
+
+void orc_tex_setup(orc_tex_t* t, const orc_dem_t* d, float init_lat, float init_lon, float viewer_lat)
+{
+    /* reference horizonator-lib.c:372-389 */
+    const float lowest_E  = init_lon - (float)d->radius_cells/d->cells_per_deg;
+    const float lowest_N  = init_lat - (float)d->radius_cells/d->cells_per_deg;
+    const float highest_E = init_lon + (float)d->radius_cells/d->cells_per_deg;
+    const float highest_N = init_lat + (float)d->radius_cells/d->cells_per_deg;
+    int hx, hy;
+    orc_osm_tile_id(&t->lowest_x, &t->lowest_y, lowest_E,  highest_N);      /* ytile decreases with lat */
+    orc_osm_tile_id(&hx,          &hy,          highest_E, lowest_N);
+    t->ntiles_x = hx - t->lowest_x + 1;
+    t->ntiles_y = hy - t->lowest_y + 1;
+    t->tex_w = t->ntiles_x*ORC_OSM_TILE_PX;
+    t->tex_h = t->ntiles_y*ORC_OSM_TILE_PX;
+    /* reference :577-582 */
+    t->origin_cell_lon_deg = (float)d->origin_tile[0] + (float)d->origin_cell[0] / (float)d->cells_per_deg;
+    t->origin_cell_lat_deg = (float)d->origin_tile[1] + (float)d->origin_cell[1] / (float)d->cells_per_deg;
+    /* reference :707-759 texture_coeffs(viewer_lat) */
+    {
+        float n = (float)(1 << ORC_OSM_ZOOM);
+        t->lon0 = n / 2.0f;
+        t->lon1 = n / ((float)M_PI * 2.0f);
+        float lat_center = viewer_lat * ((float)M_PI / 180.0f);
+        float k = -n / ((float)M_PI * 2.0f);
+        float tn = tanf( lat_center );
+        float c  = cosf( lat_center );
+        t->dlat0 = n/2.0f + k*logf( tn + 1.0f/c );
+        t->dlat1 = k / c;
+        t->dlat2 = k * tn / c / 2.0f;
+    }
+    /* reference :801: the product is formed in double, glUniform1f rounds it */
+    t->viewer_lat_rad = (float)(viewer_lat * M_PI / 180.0f);
+}
+
+/* reference vertex.glsl:116-126 with get_xtexture/get_ytexture (:53-61) in the
+ * operation order of Mesa's compiler (ST_DEBUG=nir) */
+static void vertex_tex(const orc_tex_t* t, float deg_per_cell, float i, float j, float* s_out, float* t_out)
+{
+    const float lat  = (t->origin_cell_lat_deg + j*deg_per_cell) * C_DEG2RAD;
+    const float dlat = lat + -t->viewer_lat_rad;
+    const float lon  = (t->origin_cell_lon_deg + i*deg_per_cell) * C_DEG2RAD;
+    const float xt   = t->lon1*lon + t->lon0;
+    *s_out = (xt + -(float)t->lowest_x) / (float)t->ntiles_x;
+    const float yt   = dlat*(dlat*t->dlat2 + t->dlat1) + t->dlat0;
+    *t_out = 1.0f + -((yt + -(float)t->lowest_y) / (float)t->ntiles_y);
+}
+
+void orc_vertex_tex(const orc_tex_t* t, float deg_per_cell, int i, int j, float out_st[2])
+{
+    vertex_tex(t, deg_per_cell, (float)i, (float)j, &out_st[0], &out_st[1]);
+}
+
+/* ---- texture path: the sampler (llvmpipe, GL_LINEAR, GL_REPEAT, RGB8) ------------ */
+
+static void tex_wrap_linear(float s, int size, int* i0, int* i1, int* w)
+{
+    const int pot = (size & (size-1)) == 0;
+    if(!pot)
+    {
+        s = s - floorf(s);
+        if(!(s <= 0.99999994f)) s = 0.99999994f;
+    }
+    /* 24.8 fixed point: round to nearest even of s*size*256, then -0.5 texel */
+    const int fixed = (int)lrintf((s*(float)size)*256.0f) - 128;
+    const int ip = fixed >> 8;
+    *w = fixed & 255;
+    if(pot) { *i0 = ip & (size-1); *i1 = (ip+1) & (size-1); }
+    else    { *i0 = ip < 0 ? size-1 : ip; *i1 = ip+1 > size-1 ? 0 : ip+1; }
+}
+
+void orc_tex_sample(const orc_tex_t* t, float s, float tt, uint8_t out_bgr[3])
+{
+    int i0, i1, wx, j0, j1, wy;
+    tex_wrap_linear(s,  t->tex_w, &i0, &i1, &wx);
+    tex_wrap_linear(tt, t->tex_h, &j0, &j1, &wy);
+    const uint8_t* t00 = &t->texels[((size_t)j0*t->tex_w + i0)*3];
+    const uint8_t* t10 = &t->texels[((size_t)j0*t->tex_w + i1)*3];
+    const uint8_t* t01 = &t->texels[((size_t)j1*t->tex_w + i0)*3];
+    const uint8_t* t11 = &t->texels[((size_t)j1*t->tex_w + i1)*3];
+    for(int c=0; c<3; c++)
+    {
+        const int a = t00[c] + ((wx*((int)t10[c] - (int)t00[c]) + 128) >> 8);
+        const int b = t01[c] + ((wx*((int)t11[c] - (int)t01[c]) + 128) >> 8);
+        out_bgr[c] = (uint8_t)(a + ((wy*(b - a) + 128) >> 8));
+    }
+}
+
+/* fragment.glsl:17-22 as compiled: R = 0.7*tex.r + 0.3*shade, G,B = 0.7*tex.g,b,
+ * separate multiplies and add; then the RGB8 render target */
+static uint8_t unorm8(float x)
+{
+    x = x < 1.0f ? x : 1.0f;
+    x = x > 0.0f ? x : 0.0f;
+    return (uint8_t)rintf(x * 255.f);
+}
+static void fragment_textured(const orc_tex_t* t, float s, float tt, float shade, uint8_t out_bgr[3])
+{
+    uint8_t texel[3];
+    orc_tex_sample(t, s, tt, texel);
+    const float b = 0.7f*((float)texel[0]*(1.0f/255.0f));
+    const float g = 0.7f*((float)texel[1]*(1.0f/255.0f));
+    const float r = 0.7f*((float)texel[2]*(1.0f/255.0f)) + 0.3f*shade;
+    out_bgr[0] = unorm8(b); out_bgr[1] = unorm8(g); out_bgr[2] = unorm8(r);
+}
+
 /* ---- rasteriser --------------------------------------------------------- */
 
 /* a vertex as it leaves the vertex stage: clip-space position (w = 1), its
  * viewport transform (window coordinates with pixel centres at half-integers,
  * depth in [0,1]) and colour */
-typedef struct { float xn, yn, zn, wx, wy, zw, red; } wvert_t;
+typedef struct { float xn, yn, zn, wx, wy, zw, red, s, t; } wvert_t;
 
 #define GUARD_PX 2097152.0f
 
@@ -148,6 +267,8 @@ typedef struct
     uint32_t* depth;        /* [H][SW] GL row order, 24-bit values */
     int32_t*  prim;         /* [H][SW] */
     uint8_t*  red;          /* [H][SW] */
+    uint8_t*  color;        /* [H][SW][3] B,G,R - textured draws only */
+    const orc_tex_t* tex;   /* NULL: fragment.glsl:15-16, else :17-22 */
     int SW, H, col0, col1;
 } target_t;
 
@@ -215,6 +336,15 @@ static void raster_triangle(target_t* fb, int x_lo, int x_hi,
     float drdx = dr01*dy20_ooa - dr20*dy01_ooa;
     float drdy = dr20*dx01_ooa - dr01*dx20_ooa;
     float r_org = v0->red - (drdx*x0_center + drdy*y0_center);
+    /* texture coordinates: two more attributes, same arithmetic */
+    float ds01 = v0->s - v1->s, ds20 = v2->s - v0->s;
+    float dt01 = v0->t - v1->t, dt20 = v2->t - v0->t;
+    float dsdx = ds01*dy20_ooa - ds20*dy01_ooa;
+    float dsdy = ds20*dx01_ooa - ds01*dx20_ooa;
+    float s_org = v0->s - (dsdx*x0_center + dsdy*y0_center);
+    float dtdx = dt01*dy20_ooa - dt20*dy01_ooa;
+    float dtdy = dt20*dx01_ooa - dt01*dx20_ooa;
+    float t_org = v0->t - (dtdx*x0_center + dtdy*y0_center);
 
     for(int64_t py=py0; py<=py1; py++)
         for(int64_t px=px0; px<=px1; px++)
@@ -247,10 +377,16 @@ static void raster_triangle(target_t* fb, int x_lo, int x_hi,
             if(!(zi < fb->depth[at] || (zi == fb->depth[at] && zi != 0xFFFFFFu && prim < fb->prim[at]))) continue;
 
             float r = fmaf(drdy, (float)py, fmaf(drdx, (float)px, r_org));
-            r = r < 1.0f ? r : 1.0f;
-            r = r > 0.0f ? r : 0.0f;
             fb->depth[at] = zi;
             fb->prim [at] = prim;
+            if(fb->tex)
+            {
+                const float s  = fmaf(dsdy, (float)py, fmaf(dsdx, (float)px, s_org));
+                const float tt = fmaf(dtdy, (float)py, fmaf(dtdx, (float)px, t_org));
+                fragment_textured(fb->tex, s, tt, r, &fb->color[3*at]);
+            }
+            r = r < 1.0f ? r : 1.0f;
+            r = r > 0.0f ? r : 0.0f;
             fb->red  [at] = (uint8_t)rintf(r * 255.f);      /* RGB8 unorm */
         }
 }
@@ -301,6 +437,8 @@ static wvert_t clip_interp(float t, const wvert_t* out, const wvert_t* in, float
     d.wy  = d.yn*oow*halfH + halfH;
     d.zw  = d.zn*oow*0.5f  + 0.5f;
     d.red = out->red + t*(in->red - out->red);
+    d.s   = out->s   + t*(in->s   - out->s);
+    d.t   = out->t   + t*(in->t   - out->t);
     return d;
 }
 
@@ -393,6 +531,14 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
                uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
                int nthreads)
 {
+    return orc_render_tex(mosaic, N, v, NULL, W, H, col0, col1, bgr, ranges, index, z24, nthreads);
+}
+
+int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_tex_t* tex,
+                   int W, int H, int col0, int col1,
+                   uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
+                   int nthreads)
+{
     if(N < 2 || W <= 0 || H <= 0 || col0 < 0 || col1 > W || col0 >= col1) return -1;
     const int SW = col1 - col0;
     const size_t npix = (size_t)SW*H;
@@ -402,11 +548,13 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
     fb.depth = malloc(npix*sizeof(uint32_t));
     fb.prim  = malloc(npix*sizeof(int32_t));
     fb.red   = malloc(npix);
+    fb.tex   = tex;
+    fb.color = tex ? malloc(npix*3) : NULL;
     wvert_t* vert = malloc((size_t)N*N*sizeof(wvert_t));
     float* tanel = malloc((size_t)H*sizeof(float));
-    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel)
+    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel || (tex && !fb.color))
     {
-        free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
+        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(tanel);
         return -1;
     }
 
@@ -436,6 +584,8 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
             w->wy  = o.y*halfH + halfH;
             w->zw  = o.z*0.5f + 0.5f;
             w->red = o.red;
+            w->s = w->t = 0.f;
+            if(tex) vertex_tex(tex, v->deg_per_cell, (float)i, (float)j, &w->s, &w->t);
         }
 
     /* Triangles of the index buffer (reference horizonator-lib.c:496-508).
@@ -452,7 +602,7 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
     if(!blk_lo || !blk_hi)
     {
         free(blk_lo); free(blk_hi);
-        free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
+        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(tanel);
         return -1;
     }
     #pragma omp parallel for schedule(dynamic,8) num_threads(nthreads)
@@ -519,6 +669,7 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
                 bgr[3*o+0] = sky ? 255 : 0;
                 bgr[3*o+1] = 0;
                 bgr[3*o+2] = sky ? 0 : fb.red[at];
+                if(tex && !sky) { bgr[3*o+0] = fb.color[3*at+0]; bgr[3*o+1] = fb.color[3*at+1]; bgr[3*o+2] = fb.color[3*at+2]; }
             }
             if(index) index[o] = fb.prim[at];
             if(z24)   z24[o]   = zi;
@@ -537,7 +688,7 @@ int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
         }
     }
 
-    free(fb.depth); free(fb.prim); free(fb.red); free(vert); free(tanel);
+    free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(tanel);
     return 0;
 }
 
