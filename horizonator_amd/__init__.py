@@ -220,6 +220,30 @@ class horizonator:
             raise RuntimeError("horizonator_amd_render_batch() failed")
         return z
 
+    def texture_layout(self):
+        """(lowest_x, lowest_y, ntiles_x, ntiles_y): the zoom-12 slippy-map tiles the texture
+        of this context is made of (reference horizonator-lib.c:372-389); the texture is
+        ntiles_y*256 rows of ntiles_x*256 texels"""
+        v = [C.c_int() for _ in range(4)]
+        if not self._lib.horizonator_amd_texture_layout(C.byref(self._ctx), *[C.byref(x) for x in v]):
+            raise RuntimeError("horizonator_amd_texture_layout() failed")
+        return tuple(x.value for x in v)
+
+    def set_texture(self, texels_bgr):
+        """Drape a caller-supplied map over the terrain instead of tiles read from disk:
+        uint8[ntiles_y*256, ntiles_x*256, 3], B,G,R, row 0 = southern edge.  None switches
+        texturing off.  (include/horizonator_amd.h: horizonator_amd_set_texture)"""
+        if texels_bgr is None:
+            ok = self._lib.horizonator_amd_set_texture(C.byref(self._ctx), None)
+        else:
+            _, _, nx, ny = self.texture_layout()
+            texels_bgr = np.ascontiguousarray(texels_bgr, np.uint8)
+            if texels_bgr.shape != (ny * 256, nx * 256, 3):
+                raise ValueError(f"the texture of this context is uint8[{ny * 256},{nx * 256},3]")
+            ok = self._lib.horizonator_amd_set_texture(C.byref(self._ctx), texels_bgr.ctypes.data)
+        if not ok:
+            raise RuntimeError("horizonator_amd_set_texture() failed")
+
     def set_view(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
                  znear=HORIZONATOR_ZNEAR_DEFAULT, zfar=HORIZONATOR_ZFAR_DEFAULT,
                  znear_color=-1.0, zfar_color=-1.0):

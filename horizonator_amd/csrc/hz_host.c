@@ -12,12 +12,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "horizonator.h"
 #include "horizonator_amd.h"
 #include "hz_dem.h"
 #include "hz_hip.h"
 #include "util.h"
+#include "hz_png.h"
 
 /* ------------------------------------------------------------------------ */
 /* side records                                                              */
@@ -32,6 +34,9 @@ typedef struct
     int          N;
     int          width, height;
     int          col0, col1;
+    /* texture path (reference render_texture): layout fixed at init, coefficients per move */
+    bool           textured;
+    hz_texparams_t tex;
     float*       tanel;         /* [height] */
     bool         tanel_valid;   /* ... computed for these azimuth extents: */
     float        tanel_az0, tanel_az1;
@@ -66,6 +71,101 @@ static void state_release(hz_state_t* s, horizonator_context_t* ctx)
     }
     free(s->tanel);
     memset(s, 0, sizeof(*s));
+}
+
+/* ------------------------------------------------------------------------ */
+/* texture path (row N4): host side                                          */
+
+#define OSM_RENDER_ZOOM  12         /* reference horizonator-lib.c:25-27 */
+#define OSM_TILE_PX      256
+
+/* slippy-map tile that holds (E,N) in degrees, reference horizonator-lib.c:225-246 */
+static void osm_tile_id(int* x, int* y, float E, float N)
+{
+    const float n = (float)(1 << OSM_RENDER_ZOOM);
+    E *= (float)M_PI/180.0f;
+    N *= (float)M_PI/180.0f;
+    const float lon0 = n / 2.0f;
+    const float lon1 = n / ((float)M_PI * 2.0f);
+    *x = (int)( fminf( n, fmaxf( 0.0f, E*lon1 + lon0 )));
+    *y = (int)( n/2.0f * (1.0f - logf( (sinf(N) + 1.0f)/cosf(N) ) / (float)M_PI) );
+}
+
+/* the tile range that covers the DEM window around the init viewpoint (reference
+ * :372-389), the texture size (:259-262) and the origin of the grid (:577-582) */
+static void tex_layout(hz_state_t* s, float init_lat, float init_lon)
+{
+    const hz_window_t* w = &s->tiles.win;
+    const float lowest_E  = init_lon - (float)w->radius_cells/w->cells_per_deg;
+    const float lowest_N  = init_lat - (float)w->radius_cells/w->cells_per_deg;
+    const float highest_E = init_lon + (float)w->radius_cells/w->cells_per_deg;
+    const float highest_N = init_lat + (float)w->radius_cells/w->cells_per_deg;
+    int hx, hy;
+    osm_tile_id(&s->tex.lowest_x, &s->tex.lowest_y, lowest_E,  highest_N);  /* tile y grows southwards */
+    osm_tile_id(&hx,              &hy,              highest_E, lowest_N);
+    s->tex.ntiles_x = hx - s->tex.lowest_x + 1;
+    s->tex.ntiles_y = hy - s->tex.lowest_y + 1;
+    s->tex.tex_w = s->tex.ntiles_x*OSM_TILE_PX;
+    s->tex.tex_h = s->tex.ntiles_y*OSM_TILE_PX;
+    s->tex.origin_cell_lon_deg = (float)w->origin_tile[0] + (float)w->origin_cell[0] / (float)w->cells_per_deg;
+    s->tex.origin_cell_lat_deg = (float)w->origin_tile[1] + (float)w->origin_cell[1] / (float)w->cells_per_deg;
+}
+
+/* reference horizonator-lib.c:707-759 texture_coeffs() and :801: they follow the viewer */
+static void tex_coeffs(hz_state_t* s, float viewer_lat)
+{
+    const float n = (float)(1 << OSM_RENDER_ZOOM);
+    s->tex.lon0 = n / 2.0f;
+    s->tex.lon1 = n / ((float)M_PI * 2.0f);
+    const float lat_center = viewer_lat * ((float)M_PI / 180.0f);
+    const float k = -n / ((float)M_PI * 2.0f);
+    const float t = tanf( lat_center );
+    const float c = cosf( lat_center );
+    s->tex.dlat0 = n/2.0f + k*logf( t + 1.0f/c );
+    s->tex.dlat1 = k / c;
+    s->tex.dlat2 = k * t / c / 2.0f;
+    s->tex.viewer_lat_rad = (float)(viewer_lat * M_PI / 180.0f);
+}
+
+/* reads the map tiles of the layout from dir_tiles/tiles_name/12/X/Y.png
+ * (reference :268-369) into texels[tex_h][tex_w][3], B,G,R, southern row first:
+ * the bytes and the placement FreeImage's bottom-up BGR bitmap and
+ * glTexSubImage2D(..., (highestY - Y)*256, ..., GL_BGR, ...) give the reference */
+static bool tex_load_tiles(const hz_state_t* s, unsigned char* texels,
+                           const char* dir_tiles, const char* tiles_name, bool allow_downloads)
+{
+    const hz_texparams_t* t = &s->tex;
+    unsigned char* tile = malloc((size_t)OSM_TILE_PX*OSM_TILE_PX*3);
+    if(tile == NULL) return false;
+    bool ok = true;
+    const int highest_y = t->lowest_y + t->ntiles_y - 1;
+    for(int ty = t->lowest_y; ty <= highest_y && ok; ty++)
+        for(int tx = t->lowest_x; tx < t->lowest_x + t->ntiles_x && ok; tx++)
+        {
+            char filename[1024], err[1200];
+            if((int)sizeof(filename) <= snprintf(filename, sizeof(filename), "%s/%s/%d/%d/%d.png",
+                                                 dir_tiles, tiles_name, OSM_RENDER_ZOOM, tx, ty))
+            { MSG("tile path too long"); ok = false; break; }
+            if(access(filename, R_OK) != 0)
+            {
+                if(!allow_downloads)
+                    MSG("Tile '%s' doesn't exist on disk, and downloads aren't allowed. Giving up", filename);
+                else
+                    MSG("Tile '%s' doesn't exist on disk, and this build does not download (no network access from the library). Giving up", filename);
+                ok = false; break;
+            }
+            if(0 != hz_png_load_rgb(filename, OSM_TILE_PX, OSM_TILE_PX, tile, err, sizeof(err)))
+            { MSG("Couldn't load tile: %s", err); ok = false; break; }
+            const int x0 = (tx - t->lowest_x)*OSM_TILE_PX, y0 = (highest_y - ty)*OSM_TILE_PX;
+            for(int r=0; r<OSM_TILE_PX; r++)
+            {
+                unsigned char* dst = texels + ((size_t)(y0 + OSM_TILE_PX-1 - r)*t->tex_w + x0)*3;
+                const unsigned char* src = tile + (size_t)r*OSM_TILE_PX*3;
+                for(int c=0; c<OSM_TILE_PX; c++) { dst[3*c+0] = src[3*c+2]; dst[3*c+1] = src[3*c+1]; dst[3*c+2] = src[3*c+0]; }
+            }
+        }
+    free(tile);
+    return ok;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -126,9 +226,26 @@ bool horizonator_init(horizonator_context_t* ctx,
                       const char* dir_tiles, const char* tiles_name,
                       const char* tiles_url_fmt, bool allow_downloads)
 {
-    (void)dir_tiles; (void)tiles_name; (void)tiles_url_fmt; (void)allow_downloads;
+    (void)tiles_url_fmt;
 
     memset(ctx, 0, sizeof(*ctx));       /* reference horizonator-lib.c:84 */
+
+    /* reference horizonator-lib.c:90-121 */
+    char dir_tiles_expanded[512];
+    if(tiles_name == NULL) tiles_name = "mapnik";
+    if(dir_tiles == NULL)  dir_tiles  = "~/.horizonator/tiles";
+    if(dir_tiles[0] == '~' && dir_tiles[1] == '/')
+    {
+        const char* home = getenv("HOME");
+        if(home == NULL)
+        {
+            if(render_texture) { MSG("User asked for ~, but the 'HOME' env var isn't defined"); return false; }
+            home = "";
+        }
+        if((int)sizeof(dir_tiles_expanded) <= snprintf(dir_tiles_expanded, sizeof(dir_tiles_expanded), "%s/%s", home, &dir_tiles[2]))
+        { MSG("static buffer overflow: dir_tiles"); return false; }
+        dir_tiles = dir_tiles_expanded;
+    }
 
     if(dir_dems == NULL)                /* reference horizonator-lib.c:94-97 */
         dir_dems = SRTM1 ? "~/.horizonator/DEMs_SRTM1" : "~/.horizonator/DEMs_SRTM3";
@@ -138,12 +255,6 @@ bool horizonator_init(horizonator_context_t* ctx,
         MSG("This build renders offscreen only: horizonator_init(use_glut=true, offscreen_width,height > 0). There is no OpenGL window mode");
         return false;
     }
-    if(render_texture)
-    {
-        MSG("render_texture=true is not supported by this build (it needs map-tile downloads)");
-        return false;
-    }
-
     int slot = -1;
     for(int k=0; k<HZ_MAX_CONTEXTS; k++) if(!g_state[k].live) { slot = k; break; }
     if(slot < 0)
@@ -155,6 +266,7 @@ bool horizonator_init(horizonator_context_t* ctx,
     memset(s, 0, sizeof(*s));
 
     int16_t* mosaic = NULL;
+    unsigned char* texels = NULL;
     bool     result = false;
 
     if(!load_tiles(s, ctx, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, dir_dems, SRTM1))
@@ -219,7 +331,7 @@ bool horizonator_init(horizonator_context_t* ctx,
      * SRTM1 mosaics, which the reference cannot load anyway: saturate */
     const long long ntri = 2LL*(N-1)*(N-1);
     ctx->Ntriangles     = ntri > INT_MAX ? INT_MAX : (int)ntri;
-    ctx->render_texture = false;
+    ctx->render_texture = render_texture;
     ctx->use_glut       = true;
     ctx->glut_window    = 1;
     ctx->program        = (uint32_t)(slot+1);
@@ -227,6 +339,25 @@ bool horizonator_init(horizonator_context_t* ctx,
 
     s->view.deg_per_cell = 1.0f / (float)s->tiles.win.cells_per_deg;        /* reference :577 */
     s->view.aspect = (float)offscreen_width / (float)offscreen_height;     /* reference :658-659 */
+
+    /* the texture's tile range belongs to the window around the init viewpoint
+     * whether or not tiles are loaded now: horizonator_amd_set_texture() may
+     * supply a mosaic later */
+    tex_layout(s, viewer_lat, viewer_lon);
+    if(render_texture)
+    {
+        /* reference horizonator-lib.c:259-264 (a texture of zeros), :393-400 (filled tile by tile) */
+        texels = calloc((size_t)s->tex.tex_w*s->tex.tex_h, 3);
+        if(texels == NULL) { MSG("out of memory for a %dx%d texture", s->tex.tex_w, s->tex.tex_h); goto done; }
+        if(!tex_load_tiles(s, texels, dir_tiles, tiles_name, allow_downloads)) goto done;
+        tex_coeffs(s, viewer_lat);
+        if(0 != hz_hip_set_texture(s->dev, &s->tex, texels))
+        {
+            MSG("Texture upload failed: %s", hz_hip_last_error());
+            goto done;
+        }
+        s->textured = true;
+    }
 
     if(!horizonator_move(ctx, viewer_z, viewer_lat, viewer_lon)) goto done; /* reference :611 */
     if(!horizonator_set_zextents(ctx,
@@ -242,6 +373,7 @@ bool horizonator_init(horizonator_context_t* ctx,
 
  done:
     free(mosaic);
+    free(texels);
     if(!result)
     {
         state_release(s, ctx);
@@ -296,6 +428,17 @@ bool horizonator_move(horizonator_context_t* ctx, float* viewer_z,
     /* reference horizonator-lib.c:799: the product is formed in double
      * (M_PI is a double), rounded to float by cosf's prototype */
     s->view.cos_viewer_lat = cosf((float)((double)viewer_lat * M_PI / 180.0));
+
+    if(s->textured)
+    {
+        /* reference horizonator-lib.c:761-763,801-809: the texture coefficients follow the viewer */
+        tex_coeffs(s, viewer_lat);
+        if(0 != hz_hip_set_texture(s->dev, &s->tex, NULL))
+        {
+            MSG("texture parameters: %s", hz_hip_last_error());
+            return false;
+        }
+    }
 
     ctx->viewer_lat = viewer_lat;
     ctx->viewer_lon = viewer_lon;
@@ -525,6 +668,40 @@ bool horizonator_amd_render_batch(horizonator_context_t* ctx, int n,
                           d_ranges ? d_ranges + (size_t)v*npix : NULL, NULL, NULL))
             return false;
     }
+    return true;
+}
+
+bool horizonator_amd_texture_layout(const horizonator_context_t* ctx,
+                                    int* lowest_x, int* lowest_y, int* ntiles_x, int* ntiles_y)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(lowest_x) *lowest_x = s->tex.lowest_x;
+    if(lowest_y) *lowest_y = s->tex.lowest_y;
+    if(ntiles_x) *ntiles_x = s->tex.ntiles_x;
+    if(ntiles_y) *ntiles_y = s->tex.ntiles_y;
+    return true;
+}
+
+bool horizonator_amd_set_texture(horizonator_context_t* ctx, const unsigned char* texels_bgr)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(texels_bgr == NULL)
+    {
+        (void)hz_hip_set_texture(s->dev, NULL, NULL);
+        s->textured = false;
+        ctx->render_texture = false;
+        return true;
+    }
+    tex_coeffs(s, ctx->viewer_lat);
+    if(0 != hz_hip_set_texture(s->dev, &s->tex, texels_bgr))
+    {
+        MSG("Texture upload failed: %s", hz_hip_last_error());
+        return false;
+    }
+    s->textured = true;
+    ctx->render_texture = true;
     return true;
 }
 

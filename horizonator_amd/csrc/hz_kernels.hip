@@ -23,6 +23,7 @@
 
 #include "hz_hip.h"
 #include "hz_raster.h"
+#include "hz_tex.h"
 
 /* ------------------------------------------------------------------------ */
 /* errors                                                                    */
@@ -1145,6 +1146,88 @@ void k_resolve(const unsigned long long* __restrict__ fb, const float* __restric
 }
 
 /* ------------------------------------------------------------------------ */
+/* textured resolve ("next" row N4): deferred shading                         */
+/*
+ * The rasteriser kernels do not know about the texture: the framebuffer word
+ * says which triangle won each pixel, and that is all the reference's fragment
+ * stage needs beyond the triangle itself.  So for every terrain pixel this
+ * kernel builds the winning triangle again (three vertices through the same
+ * transform, plus their texture coordinates), sets up the planes of shade, s
+ * and t with hz_tri_planes() arithmetic, evaluates them at the pixel, samples
+ * the texture and blends (hz_tex.h).  A triangle the clipper cut is clipped
+ * again, and the piece that covers the pixel with the stored depth supplies the
+ * planes.  ~1000 instructions per terrain pixel; this path is not the
+ * benchmark's.
+ */
+__device__ __noinline__ static bool hz_shade_clipped(const hz_cvert_t& a, const hz_cvert_t& b, const hz_cvert_t& c,
+                                                     const hz_params_t& p, int px, int py, uint32_t zi,
+                                                     hz_texplanes_t* planes)
+{
+    hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1], *poly;
+    const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
+    for(int k=2; k<n; k++)
+    {
+        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
+        hz_box_t box;
+        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
+        if(px < box.px0 || px > box.px1 || py < box.py0 || py > box.py1) continue;
+        hz_tri_t tri;
+        hz_tri_planes(&tri, &va, &vb, &vc);
+        if(!hz_tri_covers(&tri, px, py)) continue;
+        uint32_t z2, r8;
+        if(!hz_tri_fragment(&tri, px, py, &z2, &r8) || z2 != zi) continue;
+        hz_tri_planes_tex(planes, &poly[k-1], &poly[k], &poly[0]);
+        return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256)
+void k_shade_tex(const unsigned long long* __restrict__ fb, const int16_t* __restrict__ mosaic,
+                 const uint32_t* __restrict__ texels, hz_texparams_t tp,
+                 unsigned char* __restrict__ bgr, hz_params_t p)
+{
+    const size_t npix = (size_t)p.SW*p.H;
+    for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
+    {
+        const int yo  = (int)(o / p.SW);
+        const int x   = (int)(o - (size_t)yo*p.SW);
+        const int py  = p.H-1 - yo, px = x + p.col0;
+        const unsigned long long key = fb[(size_t)py*p.SW + x];
+        const uint32_t zi = (uint32_t)(key >> 40);
+        if(zi == HZ_Z24_MAX) continue;                      /* sky: k_resolve wrote the clear colour */
+        const uint32_t prim = (uint32_t)((key >> 8) & 0xFFFFFFFFull);
+        const uint32_t cell = prim >> 1;
+        const int t = prim & 1;
+        const int j = cell / (uint32_t)(p.N-1);
+        const int i = cell - (uint32_t)j*(uint32_t)(p.N-1);
+        /* reference horizonator-lib.c:500-506 */
+        const int ib = i+1,              jb = t == 0 ? j+1 : j;
+        const int ic = t == 0 ? i : i+1, jc = j+1;
+        hz_cvert_t a = hz_cvert(hz_transform(&p.u, (float)i,  (float)j,  (float)mosaic[(size_t)j *p.N + i ]), p.halfW, p.halfH);
+        hz_cvert_t b = hz_cvert(hz_transform(&p.u, (float)ib, (float)jb, (float)mosaic[(size_t)jb*p.N + ib]), p.halfW, p.halfH);
+        hz_cvert_t c = hz_cvert(hz_transform(&p.u, (float)ic, (float)jc, (float)mosaic[(size_t)jc*p.N + ic]), p.halfW, p.halfH);
+        hz_vertex_tex(&tp, p.u.deg_per_cell, (float)i,  (float)j,  &a.s, &a.t);
+        hz_vertex_tex(&tp, p.u.deg_per_cell, (float)ib, (float)jb, &b.s, &b.t);
+        hz_vertex_tex(&tp, p.u.deg_per_cell, (float)ic, (float)jc, &c.s, &c.t);
+        hz_texplanes_t pl;
+        if(hz_clip_mask(a.xn, a.yn, a.zn) | hz_clip_mask(b.xn, b.yn, b.zn) | hz_clip_mask(c.xn, c.yn, c.zn))
+        {
+            if(!hz_shade_clipped(a, b, c, p, px, py, zi, &pl)) continue;    /* cannot happen; keeps the untextured colour */
+        }
+        else
+            hz_tri_planes_tex(&pl, &a, &b, &c);
+        const float shade = hz_plane_at(pl.r_org, pl.drdx, pl.drdy, px, py);
+        const float s     = hz_plane_at(pl.s_org, pl.dsdx, pl.dsdy, px, py);
+        const float tt    = hz_plane_at(pl.t_org, pl.dtdx, pl.dtdy, px, py);
+        const uint32_t col = hz_fragment_textured(hz_tex_sample(texels, tp.tex_w, tp.tex_h, s, tt), shade);
+        bgr[o*3+0] = (unsigned char)(col & 255u);
+        bgr[o*3+1] = (unsigned char)((col >> 8) & 255u);
+        bgr[o*3+2] = (unsigned char)((col >> 16) & 255u);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* host side of the C-ABI                                                    */
 
 struct hz_dev
@@ -1174,6 +1257,11 @@ struct hz_dev
     int32_t*       d_index;
     uint32_t*      d_z24;
 
+    /* texture path: the mosaic of map tiles, one uint32 B|G<<8|R<<16 per texel */
+    uint32_t*      d_texels;
+    hz_texparams_t tex;
+    int            tex_on;
+
     hipEvent_t ev[7];
     int        have_times;
     hz_times_t times;
@@ -1198,6 +1286,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_midrec);
     (void)hipFree(d->d_clip);
     (void)hipFree(d->d_big_counters);
+    (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
     (void)hipFree(d->d_bgr);
@@ -1347,6 +1436,44 @@ extern "C" int hz_hip_set_raster(hz_dev_t* d, int which)
 {
     if(which < HZ_RASTER_AUTO || which > HZ_RASTER_MARCH) return -1;
     d->raster = which;
+    return 0;
+}
+
+/* texture path: uploads the mosaic of map tiles (texels_bgr: [tex_h][tex_w][3]
+ * bytes, B,G,R, row 0 = southern edge) and switches textured resolves on;
+ * texels_bgr == NULL with a texture resident only replaces the parameters
+ * (they change with every move of the viewer); params == NULL switches the
+ * path off again */
+extern "C" int hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, const unsigned char* texels_bgr)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    if(params == NULL) { d->tex_on = 0; return 0; }
+    if(params->tex_w <= 0 || params->tex_h <= 0 || params->ntiles_x <= 0 || params->ntiles_y <= 0)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_set_texture: empty texture");
+        return -1;
+    }
+    if(texels_bgr != NULL)
+    {
+        const size_t n = (size_t)params->tex_w*params->tex_h;
+        uint32_t* packed = (uint32_t*)malloc(n*sizeof(uint32_t));
+        if(!packed) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_set_texture: out of memory"); return -1; }
+        for(size_t k=0; k<n; k++)
+            packed[k] = (uint32_t)texels_bgr[3*k] | ((uint32_t)texels_bgr[3*k+1] << 8) | ((uint32_t)texels_bgr[3*k+2] << 16);
+        HZ_CHECK(hipStreamSynchronize(d->stream));
+        (void)hipFree(d->d_texels); d->d_texels = NULL;
+        hipError_t e = hipMalloc(&d->d_texels, n*sizeof(uint32_t));
+        if(e == hipSuccess) e = hipMemcpy(d->d_texels, packed, n*sizeof(uint32_t), hipMemcpyHostToDevice);
+        free(packed);
+        HZ_CHECK(e);
+    }
+    else if(d->d_texels == NULL || params->tex_w != d->tex.tex_w || params->tex_h != d->tex.tex_h)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_set_texture: no texture of that size is resident");
+        return -1;
+    }
+    d->tex = *params;
+    d->tex_on = 1;
     return 0;
 }
 
@@ -1595,6 +1722,15 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
                        (const unsigned long long*)d->d_fb, (const float*)d->d_tanel,
                        bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
     HZ_CHECK(hipGetLastError());
+    if(d->tex_on && bgr)
+    {
+        /* reference fragment.glsl:17-22 instead of :15-16 for the terrain pixels */
+        const hz_params_t p = make_params(d, view);
+        hipLaunchKernelGGL(k_shade_tex, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
+                           (const unsigned long long*)d->d_fb, (const int16_t*)d->d_mosaic,
+                           (const uint32_t*)d->d_texels, d->tex, bgr, p);
+        HZ_CHECK(hipGetLastError());
+    }
     if(prof)
     {
         HZ_CHECK(hipEventRecord(d->ev[5], d->stream));

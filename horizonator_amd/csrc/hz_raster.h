@@ -280,12 +280,12 @@ HZ_HD int hz_tri_fragment(const hz_tri_t* t, int px, int py, uint32_t* zi, uint3
  * draw on llvmpipe bit for bit as well. */
 #define HZ_MAX_CLIPPED 12
 
-typedef struct { float xn, yn, zn, wx, wy, zw, red; } hz_cvert_t;
+typedef struct { float xn, yn, zn, wx, wy, zw, red, s, t; } hz_cvert_t;     /* s,t: texture coordinates (hz_tex.h) */
 
 HZ_HD hz_cvert_t hz_cvert(hz_vertex_t v, float halfW, float halfH)
 {
     hz_cvert_t c;
-    c.xn = v.x; c.yn = v.y; c.zn = v.z; c.red = v.red;
+    c.xn = v.x; c.yn = v.y; c.zn = v.z; c.red = v.red; c.s = 0.f; c.t = 0.f;
     c.wx = v.x*halfW + halfW; c.wy = v.y*halfH + halfH; c.zw = v.z*0.5f + 0.5f;
     return c;
 }
@@ -311,6 +311,8 @@ HZ_HD hz_cvert_t hz_clip_interp(float t, const hz_cvert_t* out, const hz_cvert_t
     d.wy  = d.yn*oow*halfH + halfH;
     d.zw  = d.zn*oow*0.5f  + 0.5f;
     d.red = out->red + t*(in->red - out->red);
+    d.s   = out->s   + t*(in->s   - out->s);
+    d.t   = out->t   + t*(in->t   - out->t);
     return d;
 }
 
@@ -370,6 +372,35 @@ HZ_HD int hz_clip_triangle(hz_cvert_t* bufa, hz_cvert_t* bufb, hz_cvert_t** poly
     }
     *poly = in;
     return n;
+}
+
+/* planes of the shade and of the texture coordinates over triangle (a,b,c):
+ * hz_tri_planes() arithmetic on three more attributes (textured resolve) */
+typedef struct { float r_org, drdx, drdy, s_org, dsdx, dsdy, t_org, dtdx, dtdy; } hz_texplanes_t;
+HZ_HD void hz_tri_planes_tex(hz_texplanes_t* o, const hz_cvert_t* a, const hz_cvert_t* b, const hz_cvert_t* c)
+{
+    const hz_cvert_t *v0 = b, *v1 = a, *v2 = c;
+    const float dx01 = v0->wx - v1->wx, dy01 = v0->wy - v1->wy;
+    const float dx20 = v2->wx - v0->wx, dy20 = v2->wy - v0->wy;
+    const float ooa  = 1.0f / (dx01*dy20 - dx20*dy01);
+    const float dy20_ooa = dy20*ooa, dy01_ooa = dy01*ooa, dx20_ooa = dx20*ooa, dx01_ooa = dx01*ooa;
+    const float x0c = v0->wx - 0.5f, y0c = v0->wy - 0.5f;
+    const float dr01 = v0->red - v1->red, dr20 = v2->red - v0->red;
+    const float ds01 = v0->s   - v1->s,   ds20 = v2->s   - v0->s;
+    const float dt01 = v0->t   - v1->t,   dt20 = v2->t   - v0->t;
+    o->drdx  = dr01*dy20_ooa - dr20*dy01_ooa;
+    o->drdy  = dr20*dx01_ooa - dr01*dx20_ooa;
+    o->r_org = v0->red - (o->drdx*x0c + o->drdy*y0c);
+    o->dsdx  = ds01*dy20_ooa - ds20*dy01_ooa;
+    o->dsdy  = ds20*dx01_ooa - ds01*dx20_ooa;
+    o->s_org = v0->s - (o->dsdx*x0c + o->dsdy*y0c);
+    o->dtdx  = dt01*dy20_ooa - dt20*dy01_ooa;
+    o->dtdy  = dt20*dx01_ooa - dt01*dx20_ooa;
+    o->t_org = v0->t - (o->dtdx*x0c + o->dtdy*y0c);
+}
+HZ_HD float hz_plane_at(float org, float ddx, float ddy, int px, int py)
+{
+    return __builtin_fmaf(ddy, (float)py, __builtin_fmaf(ddx, (float)px, org));
 }
 
 /* a clipper vertex as the rasteriser wants it */

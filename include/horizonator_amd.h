@@ -35,6 +35,23 @@ bool horizonator_amd_render_device(const horizonator_context_t* ctx,
                                    int32_t* d_index, uint32_t* d_z24);
 bool horizonator_amd_sync(const horizonator_context_t* ctx);
 
+/* Texture path with a caller-supplied map ("next" row N4: reference
+ * render_texture=true without its tile downloads).  The reference drapes a
+ * mosaic of zoom-12 slippy-map tiles, 256x256 each, over the terrain: tiles
+ * x in [lowest_x, lowest_x+ntiles_x), y in [lowest_y, lowest_y+ntiles_y), the
+ * range that covers the DEM window of horizonator_init() (reference
+ * horizonator-lib.c:372-389).  horizonator_init(render_texture=true) reads them
+ * from dir_tiles/tiles_name/12/X/Y.png as the reference does (no downloads);
+ * alternatively the caller hands over the finished mosaic:
+ *   texels_bgr  HOST bytes [ntiles_y*256][ntiles_x*256][3], B,G,R, row 0 = the
+ *               SOUTHERN edge (tile row lowest_y+ntiles_y-1, bottom pixel row),
+ *               i.e. what the reference passes to glTexSubImage2D(GL_BGR).
+ * NULL switches texturing off again.  While on, image outputs are
+ * 0.7*map + 0.3*shade (reference fragment.glsl:17-22). */
+bool horizonator_amd_texture_layout(const horizonator_context_t* ctx,
+                                    int* lowest_x, int* lowest_y, int* ntiles_x, int* ntiles_y);
+bool horizonator_amd_set_texture(horizonator_context_t* ctx, const unsigned char* texels_bgr);
+
 /* A batch of viewpoints over the context's DEM window (BASELINE.json configs[3]):
  * for v in [0,n): horizonator_move(viewer_lat[v], viewer_lon[v]) followed by a
  * render into DEVICE buffers d_images[v] ([H][sector width][3] BGR) and

@@ -151,6 +151,28 @@ int  hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const float* tane
                            const hz_poi_t* pois, int npois,
                            unsigned char* visible, float* label_x, float* label_y);
 
+/* uniforms of the texture half of the reference's vertex shader
+ * (vertex.glsl:16-21; values as horizonator-lib.c:577-588,801-809 sets them)
+ * and the size of the texture, NtilesX*256 x NtilesY*256 texels */
+typedef struct
+{
+    float   viewer_lat_rad;
+    float   origin_cell_lon_deg, origin_cell_lat_deg;
+    float   lon0, lon1, dlat0, dlat1, dlat2;            /* texturemap_* */
+    int32_t ntiles_x, ntiles_y, lowest_x, lowest_y;     /* NtilesX/Y, osmtile_lowestX/Y */
+    int32_t tex_w, tex_h;
+} hz_texparams_t;
+
+/* Texture path (reference render_texture = true; vertex.glsl:41-61,116-126,
+ * fragment.glsl:17-22, horizonator-lib.c:247-266,361-366).  params: the uniform
+ * values of the texture half of the vertex shader and the size of the texture
+ * (hz_tex.h).  texels_bgr: HOST bytes [tex_h][tex_w][3], B,G,R, row 0 = texture
+ * coordinate t = 0 (the southern edge of the tile mosaic) - the layout the
+ * reference hands to glTexSubImage2D(GL_BGR); NULL keeps the resident texels and
+ * only replaces params.  params == NULL switches texturing off.  While on,
+ * hz_hip_resolve*() writes 0.7*texture + 0.3*shade into the BGR output. */
+int  hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, const unsigned char* texels_bgr);
+
 int  hz_hip_sync(hz_dev_t* d);
 int  hz_hip_last_times(hz_dev_t* d, hz_times_t* t);
 

@@ -101,6 +101,8 @@ def load():
     lib.orc_render_tex.restype = C.c_int
     lib.orc_render_tex.argtypes = [C.c_void_p, C.c_int, P(OrcView), P(OrcTex), C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_draw_triangles.restype = C.c_int
+    lib.orc_draw_triangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(OrcTex), C.c_void_p, C.c_void_p]
     lib.orc_tanel.restype = None
     lib.orc_tanel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
     _lib = lib
@@ -203,6 +205,28 @@ def render(mosaic, view, W, H, col0=0, col1=None, nthreads=0, want=("bgr", "rang
     if rc != 0:
         raise RuntimeError(f"orc_render failed ({rc})")
     return out
+
+
+def draw_triangles(tris, W, H, texels=None):
+    """raw clip-space triangles float32[n,3,6] (x,y,z, shade, s,t) through the oracle's clipper,
+    rasteriser and, with texels uint8[th,tw,3] (B,G,R, row 0 = t 0), its textured fragment stage.
+    Returns dict(bgr, z24), top row first like every other output."""
+    lib = load()
+    tris = np.ascontiguousarray(tris, np.float32)
+    bgr = np.empty((H, W, 3), np.uint8)
+    z24 = np.empty((H, W), np.uint32)
+    tex = None
+    if texels is not None:
+        texels = np.ascontiguousarray(texels, np.uint8)
+        tex = OrcTex()
+        tex.tex_h, tex.tex_w = texels.shape[:2]
+        tex.ntiles_x = tex.ntiles_y = 1
+        tex.texels = texels.ctypes.data
+    rc = lib.orc_draw_triangles(tris.ctypes.data, tris.shape[0], W, H, C.byref(tex) if tex is not None else None,
+                                bgr.ctypes.data, z24.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_draw_triangles failed")
+    return {"bgr": bgr[::-1].copy(), "z24": z24[::-1].copy()}
 
 
 def vertices(mosaic, view):

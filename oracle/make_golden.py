@@ -153,6 +153,61 @@ def batch_checksum_fixtures():
     json.dump(out, open(os.path.join(OUT, "batch_checksums.json"), "w"), indent=1)
 
 
+def texture_fixtures():
+    """the texture path ("next" row N4) on llvmpipe: texture coordinates of every vertex
+    (transform feedback), raw textured triangles through the reference's fragment shader
+    (sampler + blend, incl. wrap and non-power-of-two sizes), and whole textured draws.
+    Textures are hzutil.hash_texture(): only their size and seed are stored."""
+    # vertex stage
+    R, W, H = 48, 256, 64
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    lat = LAT + 0.011
+    v = od.view(lat, LON, W, H, -180, 180)
+    t = od.texture(LAT, LON, viewer_lat=lat)
+    cap = glsl_run.vertices_textured(m, v, t.as_glsl_job())
+    np.savez_compressed(os.path.join(OUT, "tex_vertex.npz"), mosaic=m, N=m.shape[0], tex_st=cap[..., 5:7],
+                        xyzr=cap[..., [0, 1, 2, 4]], init_lat=LAT, init_lon=LON, viewer_lat=lat,
+                        **{"t_" + k: val for k, val in t.as_glsl_job().items()}, **view_arrays(v))
+    print("tex_vertex.npz:", cap.shape)
+
+    # sampler + blend probes: two triangles per draw, texture coordinates partly outside [0,1]
+    rng = np.random.default_rng(2024)
+    PW, PH = 96, 64
+    draws = {}
+    for k, (th, tw, blocky) in enumerate([(4, 4, 1), (80, 96, 1), (32, 64, 1), (5, 3, 1), (256, 768, 8), (768, 256, 1)]):
+        s0, s1 = np.sort(rng.uniform(-0.3, 1.3, 2)) if k % 2 else (rng.uniform(0, .2), rng.uniform(.8, 1))
+        t0, t1 = np.sort(rng.uniform(-0.3, 1.3, 2)) if k % 2 else (rng.uniform(0, .2), rng.uniform(.8, 1))
+        r = rng.uniform(0, 1, 4)
+        ds, dt = rng.uniform(-.1, .1, 2)
+        A = [-1, -1, 0, r[0], s0, t0]; B = [1, -1, 0, r[1], s1, t0 + dt]
+        Cc = [1, 1, 0, r[2], s1 + ds, t1 + dt]; D = [-1, 1, 0, r[3], s0 + ds, t1]
+        tris = np.array([[A, B, Cc], [A, Cc, D]], np.float32)
+        g = glsl_run.textured_triangles(tris, PW, PH, hzutil.hash_texture(th, tw, seed=k, blocky=blocky))
+        draws[f"tris{k}"] = tris; draws[f"tex{k}"] = np.array([th, tw, k, blocky]); draws[f"bgr{k}"] = g["bgr"]
+    np.savez_compressed(os.path.join(OUT, "tex_probe.npz"), W=PW, H=PH, n=6, **draws)
+    print("tex_probe.npz: 6 draws")
+
+    # whole draws
+    for name, R, W, H, az0, az1, dlat, dlon, blocky, kw in [
+            ("T1_full360", 64, 512, 128, -180, 180, 0.0, 0.0, 1, dict(zfar=8000.0)),
+            ("T2_clipped", 150, 800, 200, -180, 180, 0.0, 0.0, 8, dict(zfar=7000.0, viewer_z=2300.0)),
+            ("T3_moved",   32, 400, 160, 30, 140, 0.006, -0.004, 4, dict(zfar=5000.0, znear_color=300.0, zfar_color=2500.0))]:
+        d = hzutil.dem_dir_for(LAT, LON, R)
+        od = oracle.Dem(LAT, LON, d, radius_cells=R)
+        m = od.mosaic()
+        v = od.view(LAT + dlat, LON + dlon, W, H, az0, az1, **kw)
+        t = od.texture(LAT, LON, viewer_lat=LAT + dlat)
+        texels = hzutil.hash_texture(t.tex_h, t.tex_w, seed=7, blocky=blocky)
+        g = glsl_run.render_textured(m, v, W, H, t.as_glsl_job(), texels)
+        np.savez_compressed(os.path.join(OUT, f"texrender_{name}.npz"), mosaic=m, N=m.shape[0], W=W, H=H,
+                            bgr=g["bgr"], z24=g["z24"], tex_seed=7, tex_blocky=blocky, tex_h=t.tex_h, tex_w=t.tex_w,
+                            init_lat=LAT, init_lon=LON, viewer_lat=LAT + dlat, viewer_lon=LON + dlon,
+                            **{"t_" + k: val for k, val in t.as_glsl_job().items()}, **view_arrays(v))
+        print(f"texrender_{name}.npz: {W}x{H}, texture {t.tex_w}x{t.tex_h}, terrain fraction {(g['z24'] != 0xFFFFFF).mean():.3f}")
+
+
 def raster_probe_fixture():
     """llvmpipe's fill rule and depth rounding on hand-made triangles (our own
     pass-through shaders; no reference code involved)"""
@@ -184,6 +239,9 @@ def main():
     if sys.argv[1:] == ["batch"]:               # only tests/golden/batch_checksums.json
         batch_checksum_fixtures()
         return
+    if sys.argv[1:] == ["texture"]:             # only the texture path's fixtures
+        texture_fixtures()
+        return
     dem_fixtures()
     raster_probe_fixture()
     # vertex stage (pins reference vertex.glsl:111-162 bit for bit)
@@ -202,6 +260,7 @@ def main():
     render_fixture("G8_on_vertex", 64, 512, 128, -180, 180, lat=34.0 + 500 / 1200.0, lon=-118.0 + 500 / 1200.0)
     checksum_fixtures()
     batch_checksum_fixtures()
+    texture_fixtures()
 
 
 if __name__ == "__main__":

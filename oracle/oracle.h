@@ -139,6 +139,11 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
                    uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
                    int nthreads);
 
+/* raw clip-space triangles, float[ntri][3][6] = x,y,z, shade, s,t (w = 1), through clipper,
+ * rasteriser and (tex != NULL) the textured fragment stage; outputs in GL row order */
+int orc_draw_triangles(const float* tris, int ntri, int W, int H, const orc_tex_t* tex,
+                       uint8_t* bgr, uint32_t* z24);
+
 /* ---- annotator passes over the range image ("next" row N2) ----------------- */
 
 /* reference horizonator-lib.c:1097-1155 / :1157-1213; return 1 on success */

@@ -442,6 +442,9 @@ static wvert_t clip_interp(float t, const wvert_t* out, const wvert_t* in, float
     return d;
 }
 
+static void clip_and_raster(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
+                            const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim);
+
 static void draw_triangle(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
                           const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
 {
@@ -449,7 +452,13 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi, float halfW, float h
     float xmax = A->xn > B->xn ? A->xn : B->xn; xmax = xmax > C->xn ? xmax : C->xn;
     float xmin = A->xn < B->xn ? A->xn : B->xn; xmin = xmin < C->xn ? xmin : C->xn;
     if(xmax - xmin > 0.5f) return;
+    clip_and_raster(fb, x_lo, x_hi, halfW, halfH, A, B, C, prim);
+}
 
+/* what GL does with a primitive after the geometry stage */
+static void clip_and_raster(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
+                            const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+{
     const unsigned ma = clip_mask(A), mb = clip_mask(B), mc = clip_mask(C);
     if(ma & mb & mc) return;                        /* wholly outside one plane */
     unsigned todo = ma | mb | mc;
@@ -508,6 +517,56 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi, float halfW, float h
     /* the polygon goes on as a fan that keeps vertex 0 last (GL provoking vertex) */
     for(int i=2; i<n; i++)
         raster_triangle(fb, x_lo, x_hi, &in[i-1], &in[i], &in[0], prim);
+}
+
+/* Raw clip-space triangles (x,y,z, shade, s,t per vertex; w = 1) through the
+ * clipper, the rasteriser and - with a texture - the textured fragment stage,
+ * in draw order.  The counterpart of glsl_golden's probe modes 2 and 5: lets
+ * the tests hold this file's rasteriser and sampler directly against what
+ * llvmpipe drew for the same triangles.  Outputs in GL row order (bottom
+ * first): bgr [H][W][3] (clear colour where nothing was drawn), z24 [H][W]. */
+int orc_draw_triangles(const float* tris, int ntri, int W, int H, const orc_tex_t* tex,
+                       uint8_t* bgr, uint32_t* z24)
+{
+    const size_t npix = (size_t)W*H;
+    target_t fb;
+    fb.SW = W; fb.H = H; fb.col0 = 0; fb.col1 = W;
+    fb.depth = malloc(npix*sizeof(uint32_t));
+    fb.prim  = malloc(npix*sizeof(int32_t));
+    fb.red   = malloc(npix);
+    fb.tex   = tex;
+    fb.color = tex ? malloc(npix*3) : NULL;
+    if(!fb.depth || !fb.prim || !fb.red || (tex && !fb.color))
+    {
+        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color);
+        return -1;
+    }
+    for(size_t k=0; k<npix; k++) { fb.depth[k] = 0xFFFFFFu; fb.prim[k] = -1; fb.red[k] = 0; }
+    const float halfW = (float)W*0.5f, halfH = (float)H*0.5f;
+    for(int n=0; n<ntri; n++)
+    {
+        wvert_t v[3];
+        for(int m=0; m<3; m++)
+        {
+            const float* p = &tris[((size_t)n*3 + m)*6];
+            v[m].xn = p[0]; v[m].yn = p[1]; v[m].zn = p[2];
+            v[m].wx = p[0]*halfW + halfW; v[m].wy = p[1]*halfH + halfH; v[m].zw = p[2]*0.5f + 0.5f;
+            v[m].red = p[3]; v[m].s = p[4]; v[m].t = p[5];
+        }
+        clip_and_raster(&fb, 0, W-1, halfW, halfH, &v[0], &v[1], &v[2], n);
+    }
+    for(size_t k=0; k<npix; k++)
+    {
+        const int sky = fb.depth[k] == 0xFFFFFFu;
+        if(z24) z24[k] = fb.depth[k];
+        if(bgr)
+        {
+            bgr[3*k+0] = sky ? 255 : 0; bgr[3*k+1] = 0; bgr[3*k+2] = sky ? 0 : fb.red[k];
+            if(tex && !sky) { bgr[3*k+0] = fb.color[3*k+0]; bgr[3*k+1] = fb.color[3*k+1]; bgr[3*k+2] = fb.color[3*k+2]; }
+        }
+    }
+    free(fb.depth); free(fb.prim); free(fb.red); free(fb.color);
+    return 0;
 }
 
 void orc_tanel(float* tanel, int W, int H, float az_deg0, float az_deg1)

@@ -47,6 +47,20 @@ def viewpoint_lattice(lat=VIEW_LAT, lon=VIEW_LON, side=16, half_span_deg=0.2):
     return lats, lons
 
 
+def hash_texture(th, tw, seed=0, blocky=1):
+    """a deterministic map-like texture without any RNG (integer hash of the texel index, so that
+    fixtures only need to store its size and seed): uint8[th,tw,3], B,G,R, row 0 = southern edge.
+    blocky > 1 repeats each value over blocky x blocky texels (flat areas with sharp borders)."""
+    y, x = np.mgrid[0:th, 0:tw].astype(np.uint64)
+    y //= np.uint64(blocky); x //= np.uint64(blocky)
+    out = np.empty((th, tw, 3), np.uint8)
+    for c in range(3):
+        h = (x * np.uint64(73856093)) ^ (y * np.uint64(19349663)) ^ np.uint64((c + 1) * 83492791 + seed * 2654435761)
+        h = (h ^ (h >> np.uint64(13))) * np.uint64(0x9E3779B97F4A7C15)
+        out[..., c] = ((h >> np.uint64(40)) & np.uint64(255)).astype(np.uint8)
+    return out
+
+
 # ---- driving the HIP path through its C-ABI (include/hz_hip.h) ---------------
 
 def hip_available():
@@ -56,7 +70,7 @@ def hip_available():
         return False
 
 
-def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None):
+def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None, tex=None, texels=None):
     """mosaic int16[N,N] + uniform values -> dict(bgr, ranges, index, z24) via
     hz_hip_create / upload_mosaic / draw / resolve_to_host.  `view` is anything
     with the hz_view_t field names as attributes (e.g. oracle.OrcView)."""
@@ -77,6 +91,14 @@ def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None):
         v = hzlib.View()
         for name, _ in hzlib.View._fields_:
             setattr(v, name, getattr(view, name))
+        if tex is not None:
+            # texture path: `tex` is anything with the hz_texparams_t field names (e.g. oracle.OrcTex)
+            tp = hzlib.TexParams()
+            for name, _ in hzlib.TexParams._fields_:
+                setattr(tp, name, getattr(tex, name))
+            texels = np.ascontiguousarray(texels, np.uint8)
+            assert texels.shape == (tp.tex_h, tp.tex_w, 3)
+            assert lib.hz_hip_set_texture(dev, C.byref(tp), texels.ctypes.data) == 0, lib.hz_hip_last_error()
         if tanel is None:
             # tan(elevation) per GL row exactly as hz_host.c / the reference derive it
             import oracle

@@ -123,9 +123,11 @@ def test_errors_behave_like_the_reference(tmp_path):
     # both radii (reference horizonator-pywrap.c:100-104)
     with pytest.raises(RuntimeError):
         horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=32, render_radius_m=1000.0)
-    # texture path and window modes are not part of this build
+    # texture path: map tiles missing on disk and no downloads -> init fails (reference
+    # horizonator-lib.c:284-289); window modes are not part of this build
     with pytest.raises(RuntimeError):
-        horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=32, render_texture=True)
+        horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=32, render_texture=True,
+                                    dir_tiles=str(tmp_path / "no_tiles_here"), allow_downloads=False)
     from horizonator_amd import _lib
     lib = _lib.load()
     ctx = _lib.Context()
