@@ -25,8 +25,8 @@
  * own dem.c compiled in place (oracle/_ref/libdem_ref.so).  The render is
  * checked against golden vectors produced by the reference's three GLSL
  * shaders, unmodified, executed by Mesa llvmpipe (oracle/glsl_golden.c,
- * tests/golden/): the vertex stage bit-exact, coverage exact, depth bit-exact
- * except in triangles llvmpipe clips (bands in tests/test_oracle_golden.py).
+ * tests/golden/): the vertex stage bit-exact, and every byte of the BGR image
+ * and of the 24-bit depth of whole draws identical, clipped triangles included.
  * horizonator-lib.c and annotator.c themselves cannot be built here (they need
  * epoxy, freeglut, FreeImage, cairo and swscale headers the image lacks), so
  * the host-side uniform derivation, the readback conversion and the annotator
