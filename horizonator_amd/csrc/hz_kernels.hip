@@ -677,6 +677,7 @@ struct mr_zones_t
     int seg0[MR_NZONES];            /* number of the zone's first segment                 */
     int nseg[MR_NZONES];            /* segments in the zone                               */
     int total;                      /* all segments = gridDim.y                           */
+    int near_first;                 /* dispatch order: segments nearest to the viewer's row first */
 };
 
 /* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
@@ -957,7 +958,9 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     #pragma unroll
     for(int z=1; z<MR_NZONES; z++)
         if((int)blockIdx.y >= zn.seg0[z] && (int)blockIdx.y < zn.seg0[z] + zn.nseg[z]) zone = z;
-    const int jbeg = zn.row0[zone] + ((int)blockIdx.y - zn.seg0[zone])*zn.rows[zone];
+    int sseg = (int)blockIdx.y - zn.seg0[zone];
+    if(zn.near_first && zone < MR_NZONES/2) sseg = zn.nseg[zone]-1 - sseg;      /* south of the viewer: northernmost first */
+    const int jbeg = zn.row0[zone] + sseg*zn.rows[zone];
     const int jend = min(jbeg + zn.rows[zone], zn.row0[zone+1]);   /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
     if(p.pass)
     {
@@ -1482,7 +1485,7 @@ extern "C" void* hz_hip_stream(hz_dev_t* d) { return (void*)d->stream; }
 
 /* segment zones of k_march for this view: a cell `r` rows away from the viewer
  * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
-static mr_zones_t mr_make_zones(const hz_params_t& p)
+static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first)
 {
     const float ppr = p.halfW * p.u.az_ndc_per_rad;
     const int   ncr = p.N-1;                                /* cell rows */
@@ -1509,8 +1512,14 @@ static mr_zones_t mr_make_zones(const hz_params_t& p)
     const int rows[MR_NZONES] = { far_rows, 16, 4, 2, 4, 16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
-     * early and the kernel ends on short ones */
-    const int order[MR_NZONES] = { 0, 6, 1, 5, 2, 4, 3 };
+     * early and the kernel ends on short ones.  With the early depth test
+     * (second round of a two-round draw) the order is from the viewer's row
+     * outwards instead, so that the ridges in between are in the framebuffer
+     * before the far field is tested against it. */
+    const int order_far_first [MR_NZONES] = { 0, 6, 1, 5, 2, 4, 3 };
+    const int order_near_first[MR_NZONES] = { 3, 2, 4, 1, 5, 0, 6 };
+    z.near_first = near_first ? 1 : 0;
+    const int* order = near_first ? order_near_first : order_far_first;
     int seg = 0;
     for(int o=0; o<MR_NZONES; o++)
     {
@@ -1573,10 +1582,11 @@ __global__ void k_reset_counters(unsigned int* counters, int all)
  * The split changes no result (the framebuffer word is order-independent and
  * the depth test only skips triangles that cannot win a pixel); it lets most
  * of the far field stop at the depth already there.  Measured on the benchmark
- * scene: 90% of the far survivors are rejected, k_march
- * drops from 1.31 to 1.12 ms, but round 1 runs at low occupancy and the total
- * is a draw (2.01 vs 2.04 ms; worse with the 40 km far clip).  So one round
- * without the test is the default; HZ_TWO_PASS=1 selects the two rounds. */
+ * scene: 95% of the far survivors are rejected, k_march
+ * drops from 1.33 to 1.07 ms, but round 1 runs at low occupancy and the total
+ * gains only 5% (1.93 vs 2.03 ms), loses 3% with the 40 km far clip and 18% on
+ * batches of smaller panoramas.  So one round without the test is the default;
+ * HZ_TWO_PASS=1 selects the two rounds. */
 extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
 {
     HZ_CHECK(hipSetDevice(d->device));
@@ -1626,7 +1636,6 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     }
     else
     {
-        const mr_zones_t zn = mr_make_zones(p);
         const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
         /* the strips next to the viewer: within near_cells cells of the viewer's cell */
         const char* e2 = getenv("HZ_TWO_PASS");
@@ -1639,6 +1648,7 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
         p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
         const bool two_pass = (e2 && atoi(e2) != 0) && near_cells > 0 && p.near_x1 >= p.near_x0;
+        const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
         {
             p.pass = 1; p.early_z = 0;
