@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--raster", type=int, default=0, help="HZ_RASTER_* (0 auto, 1 scatter, 2 march)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary zfar=40 km measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="diagnostics: gloo moves the strips through host memory (lets two ranks share one GPU "
+                         "to exercise the N>1 loop where only one GPU exists); the driver's runs use nccl = RCCL")
+    ap.add_argument("--same-gpu", action="store_true", help="diagnostics: every rank uses GPU 0 (with --backend gloo)")
     return ap.parse_args()
 
 
@@ -64,12 +68,17 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only does dmabuf IPC
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -101,31 +110,51 @@ def main():
     SW = col1 - col0
     h.set_profiling(True)
 
-    # two sets of strip buffers: while RCCL moves the strips of panorama k to
-    # rank 0, panorama k+1 is already being rendered into the other set
+    # N = 1: draw + readback conversion into BGR8 / float32 range, both left in HBM.
+    # N > 1: every rank draws its sector and ships it as one word per pixel (z24<<8 | red8:
+    # 4 bytes instead of the 7 of the finished strip - the gather is what xGMI limits);
+    # rank 0 runs the readback conversion on what arrives, into the full-width outputs.
+    # Two sets of strip buffers: while RCCL moves the strips of panorama k, panorama k+1
+    # is already being drawn into the other set.
     NBUF = 2 if world > 1 else 1
-    d_img = [torch.empty((H, SW, 3), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-    d_rng = [torch.empty((H, SW), dtype=torch.float32, device=dev) for _ in range(NBUF)]
-    pending = [[] for _ in range(NBUF)]
-    state = {"k": 0, "last": None}
+    if world == 1:
+        d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
+    else:
+        d_pk = [torch.empty((H, SW), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+        if rank == 0:
+            d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+            d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
+    pending = [None] * NBUF
+    state = {"k": 0}
 
     def finish(slot):
-        """complete the exchange that still reads buffer set `slot`"""
-        for hnd in pending[slot]:
-            state["last"] = hnd.result()         # rank 0: the assembled [H, W, ...] tensor
-        if pending[slot]:
-            torch.cuda.current_stream().synchronize()
-        pending[slot] = []
+        """complete the exchange that still reads buffer set `slot`; rank 0: turn the strips
+        into the panorama"""
+        if pending[slot] is None:
+            return
+        parts = pending[slot].parts()
+        torch.cuda.current_stream().synchronize()       # the strips have arrived (RCCL's stream -> host)
+        if parts is not None:
+            if args.backend == "gloo":
+                parts = [(t.to(dev), c0, n) for t, c0, n in parts]
+            for t, c0, n in parts:
+                h.resolve_packed(t.data_ptr(), t.shape[1], n, c0, d_img.data_ptr(), d_rng.data_ptr())
+            h.sync()                                     # ... before the strips are released
+        pending[slot] = None
 
     def step():
         slot = state["k"] % NBUF
         state["k"] += 1
+        if world == 1:
+            h.render_device(d_img.data_ptr(), d_rng.data_ptr())
+            h.sync()
+            return
         finish(slot)
-        h.render_device(d_img[slot].data_ptr(), d_rng[slot].data_ptr())
+        h.render_packed(d_pk[slot].data_ptr())
         h.sync()
-        if world > 1:
-            # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
-            pending[slot] = [gather_strips_async(d_img[slot], W), gather_strips_async(d_rng[slot], W)]
+        # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
+        pending[slot] = gather_strips_async(d_pk[slot] if args.backend == "nccl" else d_pk[slot].cpu(), W)
 
     def drain():
         for slot in range(NBUF):
@@ -136,6 +165,20 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def verify():
+        """N > 1: the panorama rank 0 assembled from the gathered strips must be, byte for byte,
+        what one GPU renders on its own"""
+        if world == 1 or rank != 0:
+            return None
+        got_img, got_rng = d_img.clone(), d_rng.clone()
+        h.set_sector(0, W)
+        one_img = torch.empty_like(d_img)
+        one_rng = torch.empty_like(d_rng)
+        h.render_device(one_img.data_ptr(), one_rng.data_ptr())
+        h.sync()
+        h.set_sector(col0, col1)
+        return bool(torch.equal(got_img, one_img) and torch.equal(got_rng, one_rng))
 
     def timed(zfar, steps, warmup):
         h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=zfar)
@@ -158,6 +201,7 @@ def main():
         return dt, kern
 
     dt, kern = timed(args.zfar, args.steps, args.warmup)
+    verified = verify()
     ms_per_step = dt / args.steps * 1e3
     value = W * H * args.steps / dt / 1e6
 
@@ -169,7 +213,7 @@ def main():
     near_ms = float(np.mean([k["near_ms"] for k in kern]))
     total_ms = float(np.mean([k["total_ms"] for k in kern]))
     # algorithmic bytes of one render: int16 DEM read once +
-    # BGR8 and float32 range written once; a sector writes its share
+    # BGR8 and float32 range written once; a sector accounts for its share
     algo_bytes = 2 * N * N + 7 * SW * H
     achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
     traffic = None
@@ -215,7 +259,7 @@ def main():
             "config": {
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
-                "parallelism": f"azimuth sectors x{world}" + (" + RCCL gather of BGR8/float32 strips to rank 0, overlapped with the next render" if world > 1 else ""),
+                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of packed depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",
                 "init_s": init_s,
@@ -231,6 +275,8 @@ def main():
             },
             "cpu_baseline": cpu,
         }
+        if verified is not None:
+            line["gathered_panorama_equals_single_gpu_render"] = verified
         line.update(extra)
         print(json.dumps(line))
     h.close()

@@ -220,6 +220,21 @@ class horizonator:
             raise RuntimeError("horizonator_amd_render_batch() failed")
         return z
 
+    def render_packed(self, d_packed):
+        """Draw with the current view and write this context's sector as uint32 z24<<8 | red8
+        per pixel into the DEVICE buffer d_packed ([H, sector width], raw pointer): the 4-byte
+        form in which strips travel between GPUs.  Asynchronous; call sync()."""
+        if not self._lib.horizonator_amd_render_packed(C.byref(self._ctx), d_packed):
+            raise RuntimeError("horizonator_amd_render_packed() failed")
+
+    def resolve_packed(self, d_packed, packed_stride, ncols, out_col0, d_image=0, d_ranges=0):
+        """Convert packed words (from any GPU, drawn with this context's view) into columns
+        [out_col0, out_col0+ncols) of the full-width DEVICE outputs image uint8[H,W,3] and
+        ranges float32[H,W] (raw pointers, 0 = skip).  Asynchronous."""
+        if not self._lib.horizonator_amd_resolve_packed(C.byref(self._ctx), d_packed, int(packed_stride), int(ncols),
+                                                        int(out_col0), d_image or None, d_ranges or None):
+            raise RuntimeError("horizonator_amd_resolve_packed() failed")
+
     def texture_layout(self):
         """(lowest_x, lowest_y, ntiles_x, ntiles_y): the zoom-12 slippy-map tiles the texture
         of this context is made of (reference horizonator-lib.c:372-389); the texture is

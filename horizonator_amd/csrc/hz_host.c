@@ -705,6 +705,36 @@ bool horizonator_amd_set_texture(horizonator_context_t* ctx, const unsigned char
     return true;
 }
 
+bool horizonator_amd_render_packed(const horizonator_context_t* ctx, uint32_t* d_packed)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || d_packed == NULL) return false;
+    if(!ctx->offscreen.inited) return false;
+    if(!horizonator_redraw(ctx)) return false;
+    if(0 != hz_hip_pack(s->dev, d_packed))
+    {
+        MSG("pack failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool horizonator_amd_resolve_packed(const horizonator_context_t* ctx,
+                                    const uint32_t* d_packed, int packed_stride, int ncols, int out_col0,
+                                    void* d_image, float* d_ranges)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || d_packed == NULL) return false;
+    if(d_ranges != NULL) fill_tanel(s);
+    if(0 != hz_hip_resolve_packed(s->dev, &s->view, s->tanel, d_packed, packed_stride, ncols, out_col0,
+                                  d_image, d_ranges))
+    {
+        MSG("resolve of packed strips failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
 bool horizonator_amd_sync(const horizonator_context_t* ctx)
 {
     hz_state_t* s = live_state(ctx);

@@ -1149,6 +1149,67 @@ void k_resolve(const unsigned long long* __restrict__ fb, const float* __restric
 }
 
 /* ------------------------------------------------------------------------ */
+/* packed strips for the multi-GPU gather                                    */
+/*
+ * A finished strip as BGR8 + float32 range is 7 bytes per pixel, and with N
+ * GPUs (N-1)/N of the panorama has to reach the gathering rank through its
+ * xGMI links: at N = 2 that is 224 MB over ONE link per panorama, more time
+ * than the render itself.  Everything the readback conversion needs is the
+ * 24-bit depth and the 8-bit shade, so a rank ships z24<<8 | red8 (4 bytes per
+ * pixel, top row first) and the gathering rank runs the conversion
+ * (reference horizonator-lib.c:936-1048) on what arrives: same bytes out.
+ */
+__global__ __launch_bounds__(256)
+void k_pack(const unsigned long long* __restrict__ fb, uint32_t* __restrict__ packed, int SW, int H)
+{
+    const size_t npix = (size_t)SW*H;
+    for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
+    {
+        const int yo = (int)(o / SW), x = (int)(o - (size_t)yo*SW);
+        const unsigned long long key = fb[(size_t)(H-1 - yo)*SW + x];
+        packed[o] = ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
+    }
+}
+
+/* packed[H][stride] (columns 0..ncols-1 used) -> columns out_col0.. of the
+ * full-width outputs bgr[H][out_W][3], ranges[H][out_W]; rows top first */
+__global__ __launch_bounds__(256)
+void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols,
+                      const float* __restrict__ tanel,
+                      unsigned char* __restrict__ bgr, float* __restrict__ ranges,
+                      int out_W, int out_col0, int H, float znear, float zfar)
+{
+    const size_t npix = (size_t)ncols*H;
+    for(size_t k = (size_t)blockIdx.x*blockDim.x + threadIdx.x; k < npix; k += (size_t)gridDim.x*blockDim.x)
+    {
+        const int yo = (int)(k / ncols), x = (int)(k - (size_t)yo*ncols);
+        const uint32_t w  = packed[(size_t)yo*stride + x];
+        const uint32_t zi = w >> 8;
+        const bool sky = (zi == HZ_Z24_MAX);
+        const size_t o = (size_t)yo*out_W + out_col0 + x;
+        if(bgr)
+        {
+            bgr[o*3+0] = sky ? 255 : 0;
+            bgr[o*3+1] = 0;
+            bgr[o*3+2] = sky ? 0 : (unsigned char)(w & 0xFF);
+        }
+        if(ranges)
+        {
+            /* reference horizonator-lib.c:1013-1025, as k_resolve */
+            float r = -1.0f;
+            if(!sky)
+            {
+                const float depth = (float)((double)zi * (1.0/16777215.0));
+                const float len   = depth * (zfar-znear) + znear;
+                const float zt    = tanel[H-1 - yo] * len;
+                r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
+            }
+            ranges[o] = r;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* textured resolve ("next" row N4): deferred shading                         */
 /*
  * The rasteriser kernels do not know about the texture: the framebuffer word
@@ -1914,6 +1975,54 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
         HZ_CHECK(hipEventRecord(d->ev[5], d->stream));
         d->have_times = 2;
     }
+    return 0;
+}
+
+/* the draw's result as one word per pixel, z24<<8 | red8, top row first:
+ * what a rank sends to the gathering rank (d_packed: DEVICE, [H][sector width]) */
+extern "C" int hz_hip_pack(hz_dev_t* d, uint32_t* d_packed)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    if(d->tex_on)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_pack: packed strips carry the shade only, not a textured colour");
+        return -1;
+    }
+    const int SW = d->col1 - d->col0;
+    const bool prof = d->profiling != 0;
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->stream));
+    const size_t npix = (size_t)SW*d->H;
+    size_t nblocks = (npix + 255)/256;
+    if(nblocks > 256*32) nblocks = 256*32;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
+                       (const unsigned long long*)d->d_fb, d_packed, SW, d->H);
+    HZ_CHECK(hipGetLastError());
+    if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->stream)); d->have_times = 2; }
+    return 0;
+}
+
+/* The readback conversion on packed words, wherever they were drawn: columns
+ * [0,ncols) of d_packed[H][stride] become columns [out_col0, out_col0+ncols) of
+ * the FULL-width outputs d_bgr[H][W][3] / d_ranges[H][W] (either may be NULL). */
+extern "C" int hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                                     const uint32_t* d_packed, int stride, int ncols, int out_col0,
+                                     unsigned char* d_bgr, float* d_ranges)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    if(ncols <= 0 || stride < ncols || out_col0 < 0 || out_col0 + ncols > d->W)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_packed: columns [%d,%d) do not fit a %d-wide image",
+                 out_col0, out_col0 + ncols, d->W);
+        return -1;
+    }
+    if(d_ranges && upload_tanel(d, tanel) != 0) return -1;
+    const size_t npix = (size_t)ncols*d->H;
+    size_t nblocks = (npix + 255)/256;
+    if(nblocks > 256*32) nblocks = 256*32;
+    hipLaunchKernelGGL(k_resolve_packed, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
+                       d_packed, stride, ncols, (const float*)d->d_tanel, d_bgr, d_ranges,
+                       d->W, out_col0, d->H, view->znear, view->zfar);
+    HZ_CHECK(hipGetLastError());
     return 0;
 }
 

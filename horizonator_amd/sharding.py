@@ -67,6 +67,22 @@ class PendingGather:
         self._work, self._bins, self._width, self._world = work, bins, width, world
         self._strip = strip                 # keeps the send buffer alive until the exchange is over
 
+    def parts(self):
+        """wait for the exchange; on the destination rank the strips as they arrived,
+        [(tensor [H, widest, ...], col0, ncols), ...] in column order - for a consumer
+        that reads them in place (horizonator.resolve_packed) instead of a copy into
+        one image; None elsewhere"""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self._bins is None:
+            return None
+        out = []
+        for r, b in enumerate(self._bins):
+            c0, c1 = sector_columns(self._width, self._world, r)
+            out.append((b, c0, c1 - c0))
+        return out
+
     def result(self):
         """wait for the exchange; the assembled [H, width, ...] tensor on the
         destination rank, None elsewhere"""
@@ -90,6 +106,7 @@ def gather_strips_async(strip, width, group=None, dst=0):
     if world == 1:
         done = PendingGather(None, None, width, world, strip)
         done.result = lambda: strip
+        done.parts = lambda: [(strip, 0, width)]
         return done
     widest = -(-width // world)
     sw = strip.shape[1]

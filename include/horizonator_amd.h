@@ -65,6 +65,19 @@ bool horizonator_amd_render_batch(horizonator_context_t* ctx, int n,
                                   const float* viewer_lat, const float* viewer_lon, float* viewer_z,
                                   void* d_images, float* d_ranges);
 
+/* The same across GPUs with fewer bytes on the wire.  A rank draws its sector and
+ * writes it as one word per pixel, z24<<8 | red8 (DEVICE uint32 [H][sector
+ * width], top row first) - 4 bytes instead of the 7 of BGR8 + float32 range;
+ * the gathering rank converts what it received (and its own strip) into the
+ * final image and ranges, columns [out_col0, out_col0+ncols) of the FULL-width
+ * DEVICE outputs.  The view (z extents, azimuth extents) of the resolving
+ * context must be the one the strips were drawn with.  Untextured draws only.
+ * Both calls are asynchronous on the context's stream. */
+bool horizonator_amd_render_packed(const horizonator_context_t* ctx, uint32_t* d_packed);
+bool horizonator_amd_resolve_packed(const horizonator_context_t* ctx,
+                                    const uint32_t* d_packed, int packed_stride, int ncols, int out_col0,
+                                    void* d_image, float* d_ranges);
+
 /* Restrict this context to image columns [col0,col1) of the panorama: the
  * azimuth-sector shard one GPU renders.  Outputs then have width col1-col0. */
 bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1);

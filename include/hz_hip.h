@@ -151,6 +151,18 @@ int  hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const float* tane
                            const hz_poi_t* pois, int npois,
                            unsigned char* visible, float* label_x, float* label_y);
 
+/* Multi-GPU gather in 4 instead of 7 bytes per pixel: hz_hip_pack() writes the
+ * last draw as z24<<8 | red8 per pixel (DEVICE uint32 [H][sector width], top row
+ * first); hz_hip_resolve_packed() runs the readback conversion (reference
+ * horizonator-lib.c:936-1048) on such words on any device that holds them:
+ * columns [0,ncols) of d_packed[H][stride] go to columns [out_col0,
+ * out_col0+ncols) of the full-width d_bgr[H][W][3] / d_ranges[H][W] (DEVICE,
+ * either may be NULL).  Same bytes as hz_hip_resolve() of an untextured draw. */
+int  hz_hip_pack(hz_dev_t* d, uint32_t* d_packed);
+int  hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                           const uint32_t* d_packed, int stride, int ncols, int out_col0,
+                           unsigned char* d_bgr, float* d_ranges);
+
 /* uniforms of the texture half of the reference's vertex shader
  * (vertex.glsl:16-21; values as horizonator-lib.c:577-588,801-809 sets them)
  * and the size of the texture, NtilesX*256 x NtilesY*256 texels */

@@ -57,6 +57,17 @@ def _worker(rank, world, port, q):
         h1 = gather_strips_async(torch.from_numpy(mine["z24"].astype(np.int64)), W)
         h2 = gather_strips_async(torch.from_numpy(mine["ranges"]), W)
         z_async, rng_async = h1.result(), h2.result()
+        # strips as one packed word per pixel (z24<<8 | red8), read in place on rank 0: what bench.py gathers
+        packed = (mine["z24"].astype(np.int64) << 8) | mine["bgr"][..., 2].astype(np.int64)
+        parts = gather_strips_async(torch.from_numpy(packed), W).parts()
+        if rank == 0:
+            whole = np.zeros((H, W), np.int64)
+            for t, c0, n in parts:
+                whole[:, c0:c0 + n] = t[:, :n].numpy()
+            ref = oracle.render(g["mosaic"], v, W, H, nthreads=1)
+            assert np.array_equal(whole, (ref["z24"].astype(np.int64) << 8) | ref["bgr"][..., 2].astype(np.int64))
+        else:
+            assert parts is None
         if rank == 0:
             full = oracle.render(g["mosaic"], v, W, H, nthreads=1)
             assert np.array_equal(z_async.numpy(), full["z24"].astype(np.int64))
