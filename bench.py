@@ -87,7 +87,7 @@ def main():
         dist.barrier()
     import hzutil
     import horizonator_amd
-    from horizonator_amd.sharding import gather_strips_async, sector_columns
+    from horizonator_amd.sharding import gather_strips_async, gatherer_weights, sector_columns
 
     cfg = CONFIGS[args.config]
     R, W, H = cfg["R"], cfg["W"], cfg["H"]
@@ -105,9 +105,15 @@ def main():
     h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R)
     init_s = time.perf_counter() - t0
     h.set_raster(args.raster)
-    col0, col1 = sector_columns(W, world, rank)
-    h.set_sector(col0, col1)
+    # Rank 0 converts the whole gathered panorama on top of drawing its own sector, so it draws a
+    # narrower one (none at all with 8 GPUs): weights from the two costs measured on this workload
+    # with tools/sector_timing.py - a sector costs about 0.32 + 1.77*share ms, the conversion 0.27 ms.
+    weights = gatherer_weights(world, 1.77, 0.27) if world > 1 else None
+    col0, col1 = sector_columns(W, world, rank, weights)
     SW = col1 - col0
+    SW_max = max(c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world)))
+    if SW > 0:
+        h.set_sector(col0, col1)
     h.set_profiling(True)
 
     # N = 1: draw + readback conversion into BGR8 / float32 range, both left in HBM.
@@ -139,7 +145,8 @@ def main():
             if args.backend == "gloo":
                 parts = [(t.to(dev), c0, n) for t, c0, n in parts]
             for t, c0, n in parts:
-                h.resolve_packed(t.data_ptr(), t.shape[1], n, c0, d_img.data_ptr(), d_rng.data_ptr())
+                if n > 0:
+                    h.resolve_packed(t.data_ptr(), t.shape[1], n, c0, d_img.data_ptr(), d_rng.data_ptr())
             h.sync()                                     # ... before the strips are released
         pending[slot] = None
 
@@ -151,10 +158,12 @@ def main():
             h.sync()
             return
         finish(slot)
-        h.render_packed(d_pk[slot].data_ptr())
-        h.sync()
+        if SW > 0:
+            h.render_packed(d_pk[slot].data_ptr())
+            h.sync()
         # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
-        pending[slot] = gather_strips_async(d_pk[slot] if args.backend == "nccl" else d_pk[slot].cpu(), W)
+        pending[slot] = gather_strips_async(d_pk[slot] if args.backend == "nccl" else d_pk[slot].cpu(), W,
+                                            weights=weights)
 
     def drain():
         for slot in range(NBUF):
@@ -177,7 +186,8 @@ def main():
         one_rng = torch.empty_like(d_rng)
         h.render_device(one_img.data_ptr(), one_rng.data_ptr())
         h.sync()
-        h.set_sector(col0, col1)
+        if SW > 0:
+            h.set_sector(col0, col1)
         return bool(torch.equal(got_img, one_img) and torch.equal(got_rng, one_rng))
 
     def timed(zfar, steps, warmup):
@@ -190,7 +200,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-            kern.append(h.last_times())
+            if SW > 0:
+                kern.append(h.last_times())
         drain()                 # every one of the K panoramas is assembled on rank 0 ...
         fence()                 # ... before the clock stops
         dt = time.perf_counter() - t0
@@ -205,16 +216,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = W * H * args.steps / dt / 1e6
 
-    # dominant kernel, measured live with HIP events on the render stream
-    raster_ms = float(np.mean([k["raster_ms"] for k in kern]))
-    big_ms = float(np.mean([k["big_ms"] for k in kern]))
-    resolve_ms = float(np.mean([k["resolve_ms"] for k in kern]))
-    clear_ms = float(np.mean([k["clear_ms"] for k in kern]))
-    near_ms = float(np.mean([k["near_ms"] for k in kern]))
-    total_ms = float(np.mean([k["total_ms"] for k in kern]))
+    # dominant kernel, measured live with HIP events on the render stream; N > 1: of the slowest rank
+    names = ("raster_ms", "big_ms", "resolve_ms", "clear_ms", "near_ms", "total_ms")
+    mine = [float(np.mean([k[n] for k in kern])) if kern else 0.0 for n in names]
+    if world > 1:
+        tk = torch.tensor(mine, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        mine = [float(x) for x in tk.tolist()]
+    raster_ms, big_ms, resolve_ms, clear_ms, near_ms, total_ms = mine
     # algorithmic bytes of one render: int16 DEM read once +
     # BGR8 and float32 range written once; a sector accounts for its share
-    algo_bytes = 2 * N * N + 7 * SW * H
+    algo_bytes = 2 * N * N + 7 * (SW_max if world > 1 else SW) * H
     achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -259,6 +271,7 @@ def main():
             "config": {
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
+                "sector_widths": [c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world))],
                 "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of packed depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",

@@ -21,20 +21,51 @@ def _world_and_rank(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
-def sector_columns(width, world_size, rank):
-    """columns [col0, col1) of `rank`: equal azimuth spans, remainder spread
-    over the first ranks.  With a viewer-centred square mosaic and a 360-degree
-    view, 2/4/8 equal sectors starting at the image edge also hold equal DEM
-    area (whole octants), so the triangle load is balanced."""
+def sector_columns(width, world_size, rank, weights=None):
+    """columns [col0, col1) of `rank`.  Default: equal azimuth spans, remainder
+    spread over the first ranks.  With a viewer-centred square mosaic and a
+    360-degree view, 2/4/8 equal sectors starting at the image edge also hold
+    equal DEM area (whole octants), so the triangle load is balanced.
+
+    weights (one per rank, >= 0): spans proportional to the weights instead - for
+    a gathering rank that has the conversion of the whole panorama to do on top
+    of its own sector and should therefore draw less, or (weight 0) nothing."""
     if not (0 <= rank < world_size):
         raise ValueError("rank outside the world")
-    base, extra = divmod(width, world_size)
-    col0 = rank * base + min(rank, extra)
-    col1 = col0 + base + (1 if rank < extra else 0)
-    return col0, col1
+    if weights is None:
+        base, extra = divmod(width, world_size)
+        col0 = rank * base + min(rank, extra)
+        col1 = col0 + base + (1 if rank < extra else 0)
+        return col0, col1
+    if len(weights) != world_size or min(weights) < 0 or sum(weights) <= 0:
+        raise ValueError("need one non-negative weight per rank, not all zero")
+    total = float(sum(weights))
+    edges = [0]
+    acc = 0.0
+    for w in weights:
+        acc += w
+        edges.append(int(round(width * acc / total)))
+    edges[-1] = width
+    return edges[rank], edges[rank + 1]
 
 
-def gather_strips(strip, width, group=None, dst=0):
+def gatherer_weights(world_size, draw_ms_per_panorama, convert_ms_per_panorama):
+    """weights for sector_columns() when rank 0 also converts the gathered strips: with a
+    sector costing (about) fixed + draw_ms*share and the conversion convert_ms, rank 0 and
+    the others finish together if rank 0's weight is (b - c*(G-1))/(b + c) of theirs
+    (b = draw_ms, c = convert_ms), or 0 when the conversion alone takes longer than a sector"""
+    if world_size == 1:
+        return [1.0]
+    b, c = float(draw_ms_per_panorama), float(convert_ms_per_panorama)
+    rho = max(0.0, (b - c * (world_size - 1)) / (b + c))
+    return [rho] + [1.0] * (world_size - 1)
+
+
+def _widest(width, world, weights):
+    return max(c1 - c0 for c0, c1 in (sector_columns(width, world, r, weights) for r in range(world)))
+
+
+def gather_strips(strip, width, group=None, dst=0, weights=None):
     """strip: this rank's [H, SW, ...] tensor (device tensor for nccl/RCCL, CPU
     tensor for gloo).  Returns the assembled [H, width, ...] tensor on `dst`,
     None elsewhere.  Strips may differ in width by one column; they travel
@@ -42,7 +73,7 @@ def gather_strips(strip, width, group=None, dst=0):
     world, rank = _world_and_rank(group)
     if world == 1:
         return strip
-    widest = -(-width // world)
+    widest = _widest(width, world, weights)
     sw = strip.shape[1]
     if sw < widest:
         pad_shape = list(strip.shape)
@@ -55,7 +86,7 @@ def gather_strips(strip, width, group=None, dst=0):
         return None
     parts = []
     for r, b in enumerate(bins):
-        c0, c1 = sector_columns(width, world, r)
+        c0, c1 = sector_columns(width, world, r, weights)
         parts.append(b[:, :c1 - c0])
     return torch.cat(parts, dim=1)
 
@@ -63,8 +94,8 @@ def gather_strips(strip, width, group=None, dst=0):
 class PendingGather:
     """a gather of strips that is in flight (see gather_strips_async)"""
 
-    def __init__(self, work, bins, width, world, strip):
-        self._work, self._bins, self._width, self._world = work, bins, width, world
+    def __init__(self, work, bins, width, world, strip, weights=None):
+        self._work, self._bins, self._width, self._world, self._weights = work, bins, width, world, weights
         self._strip = strip                 # keeps the send buffer alive until the exchange is over
 
     def parts(self):
@@ -79,7 +110,7 @@ class PendingGather:
             return None
         out = []
         for r, b in enumerate(self._bins):
-            c0, c1 = sector_columns(self._width, self._world, r)
+            c0, c1 = sector_columns(self._width, self._world, r, self._weights)
             out.append((b, c0, c1 - c0))
         return out
 
@@ -93,12 +124,12 @@ class PendingGather:
             return None
         parts = []
         for r, b in enumerate(self._bins):
-            c0, c1 = sector_columns(self._width, self._world, r)
+            c0, c1 = sector_columns(self._width, self._world, r, self._weights)
             parts.append(b[:, :c1 - c0])
         return torch.cat(parts, dim=1)
 
 
-def gather_strips_async(strip, width, group=None, dst=0):
+def gather_strips_async(strip, width, group=None, dst=0, weights=None):
     """gather_strips() without waiting: the exchange of panorama k runs (on
     RCCL's stream) while the caller renders panorama k+1 into another buffer.
     Call .result() on the returned handle before the strip's buffer is reused."""
@@ -108,7 +139,7 @@ def gather_strips_async(strip, width, group=None, dst=0):
         done.result = lambda: strip
         done.parts = lambda: [(strip, 0, width)]
         return done
-    widest = -(-width // world)
+    widest = _widest(width, world, weights)
     sw = strip.shape[1]
     if sw < widest:
         pad_shape = list(strip.shape)
@@ -117,7 +148,7 @@ def gather_strips_async(strip, width, group=None, dst=0):
     strip = strip.contiguous()
     bins = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
     work = dist.gather(strip, bins, dst=dst, group=group, async_op=True)
-    return PendingGather(work, bins, width, world, strip)
+    return PendingGather(work, bins, width, world, strip, weights)
 
 
 # ---- a batch of viewpoints (BASELINE.json configs[3]) --------------------------

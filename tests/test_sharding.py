@@ -10,8 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import (gather_strips, gather_strips_async, gather_viewpoints, sector_columns,
-                                      viewpoint_slice)
+from horizonator_amd.sharding import (gather_strips, gather_strips_async, gather_viewpoints, gatherer_weights,
+                                      sector_columns, viewpoint_slice)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -26,6 +26,28 @@ def test_sectors_partition_the_columns(width, world):
     assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         sector_columns(width, world, world)
+
+
+def test_weighted_sectors_partition_the_columns():
+    """a gathering rank that also converts the panorama draws less - or nothing"""
+    for width, weights in [(16000, [0.5, 1, 1, 1]), (1003, [0, 1, 1]), (7, [1, 0, 3]), (100, [2.5])]:
+        world = len(weights)
+        cols = [sector_columns(width, world, r, weights) for r in range(world)]
+        assert cols[0][0] == 0 and cols[-1][1] == width
+        assert all(a[1] == b[0] for a, b in zip(cols, cols[1:]))
+        assert all(c1 >= c0 for c0, c1 in cols)
+        for (c0, c1), w in zip(cols, weights):
+            assert abs((c1 - c0) - width * w / sum(weights)) <= 1
+    assert sector_columns(1003, 3, 0, [0, 1, 1]) == (0, 0)
+    with pytest.raises(ValueError):
+        sector_columns(10, 2, 0, [0, 0])
+    with pytest.raises(ValueError):
+        sector_columns(10, 2, 0, [1, -1])
+    # rank 0's share shrinks with the number of ranks and reaches zero
+    shares = [gatherer_weights(g, 1.77, 0.27)[0] for g in (2, 4, 8)]
+    assert 1 > shares[0] > shares[1] > shares[2] == 0.0
+    assert gatherer_weights(1, 1.77, 0.27) == [1.0]
+    assert gatherer_weights(4, 1.0, 0.0) == [1.0] * 4
 
 
 def _free_port():
@@ -68,6 +90,15 @@ def _worker(rank, world, port, q):
             assert np.array_equal(whole, (ref["z24"].astype(np.int64) << 8) | ref["bgr"][..., 2].astype(np.int64))
         else:
             assert parts is None
+        # unequal sectors, rank 0 drawing nothing at all
+        wts = [0.0, 1.0]
+        d0, d1 = sector_columns(W, world, rank, wts)
+        part = oracle.render(g["mosaic"], v, W, H, d0, d1, nthreads=1, want=("z24",))["z24"].astype(np.int64) \
+            if d1 > d0 else np.zeros((H, 0), np.int64)
+        wparts = gather_strips_async(torch.from_numpy(part), W, weights=wts).parts()
+        if rank == 0:
+            assert [(c0, n) for _, c0, n in wparts] == [(0, 0), (0, W)]
+            assert np.array_equal(wparts[1][0][:, :W].numpy(), oracle.render(g["mosaic"], v, W, H, nthreads=1)["z24"].astype(np.int64))
         if rank == 0:
             full = oracle.render(g["mosaic"], v, W, H, nthreads=1)
             assert np.array_equal(z_async.numpy(), full["z24"].astype(np.int64))

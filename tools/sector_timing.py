@@ -26,4 +26,21 @@ for G in (1, 2, 4, 8):
             ts.append(h.last_times()["total_ms"])
         if G == 8: print("   sector", r, {k: round(v, 3) for k, v in h.last_times().items()})
         worst = max(worst, float(np.median(ts[1:])))
-    print(f"G={G}: slowest sector {worst:.3f} ms device time -> {W*H/worst/1e3:.0f} Mpix/s if perfectly overlapped")
+        if r == 0 and G > 1:
+            # what rank 0 does on top of its own sector in bench.py: draw + pack its strip, then convert
+            # all G packed strips into the full-width outputs
+            widest = -(-W // G)
+            pk = [torch.zeros((H, widest), dtype=torch.int32, device="cuda") for _ in range(G)]
+            full_img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+            full_rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
+            tt = []
+            for k in range(6):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                h.render_packed(pk[0].data_ptr())
+                for q in range(G):
+                    q0, q1 = sector_columns(W, G, q)
+                    h.resolve_packed(pk[q].data_ptr(), widest, q1 - q0, q0, full_img.data_ptr(), full_rng.data_ptr())
+                h.sync(); tt.append((time.perf_counter() - t0) * 1e3)
+            rank0 = float(np.median(tt[1:]))
+    extra = f"; rank 0 (own sector packed + conversion of all {G} strips): {rank0:.3f} ms wall" if G > 1 else ""
+    print(f"G={G}: slowest sector {worst:.3f} ms device time -> {W*H/worst/1e3:.0f} Mpix/s if perfectly overlapped{extra}")
