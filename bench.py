@@ -144,9 +144,7 @@ def main():
         if parts is not None:
             if args.backend == "gloo":
                 parts = [(t.to(dev), c0, n) for t, c0, n in parts]
-            for t, c0, n in parts:
-                if n > 0:
-                    h.resolve_packed(t.data_ptr(), t.shape[1], n, c0, d_img.data_ptr(), d_rng.data_ptr())
+            h.resolve_gathered(parts, d_img.data_ptr(), d_rng.data_ptr())
             h.sync()                                     # ... before the strips are released
         pending[slot] = None
 

@@ -235,6 +235,22 @@ class horizonator:
                                                         int(out_col0), d_image or None, d_ranges or None):
             raise RuntimeError("horizonator_amd_resolve_packed() failed")
 
+    def resolve_gathered(self, parts, d_image=0, d_ranges=0):
+        """parts as PendingGather.parts() returns them - [(tensor [H, stride], col0, ncols), ...] -
+        converted into the full-width DEVICE outputs in one call"""
+        n = len(parts)
+        if n == 0:
+            return
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t, _, _ in parts])
+        ncols = (C.c_int * n)(*[int(k) for _, _, k in parts])
+        col0 = (C.c_int * n)(*[int(c) for _, c, _ in parts])
+        stride = int(parts[0][0].shape[1])
+        if any(int(t.shape[1]) != stride for t, _, _ in parts):
+            raise ValueError("gathered strips share one row stride")
+        if not self._lib.horizonator_amd_resolve_packed_strips(C.byref(self._ctx), n, ptrs, stride, ncols, col0,
+                                                               d_image or None, d_ranges or None):
+            raise RuntimeError("horizonator_amd_resolve_packed_strips() failed")
+
     def texture_layout(self):
         """(lowest_x, lowest_y, ntiles_x, ntiles_y): the zoom-12 slippy-map tiles the texture
         of this context is made of (reference horizonator-lib.c:372-389); the texture is

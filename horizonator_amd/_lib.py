@@ -125,6 +125,7 @@ def load():
     sig("horizonator_amd_render_batch", b, ctxp, i, vp, vp, vp, vp, vp)
     sig("horizonator_amd_render_packed", b, ctxp, vp)
     sig("horizonator_amd_resolve_packed", b, ctxp, vp, i, i, i, vp, vp)
+    sig("horizonator_amd_resolve_packed_strips", b, ctxp, i, vp, i, vp, vp, vp, vp)
     sig("horizonator_amd_sync", b, ctxp)
     sig("horizonator_amd_texture_layout", b, ctxp, P(i), P(i), P(i), P(i))
     sig("horizonator_amd_set_texture", b, ctxp, vp)
@@ -178,6 +179,7 @@ DECLARED_SYMBOLS = [
     # include/horizonator_amd.h
     "horizonator_amd_render", "horizonator_amd_render_device", "horizonator_amd_render_batch",
     "horizonator_amd_render_packed", "horizonator_amd_resolve_packed",
+    "horizonator_amd_resolve_packed_strips",
     "horizonator_amd_sync", "horizonator_amd_texture_layout", "horizonator_amd_set_texture",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",

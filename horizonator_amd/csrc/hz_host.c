@@ -735,6 +735,27 @@ bool horizonator_amd_resolve_packed(const horizonator_context_t* ctx,
     return true;
 }
 
+bool horizonator_amd_resolve_packed_strips(const horizonator_context_t* ctx, int nstrips,
+                                           const uint32_t* const* d_packed, int packed_stride,
+                                           const int* ncols, const int* out_col0,
+                                           void* d_image, float* d_ranges)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || nstrips < 0 || d_packed == NULL || ncols == NULL || out_col0 == NULL) return false;
+    if(d_ranges != NULL) fill_tanel(s);
+    for(int k=0; k<nstrips; k++)
+    {
+        if(ncols[k] == 0) continue;             /* a rank that drew nothing */
+        if(0 != hz_hip_resolve_packed(s->dev, &s->view, s->tanel, d_packed[k], packed_stride, ncols[k], out_col0[k],
+                                      d_image, d_ranges))
+        {
+            MSG("resolve of packed strip %d failed: %s", k, hz_hip_last_error());
+            return false;
+        }
+    }
+    return true;
+}
+
 bool horizonator_amd_sync(const horizonator_context_t* ctx)
 {
     hz_state_t* s = live_state(ctx);

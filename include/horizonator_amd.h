@@ -78,6 +78,13 @@ bool horizonator_amd_resolve_packed(const horizonator_context_t* ctx,
                                     const uint32_t* d_packed, int packed_stride, int ncols, int out_col0,
                                     void* d_image, float* d_ranges);
 
+/* ... the same for all gathered strips in one call (strip k: d_packed[k], ncols[k] columns
+ * that go to out_col0[k]; ncols[k] = 0 is skipped) */
+bool horizonator_amd_resolve_packed_strips(const horizonator_context_t* ctx, int nstrips,
+                                           const uint32_t* const* d_packed, int packed_stride,
+                                           const int* ncols, const int* out_col0,
+                                           void* d_image, float* d_ranges);
+
 /* Restrict this context to image columns [col0,col1) of the panorama: the
  * azimuth-sector shard one GPU renders.  Outputs then have width col1-col0. */
 bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1);

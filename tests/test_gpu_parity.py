@@ -174,6 +174,11 @@ def test_packed_strips_resolve_to_the_same_panorama():
         h.sync()
         assert np.array_equal(d_img.cpu().numpy(), image)
         assert np.array_equal(d_rng.cpu().numpy(), ranges)
+        # ... and all strips in one call, as bench.py does with what the gather delivers
+        d_img.fill_(0); d_rng.fill_(0)
+        h.resolve_gathered(strips + [(strips[0][0], 0, 0)], d_img.data_ptr(), d_rng.data_ptr())
+        h.sync()
+        assert np.array_equal(d_img.cpu().numpy(), image) and np.array_equal(d_rng.cpu().numpy(), ranges)
         with pytest.raises(RuntimeError):
             h.resolve_packed(strips[0][0].data_ptr(), widest, widest, W - 5, d_img.data_ptr(), 0)
     finally:
