@@ -175,7 +175,8 @@ __device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int
 /* clip one triangle of the grid (by id) and hand its pieces on: to the k_big
  * queue, or - `inline_ok` and no room - straight into the framebuffer */
 __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long long* fb, const mr_queue_t& q,
-                                        const hz_params_t& p, uint32_t prim, bool inline_ok)
+                                        const hz_params_t& p, uint32_t prim, bool inline_ok,
+                                        hz_cvert_t* bufa, hz_cvert_t* bufb)
 {
     const uint32_t cell = prim >> 1;
     const int t = prim & 1;
@@ -188,7 +189,7 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
     const hz_cvert_t b = hz_cvert(hz_transform(&p.u, (float)ib, (float)jb, (float)mosaic[(size_t)jb*p.N + ib]), p.halfW, p.halfH);
     const hz_cvert_t c = hz_cvert(hz_transform(&p.u, (float)ic, (float)jc, (float)mosaic[(size_t)jc*p.N + ic]), p.halfW, p.halfH);
 
-    hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1], *poly;
+    hz_cvert_t* poly;
     const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
     /* fan that keeps vertex 0 last (GL provoking-vertex convention).  First
      * pass: which pieces draw anything, and how much queue they need - so that
@@ -246,14 +247,18 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
     }
 }
 
-/* one thread per queued triangle id */
+/* one thread per queued triangle id.  The clipper's two polygon buffers are
+ * indexed dynamically, which would put them into scratch memory: a handful of
+ * threads, each a chain of dependent scratch round trips, was 40 us of every
+ * draw.  They live in LDS instead (one 64-thread block per CU is plenty here). */
 __global__ __launch_bounds__(64)
 void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
 {
+    __shared__ hz_cvert_t polygon[64][2][HZ_MAX_CLIPPED+1];
     const unsigned int n = q.counters[4];
     if(n > q.clip_capacity) return;                 /* overflow: k_clip_rescan does it all */
     for(unsigned int k = blockIdx.x*blockDim.x + threadIdx.x; k < n; k += gridDim.x*blockDim.x)
-        hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true);
+        hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
 }
 
 /* Only when the id queue overflowed (never with the default capacity): find
@@ -270,10 +275,11 @@ void k_clip_rescan(const int16_t* __restrict__ mosaic, unsigned long long* __res
         const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i, j),   v10 = hz_vertex_at(p, mosaic, i+1, j);
         const hz_wvert_t v01 = hz_vertex_at(p, mosaic, i, j+1), v11 = hz_vertex_at(p, mosaic, i+1, j+1);
         hz_box_t box;
+        hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1];
         if(hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true);
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, bufa, bufb);
         if(hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true);
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, bufa, bufb);
     }
 }
 
