@@ -4,9 +4,10 @@
  * What runs here is what the reference hands to OpenGL:
  *   vertex.glsl:111-162     per-vertex transform            -> hz_transform()
  *   horizonator-lib.c:487-512 index buffer (2 tris per cell) -> implicit from (i,j,t)
- *   geometry.glsl:21-27     wide/seam triangle discard      -> hz_tri_setup()
- *   fixed function          cull, raster, depth test        -> hz_raster.h
+ *   geometry.glsl:21-27     wide/seam triangle discard      -> hz_tri_cull()
+ *   fixed function          clip, cull, raster, depth test  -> hz_raster.h
  *   fragment.glsl:15-16     colour = (red,0,0)              -> packed red8
+ *   fragment.glsl:17-22     0.7*texture + 0.3*shade         -> k_shade_tex (hz_tex.h)
  *   horizonator-lib.c:936-1048 readback, flip, depth->range -> k_resolve
  *
  * HBM layout
