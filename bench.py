@@ -49,6 +49,9 @@ def parse():
                     help="diagnostics: gloo moves the strips through host memory (lets two ranks share one GPU "
                          "to exercise the N>1 loop where only one GPU exists); the driver's runs use nccl = RCCL")
     ap.add_argument("--same-gpu", action="store_true", help="diagnostics: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--wire", default="sparse", choices=["sparse", "packed"],
+                    help="N > 1: what a rank sends to rank 0 - sparse: terrain pixels only + mask (default); "
+                         "packed: every pixel, 4 bytes")
     return ap.parse_args()
 
 
@@ -87,7 +90,8 @@ def main():
         dist.barrier()
     import hzutil
     import horizonator_amd
-    from horizonator_amd.sharding import gather_strips_async, gatherer_weights, sector_columns
+    from horizonator_amd.sharding import (gather_flat_async, gather_strips_async, gatherer_weights, sector_columns,
+                                          sparse_header_words, sparse_mask_stride)
 
     cfg = CONFIGS[args.config]
     R, W, H = cfg["R"], cfg["W"], cfg["H"]
@@ -107,8 +111,9 @@ def main():
     h.set_raster(args.raster)
     # Rank 0 converts the whole gathered panorama on top of drawing its own sector, so it draws a
     # narrower one (none at all with 8 GPUs): weights from the two costs measured on this workload
-    # with tools/sector_timing.py - a sector costs about 0.32 + 1.77*share ms, the conversion 0.27 ms.
-    weights = gatherer_weights(world, 1.77, 0.27) if world > 1 else None
+    # with tools/sector_timing.py - a sector costs about 0.32 + 1.77*share ms, writing the own strip
+    # sparse and converting all strips 0.31 ms.
+    weights = gatherer_weights(world, 1.77, 0.31) if world > 1 else None
     col0, col1 = sector_columns(W, world, rank, weights)
     SW = col1 - col0
     SW_max = max(c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world)))
@@ -123,21 +128,41 @@ def main():
     # Two sets of strip buffers: while RCCL moves the strips of panorama k, panorama k+1
     # is already being drawn into the other set.
     NBUF = 2 if world > 1 else 1
+    sparse = args.wire == "sparse"
+    MSTRIDE = sparse_mask_stride(SW_max)
+    HDR = sparse_header_words(H, MSTRIDE)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
     if world == 1:
         d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     else:
-        d_pk = [torch.empty((H, SW), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+        if sparse:
+            # a sparse strip: header + one word per TERRAIN pixel; room for the worst case (no sky at all)
+            d_pk = [torch.zeros(HDR + H * SW_max, dtype=torch.int32, device=dev) for _ in range(NBUF)]
+        else:
+            d_pk = [torch.empty((H, SW), dtype=torch.int32, device=dev) for _ in range(NBUF)]
         if rank == 0:
             d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
             d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     pending = [None] * NBUF
-    state = {"k": 0}
+    state = {"k": 0, "wire_words": 0}
+    layout = [sector_columns(W, world, r, weights) for r in range(world)]
 
     def finish(slot):
         """complete the exchange that still reads buffer set `slot`; rank 0: turn the strips
         into the panorama"""
         if pending[slot] is None:
+            return
+        if sparse:
+            bufs = pending[slot].tensors()
+            torch.cuda.current_stream().synchronize()   # the strips have arrived (RCCL's stream -> host)
+            if bufs is not None:
+                if args.backend == "gloo":
+                    bufs = [t.to(dev) for t in bufs]
+                h.resolve_sparse_gathered([(t.data_ptr(), c0, c1 - c0) for t, (c0, c1) in zip(bufs, layout)],
+                                          MSTRIDE, d_img.data_ptr(), d_rng.data_ptr())
+                h.sync()                                 # ... before the strips are released
+            pending[slot] = None
             return
         parts = pending[slot].parts()
         torch.cuda.current_stream().synchronize()       # the strips have arrived (RCCL's stream -> host)
@@ -156,6 +181,20 @@ def main():
             h.sync()
             return
         finish(slot)
+        if sparse:
+            words = HDR
+            if SW > 0:
+                h.render_sparse(d_pk[slot].data_ptr(), MSTRIDE)
+                h.sync()
+                words = HDR + int(d_pk[slot][0].item())         # header + terrain pixels of this strip
+            # all strips of a gather have one length: that of the longest
+            n = torch.tensor([words], dtype=torch.int64, device=cdev)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            words = int(n.item())
+            state["wire_words"] = words
+            send = d_pk[slot][:words]
+            pending[slot] = gather_flat_async(send if args.backend == "nccl" else send.cpu())
+            return
         if SW > 0:
             h.render_packed(d_pk[slot].data_ptr())
             h.sync()
@@ -270,7 +309,8 @@ def main():
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
                 "sector_widths": [c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world))],
-                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of packed depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
+                "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * SW_max) if world > 1 else 0,
+                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",
                 "init_s": init_s,

@@ -251,6 +251,26 @@ class horizonator:
                                                                d_image or None, d_ranges or None):
             raise RuntimeError("horizonator_amd_resolve_packed_strips() failed")
 
+    def render_sparse(self, d_out, mask_stride):
+        """Draw and write this context's sector as a sparse strip (include/hz_hip.h: terrain
+        pixels only, plus a mask) into the DEVICE buffer d_out (raw pointer, room for
+        sharding.sparse_header_words(H, mask_stride) + H*sector_width uint32).  Asynchronous."""
+        if not self._lib.horizonator_amd_render_sparse(C.byref(self._ctx), d_out, int(mask_stride)):
+            raise RuntimeError("horizonator_amd_render_sparse() failed")
+
+    def resolve_sparse_gathered(self, strips, mask_stride, d_image=0, d_ranges=0):
+        """strips = [(device pointer of a sparse strip, col0, ncols), ...] converted into the
+        full-width DEVICE outputs in one call"""
+        n = len(strips)
+        if n == 0:
+            return
+        ptrs = (C.c_void_p * n)(*[int(p) for p, _, _ in strips])
+        ncols = (C.c_int * n)(*[int(k) for _, _, k in strips])
+        col0 = (C.c_int * n)(*[int(c) for _, c, _ in strips])
+        if not self._lib.horizonator_amd_resolve_sparse_strips(C.byref(self._ctx), n, ptrs, int(mask_stride), ncols, col0,
+                                                               d_image or None, d_ranges or None):
+            raise RuntimeError("horizonator_amd_resolve_sparse_strips() failed")
+
     def texture_layout(self):
         """(lowest_x, lowest_y, ntiles_x, ntiles_y): the zoom-12 slippy-map tiles the texture
         of this context is made of (reference horizonator-lib.c:372-389); the texture is

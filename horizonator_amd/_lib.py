@@ -126,6 +126,8 @@ def load():
     sig("horizonator_amd_render_packed", b, ctxp, vp)
     sig("horizonator_amd_resolve_packed", b, ctxp, vp, i, i, i, vp, vp)
     sig("horizonator_amd_resolve_packed_strips", b, ctxp, i, vp, i, vp, vp, vp, vp)
+    sig("horizonator_amd_render_sparse", b, ctxp, vp, i)
+    sig("horizonator_amd_resolve_sparse_strips", b, ctxp, i, vp, i, vp, vp, vp, vp)
     sig("horizonator_amd_sync", b, ctxp)
     sig("horizonator_amd_texture_layout", b, ctxp, P(i), P(i), P(i), P(i))
     sig("horizonator_amd_set_texture", b, ctxp, vp)
@@ -152,6 +154,8 @@ def load():
     sig("hz_hip_set_texture", i, vp, P(TexParams), vp)
     sig("hz_hip_pack", i, vp, vp)
     sig("hz_hip_resolve_packed", i, vp, P(View), vp, vp, i, i, i, vp, vp)
+    sig("hz_hip_pack_sparse", i, vp, vp, i)
+    sig("hz_hip_resolve_sparse", i, vp, P(View), vp, vp, i, i, i, vp, vp)
     sig("hz_hip_draw", i, vp, P(View))
     sig("hz_hip_resolve", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_resolve_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
@@ -179,7 +183,8 @@ DECLARED_SYMBOLS = [
     # include/horizonator_amd.h
     "horizonator_amd_render", "horizonator_amd_render_device", "horizonator_amd_render_batch",
     "horizonator_amd_render_packed", "horizonator_amd_resolve_packed",
-    "horizonator_amd_resolve_packed_strips",
+    "horizonator_amd_resolve_packed_strips", "horizonator_amd_render_sparse",
+    "horizonator_amd_resolve_sparse_strips",
     "horizonator_amd_sync", "horizonator_amd_texture_layout", "horizonator_amd_set_texture",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
@@ -188,7 +193,7 @@ DECLARED_SYMBOLS = [
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
-    "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
+    "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
     "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_last_error",
 ]
 

@@ -735,6 +735,40 @@ bool horizonator_amd_resolve_packed(const horizonator_context_t* ctx,
     return true;
 }
 
+bool horizonator_amd_render_sparse(const horizonator_context_t* ctx, uint32_t* d_out, int mask_stride)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || d_out == NULL || !ctx->offscreen.inited) return false;
+    if(!horizonator_redraw(ctx)) return false;
+    if(0 != hz_hip_pack_sparse(s->dev, d_out, mask_stride))
+    {
+        MSG("sparse pack failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool horizonator_amd_resolve_sparse_strips(const horizonator_context_t* ctx, int nstrips,
+                                           const uint32_t* const* d_in, int mask_stride,
+                                           const int* ncols, const int* out_col0,
+                                           void* d_image, float* d_ranges)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || nstrips < 0 || d_in == NULL || ncols == NULL || out_col0 == NULL) return false;
+    if(d_ranges != NULL) fill_tanel(s);
+    for(int k=0; k<nstrips; k++)
+    {
+        if(ncols[k] == 0) continue;
+        if(0 != hz_hip_resolve_sparse(s->dev, &s->view, s->tanel, d_in[k], mask_stride, ncols[k], out_col0[k],
+                                      d_image, d_ranges))
+        {
+            MSG("resolve of sparse strip %d failed: %s", k, hz_hip_last_error());
+            return false;
+        }
+    }
+    return true;
+}
+
 bool horizonator_amd_resolve_packed_strips(const horizonator_context_t* ctx, int nstrips,
                                            const uint32_t* const* d_packed, int packed_stride,
                                            const int* ncols, const int* out_col0,

@@ -1216,6 +1216,128 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
     }
 }
 
+/* Sparse strips: most of a panorama is sky (62 % of the benchmark image), and a
+ * sky pixel carries no information.  A strip as a stream of uint32:
+ *   [0]                    number of terrain pixels T
+ *   [1 .. 1+H)             row_base[yo]: where row yo's words start in the data
+ *   [1+H .. HDR)           terrain mask, mask_stride words per row, bit c%32 of word c/32
+ *   [HDR .. HDR+T)         z24<<8 | red8 of the terrain pixels, row by row, left to right
+ * with HDR = 1 + H + H*mask_stride, rows top first.  Rows may be laid out in
+ * any order in the data (row_base says where): one block per row, one atomic
+ * per row for its base.  The buffer must hold HDR + H*SW words; [0] must be 0
+ * on entry. */
+__global__ __launch_bounds__(256)
+void k_pack_sparse(const unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
+                   int SW, int H, int mask_stride)
+{
+    __shared__ uint32_t wave_count[4];
+    __shared__ uint32_t row_base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
+    for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
+    {
+        const unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
+        uint32_t* mask = out + 1 + H + (size_t)yo*mask_stride;
+        /* pass 1: mask and count */
+        uint32_t mine = 0;
+        for(int c0 = 0; c0 < SW; c0 += 256)
+        {
+            const int c = c0 + threadIdx.x;
+            const bool terrain = c < SW && (uint32_t)(row[c] >> 40) != HZ_Z24_MAX;
+            const unsigned long long b = __ballot(terrain);
+            if(lane == 0  && c0 + wave*64      < SW) mask[(c0 >> 5) + wave*2]     = (uint32_t)b;
+            if(lane == 32 && c0 + wave*64 + 32 < SW) mask[(c0 >> 5) + wave*2 + 1] = (uint32_t)(b >> 32);
+            mine += (uint32_t)__popcll(b);                  /* the same in every lane of the wave */
+        }
+        if(lane == 0) wave_count[wave] = mine;
+        __syncthreads();
+        if(threadIdx.x == 0)
+        {
+            const uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            const uint32_t base = atomicAdd(&out[0], total);
+            out[1 + yo] = base;
+            row_base_s = base;
+        }
+        __syncthreads();
+        /* pass 2: the words (the row is in L2 now) */
+        uint32_t run = row_base_s;
+        for(int c0 = 0; c0 < SW; c0 += 256)
+        {
+            const int c = c0 + threadIdx.x;
+            unsigned long long key = 0;
+            bool terrain = false;
+            if(c < SW) { key = row[c]; terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX; }
+            const unsigned long long b = __ballot(terrain);
+            __syncthreads();
+            if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t before = 0;
+            for(int w=0; w<wave; w++) before += wave_count[w];
+            if(terrain)
+                out[HDR + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] =
+                    ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
+            run += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        }
+        __syncthreads();
+    }
+}
+
+/* the readback conversion on a sparse strip: columns [0,ncols) of the strip go
+ * to columns out_col0.. of the full-width outputs */
+__global__ __launch_bounds__(256)
+void k_resolve_sparse(const uint32_t* __restrict__ in, int mask_stride, int ncols,
+                      const float* __restrict__ tanel,
+                      unsigned char* __restrict__ bgr, float* __restrict__ ranges,
+                      int out_W, int out_col0, int H, float znear, float zfar)
+{
+    __shared__ uint32_t wave_count[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
+    for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
+    {
+        const uint32_t* mask = in + 1 + H + (size_t)yo*mask_stride;
+        uint32_t run = in[1 + yo];
+        const float tan_row = tanel[H-1 - yo];
+        for(int c0 = 0; c0 < ncols; c0 += 256)
+        {
+            const int c = c0 + threadIdx.x;
+            const bool terrain = c < ncols && ((mask[c >> 5] >> (c & 31)) & 1u);
+            const unsigned long long b = __ballot(terrain);
+            __syncthreads();
+            if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t before = 0;
+            for(int w=0; w<wave; w++) before += wave_count[w];
+            if(c < ncols)
+            {
+                const size_t o = (size_t)yo*out_W + out_col0 + c;
+                uint32_t w = 0;
+                if(terrain) w = in[HDR + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))];
+                if(bgr)
+                {
+                    bgr[o*3+0] = terrain ? 0 : 255;
+                    bgr[o*3+1] = 0;
+                    bgr[o*3+2] = terrain ? (unsigned char)(w & 0xFF) : 0;
+                }
+                if(ranges)
+                {
+                    float r = -1.0f;
+                    if(terrain)
+                    {
+                        const float depth = (float)((double)(w >> 8) * (1.0/16777215.0));
+                        const float len   = depth * (zfar-znear) + znear;
+                        const float zt    = tan_row * len;
+                        r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
+                    }
+                    ranges[o] = r;
+                }
+            }
+            run += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        }
+        __syncthreads();
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* textured resolve ("next" row N4): deferred shading                         */
 /*
@@ -2028,6 +2150,49 @@ extern "C" int hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const f
     if(nblocks > 256*32) nblocks = 256*32;
     hipLaunchKernelGGL(k_resolve_packed, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
                        d_packed, stride, ncols, (const float*)d->d_tanel, d_bgr, d_ranges,
+                       d->W, out_col0, d->H, view->znear, view->zfar);
+    HZ_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* the draw's result as a sparse strip (see k_pack_sparse): d_out must hold
+ * 1 + H + H*mask_stride + H*(sector width) words; the first word ends up as the
+ * number of terrain pixels T, and only the first 1 + H + H*mask_stride + T words
+ * carry information.  mask_stride >= ceil(sector width / 32). */
+extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    const int SW = d->col1 - d->col0;
+    if(d->tex_on || mask_stride < (SW + 31)/32)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), d->tex_on ? "hz_hip_pack_sparse: strips carry the shade only, not a textured colour"
+                                                               : "hz_hip_pack_sparse: mask stride too small");
+        return -1;
+    }
+    const bool prof = d->profiling != 0;
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->stream));
+    HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->stream));
+    hipLaunchKernelGGL(k_pack_sparse, dim3((unsigned)d->H), dim3(256), 0, d->stream,
+                       (const unsigned long long*)d->d_fb, d_out, SW, d->H, mask_stride);
+    HZ_CHECK(hipGetLastError());
+    if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->stream)); d->have_times = 2; }
+    return 0;
+}
+
+extern "C" int hz_hip_resolve_sparse(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                                     const uint32_t* d_in, int mask_stride, int ncols, int out_col0,
+                                     unsigned char* d_bgr, float* d_ranges)
+{
+    HZ_CHECK(hipSetDevice(d->device));
+    if(ncols <= 0 || mask_stride < (ncols + 31)/32 || out_col0 < 0 || out_col0 + ncols > d->W)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_sparse: columns [%d,%d) do not fit a %d-wide image",
+                 out_col0, out_col0 + ncols, d->W);
+        return -1;
+    }
+    if(d_ranges && upload_tanel(d, tanel) != 0) return -1;
+    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)d->H), dim3(256), 0, d->stream,
+                       d_in, mask_stride, ncols, (const float*)d->d_tanel, d_bgr, d_ranges,
                        d->W, out_col0, d->H, view->znear, view->zfar);
     HZ_CHECK(hipGetLastError());
     return 0;

@@ -151,6 +151,44 @@ def gather_strips_async(strip, width, group=None, dst=0, weights=None):
     return PendingGather(work, bins, width, world, strip, weights)
 
 
+# ---- sparse strips: terrain pixels only (include/hz_hip.h, hz_hip_pack_sparse) ---
+
+def sparse_mask_stride(widest_sector):
+    """mask words per row, common to all strips of a gather"""
+    return -(-int(widest_sector) // 32)
+
+
+def sparse_header_words(height, mask_stride):
+    """words before the pixel data of a sparse strip: count, row bases, mask"""
+    return 1 + int(height) + int(height) * int(mask_stride)
+
+
+class PendingFlat:
+    """an exchange of equally long 1-D buffers that is in flight (gather_flat_async)"""
+
+    def __init__(self, work, bins, flat):
+        self._work, self._bins, self._flat = work, bins, flat
+
+    def tensors(self):
+        """wait; on the destination rank the buffers of all ranks in rank order, None elsewhere"""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._bins
+
+
+def gather_flat_async(flat, group=None, dst=0):
+    """gather 1-D buffers of one common length to `dst` without waiting (the sparse strips of a
+    panorama, cut to the longest of them: the caller agrees on the length with an all_reduce)"""
+    world, rank = _world_and_rank(group)
+    flat = flat.contiguous()
+    if world == 1:
+        return PendingFlat(None, [flat], flat)
+    bins = [torch.empty_like(flat) for _ in range(world)] if rank == dst else None
+    work = dist.gather(flat, bins, dst=dst, group=group, async_op=True)
+    return PendingFlat(work, bins, flat)
+
+
 # ---- a batch of viewpoints (BASELINE.json configs[3]) --------------------------
 
 def viewpoint_slice(n, world_size, rank):

@@ -85,6 +85,17 @@ bool horizonator_amd_resolve_packed_strips(const horizonator_context_t* ctx, int
                                            const int* ncols, const int* out_col0,
                                            void* d_image, float* d_ranges);
 
+/* ... and without the sky, which is most of a panorama and carries no information: the
+ * sparse strip format of hz_hip.h (hz_hip_pack_sparse).  d_out: DEVICE, room for
+ * 1 + H + H*mask_stride + H*(sector width) words; word 0 becomes the number T of terrain
+ * pixels and only the first 1 + H + H*mask_stride + T words need to travel.  All strips of
+ * one gather share mask_stride (>= ceil(widest sector / 32)). */
+bool horizonator_amd_render_sparse(const horizonator_context_t* ctx, uint32_t* d_out, int mask_stride);
+bool horizonator_amd_resolve_sparse_strips(const horizonator_context_t* ctx, int nstrips,
+                                           const uint32_t* const* d_in, int mask_stride,
+                                           const int* ncols, const int* out_col0,
+                                           void* d_image, float* d_ranges);
+
 /* Restrict this context to image columns [col0,col1) of the panorama: the
  * azimuth-sector shard one GPU renders.  Outputs then have width col1-col0. */
 bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1);

@@ -163,6 +163,20 @@ int  hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const float* tane
                            const uint32_t* d_packed, int stride, int ncols, int out_col0,
                            unsigned char* d_bgr, float* d_ranges);
 
+/* ... and without the sky.  A sparse strip is a stream of uint32:
+ *   [0] T = number of terrain pixels; [1..1+H) row_base[row]; then the terrain
+ *   mask, mask_stride words per row (bit c%32 of word c/32, rows top first); then,
+ *   from HDR = 1 + H + H*mask_stride on, the T words z24<<8 | red8, row `row`
+ *   starting at HDR + row_base[row], left to right.
+ * hz_hip_pack_sparse() writes the last draw in that form (d_out: DEVICE, room for
+ * HDR + H*(sector width) words; only the first HDR + T carry information - read
+ * T back, send that much).  hz_hip_resolve_sparse() converts such a strip like
+ * hz_hip_resolve_packed() does a packed one. */
+int  hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride);
+int  hz_hip_resolve_sparse(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                           const uint32_t* d_in, int mask_stride, int ncols, int out_col0,
+                           unsigned char* d_bgr, float* d_ranges);
+
 /* uniforms of the texture half of the reference's vertex shader
  * (vertex.glsl:16-21; values as horizonator-lib.c:577-588,801-809 sets them)
  * and the size of the texture, NtilesX*256 x NtilesY*256 texels */

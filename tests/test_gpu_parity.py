@@ -183,3 +183,47 @@ def test_packed_strips_resolve_to_the_same_panorama():
             h.resolve_packed(strips[0][0].data_ptr(), widest, widest, W - 5, d_img.data_ptr(), 0)
     finally:
         h.close()
+
+
+def test_sparse_strips_resolve_to_the_same_panorama():
+    """the default multi-GPU wire format on one GPU: every sector written as a sparse strip
+    (terrain pixels only + mask + row bases), cut to header + terrain words as it would travel,
+    then converted into the full-width outputs - the same bytes as the one-GPU render"""
+    import torch
+    import horizonator_amd
+    from horizonator_amd.sharding import sector_columns, sparse_header_words, sparse_mask_stride
+    R, W, H = 300, 1001, 250
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+    try:
+        image, ranges = h.render(-180, 180, zfar=30000.0)
+        weights = [0.4, 1.0, 0.0, 1.3]
+        world = len(weights)
+        layout = [sector_columns(W, world, r, weights) for r in range(world)]
+        widest = max(c1 - c0 for c0, c1 in layout)
+        ms = sparse_mask_stride(widest)
+        hdr = sparse_header_words(H, ms)
+        strips, terrain = [], 0
+        for c0, c1 in layout:
+            buf = torch.full((hdr + H * widest,), -1, dtype=torch.int32, device="cuda:0")     # garbage beyond what is written
+            if c1 > c0:
+                h.set_sector(c0, c1)
+                h.render_sparse(buf.data_ptr(), ms)
+                h.sync()
+                t = int(buf[0].item())
+            else:
+                buf.zero_()
+                t = 0
+            terrain += t
+            sent = buf[:hdr + t].clone()                     # what travels
+            strips.append((sent, c0, c1 - c0))
+        assert terrain == int((ranges > 0).sum())            # one word per terrain pixel, none for the sky
+        h.set_sector(0, W)
+        d_img = torch.full((H, W, 3), 77, dtype=torch.uint8, device="cuda:0")
+        d_rng = torch.full((H, W), -7.0, dtype=torch.float32, device="cuda:0")
+        h.resolve_sparse_gathered([(t.data_ptr(), c0, n) for t, c0, n in strips], ms, d_img.data_ptr(), d_rng.data_ptr())
+        h.sync()
+        assert np.array_equal(d_img.cpu().numpy(), image)
+        assert np.array_equal(d_rng.cpu().numpy(), ranges)
+    finally:
+        h.close()

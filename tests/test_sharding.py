@@ -10,8 +10,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import (gather_strips, gather_strips_async, gather_viewpoints, gatherer_weights,
-                                      sector_columns, viewpoint_slice)
+from horizonator_amd.sharding import (gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
+                                      gatherer_weights, sector_columns, sparse_header_words, sparse_mask_stride,
+                                      viewpoint_slice)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -90,6 +91,17 @@ def _worker(rank, world, port, q):
             assert np.array_equal(whole, (ref["z24"].astype(np.int64) << 8) | ref["bgr"][..., 2].astype(np.int64))
         else:
             assert parts is None
+        # 1-D buffers of one agreed length (the sparse strips of bench.py)
+        mine_len = torch.tensor([100 + 50 * rank], dtype=torch.int64)
+        dist.all_reduce(mine_len, op=dist.ReduceOp.MAX)
+        flat = torch.arange(int(mine_len), dtype=torch.int32) + 1000 * rank
+        got = gather_flat_async(flat).tensors()
+        if rank == 0:
+            assert len(got) == world and all(np.array_equal(t.numpy(), np.arange(150, dtype=np.int32) + 1000 * r)
+                                             for r, t in enumerate(got))
+        else:
+            assert got is None
+        assert sparse_mask_stride(33) == 2 and sparse_header_words(10, 2) == 31
         # unequal sectors, rank 0 drawing nothing at all
         wts = [0.0, 1.0]
         d0, d1 = sector_columns(W, world, rank, wts)

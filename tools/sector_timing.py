@@ -42,5 +42,21 @@ for G in (1, 2, 4, 8):
                     h.resolve_packed(pk[q].data_ptr(), widest, q1 - q0, q0, full_img.data_ptr(), full_rng.data_ptr())
                 h.sync(); tt.append((time.perf_counter() - t0) * 1e3)
             rank0 = float(np.median(tt[1:]))
-    extra = f"; rank 0 (own sector packed + conversion of all {G} strips): {rank0:.3f} ms wall" if G > 1 else ""
+            # the same with sparse strips (terrain pixels only), bench.py's default
+            from horizonator_amd.sharding import sparse_header_words, sparse_mask_stride
+            ms = sparse_mask_stride(widest); hdr = sparse_header_words(H, ms)
+            sp = [torch.zeros(hdr + H*widest, dtype=torch.int32, device="cuda") for _ in range(G)]
+            for q in range(G):
+                q0, q1 = sector_columns(W, G, q)
+                h.set_sector(q0, q1); h.render_sparse(sp[q].data_ptr(), ms); h.sync()
+            h.set_sector(c0, c1)
+            tt = []
+            for k in range(6):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                h.render_sparse(sp[0].data_ptr(), ms)
+                h.resolve_sparse_gathered([(sp[q].data_ptr(), sector_columns(W, G, q)[0], sector_columns(W, G, q)[1] - sector_columns(W, G, q)[0]) for q in range(G)],
+                                          ms, full_img.data_ptr(), full_rng.data_ptr())
+                h.sync(); tt.append((time.perf_counter() - t0) * 1e3)
+            rank0s = float(np.median(tt[1:]))
+    extra = f"; rank 0 (own sector + conversion of all {G} strips): packed {rank0:.3f} ms, sparse {rank0s:.3f} ms wall" if G > 1 else ""
     print(f"G={G}: slowest sector {worst:.3f} ms device time -> {W*H/worst/1e3:.0f} Mpix/s if perfectly overlapped{extra}")
