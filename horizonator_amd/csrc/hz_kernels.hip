@@ -1597,9 +1597,23 @@ struct hz_dev
     int raster;
     int profiling;
 
-    hipStream_t stream;
+    /* Two streams, two framebuffers.  A draw (stream) fills one framebuffer; the
+     * readback conversion of that draw (rstream) reads it; the NEXT draw goes into
+     * the other framebuffer at once, while rstream is still converting and then
+     * clearing the first.  Back-to-back renders thereby overlap the
+     * bandwidth-bound stages (convert, clear) of panorama k with the
+     * instruction-bound rasterisation of panorama k+1.
+     *   ev_drawn        stream:  the last draw is complete
+     *   ev_free[i]      rstream: framebuffer i is all ones again
+     *   ev_readers      stream:  everything queued on `stream` before the current draw
+     *                            (readers of the previous framebuffer among it) is done */
+    hipStream_t stream, rstream;
+    hipEvent_t  ev_drawn, ev_free[2], ev_readers, ev_tanel;
     int16_t*            d_mosaic;
-    unsigned long long* d_fb;           /* W*H words (sector uses a prefix) */
+    unsigned long long* d_fbs[2];       /* W*H words each (a sector uses a prefix)                    */
+    size_t              fb_used[2];     /* words of d_fbs[i] that may differ from all ones            */
+    int                 fbi;            /* framebuffer of the last draw                                */
+    unsigned long long* d_fb;           /* = d_fbs[fbi]                                               */
     hz_bigrec_t*        d_bigrec;
     hz_bigitem_t*       d_bigitem;
     hz_rec_t*           d_midrec;
@@ -1621,7 +1635,7 @@ struct hz_dev
     hz_texparams_t tex;
     int            tex_on;
 
-    hipEvent_t ev[7];
+    hipEvent_t ev[8];
     int        have_times;
     hz_times_t times;
 };
@@ -1638,8 +1652,10 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     if(!d) return;
     (void)hipSetDevice(d->device);
     if(d->stream) (void)hipStreamSynchronize(d->stream);
+    if(d->rstream) (void)hipStreamSynchronize(d->rstream);
     (void)hipFree(d->d_mosaic);
-    (void)hipFree(d->d_fb);
+    (void)hipFree(d->d_fbs[0]);
+    (void)hipFree(d->d_fbs[1]);
     (void)hipFree(d->d_bigrec);
     (void)hipFree(d->d_bigitem);
     (void)hipFree(d->d_midrec);
@@ -1652,8 +1668,14 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
     (void)hipFree(d->d_z24);
-    for(int k=0; k<7; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    for(int k=0; k<8; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    if(d->ev_drawn)   (void)hipEventDestroy(d->ev_drawn);
+    if(d->ev_free[0]) (void)hipEventDestroy(d->ev_free[0]);
+    if(d->ev_free[1]) (void)hipEventDestroy(d->ev_free[1]);
+    if(d->ev_readers) (void)hipEventDestroy(d->ev_readers);
+    if(d->ev_tanel)   (void)hipEventDestroy(d->ev_tanel);
     if(d->stream) (void)hipStreamDestroy(d->stream);
+    if(d->rstream) (void)hipStreamDestroy(d->rstream);
     free(d);
 }
 
@@ -1661,8 +1683,23 @@ static int create_impl(hz_dev_t* d)
 {
     HZ_CHECK(hipSetDevice(d->device));
     HZ_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HZ_CHECK(hipStreamCreateWithFlags(&d->rstream, hipStreamNonBlocking));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_drawn,   hipEventDisableTiming));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_free[0], hipEventDisableTiming));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_free[1], hipEventDisableTiming));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_readers, hipEventDisableTiming));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_tanel,   hipEventDisableTiming));
     HZ_CHECK(hipMalloc(&d->d_mosaic, (size_t)d->N*d->N*sizeof(int16_t)));
-    HZ_CHECK(hipMalloc(&d->d_fb, (size_t)d->W*d->H*sizeof(unsigned long long)));
+    for(int i=0; i<2; i++)
+    {
+        /* glClear (reference horizonator-lib.c:896): depth = 1.0 -> all-ones words */
+        HZ_CHECK(hipMalloc(&d->d_fbs[i], (size_t)d->W*d->H*sizeof(unsigned long long)));
+        HZ_CHECK(hipMemsetAsync(d->d_fbs[i], 0xFF, (size_t)d->W*d->H*sizeof(unsigned long long), d->rstream));
+        HZ_CHECK(hipEventRecord(d->ev_free[i], d->rstream));
+        d->fb_used[i] = 0;
+    }
+    d->fbi = 1; d->d_fb = d->d_fbs[1];
+    HZ_CHECK(hipEventRecord(d->ev_drawn, d->stream));
     /* queue of triangles too large for k_scatter's in-block pass.  cfg3
      * (16000x4000) produces ~0.3 M records and ~0.4 M items; sized for 32k-wide */
     d->bigrec_capacity  = 1u<<21;
@@ -1683,7 +1720,7 @@ static int create_impl(hz_dev_t* d)
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
     d->tanel_resident = 0;
-    for(int k=0; k<7; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
+    for(int k=0; k<8; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
     return 0;
 }
 
@@ -1820,6 +1857,7 @@ extern "C" int hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, con
         for(size_t k=0; k<n; k++)
             packed[k] = (uint32_t)texels_bgr[3*k] | ((uint32_t)texels_bgr[3*k+1] << 8) | ((uint32_t)texels_bgr[3*k+2] << 16);
         HZ_CHECK(hipStreamSynchronize(d->stream));
+        HZ_CHECK(hipStreamSynchronize(d->rstream));
         (void)hipFree(d->d_texels); d->d_texels = NULL;
         hipError_t e = hipMalloc(&d->d_texels, n*sizeof(uint32_t));
         if(e == hipSuccess) e = hipMemcpy(d->d_texels, packed, n*sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -1949,11 +1987,26 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     hz_params_t p = make_params(d, view);
     const bool prof = d->profiling != 0;
 
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->stream));
-    /* glClear (reference horizonator-lib.c:896): depth = 1.0 -> all-ones word */
-    HZ_CHECK(hipMemsetAsync(d->d_fb, 0xFF, (size_t)p.SW*p.H*sizeof(unsigned long long), d->stream));
+    /* The framebuffer of the previous draw goes back to "cleared" (glClear,
+     * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words) on rstream,
+     * behind the conversions of that draw and behind whatever `stream` still had
+     * to read from it; this draw takes the other framebuffer, cleared long ago. */
+    {
+        const int prev = d->fbi, next = prev ^ 1;
+        HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
+        HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
+        if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->rstream));
+        if(d->fb_used[prev])
+            HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
+        if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
+        d->fb_used[prev] = 0;
+        HZ_CHECK(hipEventRecord(d->ev_free[prev], d->rstream));
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
+        d->fbi = next; d->d_fb = d->d_fbs[next];
+        d->fb_used[next] = (size_t)p.SW*p.H;
+    }
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->stream));
     hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, d->d_big_counters, 1);
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->stream));
 
     mr_queue_t q = { d->d_bigrec, d->d_bigitem, d->d_midrec, d->d_clip, d->d_big_counters,
                      d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity, d->clip_capacity };
@@ -2047,6 +2100,7 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     if(prof) HZ_CHECK(hipEventRecord(d->ev[2], d->stream));
     if(queue_kernels(true) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->stream));
+    HZ_CHECK(hipEventRecord(d->ev_drawn, d->stream));
     d->have_times = prof ? 1 : 0;
     return 0;
 }
@@ -2059,9 +2113,20 @@ static int upload_tanel(hz_dev_t* d, const float* tanel)
     if(!tanel) { snprintf(g_last_error, sizeof(g_last_error), "a tanel table is required"); return -1; }
     const size_t bytes = (size_t)d->H*sizeof(float);
     if(d->tanel_resident && memcmp(d->h_tanel, tanel, bytes) == 0) return 0;
+    /* a different table (the azimuth extents changed): nothing queued on either
+     * stream may still read the old one, and both streams must see the new one */
+    HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->rstream));
     memcpy(d->h_tanel, tanel, bytes);
-    HZ_CHECK(hipMemcpyAsync(d->d_tanel, d->h_tanel, bytes, hipMemcpyHostToDevice, d->stream));
+    HZ_CHECK(hipMemcpy(d->d_tanel, d->h_tanel, bytes, hipMemcpyHostToDevice));
     d->tanel_resident = 1;
+    return 0;
+}
+
+/* conversions of the last draw run on rstream, behind that draw */
+static int rstream_after_draw(hz_dev_t* d)
+{
+    HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));
     return 0;
 }
 
@@ -2080,11 +2145,12 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
         }
         if(upload_tanel(d, tanel) != 0) return -1;
     }
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->stream));
+    if(rstream_after_draw(d) != 0) return -1;
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
     const size_t npix = (size_t)SW*d->H;
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
                        (const unsigned long long*)d->d_fb, (const float*)d->d_tanel,
                        bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
     HZ_CHECK(hipGetLastError());
@@ -2094,14 +2160,14 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
         const hz_params_t p = make_params(d, view);
         size_t nchunks = (npix + TX_CHUNK-1)/TX_CHUNK;
         if(nchunks > 256*64) nchunks = 256*64;
-        hipLaunchKernelGGL(k_shade_tex, dim3((unsigned)nchunks), dim3(64), 0, d->stream,
+        hipLaunchKernelGGL(k_shade_tex, dim3((unsigned)nchunks), dim3(64), 0, d->rstream,
                            (const unsigned long long*)d->d_fb, (const int16_t*)d->d_mosaic,
                            (const uint32_t*)d->d_texels, d->tex, bgr, p);
         HZ_CHECK(hipGetLastError());
     }
     if(prof)
     {
-        HZ_CHECK(hipEventRecord(d->ev[5], d->stream));
+        HZ_CHECK(hipEventRecord(d->ev[5], d->rstream));
         d->have_times = 2;
     }
     return 0;
@@ -2119,14 +2185,15 @@ extern "C" int hz_hip_pack(hz_dev_t* d, uint32_t* d_packed)
     }
     const int SW = d->col1 - d->col0;
     const bool prof = d->profiling != 0;
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->stream));
+    if(rstream_after_draw(d) != 0) return -1;
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
     const size_t npix = (size_t)SW*d->H;
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
                        (const unsigned long long*)d->d_fb, d_packed, SW, d->H);
     HZ_CHECK(hipGetLastError());
-    if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->stream)); d->have_times = 2; }
+    if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
     return 0;
 }
 
@@ -2148,7 +2215,7 @@ extern "C" int hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const f
     const size_t npix = (size_t)ncols*d->H;
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
-    hipLaunchKernelGGL(k_resolve_packed, dim3((unsigned)nblocks), dim3(256), 0, d->stream,
+    hipLaunchKernelGGL(k_resolve_packed, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
                        d_packed, stride, ncols, (const float*)d->d_tanel, d_bgr, d_ranges,
                        d->W, out_col0, d->H, view->znear, view->zfar);
     HZ_CHECK(hipGetLastError());
@@ -2170,12 +2237,13 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
         return -1;
     }
     const bool prof = d->profiling != 0;
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->stream));
-    HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->stream));
-    hipLaunchKernelGGL(k_pack_sparse, dim3((unsigned)d->H), dim3(256), 0, d->stream,
+    if(rstream_after_draw(d) != 0) return -1;
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
+    HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->rstream));
+    hipLaunchKernelGGL(k_pack_sparse, dim3((unsigned)d->H), dim3(256), 0, d->rstream,
                        (const unsigned long long*)d->d_fb, d_out, SW, d->H, mask_stride);
     HZ_CHECK(hipGetLastError());
-    if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->stream)); d->have_times = 2; }
+    if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
     return 0;
 }
 
@@ -2191,7 +2259,7 @@ extern "C" int hz_hip_resolve_sparse(hz_dev_t* d, const hz_view_t* view, const f
         return -1;
     }
     if(d_ranges && upload_tanel(d, tanel) != 0) return -1;
-    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)d->H), dim3(256), 0, d->stream,
+    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)d->H), dim3(256), 0, d->rstream,
                        d_in, mask_stride, ncols, (const float*)d->d_tanel, d_bgr, d_ranges,
                        d->W, out_col0, d->H, view->znear, view->zfar);
     HZ_CHECK(hipGetLastError());
@@ -2217,11 +2285,11 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
                       bgr ? d->d_bgr : NULL, ranges ? d->d_ranges : NULL,
                       index ? d->d_index : NULL, z24 ? d->d_z24 : NULL) != 0) return -1;
     const size_t npix = (size_t)(d->col1 - d->col0)*d->H;
-    if(bgr)    HZ_CHECK(hipMemcpyAsync(bgr,    d->d_bgr,    npix*3,                hipMemcpyDeviceToHost, d->stream));
-    if(ranges) HZ_CHECK(hipMemcpyAsync(ranges, d->d_ranges, npix*sizeof(float),    hipMemcpyDeviceToHost, d->stream));
-    if(index)  HZ_CHECK(hipMemcpyAsync(index,  d->d_index,  npix*sizeof(int32_t),  hipMemcpyDeviceToHost, d->stream));
-    if(z24)    HZ_CHECK(hipMemcpyAsync(z24,    d->d_z24,    npix*sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-    HZ_CHECK(hipStreamSynchronize(d->stream));
+    if(bgr)    HZ_CHECK(hipMemcpyAsync(bgr,    d->d_bgr,    npix*3,                hipMemcpyDeviceToHost, d->rstream));
+    if(ranges) HZ_CHECK(hipMemcpyAsync(ranges, d->d_ranges, npix*sizeof(float),    hipMemcpyDeviceToHost, d->rstream));
+    if(index)  HZ_CHECK(hipMemcpyAsync(index,  d->d_index,  npix*sizeof(int32_t),  hipMemcpyDeviceToHost, d->rstream));
+    if(z24)    HZ_CHECK(hipMemcpyAsync(z24,    d->d_z24,    npix*sizeof(uint32_t), hipMemcpyDeviceToHost, d->rstream));
+    HZ_CHECK(hipStreamSynchronize(d->rstream));
     return 0;
 }
 
@@ -2436,6 +2504,7 @@ extern "C" int hz_hip_sync(hz_dev_t* d)
 {
     HZ_CHECK(hipSetDevice(d->device));
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->rstream));
     return 0;
 }
 
@@ -2445,16 +2514,15 @@ extern "C" int hz_hip_last_times(hz_dev_t* d, hz_times_t* t)
     if(!d->have_times) return -1;
     HZ_CHECK(hipSetDevice(d->device));
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->rstream));
+    /* clear_ms is the clear this draw queued: that of the OTHER framebuffer, which runs on
+     * rstream beside the draw.  total_ms is the sum of the stages, not a latency. */
     HZ_CHECK(hipEventElapsedTime(&t->clear_ms,  d->ev[0], d->ev[1]));
-    HZ_CHECK(hipEventElapsedTime(&t->near_ms,   d->ev[1], d->ev[6]));
+    HZ_CHECK(hipEventElapsedTime(&t->near_ms,   d->ev[7], d->ev[6]));
     HZ_CHECK(hipEventElapsedTime(&t->raster_ms, d->ev[6], d->ev[2]));
     HZ_CHECK(hipEventElapsedTime(&t->big_ms,    d->ev[2], d->ev[3]));
     if(d->have_times == 2)
-    {
         HZ_CHECK(hipEventElapsedTime(&t->resolve_ms, d->ev[4], d->ev[5]));
-        HZ_CHECK(hipEventElapsedTime(&t->total_ms,   d->ev[0], d->ev[5]));
-    }
-    else
-        HZ_CHECK(hipEventElapsedTime(&t->total_ms, d->ev[0], d->ev[3]));
+    t->total_ms = t->clear_ms + t->near_ms + t->raster_ms + t->big_ms + t->resolve_ms;
     return 0;
 }
