@@ -111,9 +111,10 @@ def main():
     h.set_raster(args.raster)
     # Rank 0 converts the whole gathered panorama on top of drawing its own sector, so it draws a
     # narrower one (none at all with 8 GPUs): weights from the two costs measured on this workload
-    # with tools/sector_timing.py - a sector costs about 0.32 + 1.77*share ms, writing the own strip
-    # sparse and converting all strips 0.31 ms.
-    weights = gatherer_weights(world, 1.77, 0.31) if world > 1 else None
+    # with tools/sector_timing.py - a sector costs about 0.32 + 1.77*share ms; converting all strips
+    # takes 0.31 ms but runs on the library's second stream beside rank 0's own draw, which it slows
+    # by about 0.08 ms.
+    weights = gatherer_weights(world, 1.77, 0.08) if world > 1 else None
     col0, col1 = sector_columns(W, world, rank, weights)
     SW = col1 - col0
     SW_max = max(c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world)))
@@ -145,7 +146,7 @@ def main():
             d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
             d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     pending = [None] * NBUF
-    state = {"k": 0, "wire_words": 0}
+    state = {"k": 0, "wire_words": 0, "keep": None}
     layout = [sector_columns(W, world, r, weights) for r in range(world)]
 
     def finish(slot):
@@ -159,9 +160,11 @@ def main():
             if bufs is not None:
                 if args.backend == "gloo":
                     bufs = [t.to(dev) for t in bufs]
+                # queued on the library's conversion stream: it runs beside the draw that step() starts
+                # next; the strips stay referenced until that draw has been waited for
                 h.resolve_sparse_gathered([(t.data_ptr(), c0, c1 - c0) for t, (c0, c1) in zip(bufs, layout)],
                                           MSTRIDE, d_img.data_ptr(), d_rng.data_ptr())
-                h.sync()                                 # ... before the strips are released
+                state["keep"] = bufs
             pending[slot] = None
             return
         parts = pending[slot].parts()
@@ -186,7 +189,9 @@ def main():
             words = HDR
             if SW > 0:
                 h.render_sparse(d_pk[slot].data_ptr(), MSTRIDE)
-                h.sync()
+            h.sync()                                            # own strip written, pending conversion done
+            state["keep"] = None
+            if SW > 0:
                 words = HDR + int(d_pk[slot][0].item())         # header + terrain pixels of this strip
             # all strips of a gather have one length: that of the longest
             n = torch.tensor([words], dtype=torch.int64, device=cdev)
@@ -206,6 +211,8 @@ def main():
     def drain():
         for slot in range(NBUF):
             finish(slot)
+        h.sync()
+        state["keep"] = None
 
     def fence():
         torch.cuda.synchronize()
