@@ -1614,11 +1614,16 @@ struct hz_dev
     size_t              fb_used[2];     /* words of d_fbs[i] that may differ from all ones            */
     int                 fbi;            /* framebuffer of the last draw                                */
     unsigned long long* d_fb;           /* = d_fbs[fbi]                                               */
-    hz_bigrec_t*        d_bigrec;
-    hz_bigitem_t*       d_bigitem;
-    hz_rec_t*           d_midrec;
-    uint32_t*           d_clip;
-    unsigned int*       d_big_counters;     /* [0] big records [1] big items [2] first invalid big item [3] mid records */
+    /* the queues between the marching kernel and the kernels that finish a draw
+     * (clipped, medium, large triangles): two sets, like the framebuffers, so
+     * that those kernels of panorama k (qstream) run beside k_march of k+1 */
+    hipStream_t         qstream;
+    hipEvent_t          ev_marched, ev_qfree[2];
+    hz_bigrec_t*        d_bigrec_s[2];
+    hz_bigitem_t*       d_bigitem_s[2];
+    hz_rec_t*           d_midrec_s[2];
+    uint32_t*           d_clip_s[2];
+    unsigned int*       d_big_counters_s[2];    /* [0] big records [1] big items [2] first invalid big item [3] mid records [4] clip ids */
     unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
     float*              d_tanel;
     float*              h_tanel;        /* the table d_tanel holds (or is about to, in stream order) */
@@ -1635,7 +1640,7 @@ struct hz_dev
     hz_texparams_t tex;
     int            tex_on;
 
-    hipEvent_t ev[8];
+    hipEvent_t ev[9];
     int        have_times;
     hz_times_t times;
 };
@@ -1652,15 +1657,21 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     if(!d) return;
     (void)hipSetDevice(d->device);
     if(d->stream) (void)hipStreamSynchronize(d->stream);
+    if(d->qstream) (void)hipStreamSynchronize(d->qstream);
     if(d->rstream) (void)hipStreamSynchronize(d->rstream);
     (void)hipFree(d->d_mosaic);
     (void)hipFree(d->d_fbs[0]);
     (void)hipFree(d->d_fbs[1]);
-    (void)hipFree(d->d_bigrec);
-    (void)hipFree(d->d_bigitem);
-    (void)hipFree(d->d_midrec);
-    (void)hipFree(d->d_clip);
-    (void)hipFree(d->d_big_counters);
+    for(int i=0; i<2; i++)
+    {
+        (void)hipFree(d->d_bigrec_s[i]);
+        (void)hipFree(d->d_bigitem_s[i]);
+        (void)hipFree(d->d_midrec_s[i]);
+        (void)hipFree(d->d_clip_s[i]);
+        (void)hipFree(d->d_big_counters_s[i]);
+        if(d->ev_qfree[i]) (void)hipEventDestroy(d->ev_qfree[i]);
+    }
+    if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
@@ -1668,7 +1679,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
     (void)hipFree(d->d_z24);
-    for(int k=0; k<8; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    for(int k=0; k<9; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     if(d->ev_drawn)   (void)hipEventDestroy(d->ev_drawn);
     if(d->ev_free[0]) (void)hipEventDestroy(d->ev_free[0]);
     if(d->ev_free[1]) (void)hipEventDestroy(d->ev_free[1]);
@@ -1676,6 +1687,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     if(d->ev_tanel)   (void)hipEventDestroy(d->ev_tanel);
     if(d->stream) (void)hipStreamDestroy(d->stream);
     if(d->rstream) (void)hipStreamDestroy(d->rstream);
+    if(d->qstream) (void)hipStreamDestroy(d->qstream);
     free(d);
 }
 
@@ -1699,7 +1711,6 @@ static int create_impl(hz_dev_t* d)
         d->fb_used[i] = 0;
     }
     d->fbi = 1; d->d_fb = d->d_fbs[1];
-    HZ_CHECK(hipEventRecord(d->ev_drawn, d->stream));
     /* queue of triangles too large for k_scatter's in-block pass.  cfg3
      * (16000x4000) produces ~0.3 M records and ~0.4 M items; sized for 32k-wide */
     d->bigrec_capacity  = 1u<<21;
@@ -1712,15 +1723,23 @@ static int create_impl(hz_dev_t* d)
         if(cap && atoi(cap) > 0)
             d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = d->clip_capacity = (unsigned int)atoi(cap);
     }
-    HZ_CHECK(hipMalloc(&d->d_bigrec,  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
-    HZ_CHECK(hipMalloc(&d->d_bigitem, (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
-    HZ_CHECK(hipMalloc(&d->d_midrec,  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
-    HZ_CHECK(hipMalloc(&d->d_clip,    (size_t)d->clip_capacity*sizeof(uint32_t)));
-    HZ_CHECK(hipMalloc(&d->d_big_counters, 5*sizeof(unsigned int)));
+    HZ_CHECK(hipStreamCreateWithFlags(&d->qstream, hipStreamNonBlocking));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_marched, hipEventDisableTiming));
+    for(int i=0; i<2; i++)
+    {
+        HZ_CHECK(hipMalloc(&d->d_bigrec_s[i],  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
+        HZ_CHECK(hipMalloc(&d->d_bigitem_s[i], (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
+        HZ_CHECK(hipMalloc(&d->d_midrec_s[i],  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
+        HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)d->clip_capacity*sizeof(uint32_t)));
+        HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], 5*sizeof(unsigned int)));
+        HZ_CHECK(hipEventCreateWithFlags(&d->ev_qfree[i], hipEventDisableTiming));
+        HZ_CHECK(hipEventRecord(d->ev_qfree[i], d->qstream));
+    }
+    HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
     d->tanel_resident = 0;
-    for(int k=0; k<8; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
+    for(int k=0; k<9; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
     return 0;
 }
 
@@ -1995,6 +2014,7 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         const int prev = d->fbi, next = prev ^ 1;
         HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
         HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
+        HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));       /* the previous draw's last kernels (qstream) */
         if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->rstream));
         if(d->fb_used[prev])
             HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
@@ -2002,35 +2022,38 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         d->fb_used[prev] = 0;
         HZ_CHECK(hipEventRecord(d->ev_free[prev], d->rstream));
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
         d->fbi = next; d->d_fb = d->d_fbs[next];
         d->fb_used[next] = (size_t)p.SW*p.H;
     }
+    const int qs = d->fbi;                      /* queue set of this draw */
+    unsigned int* counters = d->d_big_counters_s[qs];
     if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->stream));
-    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, d->d_big_counters, 1);
+    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, counters, 1);
 
-    mr_queue_t q = { d->d_bigrec, d->d_bigitem, d->d_midrec, d->d_clip, d->d_big_counters,
+    mr_queue_t q = { d->d_bigrec_s[qs], d->d_bigitem_s[qs], d->d_midrec_s[qs], d->d_clip_s[qs], counters,
                      d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity, d->clip_capacity };
-    auto queue_kernels = [&](bool last) -> int
+    auto queue_kernels = [&](bool last, hipStream_t st) -> int
     {
-        hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, d->stream,
+        hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st,
                            (const int16_t*)d->d_mosaic, d->d_fb, q, p);
         HZ_CHECK(hipGetLastError());
         if(last)
         {
-            hipLaunchKernelGGL(k_clip_rescan, dim3(2048), dim3(256), 0, d->stream,
+            hipLaunchKernelGGL(k_clip_rescan, dim3(2048), dim3(256), 0, st,
                                (const int16_t*)d->d_mosaic, d->d_fb, q, p);
             HZ_CHECK(hipGetLastError());
         }
         if(d->raster != HZ_RASTER_SCATTER)
         {
-            hipLaunchKernelGGL(k_mid, dim3(8192), dim3(64), 0, d->stream,
-                               d->d_fb, (const hz_rec_t*)d->d_midrec, (const unsigned int*)d->d_big_counters,
+            hipLaunchKernelGGL(k_mid, dim3(8192), dim3(64), 0, st,
+                               d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)counters,
                                d->midrec_capacity, p);
             HZ_CHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, d->stream,
-                           d->d_fb, (const hz_bigrec_t*)d->d_bigrec, (const hz_bigitem_t*)d->d_bigitem,
-                           (const unsigned int*)d->d_big_counters, d->bigrec_capacity, d->bigitem_capacity, p);
+        hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, st,
+                           d->d_fb, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
+                           (const unsigned int*)counters, d->bigrec_capacity, d->bigitem_capacity, p);
         HZ_CHECK(hipGetLastError());
         return 0;
     };
@@ -2064,8 +2087,8 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
             hipLaunchKernelGGL(k_march, dim3(p.near_x1 - p.near_x0 + 1, zn.total), dim3(64), 0, d->stream,
                                (const int16_t*)d->d_mosaic, d->d_fb, q, zn, p);
             HZ_CHECK(hipGetLastError());
-            if(queue_kernels(false) != 0) return -1;
-            hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, d->d_big_counters, 0);
+            if(queue_kernels(false, d->stream) != 0) return -1;
+            hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, counters, 0);
             p.pass = 2; p.early_z = 1;
         }
         if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->stream));
@@ -2098,9 +2121,15 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         HZ_CHECK(hipGetLastError());
     }
     if(prof) HZ_CHECK(hipEventRecord(d->ev[2], d->stream));
-    if(queue_kernels(true) != 0) return -1;
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->stream));
-    HZ_CHECK(hipEventRecord(d->ev_drawn, d->stream));
+    /* the kernels that finish the draw run on qstream, so that the next draw's
+     * marching kernel can start beside them */
+    HZ_CHECK(hipEventRecord(d->ev_marched, d->stream));
+    HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_marched, 0));
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
+    if(queue_kernels(true, d->qstream) != 0) return -1;
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
+    HZ_CHECK(hipEventRecord(d->ev_qfree[qs], d->qstream));
+    HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
     return 0;
 }
@@ -2116,6 +2145,7 @@ static int upload_tanel(hz_dev_t* d, const float* tanel)
     /* a different table (the azimuth extents changed): nothing queued on either
      * stream may still read the old one, and both streams must see the new one */
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->qstream));
     HZ_CHECK(hipStreamSynchronize(d->rstream));
     memcpy(d->h_tanel, tanel, bytes);
     HZ_CHECK(hipMemcpy(d->d_tanel, d->h_tanel, bytes, hipMemcpyHostToDevice));
@@ -2296,6 +2326,7 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
 extern "C" int hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24)
 {
     HZ_CHECK(hipSetDevice(d->device));
+    HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     if(x < d->col0 || x >= d->col1 || y < 0 || y >= d->H)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_read_depth: (%d,%d) outside the drawn sector", x, y);
@@ -2435,6 +2466,7 @@ extern "C" int hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float
                                  int nx, int ny, float* lat, float* lon)
 {
     HZ_CHECK(hipSetDevice(d->device));
+    HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     if(d->col0 != 0 || d->col1 != d->W || cell_w <= 0 || cell_h <= 0 || nx <= 0 || ny <= 0)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells: needs a full-width context and positive sizes");
@@ -2467,6 +2499,7 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
                                      unsigned char* visible, float* label_x, float* label_y)
 {
     HZ_CHECK(hipSetDevice(d->device));
+    HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     if(d->col0 != 0 || d->col1 != d->W || npois < 0)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_poi_visibility: needs a full-width context");
@@ -2504,6 +2537,7 @@ extern "C" int hz_hip_sync(hz_dev_t* d)
 {
     HZ_CHECK(hipSetDevice(d->device));
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->qstream));
     HZ_CHECK(hipStreamSynchronize(d->rstream));
     return 0;
 }
@@ -2514,13 +2548,14 @@ extern "C" int hz_hip_last_times(hz_dev_t* d, hz_times_t* t)
     if(!d->have_times) return -1;
     HZ_CHECK(hipSetDevice(d->device));
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->qstream));
     HZ_CHECK(hipStreamSynchronize(d->rstream));
     /* clear_ms is the clear this draw queued: that of the OTHER framebuffer, which runs on
      * rstream beside the draw.  total_ms is the sum of the stages, not a latency. */
     HZ_CHECK(hipEventElapsedTime(&t->clear_ms,  d->ev[0], d->ev[1]));
     HZ_CHECK(hipEventElapsedTime(&t->near_ms,   d->ev[7], d->ev[6]));
     HZ_CHECK(hipEventElapsedTime(&t->raster_ms, d->ev[6], d->ev[2]));
-    HZ_CHECK(hipEventElapsedTime(&t->big_ms,    d->ev[2], d->ev[3]));
+    HZ_CHECK(hipEventElapsedTime(&t->big_ms,    d->ev[8], d->ev[3]));
     if(d->have_times == 2)
         HZ_CHECK(hipEventElapsedTime(&t->resolve_ms, d->ev[4], d->ev[5]));
     t->total_ms = t->clear_ms + t->near_ms + t->raster_ms + t->big_ms + t->resolve_ms;
