@@ -2040,13 +2040,13 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         HZ_CHECK(hipGetLastError());
         if(last)
         {
-            hipLaunchKernelGGL(k_clip_rescan, dim3(2048), dim3(256), 0, st,
+            hipLaunchKernelGGL(k_clip_rescan, dim3(256), dim3(256), 0, st,
                                (const int16_t*)d->d_mosaic, d->d_fb, q, p);
             HZ_CHECK(hipGetLastError());
         }
         if(d->raster != HZ_RASTER_SCATTER)
         {
-            hipLaunchKernelGGL(k_mid, dim3(8192), dim3(64), 0, st,
+            hipLaunchKernelGGL(k_mid, dim3(2048), dim3(64), 0, st,
                                d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)counters,
                                d->midrec_capacity, p);
             HZ_CHECK(hipGetLastError());
