@@ -90,23 +90,28 @@ def main():
         dist.barrier()
     import hzutil
     import horizonator_amd
-    from horizonator_amd.sharding import (gather_flat_async, gather_strips_async, gatherer_weights, sector_columns,
-                                          sparse_header_words, sparse_mask_stride)
+    from horizonator_amd.sharding import (broadcast_dem, gather_flat_async, gather_strips_async, gatherer_weights,
+                                          sector_columns, sparse_header_words, sparse_mask_stride)
 
     cfg = CONFIGS[args.config]
     R, W, H = cfg["R"], cfg["W"], cfg["H"]
     N = 2 * R
 
-    # synthetic SRTM tiles (tools/demgen.c), generated once per node
-    if rank == 0:
-        dems = hzutil.dem_dir_for(LAT, LON, R)
-    if world > 1:
-        dist.barrier()
-    dems = hzutil.dem_dir_for(LAT, LON, R)
-
+    # synthetic SRTM tiles (tools/demgen.c).  Rank 0 generates, reads and decodes them; the other
+    # ranks receive the int16 mosaic by broadcast (RCCL) and never touch a tile.
     os.environ["HORIZONATOR_HIP_DEVICE"] = str(local_rank)
     t0 = time.perf_counter()
-    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R)
+    h = None
+    if rank == 0:
+        dems = hzutil.dem_dir_for(LAT, LON, R)
+        t0 = time.perf_counter()
+        h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R)
+    if world > 1:
+        window, mosaic = broadcast_dem(h.window() if rank == 0 else None, h.mosaic() if rank == 0 else None,
+                                       device=dev if args.backend == "nccl" else None)
+        if rank != 0:
+            h = horizonator_amd.horizonator.from_mosaic(LAT, LON, W, H, window, mosaic)
+        del mosaic
     init_s = time.perf_counter() - t0
     h.set_raster(args.raster)
     # Rank 0 converts the whole gathered panorama on top of drawing its own sector, so it draws a

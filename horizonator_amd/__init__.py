@@ -75,6 +75,37 @@ class horizonator:
             self._ctx = None
             raise RuntimeError("horizonator_init() failed")
 
+    @classmethod
+    def from_mosaic(cls, lat, lon, width, height, window, mosaic):
+        """A context over a DEM window that another process loaded (multi-GPU: rank 0 reads the
+        tiles, the others receive `window` = (cells_per_deg, radius_cells, origin_tile_lon,
+        origin_tile_lat, origin_cell_i, origin_cell_j) and the int16 mosaic; see
+        sharding.broadcast_dem).  include/horizonator_amd.h: horizonator_amd_init_from_mosaic."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._ctx = _lib.Context()
+        w = _lib.Window()
+        w.cells_per_deg, w.radius_cells = int(window[0]), int(window[1])
+        w.origin_tile[0], w.origin_tile[1] = int(window[2]), int(window[3])
+        w.origin_cell[0], w.origin_cell[1] = int(window[4]), int(window[5])
+        mosaic = np.ascontiguousarray(mosaic, np.int16)
+        n = 2 * w.radius_cells
+        if mosaic.shape != (n, n):
+            raise ValueError(f"the mosaic of this window is int16[{n},{n}]")
+        ok = self._lib.horizonator_amd_init_from_mosaic(C.byref(self._ctx), float(lat), float(lon), None,
+                                                        int(width), int(height), C.byref(w), mosaic.ctypes.data)
+        if not ok:
+            self._ctx = None
+            raise RuntimeError("horizonator_amd_init_from_mosaic() failed")
+        return self
+
+    def window(self):
+        """(cells_per_deg, radius_cells, origin_tile_lon, origin_tile_lat, origin_cell_i, origin_cell_j)"""
+        w = _lib.Window()
+        if not self._lib.horizonator_amd_get_window(C.byref(self._ctx), C.byref(w)):
+            raise RuntimeError("horizonator_amd_get_window() failed")
+        return (w.cells_per_deg, w.radius_cells, w.origin_tile[0], w.origin_tile[1], w.origin_cell[0], w.origin_cell[1])
+
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) is not None:

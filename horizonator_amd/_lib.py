@@ -68,6 +68,12 @@ class Times(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("clear_ms", "raster_ms", "big_ms", "resolve_ms", "total_ms", "near_ms")]
 
 
+class Window(C.Structure):
+    """horizonator_amd_window_t (include/horizonator_amd.h)"""
+    _fields_ = [("cells_per_deg", C.c_int), ("radius_cells", C.c_int),
+                ("origin_tile", C.c_int * 2), ("origin_cell", C.c_int * 2)]
+
+
 class TexParams(C.Structure):
     """hz_texparams_t (include/hz_hip.h)"""
     _fields_ = [(n, C.c_float) for n in ("viewer_lat_rad", "origin_cell_lon_deg", "origin_cell_lat_deg",
@@ -120,6 +126,8 @@ def load():
     sig("horizonator_dem_sample", C.c_int16, P(DemContext), i, i)
     sig("horizonator_dem_bounds_latlon_deg", None, P(DemContext), P(f), P(f), P(f), P(f))
 
+    sig("horizonator_amd_get_window", b, ctxp, P(Window))
+    sig("horizonator_amd_init_from_mosaic", b, ctxp, f, f, P(f), i, i, P(Window), vp)
     sig("horizonator_amd_render", b, ctxp, vp, vp, vp, vp)
     sig("horizonator_amd_render_device", b, ctxp, vp, vp, vp, vp)
     sig("horizonator_amd_render_batch", b, ctxp, i, vp, vp, vp, vp, vp)
@@ -181,6 +189,7 @@ DECLARED_SYMBOLS = [
     "horizonator_dem_init", "horizonator_dem_deinit", "horizonator_dem_sample",
     "horizonator_dem_bounds_latlon_deg",
     # include/horizonator_amd.h
+    "horizonator_amd_get_window", "horizonator_amd_init_from_mosaic",
     "horizonator_amd_render", "horizonator_amd_render_device", "horizonator_amd_render_batch",
     "horizonator_amd_render_packed", "horizonator_amd_resolve_packed",
     "horizonator_amd_resolve_packed_strips", "horizonator_amd_render_sparse",

@@ -37,6 +37,9 @@ typedef struct
     /* texture path (reference render_texture): layout fixed at init, coefficients per move */
     bool           textured;
     hz_texparams_t tex;
+    /* a context made from a mosaic another process loaded (horizonator_amd_init_from_mosaic)
+     * has no tiles: horizonator_move() samples this host copy instead */
+    int16_t*       host_mosaic;
     float*       tanel;         /* [height] */
     bool         tanel_valid;   /* ... computed for these azimuth extents: */
     float        tanel_az0, tanel_az1;
@@ -70,6 +73,7 @@ static void state_release(hz_state_t* s, horizonator_context_t* ctx)
         if(ctx) horizonator_dem_deinit(&ctx->dems);
     }
     free(s->tanel);
+    free(s->host_mosaic);
     memset(s, 0, sizeof(*s));
 }
 
@@ -216,64 +220,19 @@ static bool load_tiles(hz_state_t* s, horizonator_context_t* ctx,
     return true;
 }
 
-bool horizonator_init(horizonator_context_t* ctx,
-                      float viewer_lat, float viewer_lon,
-                      float* viewer_z,
-                      int offscreen_width, int offscreen_height,
-                      int render_radius_cells, float render_radius_m,
-                      bool use_glut, bool render_texture, bool SRTM1,
-                      const char* dir_dems,
-                      const char* dir_tiles, const char* tiles_name,
-                      const char* tiles_url_fmt, bool allow_downloads)
+/* everything after the DEM window is known: device state, DEM -> HBM, the
+ * context's public fields, initial view.  `mosaic`: the N x N samples if the
+ * caller has them already (then no tile is touched), else NULL: built from
+ * s->tiles, on the host or - HORIZONATOR_INGEST=device - in a kernel */
+static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot,
+                             float viewer_lat, float viewer_lon, float* viewer_z,
+                             int offscreen_width, int offscreen_height,
+                             const int16_t* given_mosaic,
+                             bool render_texture, const char* dir_tiles, const char* tiles_name, bool allow_downloads)
 {
-    (void)tiles_url_fmt;
-
-    memset(ctx, 0, sizeof(*ctx));       /* reference horizonator-lib.c:84 */
-
-    /* reference horizonator-lib.c:90-121 */
-    char dir_tiles_expanded[512];
-    if(tiles_name == NULL) tiles_name = "mapnik";
-    if(dir_tiles == NULL)  dir_tiles  = "~/.horizonator/tiles";
-    if(dir_tiles[0] == '~' && dir_tiles[1] == '/')
-    {
-        const char* home = getenv("HOME");
-        if(home == NULL)
-        {
-            if(render_texture) { MSG("User asked for ~, but the 'HOME' env var isn't defined"); return false; }
-            home = "";
-        }
-        if((int)sizeof(dir_tiles_expanded) <= snprintf(dir_tiles_expanded, sizeof(dir_tiles_expanded), "%s/%s", home, &dir_tiles[2]))
-        { MSG("static buffer overflow: dir_tiles"); return false; }
-        dir_tiles = dir_tiles_expanded;
-    }
-
-    if(dir_dems == NULL)                /* reference horizonator-lib.c:94-97 */
-        dir_dems = SRTM1 ? "~/.horizonator/DEMs_SRTM1" : "~/.horizonator/DEMs_SRTM3";
-
-    if(!use_glut || offscreen_width <= 0 || offscreen_height <= 0)
-    {
-        MSG("This build renders offscreen only: horizonator_init(use_glut=true, offscreen_width,height > 0). There is no OpenGL window mode");
-        return false;
-    }
-    int slot = -1;
-    for(int k=0; k<HZ_MAX_CONTEXTS; k++) if(!g_state[k].live) { slot = k; break; }
-    if(slot < 0)
-    {
-        MSG("Too many live contexts (max %d)", HZ_MAX_CONTEXTS);
-        return false;
-    }
-    hz_state_t* s = &g_state[slot];
-    memset(s, 0, sizeof(*s));
-
     int16_t* mosaic = NULL;
     unsigned char* texels = NULL;
     bool     result = false;
-
-    if(!load_tiles(s, ctx, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, dir_dems, SRTM1))
-    {
-        MSG("Couldn't init DEMs. Giving up");
-        goto done;
-    }
 
     const int R = s->tiles.win.radius_cells;
     const int N = 2*R;
@@ -301,7 +260,15 @@ bool horizonator_init(horizonator_context_t* ctx,
      * mosaic and upload it.  HORIZONATOR_INGEST=device uploads the raw tiles
      * and decodes them in a kernel. */
     const char* ingest = getenv("HORIZONATOR_INGEST");
-    if(ingest != NULL && strcmp(ingest, "device") == 0)
+    if(given_mosaic != NULL)
+    {
+        if(0 != hz_hip_upload_mosaic(s->dev, given_mosaic))
+        {
+            MSG("Mosaic upload failed: %s", hz_hip_last_error());
+            goto done;
+        }
+    }
+    else if(ingest != NULL && strcmp(ingest, "device") == 0)
     {
         if(0 != hz_hip_ingest_tiles(s->dev, (const unsigned char* const*)s->tiles.tile,
                                     s->tiles.win.ntiles[0], s->tiles.win.ntiles[1],
@@ -374,6 +341,124 @@ bool horizonator_init(horizonator_context_t* ctx,
  done:
     free(mosaic);
     free(texels);
+    return result;
+}
+
+static int free_slot(void)
+{
+    for(int k=0; k<HZ_MAX_CONTEXTS; k++) if(!g_state[k].live) return k;
+    MSG("Too many live contexts (max %d)", HZ_MAX_CONTEXTS);
+    return -1;
+}
+
+bool horizonator_init(horizonator_context_t* ctx,
+                      float viewer_lat, float viewer_lon,
+                      float* viewer_z,
+                      int offscreen_width, int offscreen_height,
+                      int render_radius_cells, float render_radius_m,
+                      bool use_glut, bool render_texture, bool SRTM1,
+                      const char* dir_dems,
+                      const char* dir_tiles, const char* tiles_name,
+                      const char* tiles_url_fmt, bool allow_downloads)
+{
+    (void)tiles_url_fmt;
+
+    memset(ctx, 0, sizeof(*ctx));       /* reference horizonator-lib.c:84 */
+
+    /* reference horizonator-lib.c:90-121 */
+    char dir_tiles_expanded[512];
+    if(tiles_name == NULL) tiles_name = "mapnik";
+    if(dir_tiles == NULL)  dir_tiles  = "~/.horizonator/tiles";
+    if(dir_tiles[0] == '~' && dir_tiles[1] == '/')
+    {
+        const char* home = getenv("HOME");
+        if(home == NULL)
+        {
+            if(render_texture) { MSG("User asked for ~, but the 'HOME' env var isn't defined"); return false; }
+            home = "";
+        }
+        if((int)sizeof(dir_tiles_expanded) <= snprintf(dir_tiles_expanded, sizeof(dir_tiles_expanded), "%s/%s", home, &dir_tiles[2]))
+        { MSG("static buffer overflow: dir_tiles"); return false; }
+        dir_tiles = dir_tiles_expanded;
+    }
+
+    if(dir_dems == NULL)                /* reference horizonator-lib.c:94-97 */
+        dir_dems = SRTM1 ? "~/.horizonator/DEMs_SRTM1" : "~/.horizonator/DEMs_SRTM3";
+
+    if(!use_glut || offscreen_width <= 0 || offscreen_height <= 0)
+    {
+        MSG("This build renders offscreen only: horizonator_init(use_glut=true, offscreen_width,height > 0). There is no OpenGL window mode");
+        return false;
+    }
+    const int slot = free_slot();
+    if(slot < 0) return false;
+    hz_state_t* s = &g_state[slot];
+    memset(s, 0, sizeof(*s));
+
+    bool result = false;
+    if(!load_tiles(s, ctx, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, dir_dems, SRTM1))
+        MSG("Couldn't init DEMs. Giving up");
+    else
+        result = init_device_side(ctx, s, slot, viewer_lat, viewer_lon, viewer_z, offscreen_width, offscreen_height,
+                                  NULL, render_texture, dir_tiles, tiles_name, allow_downloads);
+    if(!result)
+    {
+        state_release(s, ctx);
+        memset(ctx, 0, sizeof(*ctx));
+    }
+    return result;
+}
+
+bool horizonator_amd_get_window(const horizonator_context_t* ctx, horizonator_amd_window_t* win)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL || win == NULL) return false;
+    const hz_window_t* w = &s->tiles.win;
+    win->cells_per_deg = w->cells_per_deg; win->radius_cells = w->radius_cells;
+    for(int a=0; a<2; a++) { win->origin_tile[a] = w->origin_tile[a]; win->origin_cell[a] = w->origin_cell[a]; }
+    return true;
+}
+
+bool horizonator_amd_init_from_mosaic(horizonator_context_t* ctx,
+                                      float viewer_lat, float viewer_lon, float* viewer_z,
+                                      int offscreen_width, int offscreen_height,
+                                      const horizonator_amd_window_t* win, const int16_t* mosaic)
+{
+    memset(ctx, 0, sizeof(*ctx));
+    if(win == NULL || mosaic == NULL || offscreen_width <= 0 || offscreen_height <= 0 ||
+       win->radius_cells <= 0 || (win->cells_per_deg != 1200 && win->cells_per_deg != 3600))
+    {
+        MSG("horizonator_amd_init_from_mosaic: bad arguments");
+        return false;
+    }
+    const int slot = free_slot();
+    if(slot < 0) return false;
+    hz_state_t* s = &g_state[slot];
+    memset(s, 0, sizeof(*s));
+
+    /* the window as the process that read the tiles computed it; no tile table here */
+    hz_window_t* w = &s->tiles.win;
+    w->cells_per_deg = win->cells_per_deg; w->radius_cells = win->radius_cells;
+    for(int a=0; a<2; a++) { w->origin_tile[a] = win->origin_tile[a]; w->origin_cell[a] = win->origin_cell[a]; w->ntiles[a] = 0; }
+    s->tiles_owned = true;              /* nothing of ctx->dems to release */
+    ctx->dems.cells_per_deg = w->cells_per_deg;
+    ctx->dems.radius_cells  = w->radius_cells;
+    for(int a=0; a<2; a++)
+    {
+        ctx->dems.origin_dem_lon_lat[a] = w->origin_tile[a];
+        ctx->dems.origin_dem_cellij [a] = w->origin_cell[a];
+    }
+
+    const size_t N = 2*(size_t)w->radius_cells;
+    bool result = false;
+    s->host_mosaic = malloc(N*N*sizeof(int16_t));
+    if(s->host_mosaic == NULL) MSG("out of memory for a %zux%zu mosaic", N, N);
+    else
+    {
+        memcpy(s->host_mosaic, mosaic, N*N*sizeof(int16_t));
+        result = init_device_side(ctx, s, slot, viewer_lat, viewer_lon, viewer_z, offscreen_width, offscreen_height,
+                                  s->host_mosaic, false, NULL, NULL, false);
+    }
     if(!result)
     {
         state_release(s, ctx);
@@ -390,6 +475,16 @@ void horizonator_deinit(horizonator_context_t* ctx)
     ctx->program     = 0;
     ctx->Ntriangles  = 0;
     ctx->offscreen.inited = false;
+}
+
+/* elevation of window sample (i,j) for the viewer's height: from the tiles, or
+ * from the host copy of the mosaic of a context that has no tiles (-1 outside
+ * the window, like horizonator_dem_sample) */
+static float sample_for_move(const hz_state_t* s, int i, int j)
+{
+    if(s->host_mosaic == NULL) return hz_tileset_sample(&s->tiles, i, j);
+    if(i < 0 || j < 0 || i >= s->N || j >= s->N) return -1.f;
+    return s->host_mosaic[(size_t)j*s->N + i];
 }
 
 bool horizonator_move(horizonator_context_t* ctx, float* viewer_z,
@@ -412,10 +507,10 @@ bool horizonator_move(horizonator_context_t* ctx, float* viewer_z,
     {
         const int i0 = (int)floorf(viewer_cell_i);
         const int j0 = (int)floorf(viewer_cell_j);
-        const float z00 = hz_tileset_sample(&s->tiles, i0,   j0  );
-        const float z10 = hz_tileset_sample(&s->tiles, i0+1, j0  );
-        const float z01 = hz_tileset_sample(&s->tiles, i0,   j0+1);
-        const float z11 = hz_tileset_sample(&s->tiles, i0+1, j0+1);
+        const float z00 = sample_for_move(s, i0,   j0  );
+        const float z10 = sample_for_move(s, i0+1, j0  );
+        const float z01 = sample_for_move(s, i0,   j0+1);
+        const float z11 = sample_for_move(s, i0+1, j0+1);
         z = fmaxf(fmaxf(z00, z10), fmaxf(z01, z11)) + 1.0f;
         if(viewer_z != NULL) *viewer_z = z;
     }

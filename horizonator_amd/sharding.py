@@ -151,6 +151,30 @@ def gather_strips_async(strip, width, group=None, dst=0, weights=None):
     return PendingGather(work, bins, width, world, strip, weights)
 
 
+# ---- DEM distribution: one rank reads the tiles -----------------------------------
+
+def broadcast_dem(window, mosaic, device=None, group=None, src=0):
+    """`src` passes (window tuple of horizonator.window(), int16 mosaic [N,N] as a numpy array);
+    the other ranks pass (None, None).  Every rank gets (window, mosaic as a numpy array): two
+    broadcasts, the 6 window numbers and the N*N samples (over RCCL when `device` is a GPU)."""
+    import numpy as np
+    world, rank = _world_and_rank(group)
+    if world == 1:
+        return window, mosaic
+    dev = device if device is not None else torch.device("cpu")
+    w = torch.tensor([int(x) for x in window] if rank == src else [0] * 6, dtype=torch.int64, device=dev)
+    dist.broadcast(w, src=src, group=group)
+    window = tuple(int(x) for x in w.tolist())
+    n = 2 * window[1]
+    # the samples travel as bytes: neither RCCL nor gloo has a 16-bit integer type
+    if rank == src:
+        m = torch.from_numpy(np.ascontiguousarray(mosaic, np.int16).view(np.uint8).reshape(n, 2 * n)).to(dev)
+    else:
+        m = torch.empty((n, 2 * n), dtype=torch.uint8, device=dev)
+    dist.broadcast(m, src=src, group=group)
+    return window, m.cpu().numpy().view(np.int16).reshape(n, n)
+
+
 # ---- sparse strips: terrain pixels only (include/hz_hip.h, hz_hip_pack_sparse) ---
 
 def sparse_mask_stride(widest_sector):

@@ -15,6 +15,25 @@
 extern "C" {
 #endif
 
+/* One process reads the DEM tiles, the others get the mosaic (multi-GPU: rank 0
+ * loads and decodes, then broadcasts int16 N x N over RCCL).
+ * horizonator_amd_get_window() describes the window of a context;
+ * horizonator_amd_get_mosaic() copies its samples out; with both,
+ * horizonator_amd_init_from_mosaic() makes an equivalent offscreen context
+ * (untextured) without touching a tile.  viewer_z as in horizonator_init(). */
+typedef struct
+{
+    int cells_per_deg;          /* 1200 | 3600 */
+    int radius_cells;           /* the mosaic is (2*radius_cells)^2 samples */
+    int origin_tile[2];         /* (lon,lat) of the tile that holds the window's SW corner */
+    int origin_cell[2];         /* sample index of that corner inside the tile */
+} horizonator_amd_window_t;
+bool horizonator_amd_get_window(const horizonator_context_t* ctx, horizonator_amd_window_t* win);
+bool horizonator_amd_init_from_mosaic(horizonator_context_t* ctx,
+                                      float viewer_lat, float viewer_lon, float* viewer_z,
+                                      int offscreen_width, int offscreen_height,
+                                      const horizonator_amd_window_t* win, const int16_t* mosaic);
+
 /* Like horizonator_render_offscreen() plus two more outputs, all HOST
  * pointers, each may be NULL, all [H][sector width], top row first:
  *   index  int32, id of the triangle that owns the pixel, -1 for sky.

@@ -214,3 +214,25 @@ def test_viewpoint_batch_equals_one_render_per_viewpoint(scene):
     assert list(z2) == [2500.0, 2600.0]
     ov = od.view(float(lats[1]), float(lons[1]), W, H, -180, 180, viewer_z=2600.0, zfar=30000.0)
     assert np.array_equal(d_img[1].cpu().numpy(), oracle.render(mosaic, ov, W, H, want=("bgr",))["bgr"])
+
+
+def test_context_from_a_broadcast_mosaic(scene):
+    """SURVEY.md 8e DEM distribution: a context made from another context's window + mosaic
+    (no tile read) renders the same bytes, also after moves with automatic viewer height"""
+    import horizonator_amd
+    h, od, W, H = scene
+    h2 = horizonator_amd.horizonator.from_mosaic(LAT, LON, W, H, h.window(), h.mosaic())
+    try:
+        assert h2.window() == h.window() and np.array_equal(h2.mosaic(), h.mosaic())
+        assert h2.Ntriangles == h.Ntriangles and h2.radius_cells == h.radius_cells
+        for lat, lon in [(LAT, LON), (LAT + 0.031, LON - 0.027)]:
+            a = h.render_full(-180, 180, lat=lat, lon=lon, zfar=20000.0)
+            b = h2.render_full(-180, 180, lat=lat, lon=lon, zfar=20000.0)
+            assert h2.view() == h.view()
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+        assert h2.texture_layout() == h.texture_layout()
+        with pytest.raises(ValueError):
+            horizonator_amd.horizonator.from_mosaic(LAT, LON, W, H, h.window(), h.mosaic()[:-1])
+    finally:
+        h2.close()

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import (gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
+from horizonator_amd.sharding import (broadcast_dem, gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
                                       gatherer_weights, sector_columns, sparse_header_words, sparse_mask_stride,
                                       viewpoint_slice)
 
@@ -91,6 +91,10 @@ def _worker(rank, world, port, q):
             assert np.array_equal(whole, (ref["z24"].astype(np.int64) << 8) | ref["bgr"][..., 2].astype(np.int64))
         else:
             assert parts is None
+        # DEM distribution: rank 0 has the window and the mosaic, everybody ends up with both
+        win0 = (1200, g["mosaic"].shape[0] // 2, -118, 34, 7, 11)
+        bw, bm = broadcast_dem(win0 if rank == 0 else None, g["mosaic"] if rank == 0 else None)
+        assert bw == win0 and bm.dtype == np.int16 and np.array_equal(bm, g["mosaic"])
         # 1-D buffers of one agreed length (the sparse strips of bench.py)
         mine_len = torch.tensor([100 + 50 * rank], dtype=torch.int64)
         dist.all_reduce(mine_len, op=dist.ReduceOp.MAX)
