@@ -609,11 +609,15 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
     fb.red   = malloc(npix);
     fb.tex   = tex;
     fb.color = tex ? malloc(npix*3) : NULL;
-    wvert_t* vert = malloc((size_t)N*N*sizeof(wvert_t));
+    /* vertex array: position/depth/shade always, texture coordinates only when
+     * texturing (the untextured draw is the CPU baseline of bench.py: keep it lean) */
+    typedef struct { float xn, yn, zn, wx, wy, zw, red; } pvert_t;
+    pvert_t* vert = malloc((size_t)N*N*sizeof(pvert_t));
+    float (*vst)[2] = tex ? malloc((size_t)N*N*sizeof(*vst)) : NULL;
     float* tanel = malloc((size_t)H*sizeof(float));
-    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel || (tex && !fb.color))
+    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel || (tex && (!fb.color || !vst)))
     {
-        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(tanel);
+        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel);
         return -1;
     }
 
@@ -637,14 +641,13 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
         for(int i=0; i<N; i++)
         {
             ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
-            wvert_t* w = &vert[(size_t)j*N + i];
+            pvert_t* w = &vert[(size_t)j*N + i];
             w->xn  = o.x; w->yn = o.y; w->zn = o.z;
             w->wx  = o.x*halfW + halfW;
             w->wy  = o.y*halfH + halfH;
             w->zw  = o.z*0.5f + 0.5f;
             w->red = o.red;
-            w->s = w->t = 0.f;
-            if(tex) vertex_tex(tex, v->deg_per_cell, (float)i, (float)j, &w->s, &w->t);
+            if(tex) vertex_tex(tex, v->deg_per_cell, (float)i, (float)j, &vst[(size_t)j*N + i][0], &vst[(size_t)j*N + i][1]);
         }
 
     /* Triangles of the index buffer (reference horizonator-lib.c:496-508).
@@ -661,7 +664,7 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
     if(!blk_lo || !blk_hi)
     {
         free(blk_lo); free(blk_hi);
-        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(tanel);
+        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel);
         return -1;
     }
     #pragma omp parallel for schedule(dynamic,8) num_threads(nthreads)
@@ -672,7 +675,7 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
         for(int j=jb; j<=jb+BLK && j<N; j++)
             for(int i=ib; i<=ib+BLK && i<N; i++)
             {
-                const wvert_t* w = &vert[(size_t)j*N + i];
+                const pvert_t* w = &vert[(size_t)j*N + i];
                 if(!(w->wx >= lo)) lo = w->wx;      /* NaN-proof: a NaN widens the range */
                 if(!(w->wx <= hi)) hi = w->wx;
                 if(w->xn < nlo) nlo = w->xn;
@@ -700,13 +703,18 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
                 for(int j=jb; j<jb+BLK && j<N-1; j++)
                     for(int i=ib; i<ib+BLK && i<N-1; i++)
                     {
-                        const wvert_t* v00 = &vert[(size_t)(j  )*N + i  ];
-                        const wvert_t* v10 = &vert[(size_t)(j  )*N + i+1];
-                        const wvert_t* v01 = &vert[(size_t)(j+1)*N + i  ];
-                        const wvert_t* v11 = &vert[(size_t)(j+1)*N + i+1];
+                        wvert_t q[4];               /* v00 v10 v01 v11 */
+                        for(int m=0; m<4; m++)
+                        {
+                            const size_t at = (size_t)(j + (m >> 1))*N + i + (m & 1);
+                            const pvert_t* pv = &vert[at];
+                            q[m].xn = pv->xn; q[m].yn = pv->yn; q[m].zn = pv->zn;
+                            q[m].wx = pv->wx; q[m].wy = pv->wy; q[m].zw = pv->zw; q[m].red = pv->red;
+                            q[m].s = tex ? vst[at][0] : 0.f; q[m].t = tex ? vst[at][1] : 0.f;
+                        }
                         const int32_t prim = (int32_t)(((int64_t)j*(N-1) + i)*2);
-                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, v00, v11, v01, prim  );
-                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, v00, v10, v11, prim+1);
+                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, &q[0], &q[3], &q[2], prim  );
+                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, &q[0], &q[1], &q[3], prim+1);
                     }
             }
     }
@@ -747,7 +755,7 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
         }
     }
 
-    free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(tanel);
+    free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel);
     return 0;
 }
 
@@ -801,7 +809,10 @@ void orc_stats(const int16_t* mosaic, int N, const orc_view_t* v, int W, int H,
                     int64_t bx0=X[0],bx1=X[0],by0=Y[0],by1=Y[0];
                     for(int m=1;m<3;m++){ if(X[m]<bx0)bx0=X[m]; if(X[m]>bx1)bx1=X[m]; if(Y[m]<by0)by0=Y[m]; if(Y[m]>by1)by1=Y[m]; }
                     int64_t px0=(bx0+255)>>8, px1=bx1>>8, py0=(by0+255)>>8, py1=by1>>8;
-                    if(px0<0)px0=0; if(px1>W-1)px1=W-1; if(py0<0)py0=0; if(py1>H-1)py1=H-1;
+                    if(px0<0) px0=0;
+                    if(px1>W-1) px1=W-1;
+                    if(py0<0) py0=0;
+                    if(py1>H-1) py1=H-1;
                     if(px0>px1||py0>py1) continue;
                     counts[4]++;
                     if((A->zw<0.f&&B->zw<0.f&&C->zw<0.f)||(A->zw>1.f&&B->zw>1.f&&C->zw>1.f)) continue;
