@@ -208,6 +208,26 @@ def texture_fixtures():
         print(f"texrender_{name}.npz: {W}x{H}, texture {t.tex_w}x{t.tex_h}, terrain fraction {(g['z24'] != 0xFFFFFF).mean():.3f}")
 
 
+def random_checksum_fixtures():
+    """24 seeded random configurations (hzutil.random_view_case): SHA-256 of the reference's draw"""
+    import hashlib
+    import json
+    out = {}
+    for seed in range(24):
+        c = hzutil.random_view_case(seed)
+        d = hzutil.dem_dir_for(LAT, LON, c["R"], rough=c["rough"])
+        od = oracle.Dem(LAT, LON, d, radius_cells=c["R"])
+        m = od.mosaic()
+        v = od.view(c["lat"], c["lon"], c["W"], c["H"], c["az0"], c["az1"], **c["kw"])
+        g = glsl_run.render(m, v, c["W"], c["H"])
+        out[str(seed)] = {"mosaic_sha256": hashlib.sha256(m.tobytes()).hexdigest(),
+                          "bgr_sha256": hashlib.sha256(g["bgr"].tobytes()).hexdigest(),
+                          "z24_sha256": hashlib.sha256(g["z24"].tobytes()).hexdigest(),
+                          "terrain_fraction": float((g["z24"] != 0xFFFFFF).mean())}
+        print(f"random {seed}: R={c['R']} {c['W']}x{c['H']} terrain {out[str(seed)]['terrain_fraction']:.3f}")
+    json.dump(out, open(os.path.join(OUT, "random_checksums.json"), "w"), indent=1)
+
+
 def raster_probe_fixture():
     """llvmpipe's fill rule and depth rounding on hand-made triangles (our own
     pass-through shaders; no reference code involved)"""
@@ -239,6 +259,9 @@ def main():
     if sys.argv[1:] == ["batch"]:               # only tests/golden/batch_checksums.json
         batch_checksum_fixtures()
         return
+    if sys.argv[1:] == ["random"]:              # only tests/golden/random_checksums.json
+        random_checksum_fixtures()
+        return
     if sys.argv[1:] == ["texture"]:             # only the texture path's fixtures
         texture_fixtures()
         return
@@ -260,6 +283,7 @@ def main():
     render_fixture("G8_on_vertex", 64, 512, 128, -180, 180, lat=34.0 + 500 / 1200.0, lon=-118.0 + 500 / 1200.0)
     checksum_fixtures()
     batch_checksum_fixtures()
+    random_checksum_fixtures()
     texture_fixtures()
 
 

@@ -47,6 +47,36 @@ def viewpoint_lattice(lat=VIEW_LAT, lon=VIEW_LON, side=16, half_span_deg=0.2):
     return lats, lons
 
 
+def random_view_case(seed):
+    """seeded random render configuration shared by the parity tests and by oracle/make_golden.py
+    (tests/golden/random_checksums.json holds what the reference's shaders drew for each):
+    viewpoint, azimuth extents (narrow, wide, wrapped, exactly 360), image size, depth/colour
+    extents, viewer height, sector"""
+    rng = np.random.default_rng(1000 + seed)
+    c = {}
+    c["R"] = int(rng.choice([24, 40, 75, 130, 200]))
+    c["W"] = int(rng.integers(17, 900))
+    c["H"] = int(rng.integers(9, 400))
+    c["rough"] = bool(seed % 3 == 0)
+    span = float(rng.choice([360.0, rng.uniform(0.5, 20.0), rng.uniform(20.0, 359.0)]))
+    c["az0"] = float(rng.uniform(-720.0, 720.0))
+    c["az1"] = c["az0"] + span
+    frac = c["R"] / 1200.0 * 0.8
+    c["lat"] = VIEW_LAT + float(rng.uniform(-frac, frac))
+    c["lon"] = VIEW_LON + float(rng.uniform(-frac, frac))
+    zfar = float(rng.choice([2000.0, 9000.0, 40000.0, 300000.0]))
+    znear = float(rng.choice([100.0, 1.0, 500.0]))
+    kw = dict(znear=znear, zfar=zfar)
+    if seed % 4 == 1:
+        kw.update(znear_color=float(rng.uniform(10.0, 3000.0)), zfar_color=float(rng.uniform(3500.0, 30000.0)))
+    if seed % 5 == 2:
+        kw.update(viewer_z=float(rng.uniform(0.0, 9000.0)))
+    c["kw"] = kw
+    c["c0"] = int(rng.integers(0, c["W"] - 1)) if seed % 2 else 0
+    c["c1"] = int(rng.integers(c["c0"] + 1, c["W"] + 1)) if seed % 2 else c["W"]
+    return c
+
+
 def hash_texture(th, tw, seed=0, blocky=1):
     """a deterministic map-like texture without any RNG (integer hash of the texel index, so that
     fixtures only need to store its size and seed): uint8[th,tw,3], B,G,R, row 0 = southern edge.
