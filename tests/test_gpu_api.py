@@ -236,3 +236,59 @@ def test_context_from_a_broadcast_mosaic(scene):
             horizonator_amd.horizonator.from_mosaic(LAT, LON, W, H, h.window(), h.mosaic()[:-1])
     finally:
         h2.close()
+
+
+def test_pipelined_renders_equal_waited_for_renders():
+    """The library overlaps consecutive renders (two framebuffers and queue sets, three streams).
+    A seeded random sequence of moves, azimuth / depth-extent / sector changes, texture switches,
+    picks and renders into separate device buffers, queued WITHOUT waiting in between, must leave
+    exactly what the same sequence leaves when every render is waited for."""
+    import torch
+    import horizonator_amd
+    R, W, H = 150, 700, 180
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    texels = None
+
+    def run(wait_every_time):
+        nonlocal texels
+        rng = np.random.default_rng(77)
+        h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+        outs, picks = [], []
+        try:
+            if texels is None:
+                _, _, nx, ny = h.texture_layout()
+                texels = hzutil.hash_texture(ny * 256, nx * 256, seed=3, blocky=4)
+            c0, c1 = 0, W
+            for step in range(40):
+                op = int(rng.integers(0, 7))
+                if op == 0:
+                    az0 = float(rng.uniform(-400, 400))
+                    h.set_view(az0, az0 + float(rng.choice([360.0, 90.0, 17.5])), zfar=float(rng.choice([8000.0, 30000.0])))
+                elif op == 1:
+                    h.set_view(-180, 180, lat=LAT + float(rng.uniform(-0.05, 0.05)), lon=LON + float(rng.uniform(-0.05, 0.05)),
+                               zfar=20000.0)
+                elif op == 2:
+                    c0 = int(rng.integers(0, W - 50)); c1 = int(rng.integers(c0 + 20, W + 1))
+                    h.set_sector(c0, c1)
+                elif op == 3:
+                    h.set_texture(texels if rng.integers(0, 2) else None)
+                elif op == 4 and outs:
+                    picks.append(h.pick(int(rng.integers(c0, c1)), int(rng.integers(0, H))))
+                # every step renders
+                img = torch.zeros((H, c1 - c0, 3), dtype=torch.uint8, device="cuda:0")
+                rng_ = torch.zeros((H, c1 - c0), dtype=torch.float32, device="cuda:0")
+                h.render_device(img.data_ptr(), rng_.data_ptr())
+                if wait_every_time:
+                    h.sync()
+                outs.append((img, rng_))
+            h.sync()
+            return [(a.cpu().numpy(), b.cpu().numpy()) for a, b in outs], picks
+        finally:
+            h.close()
+
+    waited, picks_w = run(True)
+    queued, picks_q = run(False)
+    assert len(waited) == len(queued) == 40
+    for k, ((ia, ra), (ib, rb)) in enumerate(zip(waited, queued)):
+        assert np.array_equal(ia, ib) and np.array_equal(ra, rb), k
+    assert picks_w == picks_q
