@@ -2044,7 +2044,7 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
                                (const int16_t*)d->d_mosaic, d->d_fb, q, p);
             HZ_CHECK(hipGetLastError());
         }
-        if(d->raster != HZ_RASTER_SCATTER)
+        if(d->raster != HZ_RASTER_SCATTER && p.inline_max < p.big_min)      /* else nothing is ever queued for it */
         {
             hipLaunchKernelGGL(k_mid, dim3(2048), dim3(64), 0, st,
                                d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)counters,
