@@ -114,45 +114,91 @@ def main():
         del mosaic
     init_s = time.perf_counter() - t0
     h.set_raster(args.raster)
-    # Rank 0 converts the whole gathered panorama on top of drawing its own sector, so it draws a
-    # narrower one (none at all with 8 GPUs): weights from the two costs measured on this workload
-    # with tools/sector_timing.py - a sector costs about 0.32 + 1.77*share ms; converting all strips
-    # takes 0.31 ms but runs on the library's second stream beside rank 0's own draw, which it slows
-    # by about 0.08 ms.
-    weights = gatherer_weights(world, 1.77, 0.08) if world > 1 else None
-    col0, col1 = sector_columns(W, world, rank, weights)
-    SW = col1 - col0
-    SW_max = max(c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world)))
-    if SW > 0:
-        h.set_sector(col0, col1)
     h.set_profiling(True)
+    from horizonator_amd.sharding import azimuth_density, balanced_layout
 
     # N = 1: draw + readback conversion into BGR8 / float32 range, both left in HBM.
-    # N > 1: every rank draws its sector and ships it as one word per pixel (z24<<8 | red8:
-    # 4 bytes instead of the 7 of the finished strip - the gather is what xGMI limits);
-    # rank 0 runs the readback conversion on what arrives, into the full-width outputs.
-    # Two sets of strip buffers: while RCCL moves the strips of panorama k, panorama k+1
-    # is already being drawn into the other set.
+    # N > 1: every rank draws its sector and ships it without the sky: the terrain pixels as one
+    # word each (z24<<8 | red8) plus a mask - the gather is what xGMI limits; rank 0 runs the
+    # readback conversion on what arrives, into the full-width outputs.  Two sets of strip buffers:
+    # while RCCL moves the strips of panorama k, panorama k+1 is already being drawn into the other.
+    #
+    # Who draws which columns.  Equal azimuth spans are not equal work (the DEM window is square in
+    # cells, cells are not square in metres, corners are further away than edges): the layout
+    # gives every rank the same share of the work behind the columns - first from the geometry
+    # (sharding.azimuth_density), then from what the ranks measure on this scene.  Rank 0 draws a
+    # bit less: it also converts the gathered strips (0.31 ms for 64 Mpix, on the library's second
+    # stream beside its own draw, which that slows by about 0.08 ms; a sector costs about
+    # 0.32 + 1.77*share ms: tools/sector_timing.py).
     NBUF = 2 if world > 1 else 1
     sparse = args.wire == "sparse"
-    MSTRIDE = sparse_mask_stride(SW_max)
-    HDR = sparse_header_words(H, MSTRIDE)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
+    weights = gatherer_weights(world, 1.77, 0.08) if world > 1 else None
+    S = {}                                                               # the current layout and its buffers
+
+    def apply_layout(layout):
+        S["layout"] = layout
+        S["col0"], S["col1"] = layout[rank]
+        S["SW"] = S["col1"] - S["col0"]
+        S["SW_max"] = max(c1 - c0 for c0, c1 in layout)
+        S["MSTRIDE"] = sparse_mask_stride(S["SW_max"])
+        S["HDR"] = sparse_header_words(H, S["MSTRIDE"])
+        if S["SW"] > 0:
+            h.set_sector(S["col0"], S["col1"])
+        if world > 1:
+            if sparse:
+                # a sparse strip: header + one word per TERRAIN pixel; room for the worst case (no sky at all)
+                S["d_pk"] = [torch.zeros(S["HDR"] + H * S["SW_max"], dtype=torch.int32, device=dev) for _ in range(NBUF)]
+            else:
+                S["d_pk"] = [torch.empty((H, S["SW"]), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+
     if world == 1:
+        apply_layout([(0, W)])
+    else:
+        cos_lat = float(np.cos(np.radians(LAT)))
+        apply_layout(balanced_layout(azimuth_density(W, -180.0, 180.0, cos_lat, floor=0.1), world, weights))
+    if world == 1 or rank == 0:
         d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
-    else:
-        if sparse:
-            # a sparse strip: header + one word per TERRAIN pixel; room for the worst case (no sky at all)
-            d_pk = [torch.zeros(HDR + H * SW_max, dtype=torch.int32, device=dev) for _ in range(NBUF)]
-        else:
-            d_pk = [torch.empty((H, SW), dtype=torch.int32, device=dev) for _ in range(NBUF)]
-        if rank == 0:
-            d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-            d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     pending = [None] * NBUF
     state = {"k": 0, "wire_words": 0, "keep": None}
-    layout = [sector_columns(W, world, r, weights) for r in range(world)]
+
+    def rebalance(rounds=2, probes=3):
+        """N > 1, before the warm-up: every rank times its own sector on this scene; columns are then
+        re-dealt so that the measured work per rank is equal (times rank 0's weight).  All ranks
+        compute the same layout from the same all-gathered numbers."""
+        for _ in range(rounds):
+            t = 0.0
+            if S["SW"] > 0:
+                ts = []
+                for _ in range(probes):
+                    t0 = time.perf_counter()
+                    if sparse:
+                        h.render_sparse(S["d_pk"][0].data_ptr(), S["MSTRIDE"])
+                    else:
+                        h.render_packed(S["d_pk"][0].data_ptr())
+                    h.sync()
+                    ts.append(time.perf_counter() - t0)
+                t = float(np.median(ts[1:]))
+            mine = torch.tensor([t], dtype=torch.float64, device=cdev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            times = [float(x.item()) for x in every]
+            density = np.zeros(W)
+            ok = True
+            for (c0, c1), tr in zip(S["layout"], times):
+                if c1 > c0:
+                    if not (tr > 0.0):
+                        ok = False
+                    density[c0:c1] = tr / (c1 - c0)
+            if not ok:
+                return
+            # a measurement that is off by more than 2x from the typical column is not believed
+            typical = float(np.median(density[density > 0.0]))
+            density = np.where(density > 0.0, np.clip(density, 0.5 * typical, 2.0 * typical), 0.0)
+            # columns nobody drew (a rank of weight 0): as costly as the average drawn column
+            density[density == 0.0] = density[density > 0.0].mean()
+            apply_layout(balanced_layout(density, world, weights))
 
     def finish(slot):
         """complete the exchange that still reads buffer set `slot`; rank 0: turn the strips
@@ -167,8 +213,8 @@ def main():
                     bufs = [t.to(dev) for t in bufs]
                 # queued on the library's conversion stream: it runs beside the draw that step() starts
                 # next; the strips stay referenced until that draw has been waited for
-                h.resolve_sparse_gathered([(t.data_ptr(), c0, c1 - c0) for t, (c0, c1) in zip(bufs, layout)],
-                                          MSTRIDE, d_img.data_ptr(), d_rng.data_ptr())
+                h.resolve_sparse_gathered([(t.data_ptr(), c0, c1 - c0) for t, (c0, c1) in zip(bufs, S["layout"])],
+                                          S["MSTRIDE"], d_img.data_ptr(), d_rng.data_ptr())
                 state["keep"] = bufs
             pending[slot] = None
             return
@@ -190,14 +236,15 @@ def main():
             h.render_device(d_img.data_ptr(), d_rng.data_ptr())
             return
         finish(slot)
+        d_pk = S["d_pk"]
         if sparse:
-            words = HDR
-            if SW > 0:
-                h.render_sparse(d_pk[slot].data_ptr(), MSTRIDE)
+            words = S["HDR"]
+            if S["SW"] > 0:
+                h.render_sparse(d_pk[slot].data_ptr(), S["MSTRIDE"])
             h.sync()                                            # own strip written, pending conversion done
             state["keep"] = None
-            if SW > 0:
-                words = HDR + int(d_pk[slot][0].item())         # header + terrain pixels of this strip
+            if S["SW"] > 0:
+                words = S["HDR"] + int(d_pk[slot][0].item())    # header + terrain pixels of this strip
             # all strips of a gather have one length: that of the longest
             n = torch.tensor([words], dtype=torch.int64, device=cdev)
             dist.all_reduce(n, op=dist.ReduceOp.MAX)
@@ -206,12 +253,12 @@ def main():
             send = d_pk[slot][:words]
             pending[slot] = gather_flat_async(send if args.backend == "nccl" else send.cpu())
             return
-        if SW > 0:
+        if S["SW"] > 0:
             h.render_packed(d_pk[slot].data_ptr())
             h.sync()
         # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
         pending[slot] = gather_strips_async(d_pk[slot] if args.backend == "nccl" else d_pk[slot].cpu(), W,
-                                            weights=weights)
+                                            layout=S["layout"])
 
     def drain():
         for slot in range(NBUF):
@@ -236,8 +283,8 @@ def main():
         one_rng = torch.empty_like(d_rng)
         h.render_device(one_img.data_ptr(), one_rng.data_ptr())
         h.sync()
-        if SW > 0:
-            h.set_sector(col0, col1)
+        if S["SW"] > 0:
+            h.set_sector(S["col0"], S["col1"])
         return bool(torch.equal(got_img, one_img) and torch.equal(got_rng, one_rng))
 
     def timed(zfar, steps, warmup):
@@ -250,7 +297,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-            if SW > 0 and world > 1:
+            if S["SW"] > 0 and world > 1:
                 kern.append(h.last_times())
         drain()                 # every one of the K panoramas is assembled on rank 0 ...
         h.sync()                # ... and, N = 1, converted ...
@@ -264,6 +311,9 @@ def main():
             dt = float(t.item())
         return dt, kern
 
+    if world > 1:
+        h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+        rebalance()
     dt, kern = timed(args.zfar, args.steps, args.warmup)
     verified = verify()
     ms_per_step = dt / args.steps * 1e3
@@ -279,7 +329,7 @@ def main():
     raster_ms, big_ms, resolve_ms, clear_ms, near_ms, total_ms = mine
     # algorithmic bytes of one render: int16 DEM read once +
     # BGR8 and float32 range written once; a sector accounts for its share
-    algo_bytes = 2 * N * N + 7 * (SW_max if world > 1 else SW) * H
+    algo_bytes = 2 * N * N + 7 * S["SW_max"] * H
     achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -324,8 +374,8 @@ def main():
             "config": {
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
-                "sector_widths": [c1 - c0 for c0, c1 in (sector_columns(W, world, r, weights) for r in range(world))],
-                "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * SW_max) if world > 1 else 0,
+                "sector_widths": [c1 - c0 for c0, c1 in S["layout"]],
+                "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * S["SW_max"]) if world > 1 else 0,
                 "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",

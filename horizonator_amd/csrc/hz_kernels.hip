@@ -990,13 +990,16 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                                    p.u.viewer_cell_j >= (float)(jbeg-1) && p.u.viewer_cell_j <= (float)(jend+1);
         if(!viewer_inside)
         {
+            /* lanes 0..3 take one corner each (the others repeat them): one
+             * transform's worth of instructions for the wave instead of four */
+            const hz_vertex_t v = hz_transform_en(&p.u, hz_east(&p.u, (float)((lane & 1) ? ib : ia)),
+                                                  hz_north(&p.u, (float)((lane & 2) ? jend : jbeg)), 0.f);
             float xlo = 2.f, xhi = -2.f;
             #pragma unroll
             for(int c=0; c<4; c++)
             {
-                const hz_vertex_t v = hz_transform_en(&p.u, hz_east(&p.u, (float)((c & 1) ? ib : ia)),
-                                                      hz_north(&p.u, (float)((c & 2) ? jend : jbeg)), 0.f);
-                xlo = hz_min(xlo, v.x); xhi = hz_max(xhi, v.x);
+                const float xc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), c));
+                xlo = hz_min(xlo, xc); xhi = hz_max(xhi, xc);
             }
             if(xhi - xlo <= 1.0f)       /* not across the +-180 degree seam */
             {

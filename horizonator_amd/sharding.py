@@ -49,6 +49,40 @@ def sector_columns(width, world_size, rank, weights=None):
     return edges[rank], edges[rank + 1]
 
 
+def balanced_layout(density, world_size, weights=None):
+    """[(col0, col1)] per rank such that every rank's columns hold the same share of `density`
+    (one non-negative number per image column: the work behind that column), scaled by
+    `weights` if given.  Equal azimuth spans are not equal work: the DEM window is square in
+    cells but cells are not square in metres, and the window's corners are further away than
+    its edges, so the terrain behind a column depends on its azimuth (azimuth_density())."""
+    import numpy as np
+    density = np.asarray(density, np.float64)
+    width = density.size
+    if weights is None:
+        weights = [1.0] * world_size
+    if len(weights) != world_size or min(weights) < 0 or sum(weights) <= 0 or density.min() < 0 or density.sum() <= 0:
+        raise ValueError("need non-negative weights and densities, not all zero")
+    cum = np.concatenate([[0.0], np.cumsum(density)])
+    targets = np.cumsum(np.asarray(weights, np.float64)) / float(sum(weights)) * cum[-1]
+    edges = [0] + [int(np.searchsorted(cum, t, side="left")) for t in targets[:-1]] + [width]
+    edges = [min(max(e, 0), width) for e in edges]
+    for k in range(1, len(edges)):
+        edges[k] = max(edges[k], edges[k - 1])
+    return [(edges[r], edges[r + 1]) for r in range(world_size)]
+
+
+def azimuth_density(width, az_deg0, az_deg1, cos_lat, floor=0.5):
+    """work behind each image column of a panorama over a square, viewer-centred DEM window:
+    proportional to the squared distance from the viewer to the window's border along the
+    column's azimuth (cells are 1 x cos_lat in metres), plus `floor` times the mean for what
+    does not depend on the terrain behind (near field, conversion)"""
+    import numpy as np
+    az = np.radians(az_deg0 + (az_deg1 - az_deg0) * (np.arange(width) + 0.5) / width)
+    r = np.minimum(1.0 / np.maximum(np.abs(np.cos(az)), 1e-9), cos_lat / np.maximum(np.abs(np.sin(az)), 1e-9))
+    w = r * r
+    return w + floor * w.mean()
+
+
 def gatherer_weights(world_size, draw_ms_per_panorama, convert_ms_per_panorama):
     """weights for sector_columns() when rank 0 also converts the gathered strips: with a
     sector costing (about) fixed + draw_ms*share and the conversion convert_ms, rank 0 and
@@ -61,11 +95,11 @@ def gatherer_weights(world_size, draw_ms_per_panorama, convert_ms_per_panorama):
     return [rho] + [1.0] * (world_size - 1)
 
 
-def _widest(width, world, weights):
-    return max(c1 - c0 for c0, c1 in (sector_columns(width, world, r, weights) for r in range(world)))
+def _layout(width, world, weights, layout):
+    return list(layout) if layout is not None else [sector_columns(width, world, r, weights) for r in range(world)]
 
 
-def gather_strips(strip, width, group=None, dst=0, weights=None):
+def gather_strips(strip, width, group=None, dst=0, weights=None, layout=None):
     """strip: this rank's [H, SW, ...] tensor (device tensor for nccl/RCCL, CPU
     tensor for gloo).  Returns the assembled [H, width, ...] tensor on `dst`,
     None elsewhere.  Strips may differ in width by one column; they travel
@@ -73,7 +107,8 @@ def gather_strips(strip, width, group=None, dst=0, weights=None):
     world, rank = _world_and_rank(group)
     if world == 1:
         return strip
-    widest = _widest(width, world, weights)
+    cols = _layout(width, world, weights, layout)
+    widest = max(c1 - c0 for c0, c1 in cols)
     sw = strip.shape[1]
     if sw < widest:
         pad_shape = list(strip.shape)
@@ -86,7 +121,7 @@ def gather_strips(strip, width, group=None, dst=0, weights=None):
         return None
     parts = []
     for r, b in enumerate(bins):
-        c0, c1 = sector_columns(width, world, r, weights)
+        c0, c1 = cols[r]
         parts.append(b[:, :c1 - c0])
     return torch.cat(parts, dim=1)
 
@@ -94,8 +129,9 @@ def gather_strips(strip, width, group=None, dst=0, weights=None):
 class PendingGather:
     """a gather of strips that is in flight (see gather_strips_async)"""
 
-    def __init__(self, work, bins, width, world, strip, weights=None):
+    def __init__(self, work, bins, width, world, strip, weights=None, layout=None):
         self._work, self._bins, self._width, self._world, self._weights = work, bins, width, world, weights
+        self._cols = _layout(width, world, weights, layout)
         self._strip = strip                 # keeps the send buffer alive until the exchange is over
 
     def parts(self):
@@ -110,7 +146,7 @@ class PendingGather:
             return None
         out = []
         for r, b in enumerate(self._bins):
-            c0, c1 = sector_columns(self._width, self._world, r, self._weights)
+            c0, c1 = self._cols[r]
             out.append((b, c0, c1 - c0))
         return out
 
@@ -124,12 +160,12 @@ class PendingGather:
             return None
         parts = []
         for r, b in enumerate(self._bins):
-            c0, c1 = sector_columns(self._width, self._world, r, self._weights)
+            c0, c1 = self._cols[r]
             parts.append(b[:, :c1 - c0])
         return torch.cat(parts, dim=1)
 
 
-def gather_strips_async(strip, width, group=None, dst=0, weights=None):
+def gather_strips_async(strip, width, group=None, dst=0, weights=None, layout=None):
     """gather_strips() without waiting: the exchange of panorama k runs (on
     RCCL's stream) while the caller renders panorama k+1 into another buffer.
     Call .result() on the returned handle before the strip's buffer is reused."""
@@ -139,7 +175,7 @@ def gather_strips_async(strip, width, group=None, dst=0, weights=None):
         done.result = lambda: strip
         done.parts = lambda: [(strip, 0, width)]
         return done
-    widest = _widest(width, world, weights)
+    widest = max(c1 - c0 for c0, c1 in _layout(width, world, weights, layout))
     sw = strip.shape[1]
     if sw < widest:
         pad_shape = list(strip.shape)
@@ -148,7 +184,7 @@ def gather_strips_async(strip, width, group=None, dst=0, weights=None):
     strip = strip.contiguous()
     bins = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
     work = dist.gather(strip, bins, dst=dst, group=group, async_op=True)
-    return PendingGather(work, bins, width, world, strip, weights)
+    return PendingGather(work, bins, width, world, strip, weights, layout)
 
 
 # ---- DEM distribution: one rank reads the tiles -----------------------------------

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import (broadcast_dem, gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
+from horizonator_amd.sharding import (azimuth_density, balanced_layout, broadcast_dem, gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
                                       gatherer_weights, sector_columns, sparse_header_words, sparse_mask_stride,
                                       viewpoint_slice)
 
@@ -49,6 +49,31 @@ def test_weighted_sectors_partition_the_columns():
     assert 1 > shares[0] > shares[1] > shares[2] == 0.0
     assert gatherer_weights(1, 1.77, 0.27) == [1.0]
     assert gatherer_weights(4, 1.0, 0.0) == [1.0] * 4
+
+
+def test_balanced_layouts_deal_equal_work():
+    """sectors by work instead of by azimuth: the geometric density of a square DEM window, and
+    arbitrary measured densities"""
+    W = 16000
+    d = azimuth_density(W, -180.0, 180.0, np.cos(np.radians(34.4)), floor=0.1)
+    assert d.shape == (W,) and d.min() > 0
+    lay = balanced_layout(d, 8)
+    assert lay[0][0] == 0 and lay[-1][1] == W and all(a[1] == b[0] for a, b in zip(lay, lay[1:]))
+    shares = [d[c0:c1].sum() / d.sum() for c0, c1 in lay]
+    assert max(shares) - min(shares) < 2e-3
+    widths = [c1 - c0 for c0, c1 in lay]
+    # north and south (image edges and centre) hold more terrain per degree than east and west
+    assert widths[0] < widths[1] and widths[3] < widths[2] and widths[4] < widths[5] and widths[7] < widths[6]
+    # by symmetry 2 and 4 ranks get equal sectors
+    assert all(abs((c1 - c0) - W // 4) <= 2 for c0, c1 in balanced_layout(d, 4))
+    # rank weights scale the shares; weight 0 = no columns
+    lay = balanced_layout(np.ones(1000), 4, [0.0, 1.0, 1.0, 2.0])
+    assert lay == [(0, 0), (0, 250), (250, 500), (500, 1000)]
+    # a step density: twice the cost on the left half
+    lay = balanced_layout(np.concatenate([np.full(500, 2.0), np.full(500, 1.0)]), 3)
+    assert lay == [(0, 250), (250, 500), (500, 1000)]
+    with pytest.raises(ValueError):
+        balanced_layout(np.zeros(10), 2)
 
 
 def _free_port():
