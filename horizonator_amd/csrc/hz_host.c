@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <pthread.h>
 
 #include "horizonator.h"
 #include "horizonator_amd.h"
@@ -47,6 +48,12 @@ typedef struct
 
 #define HZ_MAX_CONTEXTS 64
 static hz_state_t g_state[HZ_MAX_CONTEXTS];
+/* slots are handed out and given back under this lock, so that contexts may be
+ * created and destroyed from different threads; one context is used by one
+ * thread at a time (the reference is not thread-safe at all: one process-global
+ * GL context, reference horizonator-lib.c:127) */
+static bool            g_reserved[HZ_MAX_CONTEXTS];
+static pthread_mutex_t g_slots = PTHREAD_MUTEX_INITIALIZER;
 
 static hz_state_t* state_of(const horizonator_context_t* ctx)
 {
@@ -74,7 +81,10 @@ static void state_release(hz_state_t* s, horizonator_context_t* ctx)
     }
     free(s->tanel);
     free(s->host_mosaic);
+    pthread_mutex_lock(&g_slots);
     memset(s, 0, sizeof(*s));
+    g_reserved[s - g_state] = false;
+    pthread_mutex_unlock(&g_slots);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -344,11 +354,16 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
     return result;
 }
 
+/* reserves a slot; state_release() gives it back */
 static int free_slot(void)
 {
-    for(int k=0; k<HZ_MAX_CONTEXTS; k++) if(!g_state[k].live) return k;
-    MSG("Too many live contexts (max %d)", HZ_MAX_CONTEXTS);
-    return -1;
+    int slot = -1;
+    pthread_mutex_lock(&g_slots);
+    for(int k=0; k<HZ_MAX_CONTEXTS && slot < 0; k++)
+        if(!g_state[k].live && !g_reserved[k]) { g_reserved[k] = true; slot = k; }
+    pthread_mutex_unlock(&g_slots);
+    if(slot < 0) MSG("Too many live contexts (max %d)", HZ_MAX_CONTEXTS);
+    return slot;
 }
 
 bool horizonator_init(horizonator_context_t* ctx,

@@ -29,7 +29,7 @@
 /* ------------------------------------------------------------------------ */
 /* errors                                                                    */
 
-static char g_last_error[512];
+static thread_local char g_last_error[512];       /* per thread: contexts may live on different threads */
 extern "C" const char* hz_hip_last_error(void) { return g_last_error; }
 
 #define HZ_CHECK(call)                                                        \

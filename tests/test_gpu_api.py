@@ -292,3 +292,35 @@ def test_pipelined_renders_equal_waited_for_renders():
     for k, ((ia, ra), (ib, rb)) in enumerate(zip(waited, queued)):
         assert np.array_equal(ia, ib) and np.array_equal(ra, rb), k
     assert picks_w == picks_q
+
+
+def test_contexts_from_several_threads():
+    """contexts are created, used and destroyed concurrently from different threads (one thread
+    per context): same bytes as the serial render"""
+    import threading
+    import horizonator_amd
+    R, W, H = 64, 320, 80
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    ref = oracle.render(od.mosaic(), od.view(LAT, LON, W, H, -180, 180, zfar=9000.0), W, H, want=("bgr", "ranges"))
+    results, errors = [None] * 6, []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+                try:
+                    results[k] = h.render(-180, 180, zfar=9000.0)
+                finally:
+                    h.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for image, ranges in results:
+        assert np.array_equal(image, ref["bgr"]) and np.array_equal(ranges, ref["ranges"])
