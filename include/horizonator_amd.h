@@ -47,7 +47,7 @@ bool horizonator_amd_render(const horizonator_context_t* ctx,
                             int32_t* index, uint32_t* z24);
 
 /* Draw + resolve into DEVICE buffers owned by the caller (e.g. torch tensors
- * that an RCCL gather then moves); asynchronous on the context's stream,
+ * that an RCCL gather then moves); asynchronous (queued on the context's streams; consecutive renders overlap),
  * follow with horizonator_amd_sync(). */
 bool horizonator_amd_render_device(const horizonator_context_t* ctx,
                                    void* d_image, float* d_ranges,
@@ -91,7 +91,7 @@ bool horizonator_amd_render_batch(horizonator_context_t* ctx, int n,
  * final image and ranges, columns [out_col0, out_col0+ncols) of the FULL-width
  * DEVICE outputs.  The view (z extents, azimuth extents) of the resolving
  * context must be the one the strips were drawn with.  Untextured draws only.
- * Both calls are asynchronous on the context's stream. */
+ * Both calls are asynchronous: queued on the context's streams. */
 bool horizonator_amd_render_packed(const horizonator_context_t* ctx, uint32_t* d_packed);
 bool horizonator_amd_resolve_packed(const horizonator_context_t* ctx,
                                     const uint32_t* d_packed, int packed_stride, int ncols, int out_col0,

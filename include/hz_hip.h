@@ -95,7 +95,8 @@ int  hz_hip_set_profiling(hz_dev_t* d, int on);
 
 /* Takes over glClear + glDrawElements (reference horizonator-lib.c:896-897)
  * and with it vertex.glsl / geometry.glsl / fragment.glsl and the fixed
- * function raster + depth test.  Asynchronous on the context's stream. */
+ * function raster + depth test.  Asynchronous: queued on the context's streams (marching kernel, queue kernels and
+ * conversions have one each, so that consecutive draws overlap; hz_hip_sync() waits for all). */
 int  hz_hip_draw(hz_dev_t* d, const hz_view_t* view);
 
 /* Takes over the two glReadPixels + flip + depth->range conversion of
