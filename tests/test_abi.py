@@ -55,6 +55,24 @@ def test_context_layout_matches_c_compiler(tmp_path):
                    _lib.Context.dems.offset, _lib.Context.offscreen.offset, C.sizeof(_lib.DemContext)]
 
 
+def test_additional_structs_match_c_compiler(tmp_path):
+    """the ctypes mirrors of the build-side structs (hz_hip.h, horizonator_amd.h) agree with gcc"""
+    import subprocess
+    names = [("hz_view_t", _lib.View), ("hz_times_t", _lib.Times), ("hz_texparams_t", _lib.TexParams),
+             ("horizonator_amd_window_t", _lib.Window)]
+    body = "".join(f'printf("%zu ", sizeof({n}));' for n, _ in names)
+    last = [(n, t._fields_[-1][0]) for n, t in names]
+    body += "".join(f'printf("%zu ", offsetof({n}, {f}));' for n, f in last)
+    src = tmp_path / "structs.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "horizonator_amd.h"\n'
+                   'int main(void){' + body + 'return 0;}\n')
+    exe = tmp_path / "structs"
+    subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(t) for _, t in names] + [getattr(t, t._fields_[-1][0]).offset for _, t in names]
+    assert got == want
+
+
 def test_no_gpu_means_loud_failure():
     """without a HIP device the product refuses to run; it never falls back to a CPU path"""
     lib = _lib.load()
