@@ -24,6 +24,7 @@
 
 #include "hz_hip.h"
 #include "hz_raster.h"
+#include "hz_fast.h"
 #include "hz_tex.h"
 
 /* ------------------------------------------------------------------------ */
@@ -43,6 +44,29 @@ extern "C" const char* hz_hip_last_error(void) { return g_last_error; }
             return -1;                                                        \
         }                                                                     \
     } while(0)
+
+/* every entry point works on its context's device and leaves the caller's
+ * current device as it found it (a torch process has its own idea of it) */
+struct hz_device_guard
+{
+    int prev, dev; bool ok;
+    explicit hz_device_guard(int device) : prev(-1), dev(device), ok(true)
+    {
+        if(hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if(prev != dev)
+        {
+            const hipError_t e = hipSetDevice(dev);
+            if(e != hipSuccess)
+            {
+                ok = false;
+                snprintf(g_last_error, sizeof(g_last_error), "hipSetDevice(%d) -> %s", dev, hipGetErrorString(e));
+                fprintf(stderr, "hz_hip: %s\n", g_last_error);
+            }
+        }
+    }
+    ~hz_device_guard() { if(ok && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+#define HZ_ON_DEVICE(d) hz_device_guard device_guard_((d)->device); if(!device_guard_.ok) return -1
 
 /* ------------------------------------------------------------------------ */
 /* kernel parameters                                                         */
@@ -66,6 +90,11 @@ struct hz_params_t
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
+    float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
+    int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */
+    int   quad_max_dx;                 /* k_march: 256*(W/16 - 1): see the cull of whole cells                  */
+    int   debug;                       /* HZ_MARCH_DEBUG (timing splits, wrong pictures): 1 survivors are dropped,
+                                        * 2 survivors are dropped after the early depth test */
 };
 
 /* a set-up triangle as it travels between phases: through LDS inside
@@ -91,13 +120,13 @@ struct mr_queue_t
     hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
     uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
     unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item
-                                     * [3] mid records [4] clip ids                              */
+                                     * [3] mid records [4] clip ids [5] first invalid mid record */
     unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
 };
 
 /* triangles that cross a plane of the view volume: their ids go to k_clip.
  * One atomic per wave.  Ids that do not fit are not stored, but still counted:
- * counters[4] > capacity makes k_clip_rescan redo the job without the queue. */
+ * counters[4] > capacity makes k_clip redo the job without the queue. */
 __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint32_t prim, int lane)
 {
     const unsigned long long m = __ballot(want);
@@ -110,6 +139,7 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
     if(at < q.clip_capacity) q.clip[at] = prim;
 }
 
+#define HZ_NCOUNTERS 6
 #define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
@@ -251,24 +281,22 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
 /* one thread per queued triangle id.  The clipper's two polygon buffers are
  * indexed dynamically, which would put them into scratch memory: a handful of
  * threads, each a chain of dependent scratch round trips, was 40 us of every
- * draw.  They live in LDS instead (one 64-thread block per CU is plenty here). */
+ * draw.  They live in LDS instead (one 64-thread block per CU is plenty here).
+ *
+ * If the id queue overflowed (never with the default capacity) the ids that
+ * did not fit are lost: the kernel then finds every triangle that needs the
+ * clipper again, one thread per cell, and clips it on the spot.  Slow, correct. */
 __global__ __launch_bounds__(64)
 void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
 {
     __shared__ hz_cvert_t polygon[64][2][HZ_MAX_CLIPPED+1];
     const unsigned int n = q.counters[4];
-    if(n > q.clip_capacity) return;                 /* overflow: k_clip_rescan does it all */
-    for(unsigned int k = blockIdx.x*blockDim.x + threadIdx.x; k < n; k += gridDim.x*blockDim.x)
-        hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
-}
-
-/* Only when the id queue overflowed (never with the default capacity): find
- * the triangles that need the clipper again, one thread per cell, and clip them
- * on the spot.  Slow, correct, and out of the way of the fast kernels. */
-__global__ __launch_bounds__(256)
-void k_clip_rescan(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
-{
-    if(q.counters[4] <= q.clip_capacity) return;
+    if(n <= q.clip_capacity)
+    {
+        for(unsigned int k = blockIdx.x*blockDim.x + threadIdx.x; k < n; k += gridDim.x*blockDim.x)
+            hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
+        return;
+    }
     const size_t ncells = (size_t)(p.N-1)*(p.N-1);
     for(size_t cell = (size_t)blockIdx.x*blockDim.x + threadIdx.x; cell < ncells; cell += (size_t)gridDim.x*blockDim.x)
     {
@@ -276,11 +304,10 @@ void k_clip_rescan(const int16_t* __restrict__ mosaic, unsigned long long* __res
         const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i, j),   v10 = hz_vertex_at(p, mosaic, i+1, j);
         const hz_wvert_t v01 = hz_vertex_at(p, mosaic, i, j+1), v11 = hz_vertex_at(p, mosaic, i+1, j+1);
         hz_box_t box;
-        hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1];
         if(hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, bufa, bufb);
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
         if(hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, bufa, bufb);
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
     }
 }
 
@@ -640,7 +667,6 @@ void k_big(unsigned long long* __restrict__ fb,
 #define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
 #define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
-#define MR_EARLYZ_MAX_PIX 8         /* early depth test for boxes up to this many pixel centres */
 #define MR_NEAR_CELLS 128            /* round 1 of a draw: strips within this many cells of the viewer */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
@@ -667,6 +693,17 @@ __device__ static inline hz_wvert_t mr_load_vert(const mr_lds_t& L, int slot, in
     v.zw  = __uint_as_float(L.rows[slot][2][lane]); v.red = __uint_as_float(L.rows[slot][3][lane]);
     v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
     v.cmask = 0;
+    return v;
+}
+
+/* ... without the colour */
+__device__ static inline hz_wvert_t mr_load_vert_pos(const mr_lds_t& L, int slot, int lane)
+{
+    hz_wvert_t v;
+    v.xn  = 0.f; v.red = 0.f; v.cmask = 0;
+    v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
+    v.zw  = __uint_as_float(L.rows[slot][2][lane]);
+    v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
     return v;
 }
 
@@ -700,6 +737,20 @@ __device__ static inline float mr_from_east(float v)
 }
 
 
+
+__device__ static inline int32_t hz_imin(int32_t a, int32_t b) { return a < b ? a : b; }
+__device__ static inline int32_t hz_imax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+/* what k_march keeps of a vertex row for the cells between it and the next */
+struct mr_rowstate_t
+{
+    float    xn;                        /* NDC x (discard rule)                              */
+    int32_t  xs, ys;                    /* snapped position                                  */
+    uint32_t cmask;                     /* clip mask (0 in rows that are wholly inside)      */
+    int32_t  c_x, f_x, c_y, f_y;        /* first / last pixel column and row at or beyond / up to the vertex, clipped to the scissor */
+    int32_t  h_c_x, h_f_x, h_c_y, h_f_y;        /* the same, over the vertex and its eastern neighbour */
+    int32_t  h_dx, h_dy;                /* eastern neighbour's snapped position minus this vertex's */
+};
 
 /* inclusive prefix sum over the 64 lanes */
 __device__ static inline uint32_t mr_scan(uint32_t v, int lane)
@@ -782,7 +833,9 @@ void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ mid
            const unsigned int* __restrict__ counters, unsigned int midrec_capacity, hz_params_t p)
 {
     const int lane = threadIdx.x;
-    const unsigned int n = min(counters[3], midrec_capacity);
+    /* records from the first reservation that did not fit were not written
+     * (their triangles were rasterised by the marching wave instead) */
+    const unsigned int n = min(min(counters[3], counters[5]), midrec_capacity);
     for(unsigned int base = blockIdx.x*64u; base < n; base += gridDim.x*64u)
     {
         hz_rec_t r = {};
@@ -813,41 +866,56 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     hz_wvert_t a = {}, b = {}, c = {};
     hz_box_t box = {};
     int t = 0, l = 0, rowoff = 0;
+    int sa = 0, sb = 0, sc = 0, la = 0, lb = 0, lc = 0;      /* LDS row slot and lane of the three vertices */
     if(valid)
     {
         const uint32_t id = L.ids[(head + lane) & (MR_CAP-1)];
         t = id & 1; l = (id >> 1) & 63; rowoff = id >> 7;
         const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
         /* reference horizonator-lib.c:500-506 */
-        a = mr_load_vert(L, s0, l);
-        b = t == 0 ? mr_load_vert(L, s1, l+1) : mr_load_vert(L, s0, l+1);
-        c = t == 0 ? mr_load_vert(L, s1, l  ) : mr_load_vert(L, s1, l+1);
+        sa = s0;               la = l;
+        sb = t == 0 ? s1 : s0; lb = l+1;
+        sc = s1;               lc = t == 0 ? l : l+1;
+        /* position and depth now; the colour only for triangles that get drawn */
+        a = mr_load_vert_pos(L, sa, la);
+        b = mr_load_vert_pos(L, sb, lb);
+        c = mr_load_vert_pos(L, sc, lc);
         hz_tri_box(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);
     }
     if(p.early_z)
     {
-        /* early depth test (exact, see hz_tri_depth_floor): behind the ridges
-         * next to the viewer almost every survivor ends here, and a flush whose
-         * triangles are all hidden costs neither plane set-up nor pixel tests */
-        if(valid)
+        /* early depth test (exact, see hz_tri_hidden): behind the ridges next to
+         * the viewer almost every survivor ends here, and a flush whose triangles
+         * are all hidden costs neither plane set-up nor pixel tests.  For boxes of
+         * at most 4 x 2 pixel centres - nearly all of the far field's, which is
+         * seen at grazing angles - and with the eight depths fetched at once (a
+         * narrower box fetches pixels twice). */
+        if(valid && box.px1 - box.px0 <= 3 && box.py1 - box.py0 <= 1)
         {
-            const int ebw = box.px1 - box.px0 + 1, ebh = box.py1 - box.py0 + 1;
-            uint32_t zfloor;
-            if(ebw*ebh <= MR_EARLYZ_MAX_PIX && hz_tri_depth_floor(&a, &b, &c, p.z_guard, &zfloor))
-            {
-                bool hidden = true;
-                for(int py = box.py0; py <= box.py1; py++)
-                    for(int px = box.px0; px <= box.px1; px++)
-                        if((uint32_t)(fb[(size_t)py*p.SW + (px - p.col0)] >> 40) >= zfloor) hidden = false;
-                live = !hidden;
-            }
+            const uint32_t* fbw = (const uint32_t*)fb;              /* depth = the upper 24 bits of the upper word */
+            const uint32_t* row0 = fbw + 2*((size_t)box.py0*p.SW) + 1;
+            const uint32_t* row1 = fbw + 2*((size_t)box.py1*p.SW) + 1;
+            const int c0 = box.px0 - p.col0, cl = box.px1 - p.col0;
+            const int c1 = min(c0+1, cl), c2 = min(c0+2, cl);
+            uint32_t z[8];
+            z[0] = row0[2*c0]; z[1] = row0[2*c1]; z[2] = row0[2*c2]; z[3] = row0[2*cl];
+            z[4] = row1[2*c0]; z[5] = row1[2*c1]; z[6] = row1[2*c2]; z[7] = row1[2*cl];
+            const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
+            if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }
         if(dbg) { dbg[5] += (unsigned int)__popcll(__ballot(valid && !live)); }
+        if(p.debug == 2) return;
         if(!__any(live))
         {
             if(dbg) { dbg[0] += 1; dbg[1] += n; }
             return;
         }
+    }
+    if(live)
+    {
+        a.red = __uint_as_float(L.rows[sa][3][la]);
+        b.red = __uint_as_float(L.rows[sb][3][lb]);
+        c.red = __uint_as_float(L.rows[sc][3][lc]);
     }
     if(live)
     {
@@ -941,7 +1009,9 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
                 npix = 0;
             }
         }
-        /* else: queue full, they stay here */
+        /* else: queue full, they stay here; the slots from mbase on hold nothing
+         * of this draw and k_mid must not read them */
+        else if(lane == 0) atomicMin(&q.counters[5], mbase);
     }
 
     if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }
@@ -1010,24 +1080,45 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     }
 
     const float e = hz_east(&p.u, (float)ic);
+    /* the north offset of vertex row jbeg+lane, computed once per strip: a row
+     * then takes its n with one v_readlane instead of redoing the (wave-uniform)
+     * arithmetic with its IEEE division 64 lanes wide in every row */
+    const float n_tab = hz_north(&p.u, (float)(jbeg + lane));
+    auto north_of = [&](int rel) -> float
+    {
+        if(rel < 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n_tab), rel));
+        return hz_north(&p.u, (float)(jbeg + rel));
+    };
+    /* abridged division / square-root sequences (hz_fast.h): allowed where the
+     * operands are in range - the draw's uniforms (host), this strip's east
+     * offsets, each row's north offset */
+    const hzf_const_t fc = hzf_setup(&p.u);
+    const bool fast_strip = p.fast_ok && __all(hzf_in_range(e));
+    const unsigned long long fast_rows = __ballot(hzf_in_range(n_tab));
 
     /* pending-triangle ring, wave-uniform state */
     unsigned int head = 0, count = 0;
     int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
-    hz_wvert_t prev = {}, east = {};
+    /* what a row keeps of itself for the cells above it (the attributes of its
+     * vertices live in LDS, where mr_flush takes them from): per lane the
+     * vertex's NDC x, snapped position and clip mask, its pixel columns/rows
+     * (mr_vcull_t) and the same combined with the vertex one lane to the east */
+    mr_rowstate_t prev = {};
+    bool prev_simple = false;
     int16_t z_next = mosaic[(size_t)jbeg*p.N + ic];
     /* rows whose 64 vertices all lie safely beyond zfar (by horizontal distance
      * alone, 0.1% margin): their triangles can only be far-clipped, so a vertex
      * row is transformed only if it or a neighbouring row is not such a row.
      * With the default zfar = 40 km this is most of a large mosaic. */
-    float n_cur = hz_north(&p.u, (float)jbeg);
+    float n_cur = north_of(0);
     bool far_prev = true;
     bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
     for(int j = jbeg; j <= jend; j++)
     {
+        const int rel = j - jbeg;
         const float z = (float)z_next;
         if(j < jend) z_next = mosaic[(size_t)(j+1)*p.N + ic];
-        const float n_next   = hz_north(&p.u, (float)(j+1));
+        const float n_next   = (j == jend) ? 0.f : north_of(rel+1);
         const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
         const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
         const bool  skip_cells = far_prev && far_cur;               /* cell row j-1 entirely clipped */
@@ -1035,8 +1126,33 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         n_cur = n_next; far_prev = far_cur; far_cur = far_next;
         if(skip_row) continue;
 
-        const hz_wvert_t cur = hz_to_window(hz_transform_en(&p.u, e, n, z), p.halfW, p.halfH);
-        const int rel = j - jbeg;
+        const bool fast = fast_strip && (rel >= 64 ? hzf_in_range(n) : (int)((fast_rows >> rel) & 1ull));
+        const hz_vertex_t vtx = fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z);
+
+        /* window position as hz_to_window() computes it.  Two facts about the
+         * whole row are established on the way, which decide how its cells are
+         * culled: every vertex inside the view volume (clip mask 0: with
+         * xn + 1 < 0 <=> xn < -1 for every float, "inside" is |x|,|y|,|z| <= 1)
+         * and every vertex inside the guard band. */
+        hz_wvert_t cur;
+        cur.xn  = vtx.x;
+        cur.wx  = vtx.x*p.halfW + p.halfW;
+        cur.wy  = vtx.y*p.halfH + p.halfH;
+        cur.zw  = vtx.z*0.5f + 0.5f;
+        cur.red = vtx.red;
+        const float fxw = cur.wx - 0.5f, fyw = cur.wy - 0.5f;
+        const bool  in_guard  = hz_abs(fxw) <= HZ_GUARD_PX && hz_abs(fyw) <= HZ_GUARD_PX;     /* a NaN is outside */
+        /* fmaxf skips a NaN, as the six comparisons of hz_clip_mask() do (all false) */
+        const bool  in_volume = __builtin_fmaxf(__builtin_fmaxf(hz_abs(vtx.x), hz_abs(vtx.y)), hz_abs(vtx.z)) <= 1.0f;
+        const bool  cur_simple = __all(in_guard && in_volume);
+        cur.xs = (int32_t)hz_roundeven(fxw*256.f);
+        cur.ys = (int32_t)hz_roundeven(fyw*256.f);
+        cur.cmask = 0;
+        if(!cur_simple)
+        {
+            cur.cmask = hz_clip_mask(vtx.x, vtx.y, vtx.z);
+            if(!in_guard) { cur.xs = HZ_OUTSIDE_GUARD; cur.ys = 0; }
+        }
 
         /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
          * still need it are set up now (happens where survivors are sparse) */
@@ -1050,31 +1166,91 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         }
         mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
 
-        /* cell (i, j-1): v00 = prev, v01 = cur; v11 = cur of the lane to the
-         * east (one DPP wave shift per field); v10 = that lane's prev, which
-         * is what v11 was one row ago */
-        const hz_wvert_t v10 = east;
-        east.xn = mr_from_east(cur.xn);  east.wx = mr_from_east(cur.wx);  east.wy = mr_from_east(cur.wy);
-        east.zw = mr_from_east(cur.zw);  east.red = mr_from_east(cur.red);
-        east.xs = mr_from_east(cur.xs);  east.ys = mr_from_east(cur.ys);
-        east.cmask = (uint32_t)mr_from_east((int32_t)cur.cmask);
+        mr_rowstate_t now;
+        now.xn = cur.xn; now.xs = cur.xs; now.ys = cur.ys; now.cmask = cur.cmask;
+        /* pixel columns/rows of the vertex: a triangle's pixel box is the min of
+         * its vertices' first and the max of their last (hz_tri_box: the shifts
+         * are monotone), clipped to the scissor here already (max and min
+         * distribute over it) */
+        now.c_x = hz_imax((cur.xs + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, p.col0);
+        now.f_x = hz_imin(cur.xs >> HZ_SUBPIXEL_BITS, p.col1-1);
+        now.c_y = hz_imax((cur.ys + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, 0);
+        now.f_y = hz_imin(cur.ys >> HZ_SUBPIXEL_BITS, p.H-1);
+        /* the same over this vertex and its eastern neighbour (one DPP-fused
+         * instruction each: the neighbour's value never lands in a register of
+         * its own), and the step to that neighbour */
+        now.h_c_x  = hz_imin(mr_from_east(now.c_x), now.c_x);
+        now.h_f_x  = hz_imax(mr_from_east(now.f_x), now.f_x);
+        now.h_c_y  = hz_imin(mr_from_east(now.c_y), now.c_y);
+        now.h_f_y  = hz_imax(mr_from_east(now.f_y), now.f_y);
+        now.h_dx   = (int32_t)((uint32_t)mr_from_east(cur.xs) - (uint32_t)cur.xs);     /* (wraps for guard-band markers; unused then) */
+        now.h_dy   = (int32_t)((uint32_t)mr_from_east(cur.ys) - (uint32_t)cur.ys);
+
         if(j > jbeg && !skip_cells)
         {
-            const hz_wvert_t v11 = east;
+            /* cell (i, j-1): v00 = prev, v01 = cur, v10 / v11 = those of the lane to
+             * the east; triangles t0 = (v00,v11,v01), t1 = (v00,v10,v11), reference
+             * horizonator-lib.c:500-506 */
+            bool keep0 = false, keep1 = false;
+            bool simple = cur_simple && prev_simple;
+            /* steps from v00 to the cell's other vertices, in 1/256 pixel */
+            const int32_t d01x = (int32_t)((uint32_t)cur.xs - (uint32_t)prev.xs);               /* v01 - v00 */
+            const int32_t d01y = (int32_t)((uint32_t)cur.ys - (uint32_t)prev.ys);
+            const int32_t d11x = (int32_t)((uint32_t)d01x + (uint32_t)now.h_dx);                /* v11 - v00 = (v01 - v00) + (v11 - v01) */
+            const int32_t d11y = (int32_t)((uint32_t)d01y + (uint32_t)now.h_dy);
+            const int32_t d10x = prev.h_dx, d10y = prev.h_dy;                                   /* v10 - v00 */
+            if(simple)
+            {
+                /* reference geometry.glsl:21-27 (a triangle spanning more than 0.5 in
+                 * NDC x = a quarter of the image is dropped) cannot apply to a cell
+                 * whose vertices are all within quad_max_dx of v00 in snapped x: any
+                 * two of them are then less than a quarter of the image minus two
+                 * pixels apart, and window x follows NDC x to within a hundredth
+                 * of a pixel.  A wider cell is rare (the +-180 degree seam, cells
+                 * next to the viewer) and sends the row the long way. */
+                const int32_t lo = hz_imin(hz_imin(d01x, d11x), d10x), hi = hz_imax(hz_imax(d01x, d11x), d10x);
+                if(__any(has_cell && !(lo > -p.quad_max_dx && hi < p.quad_max_dx))) simple = false;
+            }
+            if(simple)
+            {
+                /* all four vertices inside the view volume and the guard band, no
+                 * discard: what is left of hz_tri_cull() is the back-face test on
+                 * the snapped area and the pixel box */
+                const int64_t area0 = (int64_t)d11x*(int64_t)d01y - (int64_t)d01x*(int64_t)d11y;
+                const int64_t area1 = (int64_t)d10x*(int64_t)d11y - (int64_t)d11x*(int64_t)d10y;
+                /* t0 = the row's own edge v01-v11 plus v00; t1 = the lower edge v00-v10 plus v11 */
+                const int32_t px0_0 = hz_imin(now.h_c_x, prev.c_x), px1_0 = hz_imax(now.h_f_x, prev.f_x);
+                const int32_t py0_0 = hz_imin(now.h_c_y, prev.c_y), py1_0 = hz_imax(now.h_f_y, prev.f_y);
+                const int32_t px0_1 = hz_imin(mr_from_east(now.c_x), prev.h_c_x), px1_1 = hz_imax(mr_from_east(now.f_x), prev.h_f_x);
+                const int32_t py0_1 = hz_imin(mr_from_east(now.c_y), prev.h_c_y), py1_1 = hz_imax(mr_from_east(now.f_y), prev.h_f_y);
+                keep0 = has_cell && area0 > 0 && px0_0 <= px1_0 && py0_0 <= py1_0;
+                keep1 = has_cell && area1 > 0 && px0_1 <= px1_1 && py0_1 <= py1_1;
+            }
+            else
+            {
+                hz_wvert_t v00 = {}, v01 = {}, v10 = {}, v11 = {};
+                v00.xn = prev.xn; v00.xs = prev.xs; v00.ys = prev.ys; v00.cmask = prev.cmask;
+                v01.xn = cur.xn;  v01.xs = cur.xs;  v01.ys = cur.ys;  v01.cmask = cur.cmask;
+                /* (the neighbour's snapped position from the step to it: the DPP read of it stays fused into that subtraction) */
+                v10.xn = mr_from_east(prev.xn);
+                v10.xs = (int32_t)((uint32_t)prev.xs + (uint32_t)prev.h_dx); v10.ys = (int32_t)((uint32_t)prev.ys + (uint32_t)prev.h_dy);
+                v10.cmask = (uint32_t)mr_from_east((int32_t)prev.cmask);
+                v11.xn = mr_from_east(cur.xn);
+                v11.xs = (int32_t)((uint32_t)cur.xs + (uint32_t)now.h_dx);   v11.ys = (int32_t)((uint32_t)cur.ys + (uint32_t)now.h_dy);
+                v11.cmask = (uint32_t)mr_from_east((int32_t)cur.cmask);
+                hz_box_t box;
+                const int verdict0 = has_cell ? hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
+                const int verdict1 = has_cell ? hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
+                /* crossing the image border or the near/far sphere: k_clip */
+                const uint32_t prim0 = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2);
+                hz_queue_clip(q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
+                hz_queue_clip(q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
+                keep0 = verdict0 == HZ_TRI_DRAW; keep1 = verdict1 == HZ_TRI_DRAW;
+            }
             #pragma unroll
             for(int t=0; t<2; t++)
             {
-                /* reference horizonator-lib.c:500-506 */
-                const hz_wvert_t& b = t == 0 ? v11 : v10;
-                const hz_wvert_t& c = t == 0 ? cur : v11;
-                hz_box_t box;
-                const int verdict = has_cell ? hz_tri_cull(&box, &prev, &b, &c, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
-                /* crossing the image border or the near/far sphere: k_clip */
-                {
-                    const uint32_t prim = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2 + t);
-                    hz_queue_clip(q, verdict == HZ_TRI_CLIP, prim, lane);
-                }
-                const int keep = verdict == HZ_TRI_DRAW;
+                const bool keep = (t == 0 ? keep0 : keep1) && p.debug != 1;
                 const unsigned long long m = __ballot(keep);
                 if(m)
                 {
@@ -1097,7 +1273,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                 }
             }
         }
-        prev = cur;
+        prev = now; prev_simple = cur_simple;
     }
     if(count)
     {
@@ -1117,8 +1293,13 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
 /* ------------------------------------------------------------------------ */
 /* resolve: framebuffer words -> BGR8, range, primitive id, z24; flips rows  */
 
+/* CLEAR: the kernel is the last reader of this draw: it leaves the framebuffer
+ * as glClear would (reference horizonator-lib.c:896), storing all ones behind
+ * itself where a triangle had written - the words of the sky (62 % of the
+ * benchmark image) are all ones already and are not written again */
+template<bool CLEAR>
 __global__ __launch_bounds__(256)
-void k_resolve(const unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
+void k_resolve(unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
                unsigned char* __restrict__ bgr, float* __restrict__ ranges,
                int32_t* __restrict__ index, uint32_t* __restrict__ z24,
                int SW, int H, float znear, float zfar)
@@ -1130,6 +1311,7 @@ void k_resolve(const unsigned long long* __restrict__ fb, const float* __restric
         const int x   = (int)(o - (size_t)yo*SW);
         const int row = H-1 - yo;               /* GL row, reference horizonator-lib.c:949-958 */
         const unsigned long long key = fb[(size_t)row*SW + x];
+        if(CLEAR && key != HZ_FB_CLEAR) fb[(size_t)row*SW + x] = HZ_FB_CLEAR;
         const uint32_t zi = (uint32_t)(key >> 40);
         const bool sky = (zi == HZ_Z24_MAX);
         if(bgr)
@@ -1169,14 +1351,16 @@ void k_resolve(const unsigned long long* __restrict__ fb, const float* __restric
  * pixel, top row first) and the gathering rank runs the conversion
  * (reference horizonator-lib.c:936-1048) on what arrives: same bytes out.
  */
+template<bool CLEAR>
 __global__ __launch_bounds__(256)
-void k_pack(const unsigned long long* __restrict__ fb, uint32_t* __restrict__ packed, int SW, int H)
+void k_pack(unsigned long long* __restrict__ fb, uint32_t* __restrict__ packed, int SW, int H)
 {
     const size_t npix = (size_t)SW*H;
     for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
     {
         const int yo = (int)(o / SW), x = (int)(o - (size_t)yo*SW);
         const unsigned long long key = fb[(size_t)(H-1 - yo)*SW + x];
+        if(CLEAR && key != HZ_FB_CLEAR) fb[(size_t)(H-1 - yo)*SW + x] = HZ_FB_CLEAR;
         packed[o] = ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
     }
 }
@@ -1229,8 +1413,9 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
  * any order in the data (row_base says where): one block per row, one atomic
  * per row for its base.  The buffer must hold HDR + H*SW words; [0] must be 0
  * on entry. */
+template<bool CLEAR>
 __global__ __launch_bounds__(256)
-void k_pack_sparse(const unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
+void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
                    int SW, int H, int mask_stride)
 {
     __shared__ uint32_t wave_count[4];
@@ -1239,7 +1424,7 @@ void k_pack_sparse(const unsigned long long* __restrict__ fb, uint32_t* __restri
     const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
     for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
     {
-        const unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
+        unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
         uint32_t* mask = out + 1 + H + (size_t)yo*mask_stride;
         /* pass 1: mask and count */
         uint32_t mine = 0;
@@ -1269,7 +1454,12 @@ void k_pack_sparse(const unsigned long long* __restrict__ fb, uint32_t* __restri
             const int c = c0 + threadIdx.x;
             unsigned long long key = 0;
             bool terrain = false;
-            if(c < SW) { key = row[c]; terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX; }
+            if(c < SW)
+            {
+                key = row[c];
+                terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX;
+                if(CLEAR && key != HZ_FB_CLEAR) row[c] = HZ_FB_CLEAR;
+            }
             const unsigned long long b = __ballot(terrain);
             __syncthreads();
             if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
@@ -1599,6 +1789,7 @@ struct hz_dev
     int col0, col1;
     int raster;
     int profiling;
+    int serial;                         /* HZ_SERIAL: the three streams are one */
 
     /* Two streams, two framebuffers.  A draw (stream) fills one framebuffer; the
      * readback conversion of that draw (rstream) reads it; the NEXT draw goes into
@@ -1619,15 +1810,25 @@ struct hz_dev
     unsigned long long* d_fb;           /* = d_fbs[fbi]                                               */
     /* the queues between the marching kernel and the kernels that finish a draw
      * (clipped, medium, large triangles): two sets, like the framebuffers, so
-     * that those kernels of panorama k (qstream) run beside k_march of k+1 */
-    hipStream_t         qstream;
-    hipEvent_t          ev_marched, ev_qfree[2];
-    hz_bigrec_t*        d_bigrec_s[2];
-    hz_bigitem_t*       d_bigitem_s[2];
-    hz_rec_t*           d_midrec_s[2];
-    uint32_t*           d_clip_s[2];
-    unsigned int*       d_big_counters_s[2];    /* [0] big records [1] big items [2] first invalid big item [3] mid records [4] clip ids */
+     * that those kernels of panorama k (qstream) run beside k_march of k+1.
+     * A two-round draw (see hz_hip_draw) has a second pair of sets for its first
+     * round, which runs on a stream of its own (nstream) beside the second round
+     * of the panorama before. */
+    hipStream_t         qstream, nstream;
+    hipEvent_t          ev_marched, ev_qfree[2], ev_near, ev_nqfree[2];
+    hz_bigrec_t*        d_bigrec_s[4];          /* [0..1] one-round draws and second rounds, [2..3] first rounds */
+    hz_bigitem_t*       d_bigitem_s[4];
+    hz_rec_t*           d_midrec_s[4];
+    uint32_t*           d_clip_s[4];
+    unsigned int*       d_big_counters_s[4];    /* HZ_NCOUNTERS each, see mr_queue_t */
     unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
+    /* the last draw: a conversion that clears the framebuffer behind itself
+     * (k_resolve<true>) consumes it; whoever wants to read it after that gets it
+     * drawn again first (fb_refill) */
+    hz_view_t           last_view;
+    int                 have_view;
+    int                 fb_consumed;
+    int                 resolve_clears;         /* HZ_RESOLVE_CLEARS=0 switches the fused clear off */
     float*              d_tanel;
     float*              h_tanel;        /* the table d_tanel holds (or is about to, in stream order) */
     int                 tanel_resident;
@@ -1643,7 +1844,7 @@ struct hz_dev
     hz_texparams_t tex;
     int            tex_on;
 
-    hipEvent_t ev[9];
+    hipEvent_t ev[10];
     int        have_times;
     hz_times_t times;
 };
@@ -1658,23 +1859,29 @@ extern "C" int hz_hip_device_count(void)
 extern "C" void hz_hip_destroy(hz_dev_t* d)
 {
     if(!d) return;
-    (void)hipSetDevice(d->device);
+    hz_device_guard device_guard_(d->device);
     if(d->stream) (void)hipStreamSynchronize(d->stream);
     if(d->qstream) (void)hipStreamSynchronize(d->qstream);
     if(d->rstream) (void)hipStreamSynchronize(d->rstream);
     (void)hipFree(d->d_mosaic);
     (void)hipFree(d->d_fbs[0]);
     (void)hipFree(d->d_fbs[1]);
-    for(int i=0; i<2; i++)
+    if(d->nstream) (void)hipStreamSynchronize(d->nstream);
+    for(int i=0; i<4; i++)
     {
         (void)hipFree(d->d_bigrec_s[i]);
         (void)hipFree(d->d_bigitem_s[i]);
         (void)hipFree(d->d_midrec_s[i]);
         (void)hipFree(d->d_clip_s[i]);
         (void)hipFree(d->d_big_counters_s[i]);
-        if(d->ev_qfree[i]) (void)hipEventDestroy(d->ev_qfree[i]);
+    }
+    for(int i=0; i<2; i++)
+    {
+        if(d->ev_qfree[i])  (void)hipEventDestroy(d->ev_qfree[i]);
+        if(d->ev_nqfree[i]) (void)hipEventDestroy(d->ev_nqfree[i]);
     }
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
+    if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
     (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
@@ -1682,23 +1889,31 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
     (void)hipFree(d->d_z24);
-    for(int k=0; k<9; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    for(int k=0; k<10; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     if(d->ev_drawn)   (void)hipEventDestroy(d->ev_drawn);
     if(d->ev_free[0]) (void)hipEventDestroy(d->ev_free[0]);
     if(d->ev_free[1]) (void)hipEventDestroy(d->ev_free[1]);
     if(d->ev_readers) (void)hipEventDestroy(d->ev_readers);
     if(d->ev_tanel)   (void)hipEventDestroy(d->ev_tanel);
+    if(d->rstream && d->rstream != d->stream) (void)hipStreamDestroy(d->rstream);
+    if(d->qstream && d->qstream != d->stream) (void)hipStreamDestroy(d->qstream);
+    if(d->nstream && d->nstream != d->stream) (void)hipStreamDestroy(d->nstream);
     if(d->stream) (void)hipStreamDestroy(d->stream);
-    if(d->rstream) (void)hipStreamDestroy(d->rstream);
-    if(d->qstream) (void)hipStreamDestroy(d->qstream);
     free(d);
 }
 
 static int create_impl(hz_dev_t* d)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
+    /* HZ_SERIAL=1 (profiling): one stream, nothing overlaps - per-kernel times
+     * of a trace are then those of each kernel alone on the chip */
+    {
+        const char* ser = getenv("HZ_SERIAL");
+        d->serial = ser && atoi(ser) != 0;
+    }
     HZ_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    HZ_CHECK(hipStreamCreateWithFlags(&d->rstream, hipStreamNonBlocking));
+    if(d->serial) d->rstream = d->stream;
+    else HZ_CHECK(hipStreamCreateWithFlags(&d->rstream, hipStreamNonBlocking));
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_drawn,   hipEventDisableTiming));
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_free[0], hipEventDisableTiming));
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_free[1], hipEventDisableTiming));
@@ -1726,23 +1941,38 @@ static int create_impl(hz_dev_t* d)
         if(cap && atoi(cap) > 0)
             d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = d->clip_capacity = (unsigned int)atoi(cap);
     }
-    HZ_CHECK(hipStreamCreateWithFlags(&d->qstream, hipStreamNonBlocking));
+    if(d->serial) d->qstream = d->nstream = d->stream;
+    else
+    {
+        HZ_CHECK(hipStreamCreateWithFlags(&d->qstream, hipStreamNonBlocking));
+        HZ_CHECK(hipStreamCreateWithFlags(&d->nstream, hipStreamNonBlocking));
+    }
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_marched, hipEventDisableTiming));
-    for(int i=0; i<2; i++)
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_near,    hipEventDisableTiming));
+    for(int i=0; i<4; i++)
     {
         HZ_CHECK(hipMalloc(&d->d_bigrec_s[i],  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
         HZ_CHECK(hipMalloc(&d->d_bigitem_s[i], (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
         HZ_CHECK(hipMalloc(&d->d_midrec_s[i],  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
         HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)d->clip_capacity*sizeof(uint32_t)));
-        HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], 5*sizeof(unsigned int)));
-        HZ_CHECK(hipEventCreateWithFlags(&d->ev_qfree[i], hipEventDisableTiming));
-        HZ_CHECK(hipEventRecord(d->ev_qfree[i], d->qstream));
+        HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], HZ_NCOUNTERS*sizeof(unsigned int)));
+    }
+    for(int i=0; i<2; i++)
+    {
+        HZ_CHECK(hipEventCreateWithFlags(&d->ev_qfree[i],  hipEventDisableTiming));
+        HZ_CHECK(hipEventCreateWithFlags(&d->ev_nqfree[i], hipEventDisableTiming));
+        HZ_CHECK(hipEventRecord(d->ev_qfree[i],  d->qstream));
+        HZ_CHECK(hipEventRecord(d->ev_nqfree[i], d->nstream));
     }
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
+    {
+        const char* rc = getenv("HZ_RESOLVE_CLEARS");
+        d->resolve_clears = !(rc && atoi(rc) == 0);
+    }
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
     d->tanel_resident = 0;
-    for(int k=0; k<9; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
+    for(int k=0; k<10; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
     return 0;
 }
 
@@ -1764,7 +1994,7 @@ extern "C" hz_dev_t* hz_hip_create(int device, int N, int width, int height)
 
 extern "C" int hz_hip_upload_mosaic(hz_dev_t* d, const int16_t* mosaic)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     HZ_CHECK(hipMemcpyAsync(d->d_mosaic, mosaic, (size_t)d->N*d->N*sizeof(int16_t), hipMemcpyHostToDevice, d->stream));
     HZ_CHECK(hipStreamSynchronize(d->stream));
     return 0;
@@ -1772,7 +2002,7 @@ extern "C" int hz_hip_upload_mosaic(hz_dev_t* d, const int16_t* mosaic)
 
 extern "C" int hz_hip_download_mosaic(hz_dev_t* d, int16_t* mosaic)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     HZ_CHECK(hipMemcpyAsync(mosaic, d->d_mosaic, (size_t)d->N*d->N*sizeof(int16_t), hipMemcpyDeviceToHost, d->stream));
     HZ_CHECK(hipStreamSynchronize(d->stream));
     return 0;
@@ -1807,7 +2037,7 @@ void k_ingest(const unsigned char* const* __restrict__ tiles, int16_t* __restric
 extern "C" int hz_hip_ingest_tiles(hz_dev_t* d, const unsigned char* const* tiles,
                                    int ntx, int nty, int cpd, int oc_x, int oc_y)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     const int nt = ntx*nty;
     const size_t tile_bytes = (size_t)(cpd+1)*(cpd+1)*2;
     unsigned char** h_ptrs = (unsigned char**)calloc(nt, sizeof(*h_ptrs));
@@ -1864,7 +2094,7 @@ extern "C" int hz_hip_set_raster(hz_dev_t* d, int which)
  * path off again */
 extern "C" int hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, const unsigned char* texels_bgr)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     if(params == NULL) { d->tex_on = 0; return 0; }
     if(params->tex_w <= 0 || params->tex_h <= 0 || params->ntiles_x <= 0 || params->ntiles_y <= 0)
     {
@@ -1897,7 +2127,15 @@ extern "C" int hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, con
 }
 
 extern "C" int hz_hip_set_profiling(hz_dev_t* d, int on) { d->profiling = on; return 0; }
-extern "C" void* hz_hip_stream(hz_dev_t* d) { return (void*)d->stream; }
+extern "C" void* hz_hip_stream(hz_dev_t* d) { return (void*)d->rstream; }
+
+extern "C" int hz_hip_wait_outputs(hz_dev_t* d, void* stream)
+{
+    HZ_ON_DEVICE(d);
+    HZ_CHECK(hipEventRecord(d->ev_tanel, d->rstream));          /* a spare untimed event */
+    HZ_CHECK(hipStreamWaitEvent((hipStream_t)stream, d->ev_tanel, 0));
+    return 0;
+}
 
 /* segment zones of k_march for this view: a cell `r` rows away from the viewer
  * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
@@ -1977,44 +2215,67 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.far_dd = (v->zfar*1.001f)*(v->zfar*1.001f);
     p.big_min    = HZ_INLINE_MAX_PIX;
     p.z_guard = 1.0f/500.0f + (float)(d->W > d->H ? d->W : d->H) * (1.0f/4194304.0f);
+    p.z_hide_k = 1.03f * p.z_guard * 16777215.f;
+    p.quad_max_dx = d->W >= 64 && d->W <= (1<<20) ? 256*(d->W/16 - 1) : 0;
+    {
+        const char* dbg = getenv("HZ_MARCH_DEBUG");
+        p.debug = dbg ? atoi(dbg) : 0;
+        const char* nf = getenv("HZ_NO_FAST_MATH");         /* diagnostics: the unabridged transform everywhere */
+        p.fast_ok = hzf_draw_ok(&p.u) && !(nf && atoi(nf) != 0);
+    }
     return p;
 }
 
-/* start of a draw / between the two rounds of a draw: empty the big and mid
- * queues; the clip-id queue only at the start (its second round then runs over
- * the ids of the first once more, which changes nothing: min is idempotent) */
-__global__ void k_reset_counters(unsigned int* counters, int all)
+/* start of a round: empty its queues */
+__global__ void k_reset_counters(unsigned int* counters)
 {
     counters[0] = 0u; counters[1] = 0u; counters[2] = 0xFFFFFFFFu; counters[3] = 0u;
-    if(all) counters[4] = 0u;
+    counters[4] = 0u; counters[5] = 0xFFFFFFFFu;
 }
 
-/* One draw =
- *   clear
- *   round 1  k_march over the strips next to the viewer, then the queue kernels:
- *            everything large on screen - the occluders - is in the framebuffer
- *   round 2  k_march over all the other strips with the early depth test on
- *            (mr_flush), then the queue kernels again
- * The split changes no result (the framebuffer word is order-independent and
- * the depth test only skips triangles that cannot win a pixel); it lets most
- * of the far field stop at the depth already there.  Measured on the benchmark
- * scene: 95% of the far survivors are rejected, k_march
- * drops from 1.33 to 1.07 ms, but round 1 runs at low occupancy and the total
- * gains only 5% (1.93 vs 2.03 ms), loses 3% with the 40 km far clip and 18% on
- * batches of smaller panoramas.  So one round without the test is the default;
- * HZ_TWO_PASS=1 selects the two rounds. */
+/* One draw = (clear: see below), then one or two rounds of
+ *   k_march            every strip (one round), or: round 1 the strips next to the
+ *                      viewer, round 2 all the others
+ *   k_clip k_mid k_big what the marching waves queued
+ * In a two-round draw the second round tests its survivors against the depth
+ * the first left in the framebuffer (mr_flush, early_z): everything large on
+ * screen - the occluders - is there by then, and in the benchmark scene 95 % of
+ * the far field's survivors stop at that test.  The split changes no result: the
+ * framebuffer word is order-independent and the test only skips triangles that
+ * cannot win a pixel (hz_tri_depth_floor).  Round 1 is a few waves followed by
+ * k_big on its own; run alone it costs most of what round 2 saves, so it runs
+ * on a stream of its own (nstream) and thereby beside round 2 of the panorama
+ * BEFORE, whenever renders are queued back to back: the framebuffers alternate,
+ * so round 1 of panorama k+1 needs nothing of panorama k.
+ *
+ *   nstream | round1 k+1: march(near) clip big | round1 k+2 ...
+ *   stream  | round2 k:   march(far, early z)  | round2 k+1 (waits ev_near)
+ *   qstream |             clip mid big of k (waits ev_marched)
+ *   rstream |             resolve k-1 (clears behind itself)      | resolve k
+ *
+ * HZ_TWO_PASS=0/1 forces one / two rounds; otherwise full-width contexts of at
+ * least HZ_TWO_PASS_MIN_MPIX (default 24) megapixels draw in two rounds. */
+static int draw_impl(hz_dev_t* d, const hz_view_t* view);
+
 extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
+    return draw_impl(d, view);
+}
+
+static int draw_impl(hz_dev_t* d, const hz_view_t* view)
+{
     hz_params_t p = make_params(d, view);
     const bool prof = d->profiling != 0;
+    d->last_view = *view; d->have_view = 1; d->fb_consumed = 0;
 
     /* The framebuffer of the previous draw goes back to "cleared" (glClear,
-     * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words) on rstream,
-     * behind the conversions of that draw and behind whatever `stream` still had
-     * to read from it; this draw takes the other framebuffer, cleared long ago. */
+     * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words): its
+     * conversion did that already (k_resolve<true>), or a memset does it now on
+     * rstream, behind the conversions of that draw and behind whatever `stream`
+     * still had to read from it; this draw takes the other framebuffer. */
+    const int prev = d->fbi, next = prev ^ 1;
     {
-        const int prev = d->fbi, next = prev ^ 1;
         HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
         HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
         HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));       /* the previous draw's last kernels (qstream) */
@@ -2024,46 +2285,43 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
         d->fb_used[prev] = 0;
         HZ_CHECK(hipEventRecord(d->ev_free[prev], d->rstream));
-        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
-        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
         d->fbi = next; d->d_fb = d->d_fbs[next];
         d->fb_used[next] = (size_t)p.SW*p.H;
     }
-    const int qs = d->fbi;                      /* queue set of this draw */
-    unsigned int* counters = d->d_big_counters_s[qs];
-    if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->stream));
-    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, counters, 1);
 
-    mr_queue_t q = { d->d_bigrec_s[qs], d->d_bigitem_s[qs], d->d_midrec_s[qs], d->d_clip_s[qs], counters,
-                     d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity, d->clip_capacity };
-    auto queue_kernels = [&](bool last, hipStream_t st) -> int
+    auto queue_set = [&](int k) -> mr_queue_t
     {
-        hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st,
-                           (const int16_t*)d->d_mosaic, d->d_fb, q, p);
+        mr_queue_t q = { d->d_bigrec_s[k], d->d_bigitem_s[k], d->d_midrec_s[k], d->d_clip_s[k], d->d_big_counters_s[k],
+                         d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity, d->clip_capacity };
+        return q;
+    };
+    auto queue_kernels = [&](const mr_queue_t& q, const hz_params_t& pp, hipStream_t st) -> int
+    {
+        hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
         HZ_CHECK(hipGetLastError());
-        if(last)
-        {
-            hipLaunchKernelGGL(k_clip_rescan, dim3(256), dim3(256), 0, st,
-                               (const int16_t*)d->d_mosaic, d->d_fb, q, p);
-            HZ_CHECK(hipGetLastError());
-        }
-        if(d->raster != HZ_RASTER_SCATTER && p.inline_max < p.big_min)      /* else nothing is ever queued for it */
+        if(d->raster != HZ_RASTER_SCATTER && pp.inline_max < pp.big_min)      /* else nothing is ever queued for it */
         {
             hipLaunchKernelGGL(k_mid, dim3(2048), dim3(64), 0, st,
-                               d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)counters,
-                               d->midrec_capacity, p);
+                               d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)q.counters,
+                               d->midrec_capacity, pp);
             HZ_CHECK(hipGetLastError());
         }
         hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, st,
                            d->d_fb, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
-                           (const unsigned int*)counters, d->bigrec_capacity, d->bigitem_capacity, p);
+                           (const unsigned int*)q.counters, d->bigrec_capacity, d->bigitem_capacity, pp);
         HZ_CHECK(hipGetLastError());
         return 0;
     };
 
+    const mr_queue_t q = queue_set(next);           /* one-round draw, or second round */
+
     if(d->raster == HZ_RASTER_SCATTER)
     {
-        if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->stream));
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
+        if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
+        hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, q.counters);
+        if(prof) HZ_CHECK(hipEventRecord(d->ev[9], d->stream));
         dim3 grid((p.N-1 + SC_CX-1)/SC_CX, (p.N-1 + SC_CY-1)/SC_CY);
         hipLaunchKernelGGL(k_scatter, grid, dim3(SC_THREADS), 0, d->stream,
                            (const int16_t*)d->d_mosaic, d->d_fb, q, p);
@@ -2075,6 +2333,7 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         /* the strips next to the viewer: within near_cells cells of the viewer's cell */
         const char* e2 = getenv("HZ_TWO_PASS");
         const char* en = getenv("HZ_NEAR_CELLS");
+        const char* em = getenv("HZ_TWO_PASS_MIN_MPIX");
         const int near_cells = en ? atoi(en) : MR_NEAR_CELLS;
         p.near_x0 = (int)floorf((p.u.viewer_cell_i - (float)near_cells)/(float)MR_COLS);
         p.near_x1 = (int)floorf((p.u.viewer_cell_i + (float)near_cells)/(float)MR_COLS);
@@ -2082,19 +2341,36 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
         if(p.near_x1 > nsx-1) p.near_x1 = nsx-1;
         p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
         p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
-        const bool two_pass = (e2 && atoi(e2) != 0) && near_cells > 0 && p.near_x1 >= p.near_x0;
+        const double min_mpix = em ? atof(em) : 24.0;
+        const bool want_two = e2 ? atoi(e2) != 0
+                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6);
+        const bool two_pass = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
         const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
         {
-            p.pass = 1; p.early_z = 0;
-            hipLaunchKernelGGL(k_march, dim3(p.near_x1 - p.near_x0 + 1, zn.total), dim3(64), 0, d->stream,
-                               (const int16_t*)d->d_mosaic, d->d_fb, q, zn, p);
+            /* round 1, on its own stream */
+            const mr_queue_t qn = queue_set(2 + next);
+            HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_free[next], 0));
+            HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_nqfree[next], 0));
+            if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
+            hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->nstream, qn.counters);
+            hz_params_t p1 = p;
+            p1.pass = 1; p1.early_z = 0;
+            hipLaunchKernelGGL(k_march, dim3(p.near_x1 - p.near_x0 + 1, zn.total), dim3(64), 0, d->nstream,
+                               (const int16_t*)d->d_mosaic, d->d_fb, qn, zn, p1);
             HZ_CHECK(hipGetLastError());
-            if(queue_kernels(false, d->stream) != 0) return -1;
-            hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, counters, 0);
+            if(queue_kernels(qn, p1, d->nstream) != 0) return -1;
+            if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
+            HZ_CHECK(hipEventRecord(d->ev_nqfree[next], d->nstream));
+            HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
+            HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
             p.pass = 2; p.early_z = 1;
         }
-        if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->stream));
+        else if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
+        hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, q.counters);
+        if(prof) HZ_CHECK(hipEventRecord(d->ev[9], d->stream));
 
         dim3 grid(nsx, zn.total);
         /* diagnostics: HZ_WAVE_TIMING=<file> dumps the duration (shader clock
@@ -2129,11 +2405,31 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     HZ_CHECK(hipEventRecord(d->ev_marched, d->stream));
     HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_marched, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
-    if(queue_kernels(true, d->qstream) != 0) return -1;
+    if(queue_kernels(q, p, d->qstream) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
-    HZ_CHECK(hipEventRecord(d->ev_qfree[qs], d->qstream));
+    HZ_CHECK(hipEventRecord(d->ev_qfree[next], d->qstream));
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
+    return 0;
+}
+
+/* a reader of the framebuffer finds it consumed (cleared by the conversion
+ * that ran before): the draw is repeated - same view, same bytes */
+static int fb_refill(hz_dev_t* d)
+{
+    if(!d->fb_consumed) return 0;
+    if(!d->have_view) { snprintf(g_last_error, sizeof(g_last_error), "nothing has been drawn yet"); return -1; }
+    const hz_view_t v = d->last_view;
+    return draw_impl(d, &v);
+}
+
+/* the conversion just queued on rstream left the framebuffer of the last draw
+ * all ones */
+static int fb_mark_consumed(hz_dev_t* d)
+{
+    d->fb_consumed = 1;
+    d->fb_used[d->fbi] = 0;
+    HZ_CHECK(hipEventRecord(d->ev_free[d->fbi], d->rstream));
     return 0;
 }
 
@@ -2148,6 +2444,7 @@ static int upload_tanel(hz_dev_t* d, const float* tanel)
     /* a different table (the azimuth extents changed): nothing queued on either
      * stream may still read the old one, and both streams must see the new one */
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->nstream));
     HZ_CHECK(hipStreamSynchronize(d->qstream));
     HZ_CHECK(hipStreamSynchronize(d->rstream));
     memcpy(d->h_tanel, tanel, bytes);
@@ -2166,7 +2463,7 @@ static int rstream_after_draw(hz_dev_t* d)
 extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                               unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     const int SW = d->col1 - d->col0;
     const bool prof = d->profiling != 0;
     if(ranges)
@@ -2178,15 +2475,24 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
         }
         if(upload_tanel(d, tanel) != 0) return -1;
     }
+    if(fb_refill(d) != 0) return -1;
     if(rstream_after_draw(d) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
     const size_t npix = (size_t)SW*d->H;
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
-                       (const unsigned long long*)d->d_fb, (const float*)d->d_tanel,
-                       bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+    /* the textured resolve reads the framebuffer after this kernel: no fused clear then */
+    const bool clears = d->resolve_clears && !(d->tex_on && bgr);
+    if(clears)
+        hipLaunchKernelGGL(k_resolve<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
+                           d->d_fb, (const float*)d->d_tanel,
+                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+    else
+        hipLaunchKernelGGL(k_resolve<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
+                           d->d_fb, (const float*)d->d_tanel,
+                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
     HZ_CHECK(hipGetLastError());
+    if(clears && fb_mark_consumed(d) != 0) return -1;
     if(d->tex_on && bgr)
     {
         /* reference fragment.glsl:17-22 instead of :15-16 for the terrain pixels */
@@ -2210,7 +2516,7 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
  * what a rank sends to the gathering rank (d_packed: DEVICE, [H][sector width]) */
 extern "C" int hz_hip_pack(hz_dev_t* d, uint32_t* d_packed)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     if(d->tex_on)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_pack: packed strips carry the shade only, not a textured colour");
@@ -2218,13 +2524,20 @@ extern "C" int hz_hip_pack(hz_dev_t* d, uint32_t* d_packed)
     }
     const int SW = d->col1 - d->col0;
     const bool prof = d->profiling != 0;
+    if(fb_refill(d) != 0) return -1;
     if(rstream_after_draw(d) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
     const size_t npix = (size_t)SW*d->H;
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
-                       (const unsigned long long*)d->d_fb, d_packed, SW, d->H);
+    if(d->resolve_clears)
+    {
+        hipLaunchKernelGGL(k_pack<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H);
+        HZ_CHECK(hipGetLastError());
+        if(fb_mark_consumed(d) != 0) return -1;
+    }
+    else
+        hipLaunchKernelGGL(k_pack<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H);
     HZ_CHECK(hipGetLastError());
     if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
     return 0;
@@ -2237,7 +2550,7 @@ extern "C" int hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const f
                                      const uint32_t* d_packed, int stride, int ncols, int out_col0,
                                      unsigned char* d_bgr, float* d_ranges)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     if(ncols <= 0 || stride < ncols || out_col0 < 0 || out_col0 + ncols > d->W)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_packed: columns [%d,%d) do not fit a %d-wide image",
@@ -2261,7 +2574,7 @@ extern "C" int hz_hip_resolve_packed(hz_dev_t* d, const hz_view_t* view, const f
  * carry information.  mask_stride >= ceil(sector width / 32). */
 extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     const int SW = d->col1 - d->col0;
     if(d->tex_on || mask_stride < (SW + 31)/32)
     {
@@ -2270,11 +2583,18 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
         return -1;
     }
     const bool prof = d->profiling != 0;
+    if(fb_refill(d) != 0) return -1;
     if(rstream_after_draw(d) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
     HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->rstream));
-    hipLaunchKernelGGL(k_pack_sparse, dim3((unsigned)d->H), dim3(256), 0, d->rstream,
-                       (const unsigned long long*)d->d_fb, d_out, SW, d->H, mask_stride);
+    if(d->resolve_clears)
+    {
+        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride);
+        HZ_CHECK(hipGetLastError());
+        if(fb_mark_consumed(d) != 0) return -1;
+    }
+    else
+        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride);
     HZ_CHECK(hipGetLastError());
     if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
     return 0;
@@ -2284,7 +2604,7 @@ extern "C" int hz_hip_resolve_sparse(hz_dev_t* d, const hz_view_t* view, const f
                                      const uint32_t* d_in, int mask_stride, int ncols, int out_col0,
                                      unsigned char* d_bgr, float* d_ranges)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     if(ncols <= 0 || mask_stride < (ncols + 31)/32 || out_col0 < 0 || out_col0 + ncols > d->W)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_sparse: columns [%d,%d) do not fit a %d-wide image",
@@ -2312,7 +2632,7 @@ static int ensure_out_buffers(hz_dev_t* d, bool bgr, bool ranges, bool index, bo
 extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                                       unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     if(ensure_out_buffers(d, bgr != NULL, ranges != NULL, index != NULL, z24 != NULL) != 0) return -1;
     if(hz_hip_resolve(d, view, tanel,
                       bgr ? d->d_bgr : NULL, ranges ? d->d_ranges : NULL,
@@ -2328,7 +2648,8 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
 
 extern "C" int hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
+    if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     if(x < d->col0 || x >= d->col1 || y < 0 || y >= d->H)
     {
@@ -2468,7 +2789,8 @@ extern "C" int hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float
                                  int cell_w, int cell_h, int cut_off_bottom_px,
                                  int nx, int ny, float* lat, float* lon)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
+    if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     if(d->col0 != 0 || d->col1 != d->W || cell_w <= 0 || cell_h <= 0 || nx <= 0 || ny <= 0)
     {
@@ -2501,7 +2823,8 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
                                      const hz_poi_t* pois, int npois,
                                      unsigned char* visible, float* label_x, float* label_y)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
+    if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     if(d->col0 != 0 || d->col1 != d->W || npois < 0)
     {
@@ -2536,10 +2859,100 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
     return rc;
 }
 
+/* ------------------------------------------------------------------------ */
+/* self-check of hz_fast.h: the abridged sequences against `/` and sqrtf       */
+
+__device__ static inline unsigned long long hz_mix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+/* a float with seeded mantissa and sign and an exponent in [elo, ehi] (biased) */
+__device__ static inline float hz_seeded_float(unsigned long long r, int elo, int ehi)
+{
+    const uint32_t mant = (uint32_t)r & 0x7FFFFFu, sign = (uint32_t)(r >> 23) & 1u;
+    const uint32_t ex = (uint32_t)elo + (uint32_t)((r >> 24) % (unsigned long long)(ehi - elo + 1));
+    return __uint_as_float((sign << 31) | (ex << 23) | mant);
+}
+
+__global__ __launch_bounds__(256)
+void k_check_fastmath(int what, unsigned long long seed, unsigned long long n, unsigned long long* mismatches, float* first_bad)
+{
+    unsigned long long bad = 0;
+    for(unsigned long long k = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; k < n; k += (unsigned long long)gridDim.x*blockDim.x)
+    {
+        float a = 0.f, b = 0.f, want = 0.f, got = 0.f;
+        bool in_range = true;
+        if(what == 0)                       /* reciprocal: every bit pattern (k = the pattern), those in range checked */
+        {
+            b = __uint_as_float((uint32_t)k);
+            in_range = hzf_in_range(b);
+            if(in_range) { want = 1.0f / b; got = hzf_rcp(b); }
+        }
+        else if(what == 1)                  /* square root: every bit pattern from 2^-96 up to the largest finite float */
+        {
+            b = __uint_as_float((uint32_t)k);
+            in_range = b >= 1.26217745e-29f && b <= 3.40282347e38f;
+            if(in_range) { want = __builtin_sqrtf(b); got = hzf_sqrt(b); }
+        }
+        else if(what == 2)                  /* division: seeded pairs, numerator 0 or 2^-60..2^60, denominator 2^-31..2^31 */
+        {
+            const unsigned long long r1 = hz_mix64(seed + 2*k), r2 = hz_mix64(seed + 2*k + 1);
+            a = hz_seeded_float(r1, 127-60, 127+60);
+            b = hz_seeded_float(r2, 127-31, 127+31);
+            /* the shapes the transform divides: any pair, min/max of a pair and 1, a shared mantissa, zero */
+            if((r2 >> 61) == 1) { const float t = hz_abs(a); a = hz_min(t, 1.0f); b = hz_max(t, 1.0f); }
+            if((r2 >> 61) == 2) a = __uint_as_float((__float_as_uint(a) & 0xFF800000u) | (__float_as_uint(b) & 0x7FFFFFu));
+            if((r1 >> 60) == 0) a = 0.0f;            /* +0 */
+            want = a / b; got = hzf_div(a, b);
+        }
+        else                                /* division by a per-draw constant through hzf_div_by: k = numerator pattern */
+        {
+            b = __uint_as_float((uint32_t)seed);
+            a = __uint_as_float((uint32_t)k);
+            const float aa = hz_abs(a);
+            /* (+0 only: a negative zero would come out positive - see hz_fast.h on why none gets here) */
+            in_range = __float_as_uint(a) == 0u || (aa >= 8.67361738e-19f && aa <= 1.15292150e18f);
+            if(in_range) { want = a / b; got = hzf_div_by(a, b, hzf_refined_rcp(b)); }
+        }
+        if(in_range && __float_as_uint(want) != __float_as_uint(got))
+        {
+            if(bad == 0 && atomicAdd(mismatches + 1, 1ull) == 0) { first_bad[0] = a; first_bad[1] = b; first_bad[2] = want; first_bad[3] = got; }
+            bad++;
+        }
+    }
+    if(bad) atomicAdd(mismatches, bad);
+}
+
+extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsigned long long n,
+                                     unsigned long long* mismatches, float* first_bad)
+{
+    hz_device_guard device_guard_(device);
+    if(!device_guard_.ok) return -1;
+    if(what < 0 || what > 3) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
+    if(what == 0 || what == 1 || what == 3) n = 1ull << 32;
+    unsigned long long* d_bad = NULL; float* d_first = NULL;
+    HZ_CHECK(hipMalloc(&d_bad, 2*sizeof(unsigned long long)));
+    HZ_CHECK(hipMalloc(&d_first, 4*sizeof(float)));
+    HZ_CHECK(hipMemset(d_bad, 0, 2*sizeof(unsigned long long)));
+    HZ_CHECK(hipMemset(d_first, 0, 4*sizeof(float)));
+    hipLaunchKernelGGL(k_check_fastmath, dim3(256*32), dim3(256), 0, 0, what, seed, n, d_bad, d_first);
+    HZ_CHECK(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    HZ_CHECK(hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost));
+    if(first_bad) HZ_CHECK(hipMemcpy(first_bad, d_first, 4*sizeof(float), hipMemcpyDeviceToHost));
+    *mismatches = h[0];
+    (void)hipFree(d_bad); (void)hipFree(d_first);
+    return 0;
+}
+
 extern "C" int hz_hip_sync(hz_dev_t* d)
 {
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->nstream));
     HZ_CHECK(hipStreamSynchronize(d->qstream));
     HZ_CHECK(hipStreamSynchronize(d->rstream));
     return 0;
@@ -2549,15 +2962,16 @@ extern "C" int hz_hip_last_times(hz_dev_t* d, hz_times_t* t)
 {
     memset(t, 0, sizeof(*t));
     if(!d->have_times) return -1;
-    HZ_CHECK(hipSetDevice(d->device));
+    HZ_ON_DEVICE(d);
     HZ_CHECK(hipStreamSynchronize(d->stream));
+    HZ_CHECK(hipStreamSynchronize(d->nstream));
     HZ_CHECK(hipStreamSynchronize(d->qstream));
     HZ_CHECK(hipStreamSynchronize(d->rstream));
     /* clear_ms is the clear this draw queued: that of the OTHER framebuffer, which runs on
      * rstream beside the draw.  total_ms is the sum of the stages, not a latency. */
     HZ_CHECK(hipEventElapsedTime(&t->clear_ms,  d->ev[0], d->ev[1]));
     HZ_CHECK(hipEventElapsedTime(&t->near_ms,   d->ev[7], d->ev[6]));
-    HZ_CHECK(hipEventElapsedTime(&t->raster_ms, d->ev[6], d->ev[2]));
+    HZ_CHECK(hipEventElapsedTime(&t->raster_ms, d->ev[9], d->ev[2]));
     HZ_CHECK(hipEventElapsedTime(&t->big_ms,    d->ev[8], d->ev[3]));
     if(d->have_times == 2)
         HZ_CHECK(hipEventElapsedTime(&t->resolve_ms, d->ev[4], d->ev[5]));

@@ -220,6 +220,28 @@ HZ_HD int hz_tri_depth_floor(const hz_wvert_t* a, const hz_wvert_t* b, const hz_
     return 1;
 }
 
+/* The same test without the division, for a box whose pixel centres all hold a
+ * depth of at most `zs` (24-bit): true only if no fragment of (a,b,c) can pass
+ * GL_LESS there.  hz_tri_depth_floor() asks  zs < floor(zmin*M - (G*guard*M + 8)),
+ * G = 1.01*num/|area|, M = 2^24-1; multiplied through by |area| that follows from
+ *     (zmin*M - (zs + 12)) * |area|  >=  num * (1.03*guard*M)      and  |area| > 0
+ * with room for this evaluation's own rounding: zmin*M and the subtraction are
+ * off by at most 1.5 units (12 instead of 9), the two products and num by a few
+ * 2^-24 relative (1.03 instead of 1.01).  `area` is the expression hz_tri_planes()
+ * divides by, bit for bit, as there.  k = 1.03*guard*M.  A NaN anywhere: false. */
+HZ_HD int hz_tri_hidden(const hz_wvert_t* a, const hz_wvert_t* b, const hz_wvert_t* c, float k, uint32_t zs)
+{
+    const hz_wvert_t *v0 = b, *v1 = a, *v2 = c;             /* as hz_tri_planes */
+    const float dx01 = v0->wx - v1->wx, dy01 = v0->wy - v1->wy;
+    const float dx20 = v2->wx - v0->wx, dy20 = v2->wy - v0->wy;
+    const float area = hz_abs(dx01*dy20 - dx20*dy01);
+    const float dz01 = hz_abs(v0->zw - v1->zw), dz20 = hz_abs(v2->zw - v0->zw);
+    const float num  = dz01*(hz_abs(dy20) + hz_abs(dx20)) + dz20*(hz_abs(dy01) + hz_abs(dx01));
+    const float zmin = hz_min(v0->zw, hz_min(v1->zw, v2->zw));
+    const float room = zmin*16777215.f - ((float)zs + 12.f);
+    return room > 0.f && area > 0.f && room*area >= num*k;
+}
+
 /* edge function of edge m (vertex m -> m+1) at pixel centre (px,py), and
  * whether a zero belongs to the triangle */
 HZ_HD int64_t hz_edge(const hz_tri_t* t, int m, int px, int py)

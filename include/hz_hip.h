@@ -203,8 +203,24 @@ int  hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, const unsigne
 int  hz_hip_sync(hz_dev_t* d);
 int  hz_hip_last_times(hz_dev_t* d, hz_times_t* t);
 
-/* the HIP stream the context launches on, as a void* (hipStream_t) */
+/* A context works on several HIP streams of its own.  Everything a conversion
+ * (hz_hip_resolve*, hz_hip_pack*) writes is written on ONE of them, in call
+ * order: hz_hip_stream() returns that stream (as a void* = hipStream_t), so work
+ * queued on it after a conversion sees the outputs.  hz_hip_wait_outputs() makes
+ * any other stream of the caller's wait (on the device, not on the host) for
+ * every conversion queued so far.  hz_hip_sync() waits on the host. */
 void* hz_hip_stream(hz_dev_t* d);
+int   hz_hip_wait_outputs(hz_dev_t* d, void* stream);
+
+/* Self-check of the marching kernel's abridged division / square-root
+ * sequences (horizonator_amd/csrc/hz_fast.h) against the device's own `/` and
+ * sqrtf, bit for bit.  what: 0 reciprocal, every float32 pattern in the
+ * sequences' operand range; 1 square root, every pattern from 2^-96 up; 2
+ * division, n seeded pairs; 3 division by the constant whose bit pattern is
+ * `seed`, every numerator pattern.  *mismatches = how many differed (0 is the
+ * only acceptable answer); first_bad (4 floats: a, b, want, got) may be NULL. */
+int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsigned long long n,
+                           unsigned long long* mismatches, float* first_bad);
 
 const char* hz_hip_last_error(void);
 

@@ -100,35 +100,57 @@ def hip_available():
         return False
 
 
-def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None, tex=None, texels=None):
-    """mosaic int16[N,N] + uniform values -> dict(bgr, ranges, index, z24) via
-    hz_hip_create / upload_mosaic / draw / resolve_to_host.  `view` is anything
-    with the hz_view_t field names as attributes (e.g. oracle.OrcView)."""
-    import ctypes as C
-    lib = hzlib.load()
-    mosaic = np.ascontiguousarray(mosaic, np.int16)
-    N = mosaic.shape[0]
-    if col1 is None:
-        col1 = W
-    SW = col1 - col0
-    dev = lib.hz_hip_create(0, N, W, H)
-    if not dev:
-        raise RuntimeError("hz_hip_create failed: " + lib.hz_hip_last_error().decode())
-    try:
-        assert lib.hz_hip_upload_mosaic(dev, mosaic.ctypes.data) == 0
-        assert lib.hz_hip_set_sector(dev, col0, col1) == 0
-        assert lib.hz_hip_set_raster(dev, raster) == 0
+class HipDev:
+    """one device context of the C-ABI shim (include/hz_hip.h), reusable for several draws:
+    hz_hip_create / upload_mosaic, then render(view, col0, col1) = set_sector / draw /
+    resolve_to_host as often as wanted"""
+
+    def __init__(self, mosaic, W, H, raster=0):
+        self.lib = hzlib.load()
+        mosaic = np.ascontiguousarray(mosaic, np.int16)
+        self.W, self.H = W, H
+        self.dev = self.lib.hz_hip_create(0, mosaic.shape[0], W, H)
+        if not self.dev:
+            raise RuntimeError("hz_hip_create failed: " + self.lib.hz_hip_last_error().decode())
+        try:
+            assert self.lib.hz_hip_upload_mosaic(self.dev, mosaic.ctypes.data) == 0
+            assert self.lib.hz_hip_set_raster(self.dev, raster) == 0
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if self.dev:
+            self.lib.hz_hip_destroy(self.dev)
+            self.dev = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_texture(self, tex, texels):
+        """texture path: `tex` is anything with the hz_texparams_t field names (e.g. oracle.OrcTex)"""
+        import ctypes as C
+        tp = hzlib.TexParams()
+        for name, _ in hzlib.TexParams._fields_:
+            setattr(tp, name, getattr(tex, name))
+        texels = np.ascontiguousarray(texels, np.uint8)
+        assert texels.shape == (tp.tex_h, tp.tex_w, 3)
+        assert self.lib.hz_hip_set_texture(self.dev, C.byref(tp), texels.ctypes.data) == 0, self.lib.hz_hip_last_error()
+
+    def render(self, view, col0=0, col1=None, tanel=None):
+        """`view` is anything with the hz_view_t field names as attributes (e.g. oracle.OrcView)"""
+        import ctypes as C
+        lib, W, H = self.lib, self.W, self.H
+        if col1 is None:
+            col1 = W
+        SW = col1 - col0
+        assert lib.hz_hip_set_sector(self.dev, col0, col1) == 0
         v = hzlib.View()
         for name, _ in hzlib.View._fields_:
             setattr(v, name, getattr(view, name))
-        if tex is not None:
-            # texture path: `tex` is anything with the hz_texparams_t field names (e.g. oracle.OrcTex)
-            tp = hzlib.TexParams()
-            for name, _ in hzlib.TexParams._fields_:
-                setattr(tp, name, getattr(tex, name))
-            texels = np.ascontiguousarray(texels, np.uint8)
-            assert texels.shape == (tp.tex_h, tp.tex_w, 3)
-            assert lib.hz_hip_set_texture(dev, C.byref(tp), texels.ctypes.data) == 0, lib.hz_hip_last_error()
         if tanel is None:
             # tan(elevation) per GL row exactly as hz_host.c / the reference derive it
             import oracle
@@ -136,13 +158,20 @@ def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None, tex=
         tanel = np.ascontiguousarray(tanel, np.float32)
         out = {"bgr": np.empty((H, SW, 3), np.uint8), "ranges": np.empty((H, SW), np.float32),
                "index": np.empty((H, SW), np.int32), "z24": np.empty((H, SW), np.uint32)}
-        assert lib.hz_hip_draw(dev, C.byref(v)) == 0, lib.hz_hip_last_error()
-        rc = lib.hz_hip_resolve_to_host(dev, C.byref(v), tanel.ctypes.data, out["bgr"].ctypes.data,
+        assert lib.hz_hip_draw(self.dev, C.byref(v)) == 0, lib.hz_hip_last_error()
+        rc = lib.hz_hip_resolve_to_host(self.dev, C.byref(v), tanel.ctypes.data, out["bgr"].ctypes.data,
                                         out["ranges"].ctypes.data, out["index"].ctypes.data, out["z24"].ctypes.data)
         assert rc == 0, lib.hz_hip_last_error()
         return out
-    finally:
-        lib.hz_hip_destroy(dev)
+
+
+def hip_render(mosaic, view, W, H, col0=0, col1=None, raster=0, tanel=None, tex=None, texels=None):
+    """mosaic int16[N,N] + uniform values -> dict(bgr, ranges, index, z24) via
+    hz_hip_create / upload_mosaic / draw / resolve_to_host on a fresh context"""
+    with HipDev(mosaic, W, H, raster=raster) as dev:
+        if tex is not None:
+            dev.set_texture(tex, texels)
+        return dev.render(view, col0, col1, tanel=tanel)
 
 
 def assert_same_render(a, b, what=""):

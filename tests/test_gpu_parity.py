@@ -125,6 +125,28 @@ def test_full_triangle_queues_fall_back_correctly(raster, capacity, monkeypatch)
         assert np.array_equal(sect[k], orc[k][:, 300:425]), k
 
 
+def test_full_medium_queue_on_a_reused_context(monkeypatch):
+    """a context whose medium-triangle queue overflowed keeps records of earlier draws (other
+    sectors, other viewpoints) in the slots the overflowing draw reserved but never wrote: the
+    queue kernel must not read them.  Draws with different sectors and viewers on ONE context,
+    each against the oracle."""
+    monkeypatch.setenv("HZ_QUEUE_CAPACITY", "40")
+    R, W, H = 200, 1000, 250
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    views = [(od.view(LAT, LON, W, H, -180, 180, zfar=30000.0), 600, 1000),
+             (od.view(LAT + 0.01, LON - 0.02, W, H, -180, 180, zfar=30000.0), 0, 130),
+             (od.view(LAT - 0.02, LON + 0.01, W, H, -100, 120, zfar=30000.0), 300, 425),
+             (od.view(LAT, LON, W, H, -180, 180, zfar=30000.0), 0, 1000)]
+    with hzutil.HipDev(m, W, H, raster=2) as dev:
+        for rounds in range(2):
+            for k, (v, c0, c1) in enumerate(views):
+                got = dev.render(v, c0, c1)
+                ref = oracle.render(m, v, W, H, c0, c1)
+                hzutil.assert_same_render(got, ref, f"round {rounds} draw {k} sector [{c0},{c1})")
+
+
 def test_two_round_draw_with_early_depth_test_changes_nothing(monkeypatch):
     """HZ_TWO_PASS=1: strips next to the viewer first, then everything else with the early
     depth test of mr_flush (hz_tri_depth_floor) - byte-identical to the one-round draw and to
@@ -135,7 +157,7 @@ def test_two_round_draw_with_early_depth_test_changes_nothing(monkeypatch):
     m = od.mosaic()
     for viewer_z in (-1.0, 6000.0):
         v = od.view(LAT, LON, W, H, -180, 180, viewer_z=viewer_z, zfar=200000.0)
-        monkeypatch.delenv("HZ_TWO_PASS", raising=False)
+        monkeypatch.setenv("HZ_TWO_PASS", "0")
         one = hzutil.hip_render(m, v, W, H, raster=2)
         monkeypatch.setenv("HZ_TWO_PASS", "1")
         monkeypatch.setenv("HZ_NEAR_CELLS", "96")
