@@ -265,7 +265,7 @@ typedef struct { float xn, yn, zn, wx, wy, zw, red, s, t; } wvert_t;
 typedef struct
 {
     uint32_t* depth;        /* [H][SW] GL row order, 24-bit values */
-    int32_t*  prim;         /* [H][SW] */
+    uint32_t* prim;         /* [H][SW]; ids reach beyond 2^31 on BASELINE's largest mosaic */
     uint8_t*  red;          /* [H][SW] */
     uint8_t*  color;        /* [H][SW][3] B,G,R - textured draws only */
     const orc_tex_t* tex;   /* NULL: fragment.glsl:15-16, else :17-22 */
@@ -274,7 +274,7 @@ typedef struct
 
 /* rasterise one window-space triangle (a whole one, or a piece the clipper made) */
 static void raster_triangle(target_t* fb, int x_lo, int x_hi,
-                            const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+                            const wvert_t* A, const wvert_t* B, const wvert_t* C, uint32_t prim)
 {
     /* positions relative to the pixel-centre grid (llvmpipe's "pixel offset"):
      * centres at integers */
@@ -443,10 +443,10 @@ static wvert_t clip_interp(float t, const wvert_t* out, const wvert_t* in, float
 }
 
 static void clip_and_raster(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
-                            const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim);
+                            const wvert_t* A, const wvert_t* B, const wvert_t* C, uint32_t prim);
 
 static void draw_triangle(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
-                          const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+                          const wvert_t* A, const wvert_t* B, const wvert_t* C, uint32_t prim)
 {
     /* reference geometry.glsl:21-27 */
     float xmax = A->xn > B->xn ? A->xn : B->xn; xmax = xmax > C->xn ? xmax : C->xn;
@@ -457,7 +457,7 @@ static void draw_triangle(target_t* fb, int x_lo, int x_hi, float halfW, float h
 
 /* what GL does with a primitive after the geometry stage */
 static void clip_and_raster(target_t* fb, int x_lo, int x_hi, float halfW, float halfH,
-                            const wvert_t* A, const wvert_t* B, const wvert_t* C, int32_t prim)
+                            const wvert_t* A, const wvert_t* B, const wvert_t* C, uint32_t prim)
 {
     const unsigned ma = clip_mask(A), mb = clip_mask(B), mc = clip_mask(C);
     if(ma & mb & mc) return;                        /* wholly outside one plane */
@@ -532,7 +532,7 @@ int orc_draw_triangles(const float* tris, int ntri, int W, int H, const orc_tex_
     target_t fb;
     fb.SW = W; fb.H = H; fb.col0 = 0; fb.col1 = W;
     fb.depth = malloc(npix*sizeof(uint32_t));
-    fb.prim  = malloc(npix*sizeof(int32_t));
+    fb.prim  = malloc(npix*sizeof(uint32_t));
     fb.red   = malloc(npix);
     fb.tex   = tex;
     fb.color = tex ? malloc(npix*3) : NULL;
@@ -541,7 +541,7 @@ int orc_draw_triangles(const float* tris, int ntri, int W, int H, const orc_tex_
         free(fb.depth); free(fb.prim); free(fb.red); free(fb.color);
         return -1;
     }
-    for(size_t k=0; k<npix; k++) { fb.depth[k] = 0xFFFFFFu; fb.prim[k] = -1; fb.red[k] = 0; }
+    for(size_t k=0; k<npix; k++) { fb.depth[k] = 0xFFFFFFu; fb.prim[k] = 0xFFFFFFFFu; fb.red[k] = 0; }
     const float halfW = (float)W*0.5f, halfH = (float)H*0.5f;
     for(int n=0; n<ntri; n++)
     {
@@ -553,7 +553,7 @@ int orc_draw_triangles(const float* tris, int ntri, int W, int H, const orc_tex_
             v[m].wx = p[0]*halfW + halfW; v[m].wy = p[1]*halfH + halfH; v[m].zw = p[2]*0.5f + 0.5f;
             v[m].red = p[3]; v[m].s = p[4]; v[m].t = p[5];
         }
-        clip_and_raster(&fb, 0, W-1, halfW, halfH, &v[0], &v[1], &v[2], n);
+        clip_and_raster(&fb, 0, W-1, halfW, halfH, &v[0], &v[1], &v[2], (uint32_t)n);
     }
     for(size_t k=0; k<npix; k++)
     {
@@ -605,24 +605,31 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
     target_t fb;
     fb.SW = SW; fb.H = H; fb.col0 = col0; fb.col1 = col1;
     fb.depth = malloc(npix*sizeof(uint32_t));
-    fb.prim  = malloc(npix*sizeof(int32_t));
+    fb.prim  = malloc(npix*sizeof(uint32_t));
     fb.red   = malloc(npix);
     fb.tex   = tex;
     fb.color = tex ? malloc(npix*3) : NULL;
-    /* vertex array: position/depth/shade always, texture coordinates only when
-     * texturing (the untextured draw is the CPU baseline of bench.py: keep it lean) */
+    /* vertices: position/depth/shade always, texture coordinates only when
+     * texturing (the untextured draw is the CPU baseline of bench.py: keep it
+     * lean).  The grid is walked in bands of BLK cell rows, and only the BLK+1
+     * vertex rows of the current band are kept: 3.1 G triangles over 39600^2
+     * samples (BASELINE configs[4]) would otherwise need 44 GB of vertices. */
+    enum { BLK = 32 };
     typedef struct { float xn, yn, zn, wx, wy, zw, red; } pvert_t;
-    pvert_t* vert = malloc((size_t)N*N*sizeof(pvert_t));
-    float (*vst)[2] = tex ? malloc((size_t)N*N*sizeof(*vst)) : NULL;
+    pvert_t* vert = malloc((size_t)(BLK+1)*N*sizeof(pvert_t));
+    float (*vst)[2] = tex ? malloc((size_t)(BLK+1)*N*sizeof(*vst)) : NULL;
     float* tanel = malloc((size_t)H*sizeof(float));
-    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel || (tex && (!fb.color || !vst)))
+    const int nb = (N-1 + BLK-1)/BLK;
+    int* blk_lo = malloc((size_t)nb*sizeof(int));
+    int* blk_hi = malloc((size_t)nb*sizeof(int));
+    if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel || !blk_lo || !blk_hi || (tex && (!fb.color || !vst)))
     {
-        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel);
+        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel); free(blk_lo); free(blk_hi);
         return -1;
     }
 
     /* glClear: depth 1.0 -> 0xFFFFFF, colour (0,0,1) (reference horizonator-lib.c:185,896) */
-    for(size_t k=0; k<npix; k++) { fb.depth[k] = 0xFFFFFFu; fb.prim[k] = -1; fb.red[k] = 0; }
+    for(size_t k=0; k<npix; k++) { fb.depth[k] = 0xFFFFFFu; fb.prim[k] = 0xFFFFFFFFu; fb.red[k] = 0; }
 
 #ifdef _OPENMP
     if(nthreads <= 0) nthreads = omp_get_max_threads();
@@ -634,89 +641,84 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
     az_constants(v, &c, &k);
     const float halfW = (float)W*0.5f, halfH = (float)H*0.5f;
 
-    /* vertex stage + viewport transform (glViewport(0,0,W,H), reference
-     * horizonator-lib.c:657; depth range 0..1) */
-    #pragma omp parallel for schedule(static) num_threads(nthreads)
-    for(int j=0; j<N; j++)
-        for(int i=0; i<N; i++)
-        {
-            ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
-            pvert_t* w = &vert[(size_t)j*N + i];
-            w->xn  = o.x; w->yn = o.y; w->zn = o.z;
-            w->wx  = o.x*halfW + halfW;
-            w->wy  = o.y*halfH + halfH;
-            w->zw  = o.z*0.5f + 0.5f;
-            w->red = o.red;
-            if(tex) vertex_tex(tex, v->deg_per_cell, (float)i, (float)j, &vst[(size_t)j*N + i][0], &vst[(size_t)j*N + i][1]);
-        }
+    for(int jb=0; jb<N-1; jb+=BLK)
+    {
+        const int jrows = (jb + BLK < N-1 ? BLK : N-1 - jb) + 1;        /* vertex rows of this band */
+        /* vertex stage + viewport transform (glViewport(0,0,W,H), reference
+         * horizonator-lib.c:657; depth range 0..1) */
+        #pragma omp parallel for schedule(static) num_threads(nthreads) collapse(2)
+        for(int jj=0; jj<jrows; jj++)
+            for(int i=0; i<N; i++)
+            {
+                const int j = jb + jj;
+                ndc_t o = vertex_shader(v, c, k, (float)i, (float)j, (float)mosaic[(size_t)j*N + i]);
+                pvert_t* w = &vert[(size_t)jj*N + i];
+                w->xn  = o.x; w->yn = o.y; w->zn = o.z;
+                w->wx  = o.x*halfW + halfW;
+                w->wy  = o.y*halfH + halfH;
+                w->zw  = o.z*0.5f + 0.5f;
+                w->red = o.red;
+                if(tex) vertex_tex(tex, v->deg_per_cell, (float)i, (float)j, &vst[(size_t)jj*N + i][0], &vst[(size_t)jj*N + i][1]);
+            }
 
-    /* Triangles of the index buffer (reference horizonator-lib.c:496-508).
-     * GL draws them in order and keeps the first of equal depths (GL_LESS);
-     * draw_triangle() implements that as "lower depth wins, then lower
-     * primitive id", which does not depend on the order of processing.  So the
-     * grid can be walked in blocks of 32x32 cells, threads owning disjoint
-     * column strips of the image and skipping the blocks whose window x-range
-     * (from their 33x33 vertices) misses their strip. */
-    enum { BLK = 32 };
-    const int nb = (N-1 + BLK-1)/BLK;
-    int* blk_lo = malloc((size_t)nb*nb*sizeof(int));
-    int* blk_hi = malloc((size_t)nb*nb*sizeof(int));
-    if(!blk_lo || !blk_hi)
-    {
-        free(blk_lo); free(blk_hi);
-        free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel);
-        return -1;
-    }
-    #pragma omp parallel for schedule(dynamic,8) num_threads(nthreads)
-    for(int b=0; b<nb*nb; b++)
-    {
-        const int jb = (b/nb)*BLK, ib = (b%nb)*BLK;
-        float lo = INFINITY, hi = -INFINITY, nlo = INFINITY, nhi = -INFINITY;
-        for(int j=jb; j<=jb+BLK && j<N; j++)
-            for(int i=ib; i<=ib+BLK && i<N; i++)
-            {
-                const pvert_t* w = &vert[(size_t)j*N + i];
-                if(!(w->wx >= lo)) lo = w->wx;      /* NaN-proof: a NaN widens the range */
-                if(!(w->wx <= hi)) hi = w->wx;
-                if(w->xn < nlo) nlo = w->xn;
-                if(w->xn > nhi) nhi = w->xn;
-            }
-        /* a block that reaches across the +-180 degree seam (or holds the
-         * viewer) spans the image: keep it for every strip */
-        if(!(lo == lo) || !(hi == hi) || nhi - nlo > 0.5f) { blk_lo[b] = INT32_MIN; blk_hi[b] = INT32_MAX; }
-        else { blk_lo[b] = (int)floorf(fmaxf(lo, -1e9f)) - 2; blk_hi[b] = (int)ceilf(fminf(hi, 1e9f)) + 2; }
-    }
-    #pragma omp parallel num_threads(nthreads)
-    {
+        /* Triangles of the index buffer (reference horizonator-lib.c:496-508).
+         * GL draws them in order and keeps the first of equal depths (GL_LESS);
+         * draw_triangle() implements that as "lower depth wins, then lower
+         * primitive id", which does not depend on the order of processing.  So the
+         * band can be walked in blocks of 32x32 cells, threads owning disjoint
+         * column strips of the image and skipping the blocks whose window x-range
+         * (from their 33x33 vertices) misses their strip. */
+        #pragma omp parallel for schedule(dynamic,8) num_threads(nthreads)
+        for(int b=0; b<nb; b++)
+        {
+            const int ib = b*BLK;
+            float lo = INFINITY, hi = -INFINITY, nlo = INFINITY, nhi = -INFINITY;
+            for(int jj=0; jj<jrows; jj++)
+                for(int i=ib; i<=ib+BLK && i<N; i++)
+                {
+                    const pvert_t* w = &vert[(size_t)jj*N + i];
+                    if(!(w->wx >= lo)) lo = w->wx;      /* NaN-proof: a NaN widens the range */
+                    if(!(w->wx <= hi)) hi = w->wx;
+                    if(w->xn < nlo) nlo = w->xn;
+                    if(w->xn > nhi) nhi = w->xn;
+                }
+            /* a block that reaches across the +-180 degree seam (or holds the
+             * viewer) spans the image: keep it for every strip */
+            if(!(lo == lo) || !(hi == hi) || nhi - nlo > 0.5f) { blk_lo[b] = INT32_MIN; blk_hi[b] = INT32_MAX; }
+            else { blk_lo[b] = (int)floorf(fmaxf(lo, -1e9f)) - 2; blk_hi[b] = (int)ceilf(fminf(hi, 1e9f)) + 2; }
+        }
+        #pragma omp parallel num_threads(nthreads)
+        {
 #ifdef _OPENMP
-        const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+            const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
 #else
-        const int tid = 0, nth = 1;
+            const int tid = 0, nth = 1;
 #endif
-        const int x_lo = col0 + (int)((long long)SW*tid/nth);
-        const int x_hi = col0 + (int)((long long)SW*(tid+1)/nth) - 1;
-        if(x_lo <= x_hi)
-            for(int b=0; b<nb*nb; b++)
-            {
-                if(blk_hi[b] < x_lo || blk_lo[b] > x_hi) continue;
-                const int jb = (b/nb)*BLK, ib = (b%nb)*BLK;
-                for(int j=jb; j<jb+BLK && j<N-1; j++)
-                    for(int i=ib; i<ib+BLK && i<N-1; i++)
-                    {
-                        wvert_t q[4];               /* v00 v10 v01 v11 */
-                        for(int m=0; m<4; m++)
+            const int x_lo = col0 + (int)((long long)SW*tid/nth);
+            const int x_hi = col0 + (int)((long long)SW*(tid+1)/nth) - 1;
+            if(x_lo <= x_hi)
+                for(int b=0; b<nb; b++)
+                {
+                    if(blk_hi[b] < x_lo || blk_lo[b] > x_hi) continue;
+                    const int ib = b*BLK;
+                    for(int jj=0; jj<jrows-1; jj++)
+                        for(int i=ib; i<ib+BLK && i<N-1; i++)
                         {
-                            const size_t at = (size_t)(j + (m >> 1))*N + i + (m & 1);
-                            const pvert_t* pv = &vert[at];
-                            q[m].xn = pv->xn; q[m].yn = pv->yn; q[m].zn = pv->zn;
-                            q[m].wx = pv->wx; q[m].wy = pv->wy; q[m].zw = pv->zw; q[m].red = pv->red;
-                            q[m].s = tex ? vst[at][0] : 0.f; q[m].t = tex ? vst[at][1] : 0.f;
+                            wvert_t q[4];               /* v00 v10 v01 v11 */
+                            for(int m=0; m<4; m++)
+                            {
+                                const size_t at = (size_t)(jj + (m >> 1))*N + i + (m & 1);
+                                const pvert_t* pv = &vert[at];
+                                q[m].xn = pv->xn; q[m].yn = pv->yn; q[m].zn = pv->zn;
+                                q[m].wx = pv->wx; q[m].wy = pv->wy; q[m].zw = pv->zw; q[m].red = pv->red;
+                                q[m].s = tex ? vst[at][0] : 0.f; q[m].t = tex ? vst[at][1] : 0.f;
+                            }
+                            const uint32_t prim = (uint32_t)(((uint64_t)(jb + jj)*(uint64_t)(N-1) + (uint64_t)i)*2u);
+                            draw_triangle(&fb, x_lo, x_hi, halfW, halfH, &q[0], &q[3], &q[2], prim  );
+                            draw_triangle(&fb, x_lo, x_hi, halfW, halfH, &q[0], &q[1], &q[3], prim+1);
                         }
-                        const int32_t prim = (int32_t)(((int64_t)j*(N-1) + i)*2);
-                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, &q[0], &q[3], &q[2], prim  );
-                        draw_triangle(&fb, x_lo, x_hi, halfW, halfH, &q[0], &q[1], &q[3], prim+1);
-                    }
-            }
+                }
+        }
     }
     free(blk_lo); free(blk_hi);
 
@@ -738,7 +740,7 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
                 bgr[3*o+2] = sky ? 0 : fb.red[at];
                 if(tex && !sky) { bgr[3*o+0] = fb.color[3*at+0]; bgr[3*o+1] = fb.color[3*at+1]; bgr[3*o+2] = fb.color[3*at+2]; }
             }
-            if(index) index[o] = fb.prim[at];
+            if(index) index[o] = (int32_t)fb.prim[at];      /* sky: -1 */
             if(z24)   z24[o]   = zi;
             if(ranges)
             {
