@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--raster", type=int, default=0, help="HZ_RASTER_* (0 auto, 1 scatter, 2 march)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary zfar=40 km measurement")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-inclusive measurement (results into host memory)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="diagnostics: gloo moves the strips through host memory (lets two ranks share one GPU "
                          "to exercise the N>1 loop where only one GPU exists); the driver's runs use nccl = RCCL")
@@ -359,6 +360,38 @@ def main():
                               "ms_per_step": dt40 / n40 * 1e3,
                               "note": "API default far clip (reference horizonator.h:10); >95% of the mosaic is beyond it"}
 
+    # the reference hands its results over in HOST memory.  The same panorama through
+    # horizonator_render_offscreen() into caller-owned (pageable) buffers that the caller keeps, as
+    # standalone.c does: device time + PCIe + the copy into the caller's pages.  Reported beside
+    # `value`, never as it.
+    host_incl = None
+    if rank == 0 and world == 1 and not args.no_host:
+        h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+        himg = np.zeros((H, W, 3), np.uint8)
+        hrng = np.zeros((H, W), np.float32)
+        ts = []
+        for k in range(7):
+            t0 = time.perf_counter()
+            h.render_into(himg, hrng)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts[2:]))
+        del ts[:]
+        for k in range(5):          # the reference's Python wrapper: new arrays (untouched pages) on every call
+            t0 = time.perf_counter()
+            fresh = h.render(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+            ts.append(time.perf_counter() - t0)
+            del fresh
+        t_fresh = float(np.median(ts[1:]))
+        h.render_device(d_img.data_ptr(), d_rng.data_ptr())
+        h.sync()
+        same = bool(np.array_equal(himg, d_img.cpu().numpy()) and np.array_equal(hrng, d_rng.cpu().numpy()))
+        host_incl = {"ms": t * 1e3, "value": W * H / t / 1e6, "unit": "Mpix/s", "results_GBps": 7 * W * H / t / 1e9,
+                     "what": "horizonator_render_offscreen() into the caller's pageable host buffers (BGR8 + float32 range), "
+                             "one call waited for: draw + conversion + PCIe + copy into the caller's pages",
+                     "ms_with_fresh_arrays_per_call": t_fresh * 1e3,
+                     "copy_threads": int(os.environ.get("HZ_COPY_THREADS", "12")), "equals_device_render": same}
+        del himg, hrng
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU restatement (oracle/, test infrastructure) timed on this box's
@@ -402,6 +435,8 @@ def main():
             },
             "cpu_baseline": cpu,
         }
+        if host_incl is not None:
+            line["host_inclusive"] = host_incl
         if verified is not None:
             line["gathered_panorama_equals_single_gpu_render"] = verified
         line.update(extra)

@@ -202,6 +202,20 @@ class horizonator:
             return ranges
         return image, ranges
 
+    def render_into(self, image=None, ranges=None):
+        """horizonator_render_offscreen() (reference horizonator.h:165-169) with the current view
+        into caller-owned numpy arrays (uint8[H,W,3] / float32[H,W], C-contiguous; either may be
+        None): what a C caller that keeps its buffers does."""
+        c0, c1 = self.sector
+        H, W = self._ctx.offscreen.height, c1 - c0
+        for a, shape, dt in ((image, (H, W, 3), np.uint8), (ranges, (H, W), np.float32)):
+            if a is not None and (a.shape != shape or a.dtype != dt or not a.flags.c_contiguous):
+                raise ValueError("render_into() wants C-contiguous %s arrays of shape %s" % (np.dtype(dt).name, shape))
+        if not self._lib.horizonator_render_offscreen(C.byref(self._ctx),
+                                                      image.ctypes.data if image is not None else None,
+                                                      ranges.ctypes.data if ranges is not None else None):
+            raise RuntimeError("horizonator_render_offscreen() failed")
+
     # -- build-side additions ------------------------------------------------
     def render_full(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
                     az_extents_use_pixel_centers=False,

@@ -22,6 +22,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 #include "hz_hip.h"
 #include "hz_raster.h"
 #include "hz_fast.h"
@@ -140,6 +145,8 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
 }
 
 #define HZ_NCOUNTERS 6
+#define HZ_STAGE_SLOTS 4                /* pinned staging chunks in flight between device and caller memory */
+#define HZ_STAGE_BYTES ((size_t)32 << 20)
 #define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
@@ -1833,6 +1840,14 @@ struct hz_dev
     float*              h_tanel;        /* the table d_tanel holds (or is about to, in stream order) */
     int                 tanel_resident;
 
+    /* results into caller-owned host memory (hz_hip_resolve_to_host): a ring of
+     * pinned staging chunks between the copy engine and the threads that move
+     * the bytes on into the caller's (pageable) buffers */
+    hipStream_t    cstream;
+    unsigned char* h_stage[HZ_STAGE_SLOTS];
+    hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
+    hipEvent_t     ev_resolved;
+
     /* internal output buffers for *_to_host */
     unsigned char* d_bgr;
     float*         d_ranges;
@@ -1885,6 +1900,14 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
+    if(d->cstream) (void)hipStreamSynchronize(d->cstream);
+    for(int k=0; k<HZ_STAGE_SLOTS; k++)
+    {
+        if(d->h_stage[k])  (void)hipHostFree(d->h_stage[k]);
+        if(d->ev_stage[k]) (void)hipEventDestroy(d->ev_stage[k]);
+    }
+    if(d->ev_resolved) (void)hipEventDestroy(d->ev_resolved);
+    if(d->cstream) (void)hipStreamDestroy(d->cstream);
     (void)hipFree(d->d_bgr);
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
@@ -2629,6 +2652,131 @@ static int ensure_out_buffers(hz_dev_t* d, bool bgr, bool ranges, bool index, bo
     return 0;
 }
 
+/* ---- device -> caller memory --------------------------------------------------
+ * The reference hands its results to the caller in host memory (reference
+ * horizonator-lib.c:936-1048: glReadPixels into the caller's buffers), and so
+ * does horizonator_render_offscreen().  A 16000x4000 panorama is 448 MB of
+ * results.  hipMemcpy into pageable memory moves that at ~11 GB/s (40 ms,
+ * twenty times the render); here the copy engine writes 32 MB chunks into a
+ * ring of pinned staging buffers at the link's rate while a few host threads
+ * move each finished chunk on into the caller's buffer (non-temporal memcpy,
+ * the pages faulted in by several threads at once), chunk k+1.. being in
+ * flight meanwhile. */
+struct hz_copy_pool
+{
+    std::mutex m, busy;                 /* busy: one copy() at a time (contexts on several threads share the pool) */
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    unsigned char* dst = nullptr; const unsigned char* src = nullptr;
+    size_t bytes = 0;
+    int nparts = 0, next = 0, pending = 0;
+    unsigned long long generation = 0;
+    bool stop = false;
+
+    explicit hz_copy_pool(int n)
+    {
+        for(int k=0; k<n; k++) threads.emplace_back([this] { run(); });
+    }
+    ~hz_copy_pool()
+    {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv_work.notify_all();
+        for(auto& t : threads) t.join();
+    }
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for(;;)
+        {
+            cv_work.wait(lk, [this] { return stop || next < nparts; });
+            if(stop) return;
+            const int part = next++;
+            const size_t lo = bytes*(size_t)part/(size_t)nparts, hi = bytes*(size_t)(part+1)/(size_t)nparts;
+            unsigned char* d = dst; const unsigned char* s = src;
+            lk.unlock();
+            memcpy(d + lo, s + lo, hi - lo);
+            lk.lock();
+            if(--pending == 0) cv_done.notify_all();
+        }
+    }
+    /* dst[0..bytes) = src[0..bytes), split over the pool; returns when done */
+    void copy(unsigned char* d, const unsigned char* s, size_t n)
+    {
+        std::lock_guard<std::mutex> one(busy);
+        std::unique_lock<std::mutex> lk(m);
+        dst = d; src = s; bytes = n;
+        nparts = (int)threads.size(); if((size_t)nparts > n/65536 + 1) nparts = (int)(n/65536 + 1);
+        next = 0; pending = nparts;
+        cv_work.notify_all();
+        cv_done.wait(lk, [this] { return pending == 0; });
+        nparts = 0;
+    }
+};
+
+static hz_copy_pool* copy_pool()
+{
+    /* one pool per process, created on first use, never torn down (its threads
+     * sleep on a condition variable) */
+    static hz_copy_pool* pool = nullptr;
+    static std::mutex m;
+    std::lock_guard<std::mutex> g(m);
+    if(!pool)
+    {
+        int n = 12;
+        const char* e = getenv("HZ_COPY_THREADS");
+        if(e && atoi(e) > 0) n = atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if(hw && (unsigned)n > hw) n = (int)hw;
+        pool = new hz_copy_pool(n);
+    }
+    return pool;
+}
+
+static int ensure_staging(hz_dev_t* d)
+{
+    if(d->cstream) return 0;
+    HZ_CHECK(hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking));
+    HZ_CHECK(hipEventCreateWithFlags(&d->ev_resolved, hipEventDisableTiming));
+    for(int k=0; k<HZ_STAGE_SLOTS; k++)
+    {
+        HZ_CHECK(hipHostMalloc((void**)&d->h_stage[k], HZ_STAGE_BYTES, hipHostMallocDefault));
+        HZ_CHECK(hipEventCreateWithFlags(&d->ev_stage[k], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+/* the device buffers of the last conversion -> the caller's host buffers */
+static int copy_out(hz_dev_t* d, int nbuf, unsigned char* const* dst, const unsigned char* const* src, const size_t* bytes)
+{
+    if(ensure_staging(d) != 0) return -1;
+    hz_copy_pool* pool = copy_pool();
+    HZ_CHECK(hipEventRecord(d->ev_resolved, d->rstream));
+    HZ_CHECK(hipStreamWaitEvent(d->cstream, d->ev_resolved, 0));
+    /* the chunks of all buffers, in order */
+    struct chunk_t { unsigned char* dst; const unsigned char* src; size_t n; };
+    std::vector<chunk_t> chunks;
+    for(int b=0; b<nbuf; b++)
+        for(size_t off=0; off<bytes[b]; off+=HZ_STAGE_BYTES)
+            chunks.push_back({ dst[b] + off, src[b] + off, bytes[b] - off < HZ_STAGE_BYTES ? bytes[b] - off : HZ_STAGE_BYTES });
+    const size_t nc = chunks.size();
+    size_t issued = 0;
+    for(size_t k=0; k<nc; k++)
+    {
+        /* keep the copy engine HZ_STAGE_SLOTS chunks ahead of the host threads; slot
+         * k % SLOTS is free again once chunk k - SLOTS has been moved out (done below, in order) */
+        for(; issued < nc && issued < k + HZ_STAGE_SLOTS; issued++)
+        {
+            const int slot = (int)(issued % HZ_STAGE_SLOTS);
+            HZ_CHECK(hipMemcpyAsync(d->h_stage[slot], chunks[issued].src, chunks[issued].n, hipMemcpyDeviceToHost, d->cstream));
+            HZ_CHECK(hipEventRecord(d->ev_stage[slot], d->cstream));
+        }
+        const int slot = (int)(k % HZ_STAGE_SLOTS);
+        HZ_CHECK(hipEventSynchronize(d->ev_stage[slot]));
+        pool->copy(chunks[k].dst, d->h_stage[slot], chunks[k].n);
+    }
+    return 0;
+}
+
 extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                                       unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
@@ -2638,12 +2786,20 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
                       bgr ? d->d_bgr : NULL, ranges ? d->d_ranges : NULL,
                       index ? d->d_index : NULL, z24 ? d->d_z24 : NULL) != 0) return -1;
     const size_t npix = (size_t)(d->col1 - d->col0)*d->H;
-    if(bgr)    HZ_CHECK(hipMemcpyAsync(bgr,    d->d_bgr,    npix*3,                hipMemcpyDeviceToHost, d->rstream));
-    if(ranges) HZ_CHECK(hipMemcpyAsync(ranges, d->d_ranges, npix*sizeof(float),    hipMemcpyDeviceToHost, d->rstream));
-    if(index)  HZ_CHECK(hipMemcpyAsync(index,  d->d_index,  npix*sizeof(int32_t),  hipMemcpyDeviceToHost, d->rstream));
-    if(z24)    HZ_CHECK(hipMemcpyAsync(z24,    d->d_z24,    npix*sizeof(uint32_t), hipMemcpyDeviceToHost, d->rstream));
-    HZ_CHECK(hipStreamSynchronize(d->rstream));
-    return 0;
+    unsigned char* dst[4]; const unsigned char* src[4]; size_t bytes[4];
+    int nbuf = 0;
+    if(bgr)    { dst[nbuf] = bgr;                    src[nbuf] = d->d_bgr;                            bytes[nbuf++] = npix*3; }
+    if(ranges) { dst[nbuf] = (unsigned char*)ranges; src[nbuf] = (const unsigned char*)d->d_ranges;   bytes[nbuf++] = npix*sizeof(float); }
+    if(index)  { dst[nbuf] = (unsigned char*)index;  src[nbuf] = (const unsigned char*)d->d_index;    bytes[nbuf++] = npix*sizeof(int32_t); }
+    if(z24)    { dst[nbuf] = (unsigned char*)z24;    src[nbuf] = (const unsigned char*)d->d_z24;      bytes[nbuf++] = npix*sizeof(uint32_t); }
+    const char* plain = getenv("HZ_PLAIN_COPY");        /* diagnostics: hipMemcpy into the caller's memory as it is */
+    if(plain && atoi(plain) != 0)
+    {
+        for(int b=0; b<nbuf; b++) HZ_CHECK(hipMemcpyAsync(dst[b], src[b], bytes[b], hipMemcpyDeviceToHost, d->rstream));
+        HZ_CHECK(hipStreamSynchronize(d->rstream));
+        return 0;
+    }
+    return copy_out(d, nbuf, dst, src, bytes);
 }
 
 extern "C" int hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24)
