@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhorizonator.so")
+# HORIZONATOR_AMD_LIB: another build of the same library (tests/test_sanitizers.py loads the
+# address/undefined-behaviour-sanitized host code through it)
+LIB_PATH = os.environ.get("HORIZONATOR_AMD_LIB") or os.path.join(_HERE, "libhorizonator.so")
 DEMGEN_PATH = os.path.join(_HERE, "libhzdemgen.so")
 
 MAX_NDEMS_IJ = 4

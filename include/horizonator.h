@@ -9,12 +9,28 @@
  * What is different from the GL implementation, by design:
  *  - only the offscreen mode exists (use_glut = true, offscreen_width > 0).
  *    The two on-screen modes need a GL context and return false with a message.
- *  - render_texture = true returns false (needs network tile downloads).
+ *  - render_texture = true works as in the reference (0.7*map + 0.3*shade,
+ *    reference fragment.glsl:17-22) with the map tiles read from
+ *    dir_tiles/tiles_name/12/X/Y.png; nothing is ever downloaded (no
+ *    system("wget"), reference horizonator-lib.c:291-320): a tile that is not on
+ *    disk makes horizonator_init() fail with a message, whatever allow_downloads
+ *    says, and tiles_url_fmt is not used.
  *  - ctx->program holds a handle to the device-side state; the uniform_* slots
  *    are unused and left 0.  Everything a caller is known to read
  *    (Ntriangles, offscreen.*, viewer_lat/lon, dems.*) stays truthful.
- *  - one context = one HIP stream; calls on a context are synchronous and a
- *    context must be driven from one thread at a time.
+ *  - a context works on HIP streams of its own.  horizonator_render_offscreen()
+ *    and horizonator_pick() return when their results are in the caller's memory
+ *    (as the reference's do); horizonator_redraw() only queues the draw; the
+ *    horizonator_amd_*_device calls of horizonator_amd.h queue work and need
+ *    horizonator_amd_sync().  A context must be driven from one thread at a
+ *    time; different contexts may live on different threads.
+ *  - every call leaves the calling thread's current HIP device as it found it.
+ *  - annotate() (reference annotator.h:10-25; the reference's Makefile:21 puts
+ *    annotator.c into its libhorizonator) is NOT in this library: it is cairo
+ *    drawing, out of scope here.  The reference's standalone.c calls it
+ *    (standalone.c:499) and therefore links against this library PLUS the
+ *    reference's own annotator.o; annotator.c itself only
+ *    needs horizonator_project/_unproject, which are exported.
  */
 #pragma once
 
@@ -88,8 +104,10 @@ static bool horizonator_context_isvalid(const horizonator_context_t* ctx)
  * non-NULL, report it back; *viewer_z >= 0 -> use as given.
  * Exactly one of render_radius_cells / render_radius_m must be > 0.
  * dir_dems == NULL -> "~/.horizonator/DEMs_SRTM3" (or ..._SRTM1).
- * dir_tiles, tiles_name, tiles_url_fmt, allow_downloads belong to the texture
- * path and are ignored. */
+ * render_texture: dir_tiles (NULL -> "~/.horizonator/tiles") and tiles_name
+ * (NULL -> "mapnik") say where the zoom-12 map tiles are, defaults as
+ * reference horizonator-lib.c:102-120; tiles_url_fmt and allow_downloads are
+ * accepted and not acted upon: a missing tile is an error. */
 bool horizonator_init(horizonator_context_t* ctx,
                       float viewer_lat, float viewer_lon,
                       float* viewer_z,
