@@ -50,6 +50,9 @@ def parse():
                     help="diagnostics: gloo moves the strips through host memory (lets two ranks share one GPU "
                          "to exercise the N>1 loop where only one GPU exists); the driver's runs use nccl = RCCL")
     ap.add_argument("--same-gpu", action="store_true", help="diagnostics: every rank uses GPU 0 (with --backend gloo)")
+    ap.add_argument("--exchange-anyway", action="store_true",
+                    help="diagnostics, 1 GPU: run the N > 1 loop (sparse strip, device-side stream ordering, exchange, "
+                         "conversion of the 'gathered' strips) with the one rank there is")
     ap.add_argument("--wire", default="sparse", choices=["sparse", "packed"],
                     help="N > 1: what a rank sends to rank 0 - sparse: terrain pixels only + mask (default); "
                          "packed: every pixel, 4 bytes")
@@ -101,7 +104,7 @@ def main():
         dist.barrier()
     import hzutil
     import horizonator_amd
-    from horizonator_amd.sharding import (broadcast_dem, gather_flat_async, gather_strips_async, gatherer_weights,
+    from horizonator_amd.sharding import (StripExchange, agree_on_capacity, broadcast_dem, gather_strips_async, gatherer_weights,
                                           sector_columns, sparse_header_words, sparse_mask_stride)
 
     cfg = CONFIGS[args.config]
@@ -141,7 +144,8 @@ def main():
     # bit less: it also converts the gathered strips (0.31 ms for 64 Mpix, on the library's second
     # stream beside its own draw, which that slows by about 0.08 ms; a sector costs about
     # 0.32 + 1.77*share ms: tools/sector_timing.py).
-    NBUF = 2 if world > 1 else 1
+    multi = world > 1 or args.exchange_anyway
+    NBUF = 2 if multi else 1
     sparse = args.wire == "sparse"
     cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
     weights = gatherer_weights(world, 1.77, 0.08) if world > 1 else None
@@ -154,16 +158,18 @@ def main():
         S["SW_max"] = max(c1 - c0 for c0, c1 in layout)
         S["MSTRIDE"] = sparse_mask_stride(S["SW_max"])
         S["HDR"] = sparse_header_words(H, S["MSTRIDE"])
+        S["ex"] = None
         if S["SW"] > 0:
             h.set_sector(S["col0"], S["col1"])
-        if world > 1:
+        if multi:
             if sparse:
                 # a sparse strip: header + one word per TERRAIN pixel; room for the worst case (no sky at all)
-                S["d_pk"] = [torch.zeros(S["HDR"] + H * S["SW_max"], dtype=torch.int32, device=dev) for _ in range(NBUF)]
+                S["FULL"] = S["HDR"] + H * S["SW_max"]
+                S["d_pk"] = [torch.zeros(S["FULL"], dtype=torch.int32, device=dev) for _ in range(NBUF)]
             else:
                 S["d_pk"] = [torch.empty((H, S["SW"]), dtype=torch.int32, device=dev) for _ in range(NBUF)]
 
-    if world == 1:
+    if not multi:
         apply_layout([(0, W)])
     else:
         cos_lat = float(np.cos(np.radians(LAT)))
@@ -173,6 +179,10 @@ def main():
         d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     pending = [None] * NBUF
     state = {"k": 0, "wire_words": 0, "keep": None}
+    on_gpu = args.backend == "nccl"
+
+    def my_stream():
+        return torch.cuda.current_stream().cuda_stream
 
     def rebalance(rounds=2, probes=3):
         """N > 1, before the warm-up: every rank times its own sector on this scene; columns are then
@@ -211,22 +221,47 @@ def main():
             density[density == 0.0] = density[density > 0.0].mean()
             apply_layout(balanced_layout(density, world, weights))
 
+    def exchange():
+        """N > 1, sparse strips: the ranks agree ONCE per layout on how many words a strip sends
+        (the longest strip of this scene + 10 %); from then on a panorama's gather needs nothing from
+        the host - no length read back, no all_reduce (sharding.StripExchange)"""
+        if S["ex"] is None:
+            words = S["HDR"]
+            if S["SW"] > 0:
+                h.render_sparse(S["d_pk"][0].data_ptr(), S["MSTRIDE"])
+                h.sync()
+                words += int(S["d_pk"][0][0].item())
+            cap = agree_on_capacity(words, S["HDR"], S["FULL"], cdev)
+            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF)
+            S["sent"] = [None] * NBUF
+            state["wire_words"] = S["ex"].cap
+        return S["ex"]
+
+    def convert(bins):
+        """rank 0: the strips of one panorama -> the full-width outputs, on the library's conversion
+        stream, behind their arrival (a device-side wait) and beside the draw that follows"""
+        if on_gpu:
+            h.waits_for_stream(my_stream())
+        else:
+            bins = [t.to(dev) for t in bins]
+        h.resolve_sparse_gathered([(t.data_ptr(), c0, c1 - c0) for t, (c0, c1) in zip(bins, S["layout"])],
+                                  S["MSTRIDE"], d_img.data_ptr(), d_rng.data_ptr())
+        if not on_gpu:
+            h.sync()                                    # the uploaded copies go away with this frame
+
     def finish(slot):
         """complete the exchange that still reads buffer set `slot`; rank 0: turn the strips
         into the panorama"""
         if pending[slot] is None:
             return
         if sparse:
-            bufs = pending[slot].tensors()
-            torch.cuda.current_stream().synchronize()   # the strips have arrived (RCCL's stream -> host)
-            if bufs is not None:
-                if args.backend == "gloo":
-                    bufs = [t.to(dev) for t in bufs]
-                # queued on the library's conversion stream: it runs beside the draw that step() starts
-                # next; the strips stay referenced until that draw has been waited for
-                h.resolve_sparse_gathered([(t.data_ptr(), c0, c1 - c0) for t, (c0, c1) in zip(bufs, S["layout"])],
-                                          S["MSTRIDE"], d_img.data_ptr(), d_rng.data_ptr())
-                state["keep"] = bufs
+            ex = S["ex"]
+            bins, overflow = ex.complete(slot)
+            if overflow:                                # a strip outgrew the agreed capacity: once more, with more room
+                bins = ex.grow(slot, S["sent"][slot])
+                state["wire_words"] = ex.cap
+            if bins is not None:
+                convert(bins)
             pending[slot] = None
             return
         parts = pending[slot].parts()
@@ -241,7 +276,7 @@ def main():
     def step():
         slot = state["k"] % NBUF
         state["k"] += 1
-        if world == 1:
+        if not multi:
             # no wait in between: the library overlaps the readback conversion and the clear of
             # panorama k (its second stream) with the rasterisation of panorama k+1
             h.render_device(d_img.data_ptr(), d_rng.data_ptr())
@@ -249,20 +284,19 @@ def main():
         finish(slot)
         d_pk = S["d_pk"]
         if sparse:
-            words = S["HDR"]
+            ex = exchange()
             if S["SW"] > 0:
                 h.render_sparse(d_pk[slot].data_ptr(), S["MSTRIDE"])
-            h.sync()                                            # own strip written, pending conversion done
-            state["keep"] = None
-            if S["SW"] > 0:
-                words = S["HDR"] + int(d_pk[slot][0].item())    # header + terrain pixels of this strip
-            # all strips of a gather have one length: that of the longest
-            n = torch.tensor([words], dtype=torch.int64, device=cdev)
-            dist.all_reduce(n, op=dist.ReduceOp.MAX)
-            words = int(n.item())
-            state["wire_words"] = words
-            send = d_pk[slot][:words]
-            pending[slot] = gather_flat_async(send if args.backend == "nccl" else send.cpu())
+            if on_gpu:
+                # the gather runs behind the strip's conversion on the device; the host goes on to the next panorama
+                h.stream_waits_for_outputs(my_stream())
+                send = d_pk[slot]
+            else:
+                h.sync()
+                send = d_pk[slot].cpu()                 # gloo (diagnostics): through host memory
+            S["sent"][slot] = send
+            ex.post(slot, send)
+            pending[slot] = True
             return
         if S["SW"] > 0:
             h.render_packed(d_pk[slot].data_ptr())
@@ -286,7 +320,7 @@ def main():
     def verify():
         """N > 1: the panorama rank 0 assembled from the gathered strips must be, byte for byte,
         what one GPU renders on its own"""
-        if world == 1 or rank != 0:
+        if not multi or rank != 0:
             return None
         got_img, got_rng = d_img.clone(), d_rng.clone()
         h.set_sector(0, W)
@@ -300,6 +334,8 @@ def main():
 
     def timed(zfar, steps, warmup):
         h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=zfar)
+        if multi:
+            S["ex"] = None      # another scene: the strips' common capacity is agreed on again (outside the clock)
         for _ in range(warmup):
             step()
         drain()
@@ -307,14 +343,12 @@ def main():
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
-            if S["SW"] > 0 and world > 1:
-                kern.append(h.last_times())
+            step()              # N > 1: nothing in here waits on the host for the device (sharding.StripExchange)
         drain()                 # every one of the K panoramas is assembled on rank 0 ...
         h.sync()                # ... and, N = 1, converted ...
         fence()                 # ... before the clock stops
         dt = time.perf_counter() - t0
-        if world == 1:
+        if not multi or S["SW"] > 0:
             kern.append(h.last_times())         # HIP events of the last of the K panoramas
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -418,7 +452,8 @@ def main():
                 "workload": f"{args.config}: {cfg['tiles']}, R={R} ({N}x{N} samples, {2*(N-1)**2/1e6:.1f} M triangles), "
                             f"{W}x{H} 360deg panorama, znear {ZNEAR:g} m, zfar {args.zfar:g} m",
                 "sector_widths": [c1 - c0 for c0, c1 in S["layout"]],
-                "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * S["SW_max"]) if world > 1 else 0,
+                "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * S["SW_max"]) if multi else 0,
+                "strip_resends": (S["ex"].resends if multi and sparse and S.get("ex") is not None else 0),
                 "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",

@@ -350,6 +350,17 @@ class horizonator:
         if not self._lib.horizonator_amd_sync(C.byref(self._ctx)):
             raise RuntimeError("horizonator_amd_sync() failed")
 
+    def stream_waits_for_outputs(self, stream):
+        """work queued on `stream` (a raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) from
+        now on runs after every conversion queued on this context so far - on the device, no host wait"""
+        if not self._lib.horizonator_amd_stream_waits_for_outputs(C.byref(self._ctx), C.c_void_p(int(stream))):
+            raise RuntimeError("horizonator_amd_stream_waits_for_outputs() failed")
+
+    def waits_for_stream(self, stream):
+        """conversions queued on this context from now on run after everything queued on `stream` so far"""
+        if not self._lib.horizonator_amd_waits_for_stream(C.byref(self._ctx), C.c_void_p(int(stream))):
+            raise RuntimeError("horizonator_amd_waits_for_stream() failed")
+
     def set_sector(self, col0, col1):
         if not self._lib.horizonator_amd_set_sector(C.byref(self._ctx), int(col0), int(col1)):
             raise RuntimeError("horizonator_amd_set_sector() failed")

@@ -176,6 +176,9 @@ def load():
     sig("hz_hip_last_times", i, vp, P(Times))
     sig("hz_hip_stream", vp, vp)
     sig("hz_hip_wait_outputs", i, vp, vp)
+    sig("hz_hip_wait_for", i, vp, vp)
+    sig("horizonator_amd_stream_waits_for_outputs", b, ctxp, vp)
+    sig("horizonator_amd_waits_for_stream", b, ctxp, vp)
     sig("hz_hip_check_fastmath", i, i, i, C.c_uint64, C.c_uint64, P(C.c_uint64), vp)
     sig("hz_hip_last_error", C.c_char_p)
     _lib = lib
@@ -198,7 +201,7 @@ DECLARED_SYMBOLS = [
     "horizonator_amd_render_packed", "horizonator_amd_resolve_packed",
     "horizonator_amd_resolve_packed_strips", "horizonator_amd_render_sparse",
     "horizonator_amd_resolve_sparse_strips",
-    "horizonator_amd_sync", "horizonator_amd_texture_layout", "horizonator_amd_set_texture",
+    "horizonator_amd_sync", "horizonator_amd_stream_waits_for_outputs", "horizonator_amd_waits_for_stream", "horizonator_amd_texture_layout", "horizonator_amd_set_texture",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
     "horizonator_amd_get_mosaic", "horizonator_amd_link_cells_size", "horizonator_amd_link_cells",
@@ -207,7 +210,7 @@ DECLARED_SYMBOLS = [
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
     "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
-    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_check_fastmath", "hz_hip_last_error",
+    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_check_fastmath", "hz_hip_last_error",
 ]
 
 

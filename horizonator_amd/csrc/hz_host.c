@@ -906,6 +906,18 @@ bool horizonator_amd_sync(const horizonator_context_t* ctx)
     return s != NULL && 0 == hz_hip_sync(s->dev);
 }
 
+bool horizonator_amd_stream_waits_for_outputs(const horizonator_context_t* ctx, void* stream)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_wait_outputs(s->dev, stream);
+}
+
+bool horizonator_amd_waits_for_stream(const horizonator_context_t* ctx, void* stream)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && 0 == hz_hip_wait_for(s->dev, stream);
+}
+
 bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int col1)
 {
     hz_state_t* s = live_state(ctx);

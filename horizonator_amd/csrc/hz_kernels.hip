@@ -2160,6 +2160,14 @@ extern "C" int hz_hip_wait_outputs(hz_dev_t* d, void* stream)
     return 0;
 }
 
+extern "C" int hz_hip_wait_for(hz_dev_t* d, void* stream)
+{
+    HZ_ON_DEVICE(d);
+    HZ_CHECK(hipEventRecord(d->ev_tanel, (hipStream_t)stream));
+    HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_tanel, 0));
+    return 0;
+}
+
 /* segment zones of k_march for this view: a cell `r` rows away from the viewer
  * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
 static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first)

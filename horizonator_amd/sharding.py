@@ -249,6 +249,116 @@ def gather_flat_async(flat, group=None, dst=0):
     return PendingFlat(work, bins, flat)
 
 
+class StripExchange:
+    """The gather of a panorama's sparse strips with nothing on the host in its way.
+
+    A strip's length (header + one word per terrain pixel) is only known on the device once it is
+    drawn.  Reading it back, agreeing on the longest with an all_reduce and reading that back too
+    puts two host round trips and a collective on the critical path of every panorama.  Instead
+    the ranks agree ONCE on a capacity (`cap_words`: the longest strip seen so far plus a margin)
+    and every panorama sends exactly that many words: the strip's own first word says how many of
+    them mean anything.  Buffers - send side and the gathering rank's bins - are allocated once per
+    slot and reused.  Whether any strip did not fit travels beside the strips as one flag word,
+    all-reduced asynchronously; it is looked at when the exchange is completed, a panorama
+    later and off the critical path, and grow() then redoes that one exchange with more room.
+
+        ex = StripExchange(cap_words, full_words, header_words, device, nslots=2)
+        ex.post(slot, d_strip)      # d_strip: the rank's full-size strip buffer (int32, 1-D), drawn on
+                                    # the current stream or ordered before it; no host wait
+        bins, overflow = ex.complete(slot)      # waits; bins on dst (one 1-D tensor per rank), else None
+        if overflow: bins = ex.grow(slot, d_strip)
+    """
+
+    def __init__(self, cap_words, full_words, header_words, device, nslots=2, group=None, dst=0):
+        self.world, self.rank = _world_and_rank(group)
+        self.group, self.dst, self.device = group, dst, device
+        self.full, self.hdr = int(full_words), int(header_words)
+        self.nslots = nslots
+        self._alloc(cap_words)
+        self.resends = 0
+
+    def _alloc(self, cap_words):
+        self.cap = int(min(max(cap_words, self.hdr + 1), self.full))
+        self.bins = [[torch.empty(self.cap, dtype=torch.int32, device=self.device) for _ in range(self.world)]
+                     if self.rank == self.dst else None for _ in range(self.nslots)]
+        self.flags = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.nslots)]
+        self.work = [None] * self.nslots
+        # on a GPU the flag reaches the host through a stream of its own, so that looking at it
+        # waits for that exchange only - not for whatever the caller has queued since
+        self.cuda = torch.device(self.device).type == "cuda"
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=self.device)
+            self.flag_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(self.nslots)]
+            self.flag_ready = [torch.cuda.Event() for _ in range(self.nslots)]
+
+    def post(self, slot, strip):
+        """start the exchange of `strip` (this rank's strip buffer, full_words long) in `slot`"""
+        assert self.work[slot] is None, "complete() the slot's previous exchange first"
+        # does this rank's strip fit?  (device-side: no value leaves the device here)
+        self.flags[slot].copy_((strip[0:1] > (self.cap - self.hdr)).to(torch.int32))
+        send = strip[:self.cap]
+        if self.world == 1:
+            self.bins[slot][0].copy_(send)
+            w1 = w2 = None
+        else:
+            w1 = dist.gather(send, self.bins[slot], dst=self.dst, group=self.group, async_op=True)
+            w2 = dist.all_reduce(self.flags[slot], op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self.side):
+                if w2 is not None:
+                    w2.wait()                       # the side stream waits for the flag's all_reduce ...
+                else:
+                    self.side.wait_stream(cur)
+                self.flag_host[slot].copy_(self.flags[slot], non_blocking=True)
+                self.flag_ready[slot].record(self.side)
+        self.work[slot] = (w1, w2)
+
+    def complete(self, slot):
+        """the slot's exchange is over: (bins on the gathering rank else None, did a strip not fit).
+        On a GPU the caller's current stream waits for the strips (the host does not); the host waits
+        for the flag word of THIS exchange only."""
+        if self.work[slot] is None:
+            return None, False
+        w1, w2 = self.work[slot]
+        self.work[slot] = None
+        if w1 is not None:
+            w1.wait()                               # nccl: the current stream waits; gloo: the host does
+        if self.cuda:
+            self.flag_ready[slot].synchronize()
+            overflow = bool(int(self.flag_host[slot][0]))
+        else:
+            if w2 is not None:
+                w2.wait()
+            overflow = bool(int(self.flags[slot][0]))
+        return self.bins[slot], overflow
+
+    def grow(self, slot, strip):
+        """a strip did not fit: agree on a new capacity (every rank calls this - they all saw the
+        same flag), reallocate, and redo the slot's exchange, waiting for it"""
+        n = torch.tensor([self.hdr + int(strip[0].item())], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+        for k in range(self.nslots):                        # exchanges still in flight use the old bins: finish them first
+            assert self.work[k] is None or k == slot
+        self._alloc(int(int(n.item()) * 1.1) + 1024)
+        self.resends += 1
+        self.post(slot, strip)
+        bins, overflow = self.complete(slot)
+        assert not overflow
+        return bins
+
+
+def agree_on_capacity(words, header_words, full_words, device, group=None, margin=1.1):
+    """one-off: the capacity for a StripExchange from this rank's current strip length"""
+    world, _ = _world_and_rank(group)
+    n = torch.tensor([int(words)], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    longest = int(n.item())
+    return int(min(full_words, header_words + (longest - header_words) * margin + 1024))
+
+
 # ---- a batch of viewpoints (BASELINE.json configs[3]) --------------------------
 
 def viewpoint_slice(n, world_size, rank):
@@ -258,25 +368,33 @@ def viewpoint_slice(n, world_size, rank):
     return sector_columns(n, world_size, rank)
 
 
-def gather_viewpoints(images, n, group=None, dst=0):
+def gather_viewpoints(images, n, group=None, dst=0, chunk=16, out=None):
     """images: this rank's [n_local, ...] tensor of finished panoramas.
     Returns the [n, ...] batch on `dst` (viewpoint order), None elsewhere.
-    Blocks may differ in length by one; they travel padded to the longest."""
+
+    The batch travels in chunks of at most `chunk` viewpoints per rank, through one pair of
+    preallocated bins, each chunk copied straight to its place in the result: 256 panoramas of
+    8000x2000 are 12.3 GB, which a single gather would hold twice on the gathering rank (bins +
+    concatenation).  out: the [n, ...] result tensor on `dst`, if the caller has one."""
     world, rank = _world_and_rank(group)
     if world == 1:
         return images
     longest = -(-n // world)
-    if images.shape[0] < longest:
-        pad_shape = list(images.shape)
-        pad_shape[0] = longest - images.shape[0]
-        images = torch.cat([images, images.new_zeros(pad_shape)], dim=0)
-    images = images.contiguous()
-    bins = [torch.empty_like(images) for _ in range(world)] if rank == dst else None
-    dist.gather(images, bins, dst=dst, group=group)
-    if rank != dst:
-        return None
-    parts = []
-    for r, b in enumerate(bins):
-        v0, v1 = viewpoint_slice(n, world, r)
-        parts.append(b[:v1 - v0])
-    return torch.cat(parts, dim=0)
+    chunk = max(1, min(int(chunk), longest))
+    item_shape = list(images.shape[1:])
+    if rank == dst and out is None:
+        out = torch.empty([n] + item_shape, dtype=images.dtype, device=images.device)
+    send = torch.zeros([chunk] + item_shape, dtype=images.dtype, device=images.device)
+    bins = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    for c0 in range(0, longest, chunk):
+        have = max(0, min(images.shape[0] - c0, chunk))
+        if have:
+            send[:have].copy_(images[c0:c0 + have])
+        dist.gather(send, bins, dst=dst, group=group)
+        if rank == dst:
+            for r, b in enumerate(bins):
+                v0, v1 = viewpoint_slice(n, world, r)
+                m = max(0, min(v1 - v0 - c0, chunk))
+                if m:
+                    out[v0 + c0:v0 + c0 + m].copy_(b[:m])
+    return out if rank == dst else None

@@ -54,6 +54,16 @@ bool horizonator_amd_render_device(const horizonator_context_t* ctx,
                                    int32_t* d_index, uint32_t* d_z24);
 bool horizonator_amd_sync(const horizonator_context_t* ctx);
 
+/* Ordering against a HIP stream of the caller's (hipStream_t as a void*; e.g. the stream a
+ * collective is queued on) without involving the host:
+ *   horizonator_amd_stream_waits_for_outputs: work queued on `stream` from now on runs after
+ *     every conversion (the *_device, *_packed, *_sparse calls) queued on the context so far;
+ *   horizonator_amd_waits_for_stream: conversions queued on the context from now on (e.g.
+ *     horizonator_amd_resolve_sparse_strips of strips that `stream` is still receiving) run after
+ *     everything queued on `stream` so far. */
+bool horizonator_amd_stream_waits_for_outputs(const horizonator_context_t* ctx, void* stream);
+bool horizonator_amd_waits_for_stream(const horizonator_context_t* ctx, void* stream);
+
 /* Texture path with a caller-supplied map ("next" row N4: reference
  * render_texture=true without its tile downloads).  The reference drapes a
  * mosaic of zoom-12 slippy-map tiles, 256x256 each, over the terrain: tiles

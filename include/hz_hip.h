@@ -211,6 +211,9 @@ int  hz_hip_last_times(hz_dev_t* d, hz_times_t* t);
  * every conversion queued so far.  hz_hip_sync() waits on the host. */
 void* hz_hip_stream(hz_dev_t* d);
 int   hz_hip_wait_outputs(hz_dev_t* d, void* stream);
+/* ... and the other way round: conversions queued from now on run after
+ * everything queued on `stream` so far (strips a collective is still delivering) */
+int   hz_hip_wait_for(hz_dev_t* d, void* stream);
 
 /* Self-check of the marching kernel's abridged division / square-root
  * sequences (horizonator_amd/csrc/hz_fast.h) against the device's own `/` and

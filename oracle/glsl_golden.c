@@ -58,6 +58,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <GL/glcorearb.h>
@@ -411,6 +412,32 @@ int main(int argc, char** argv)
             free(idx);
 
             setup_fbo(W, H);
+            /* HZ_GL_TIMING=n: the reference's per-frame GL calls (glClear + glDrawElements, reference
+             * horizonator-lib.c:896-897) and its two readbacks (:938,:962) timed n times on stderr -
+             * tools/llvmpipe_timing.py turns the lines into the baseline figures of BASELINE.md */
+            const char* tim = getenv("HZ_GL_TIMING");
+            const int reps = tim && atoi(tim) > 0 ? atoi(tim) : 0;
+            for(int r=0; r<reps; r++)
+            {
+                struct timespec t0, t1, t2;
+                p_glFinish();
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                p_glClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT);
+                p_glDrawElements(GL_TRIANGLES, (GLsizei)(ntri*3), GL_UNSIGNED_INT, NULL);
+                p_glFinish();
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                {
+                    const size_t npix = (size_t)W*H;
+                    unsigned char* bgr = malloc(npix*3); float* df = malloc(npix*sizeof(float));
+                    p_glReadPixels(0,0, W,H, GL_BGR, GL_UNSIGNED_BYTE, bgr);
+                    p_glReadPixels(0,0, W,H, GL_DEPTH_COMPONENT, GL_FLOAT, df);
+                    free(bgr); free(df);
+                }
+                clock_gettime(CLOCK_MONOTONIC, &t2);
+                fprintf(stderr, "timing rep %d draw_s %.6f readback_s %.6f\n", r,
+                        (double)(t1.tv_sec - t0.tv_sec) + 1e-9*(double)(t1.tv_nsec - t0.tv_nsec),
+                        (double)(t2.tv_sec - t1.tv_sec) + 1e-9*(double)(t2.tv_nsec - t1.tv_nsec));
+            }
             p_glClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT);
             p_glDrawElements(GL_TRIANGLES, (GLsizei)(ntri*3), GL_UNSIGNED_INT, NULL);
             GLCHECK("draw");

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from horizonator_amd.sharding import (azimuth_density, balanced_layout, broadcast_dem, gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
+from horizonator_amd.sharding import (StripExchange, agree_on_capacity, azimuth_density, balanced_layout, broadcast_dem, gather_flat_async, gather_strips, gather_strips_async, gather_viewpoints,
                                       gatherer_weights, sector_columns, sparse_header_words, sparse_mask_stride,
                                       viewpoint_slice)
 
@@ -131,6 +131,42 @@ def _worker(rank, world, port, q):
         else:
             assert got is None
         assert sparse_mask_stride(33) == 2 and sparse_header_words(10, 2) == 31
+        # the same without a host round trip per panorama: one agreed capacity, preallocated bins, the
+        # strip's own first word says how much of it counts; a strip that does not fit is flagged
+        # beside the data and the exchange redone with more room
+        HDR, FULL = 8, 4000
+
+        def strip_of(r, t, salt):
+            b = torch.zeros(FULL, dtype=torch.int32)
+            b[0] = t
+            b[1:HDR] = 7 * r + salt
+            b[HDR:HDR + t] = torch.arange(t, dtype=torch.int32) + 100000 * r + salt
+            return b
+        cap = agree_on_capacity(HDR + 300 + 100 * rank, HDR, FULL, torch.device("cpu"))
+        assert cap == int(HDR + 400 * 1.1 + 1024) and cap < FULL
+        ex = StripExchange(cap, FULL, HDR, torch.device("cpu"), nslots=2)
+        sent = [strip_of(rank, 300 + 100 * rank, 1), strip_of(rank, 250 + 30 * rank, 2)]
+        ex.post(0, sent[0])
+        ex.post(1, sent[1])                                 # two panoramas in flight
+        for slot, salt, counts in ((0, 1, (300, 400)), (1, 2, (250, 280))):
+            bins, overflow = ex.complete(slot)
+            assert not overflow
+            if rank == 0:
+                for r, b in enumerate(bins):
+                    assert b.numel() == cap and int(b[0]) == counts[r]
+                    assert np.array_equal(b[:HDR + counts[r]].numpy(), strip_of(r, counts[r], salt)[:HDR + counts[r]].numpy())
+            else:
+                assert bins is None
+        # rank 1 suddenly sees much more terrain than the capacity allows for
+        big = strip_of(rank, 3000 if rank == 1 else 200, 3)
+        ex.post(0, big)
+        bins, overflow = ex.complete(0)
+        assert overflow                                     # ... on every rank
+        bins = ex.grow(0, big)
+        assert ex.resends == 1 and ex.cap >= HDR + 3000
+        if rank == 0:
+            for r, t in enumerate((200, 3000)):
+                assert np.array_equal(bins[r][:HDR + t].numpy(), strip_of(r, t, 3)[:HDR + t].numpy())
         # unequal sectors, rank 0 drawing nothing at all
         wts = [0.0, 1.0]
         d0, d1 = sector_columns(W, world, rank, wts)
@@ -197,6 +233,15 @@ def _batch_worker(rank, world, port, q):
         mine = np.stack([oracle.render(g["mosaic"], views[v], W, H, nthreads=1, want=("bgr",))["bgr"]
                          for v in range(v0, v1)])
         batch = gather_viewpoints(torch.from_numpy(mine), n)
+        # ... in chunks smaller than a rank's block (3 of 4), and into a result the caller owns
+        mine_t = torch.from_numpy(mine)
+        own = torch.zeros((n,) + tuple(mine_t.shape[1:]), dtype=mine_t.dtype) if rank == 0 else None
+        chunked = gather_viewpoints(mine_t, n, chunk=3, out=own)
+        one_by_one = gather_viewpoints(mine_t, n, chunk=1)
+        if rank == 0:
+            assert chunked is own and torch.equal(chunked, batch) and torch.equal(one_by_one, batch)
+        else:
+            assert chunked is None and one_by_one is None
         if rank == 0:
             assert batch.shape == (n, H, W, 3)
             ok = all(np.array_equal(batch[v].numpy(),
