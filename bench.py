@@ -441,6 +441,20 @@ def main():
         cpu = {"value": W * H / cdt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
                "sample": f"1 full {W}x{H} render of the same workload by oracle/ (C + OpenMP, {cores} threads), {cdt:.1f} s"}
 
+    # the reference's own shaders on Mesa llvmpipe cannot run on the GPU box (neither /root/reference nor Mesa's
+    # software driver is there): what tools/llvmpipe_timing.py measured in the build container, with its machine
+    ref_rec = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "llvmpipe_timing.json")))
+        rows = [r for r in rec["rows"] if r["config"] == args.config and abs(r["zfar"] - args.zfar) < 1]
+        if rows:
+            ref_rec = {"value": rows[0]["mpix_per_s_draw_plus_readback"], "unit": "Mpix/s", "draw_s": rows[0]["draw_s"],
+                       "cores": rec["machine"]["cores"], "cpu": rec["machine"]["cpu"],
+                       "what": "reference vertex/geometry/fragment.glsl on Mesa llvmpipe, glClear+glDrawElements+2 glReadPixels per frame; "
+                               "recorded in the build container by tools/llvmpipe_timing.py (profiles/llvmpipe_timing.json), not measured in this run"}
+    except Exception:
+        ref_rec = None
+
     if rank == 0:
         line = {
             "metric": "panorama Mpix/s (360deg, 16k-wide, 7x7 SRTM3 tiles)" if args.config == "cfg3"
@@ -469,6 +483,7 @@ def main():
                 "achieved_whole_render": algo_bytes / (ms_per_step * 1e-3) / 1e9,
             },
             "cpu_baseline": cpu,
+            "reference_llvmpipe_recorded": ref_rec,
         }
         if host_incl is not None:
             line["host_inclusive"] = host_incl

@@ -166,6 +166,22 @@ def test_two_round_draw_with_early_depth_test_changes_nothing(monkeypatch):
         hzutil.assert_same_render(two, oracle.render(m, v, W, H), f"two rounds vs oracle, viewer_z {viewer_z}")
 
 
+@pytest.mark.parametrize("capacity", [1, 70, 5000])
+def test_two_round_draw_with_full_queues(capacity, monkeypatch):
+    """the second round hands the few triangles that pass its early depth test to k_live through a
+    queue of ids; with that queue (and all the others) too small the marching waves must draw the
+    overflow themselves - same bytes"""
+    monkeypatch.setenv("HZ_TWO_PASS", "1")
+    monkeypatch.setenv("HZ_NEAR_CELLS", "64")
+    monkeypatch.setenv("HZ_QUEUE_CAPACITY", str(capacity))
+    R, W, H = 500, 3000, 750
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    v = od.view(LAT, LON, W, H, -180, 180, zfar=200000.0)
+    hzutil.assert_same_render(hzutil.hip_render(m, v, W, H, raster=2), oracle.render(m, v, W, H), f"two rounds, capacity {capacity}")
+
+
 def test_packed_strips_resolve_to_the_same_panorama():
     """the multi-GPU route on one GPU: every sector drawn and written as z24<<8 | red8 words
     (what a rank ships), then converted into the full-width outputs (what rank 0 does with the
