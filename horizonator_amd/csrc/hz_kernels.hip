@@ -150,20 +150,20 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
 #define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
-/* k_big walks a triangle's box in tiles of 64 pixels, one wave per 64 tiles.
- * The tile is as wide as the box allows (64x1 for the flat slivers next to the
- * viewer: 512 contiguous bytes of framebuffer per atomic instruction; down to
- * 8x8 for narrow boxes, so that the 64 lanes stay busy).  Producer (queueing)
- * and consumer (k_big) derive the tiling from the box alone. */
-struct hz_tiling_t { int tw_log2, tiles_x, tiles_y; };
-__device__ static inline hz_tiling_t hz_big_tiling(int bw, int bh)
+/* k_big walks a triangle's box in chunks of pixel rows, one wave per chunk
+ * (lane = row for the row's span of covered pixels, then lane = pixel): 64 rows,
+ * fewer for wide boxes so that a chunk holds at most ~8192 box pixels (the
+ * triangles next to the viewer reach thousands of pixels in width; a wave that
+ * had 64 such rows to itself would set the kernel's duration).  Producer
+ * (queueing) and consumer (k_big) derive the chunking from the box alone. */
+__device__ static inline int hz_big_rows_log2(int bw)
 {
-    hz_tiling_t t;
-    t.tw_log2 = bw > 32 ? 6 : bw > 16 ? 5 : bw > 8 ? 4 : 3;
-    const int tw = 1 << t.tw_log2, th = 64 >> t.tw_log2;
-    t.tiles_x = (bw + tw-1) >> t.tw_log2;
-    t.tiles_y = (bh + th-1) / th;
-    return t;
+    return bw <= 128 ? 6 : bw <= 256 ? 5 : bw <= 512 ? 4 : bw <= 1024 ? 3 : bw <= 2048 ? 2 : bw <= 4096 ? 1 : 0;
+}
+__device__ static inline uint32_t hz_big_chunks(int bw, int bh)
+{
+    const int rl = hz_big_rows_log2(bw);
+    return ((uint32_t)bh + (1u << rl) - 1u) >> rl;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -240,9 +240,8 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
         const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
         hz_box_t box;
         if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
-        const hz_tiling_t tl = hz_big_tiling(box.px1 - box.px0 + 1, box.py1 - box.py0 + 1);
         npieces++;
-        nchunks += ((uint32_t)tl.tiles_x*(uint32_t)tl.tiles_y + 63)/64;
+        nchunks += hz_big_chunks(box.px1 - box.px0 + 1, box.py1 - box.py0 + 1);
     }
     if(npieces == 0) return;
     bool queued = false;
@@ -277,8 +276,7 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
         br.r.inv_bw = 1.0f / (float)br.r.bw;
         br.r.prim = prim;
         br.bh = box.py1 - box.py0 + 1;
-        const hz_tiling_t tl = hz_big_tiling(br.r.bw, br.bh);
-        const uint32_t chunks = ((uint32_t)tl.tiles_x*(uint32_t)tl.tiles_y + 63)/64;
+        const uint32_t chunks = hz_big_chunks(br.r.bw, br.bh);
         q.bigrec[ri] = br;
         for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
         ri++; ii += chunks;
@@ -472,9 +470,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             else
             {
                 /* large: hand over to k_big, 64 tiles per work item */
-                const hz_tiling_t tl = hz_big_tiling(r.bw, bh);
-                const unsigned int tiles  = (unsigned int)tl.tiles_x*(unsigned int)tl.tiles_y;
-                const unsigned int chunks = (tiles + 63)/64;
+                const unsigned int chunks = hz_big_chunks(r.bw, bh);
                 unsigned int ri = atomicAdd(&big_counters[0], 1u), ii = 0;
                 bool queued = false;
                 if(ri < bigrec_capacity)
@@ -549,18 +545,52 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
     }
 }
 
-/* large triangles: one wave per work item = 64 tiles of 64 pixels (hz_big_tiling).  Lane =
- * tile for a trivial-reject test against the three edges (long thin slivers
- * near the viewer cover a small part of their box), then lane = pixel inside
- * every tile that survived. */
+/* inclusive prefix sum over the 64 lanes */
+__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
+{
+    #pragma unroll
+    for(int d=1; d<64; d<<=1)
+    {
+        const uint32_t up = __shfl_up(v, d);
+        if(lane >= d) v += up;
+    }
+    return v;
+}
+
+/* floor(n / d) for d > 0: a double-precision estimate (r = 1/d to full double
+ * accuracy, computed by the caller once per edge), then the remainder decides -
+ * exactly.  |n| < 2^55, d < 2^31; results beyond +-2^30 come back clamped (the
+ * caller only compares them with pixel columns). */
+__device__ static inline int32_t hz_floor_div(int64_t n, int32_t d, double r)
+{
+    double qd = __builtin_floor((double)n * r);
+    qd = qd < -1073741824.0 ? -1073741824.0 : (qd > 1073741824.0 ? 1073741824.0 : qd);
+    int32_t q = (int32_t)qd;
+    int64_t rem = n - (int64_t)q*(int64_t)d;
+    /* the estimate is off by one at most (two steps each way for good measure) */
+    if(rem < 0)  { q--; rem += d; }
+    if(rem < 0)  { q--; rem += d; }
+    if(rem >= d) { q++; rem -= d; }
+    if(rem >= d) { q++; rem -= d; }
+    return q;
+}
+
+/* large triangles: one wave per work item = 64 pixel rows of a queued triangle.
+ * Lane = row: the covered pixel centres of a row are a span [x0, x1] - each
+ * edge function is linear in px, so each edge bounds the span from one side, at
+ * a column that an integer division gives exactly (the ownership of zeros
+ * included).  Then lane = pixel: the spans of the 64 rows are laid end to end
+ * (wave prefix sum) and every lane takes one covered pixel per pass, whatever
+ * the shape of the triangle - the long thin slivers next to the viewer cover a
+ * quarter of their boxes. */
 __global__ __launch_bounds__(256)
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
            const unsigned int* __restrict__ big_counters,
            unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
 {
-    /* items at and beyond the first overflow were rasterised inline by k_scatter */
-    unsigned int nitems = min(big_counters[1], big_counters[2]);
+    /* items at and beyond the first overflow were rasterised inline by their producer */
+    const unsigned int nitems = min(big_counters[1], big_counters[2]);
     (void)bigrec_capacity; (void)bigitem_capacity;
     const int lane = threadIdx.x & 63;
     const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
@@ -580,72 +610,61 @@ void k_big(unsigned long long* __restrict__ fb,
         hz_tri_from_rec(tri, br.r);
         const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;
         const uint32_t prim = br.r.prim;
-        const hz_tiling_t tl = hz_big_tiling(bw, bh);
-        const int tiles_x = tl.tiles_x, tiles_y = tl.tiles_y;
-        const int tw = 1 << tl.tw_log2, th = 64 >> tl.tw_log2;
 
-        /* The edge functions are linear in the pixel position, so they are
-         * evaluated with 64-bit multiplies only once per tile (at its origin, by
-         * the tile's lane) and once per lane (the offset of the lane's pixel
-         * inside any tile); per pixel it is one 64-bit add per edge.  The
-         * ownership of zeros (hz_edge_owns_zero) is folded into the offset:
-         * inside <=> all three sums are >= 0. */
-        const int lx = lane & (tw-1), ly = lane >> tl.tw_log2;
-        int64_t step_x[3], step_y[3], lane_off[3];
+        /* lane = row */
+        const int rows_log2 = hz_big_rows_log2(bw);
+        const int row_first = py0 + ((int)item.chunk << rows_log2);
+        const int row = row_first + lane;
+        int32_t x0 = px0, x1 = px0 + bw - 1;
+        bool any = lane < (1 << rows_log2) && row < py0 + bh;
         #pragma unroll
         for(int m=0; m<3; m++)
         {
+            /* edge m (vertex m -> m+1), hz_edge():  E(px) = K - dy*256*px  with
+             * K = dx*(row*256 - ys[a]) + dy*xs[a];  covered <=> E >= c, c = 0 if the
+             * edge owns its zeros, else 1 (hz_tri_covers) */
             const int a = m, b = (m == 2) ? 0 : m+1;
-            const int32_t dx = tri.xs[b] - tri.xs[a], dy = tri.ys[b] - tri.ys[a];
-            step_x[m] = -(int64_t)dy * HZ_SUBPIXEL_ONE;         /* one pixel to the right */
-            step_y[m] =  (int64_t)dx * HZ_SUBPIXEL_ONE;         /* one pixel up           */
-            lane_off[m] = step_x[m]*lx + step_y[m]*ly - (hz_edge_owns_zero(&tri, m) ? 0 : 1);
+            const int32_t dx = tri.xs[b] - tri.xs[a], dy = tri.ys[b] - tri.ys[a];       /* wave-uniform */
+            const int64_t K  = (int64_t)dx*(((int64_t)row << HZ_SUBPIXEL_BITS) - tri.ys[a]) + (int64_t)dy*(int64_t)tri.xs[a];
+            const int64_t num = K - (hz_edge_owns_zero(&tri, m) ? 0 : 1);
+            if(dy > 0)
+            {
+                /* px <= floor(num / (256*dy)) = floor(floor(num/256) / dy) */
+                const int32_t q = hz_floor_div(num >> HZ_SUBPIXEL_BITS, dy, 1.0/(double)dy);
+                x1 = x1 < q ? x1 : q;
+            }
+            else if(dy < 0)
+            {
+                /* 256*|dy|*px >= -num  <=>  px >= ceil(-num / (256*|dy|)) = -floor(num / (256*|dy|)) */
+                const int32_t q = hz_floor_div(num >> HZ_SUBPIXEL_BITS, -dy, 1.0/(double)(-dy));
+                x0 = x0 > -q ? x0 : -q;
+            }
+            else if(num < 0) any = false;               /* a horizontal edge: the whole row is on one side */
         }
+        const uint32_t count = (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
 
-        /* lane = tile: can any pixel centre of the tile be inside? */
-        const int tile = (int)item.chunk*64 + lane;
-        int alive = 0;
-        int ox = 0, oy = 0;
-        int64_t e_org[3] = {0, 0, 0};
-        if(tile < tiles_x*tiles_y)
+        /* lane = pixel */
+        const uint32_t incl  = mr_scan(count, lane);
+        const uint32_t excl  = incl - count;
+        const uint32_t total = __shfl(incl, 63);
+        for(uint32_t base = 0; base < total; base += 64)
         {
-            const int ty = tile / tiles_x, tx = tile - ty*tiles_x;
-            ox = px0 + tx*tw; oy = py0 + ty*th;
-            const int x1 = min(ox + tw-1, px0 + bw-1), y1 = min(oy + th-1, py0 + bh-1);
-            alive = 1;
+            const uint32_t k = base + lane;
+            /* the row that holds pixel k: last lane whose exclusive prefix is <= k */
+            int own = 0;
             #pragma unroll
-            for(int m=0; m<3; m++)
+            for(int step=32; step>=1; step>>=1)
             {
-                e_org[m] = hz_edge(&tri, m, ox, oy);
-                /* the edge function grows with px when step_x > 0 and with py when step_y > 0 */
-                const int64_t emax = e_org[m] + (step_x[m] > 0 ? step_x[m]*(x1 - ox) : 0)
-                                              + (step_y[m] > 0 ? step_y[m]*(y1 - oy) : 0);
-                if(emax < 0 || (emax == 0 && !hz_edge_owns_zero(&tri, m))) alive = 0;
+                const uint32_t v = __shfl(excl, own + step);
+                if(v <= k) own += step;
             }
-        }
-        unsigned long long live = __ballot(alive);
-        while(live)
-        {
-            const int src = __builtin_ctzll(live);
-            live &= live - 1;
-            const int px = __builtin_amdgcn_readlane(ox, src) + lx, py = __builtin_amdgcn_readlane(oy, src) + ly;
-            int64_t any = 0;
-            #pragma unroll
-            for(int m=0; m<3; m++)
-            {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e_org[m], src);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e_org[m] >> 32), src);
-                any |= (int64_t)(((uint64_t)hi << 32) | lo) + lane_off[m];
-            }
-            if(any >= 0 && px < px0 + bw && py < py0 + bh)
+            const int px = __shfl(x0, own) + (int)(k - __shfl(excl, own));
+            const int py = row_first + own;
+            if(k < total)
             {
                 uint32_t zi, r8;
                 if(hz_tri_fragment(&tri, px, py, &zi, &r8))
-                {
-                    unsigned long long* dst = &fb[(size_t)py*p.SW + (px - p.col0)];
-                    const unsigned long long key = hz_pack(zi, prim, r8);
-                    atomicMin(dst, key);
-                }
+                    atomicMin(&fb[(size_t)py*p.SW + (px - p.col0)], hz_pack(zi, prim, r8));
             }
         }
     }
@@ -759,17 +778,6 @@ struct mr_rowstate_t
     int32_t  h_dx, h_dy;                /* eastern neighbour's snapped position minus this vertex's */
 };
 
-/* inclusive prefix sum over the 64 lanes */
-__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
-{
-    #pragma unroll
-    for(int d=1; d<64; d<<=1)
-    {
-        const uint32_t up = __shfl_up(v, d);
-        if(lane >= d) v += up;
-    }
-    return v;
-}
 
 /* lane k holds triangle record r with npix pixel centres in its box (0 = none):
  * spread all those pixel centres over the 64 lanes (wave prefix sum + search),
@@ -955,9 +963,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         uint32_t chunks = 0;
         if(is_big)
         {
-            const hz_tiling_t tl = hz_big_tiling(r.bw, bh);
-            const uint32_t tiles = (uint32_t)tl.tiles_x*(uint32_t)tl.tiles_y;
-            chunks = (tiles + 63)/64;
+            chunks = hz_big_chunks(r.bw, bh);
         }
         const uint32_t incl  = mr_scan(chunks, lane);
         const uint32_t total = __shfl(incl, 63);
@@ -2285,7 +2291,8 @@ __global__ void k_reset_counters(unsigned int* counters)
  *   rstream |             resolve k-1 (clears behind itself)      | resolve k
  *
  * HZ_TWO_PASS=0/1 forces one / two rounds; otherwise full-width contexts of at
- * least HZ_TWO_PASS_MIN_MPIX (default 24) megapixels draw in two rounds. */
+ * least HZ_TWO_PASS_MIN_MPIX (default 24) megapixels whose far clip lies well
+ * beyond the first round's strips draw in two rounds. */
 static int draw_impl(hz_dev_t* d, const hz_view_t* view);
 
 extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
@@ -2373,8 +2380,14 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
         p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
         p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
         const double min_mpix = em ? atof(em) : 24.0;
+        /* two rounds pay where there is a lot of terrain behind the first round's
+         * strips: a large image (many pixel tests to save) and a far clip well
+         * beyond them - with the API's default 40 km far clip most of a large
+         * mosaic is never transformed at all and one round is faster (measured:
+         * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms) */
+        const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
         const bool want_two = e2 ? atoi(e2) != 0
-                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6);
+                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 12.0f*(float)near_cells);
         const bool two_pass = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
         const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
@@ -3109,6 +3122,32 @@ extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long se
     if(first_bad) HZ_CHECK(hipMemcpy(first_bad, d_first, 4*sizeof(float), hipMemcpyDeviceToHost));
     *mismatches = h[0];
     (void)hipFree(d_bad); (void)hipFree(d_first);
+    return 0;
+}
+
+/* diagnostics: the large-triangle queue of the last draw (set 0: its only or
+ * second round, set 1: the first round of a two-round draw): counters[6] and,
+ * for the first min(max_rec, counters[0]) records, px0 py0 bw bh + the six
+ * snapped vertex coordinates (10 int32 each) */
+extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counters, int max_rec, int32_t* recs)
+{
+    HZ_ON_DEVICE(d);
+    if(hz_hip_sync(d) != 0) return -1;
+    const int k = (set ? 2 : 0) + d->fbi;
+    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k], HZ_NCOUNTERS*sizeof(unsigned int), hipMemcpyDeviceToHost));
+    unsigned int n = counters[0] < d->bigrec_capacity ? counters[0] : d->bigrec_capacity;
+    if((int)n > max_rec) n = (unsigned int)max_rec;
+    if(n == 0 || recs == NULL) return 0;
+    hz_bigrec_t* h = (hz_bigrec_t*)malloc((size_t)n*sizeof(hz_bigrec_t));
+    if(!h) return -1;
+    HZ_CHECK(hipMemcpy(h, d->d_bigrec_s[k], (size_t)n*sizeof(hz_bigrec_t), hipMemcpyDeviceToHost));
+    for(unsigned int r=0; r<n; r++)
+    {
+        int32_t* o = recs + (size_t)r*10;
+        o[0] = h[r].r.px0; o[1] = h[r].r.py0; o[2] = h[r].r.bw; o[3] = h[r].bh;
+        for(int m=0; m<3; m++) { o[4+m] = h[r].r.xs[m]; o[7+m] = h[r].r.ys[m]; }
+    }
+    free(h);
     return 0;
 }
 
