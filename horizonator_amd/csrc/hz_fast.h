@@ -94,7 +94,13 @@ __device__ static inline hzf_const_t hzf_setup(const hz_xform_t* u)
     hzf_const_t c;
     c.zrange = u->zfar - u->znear;
     c.crange = u->zfar_color - u->znear_color;
-    c.rr_two_pi = hzf_refined_rcp(HZ_TWO_PI);
+    /* (the divisor goes through a register the compiler cannot see into: a
+     * constant-folded reciprocal would be the correctly rounded 1/(2 pi), not
+     * necessarily what v_rcp_f32 returns - and "the same sequence as `/`" means
+     * the hardware's) */
+    float two_pi = HZ_TWO_PI;
+    asm volatile("" : "+v"(two_pi));
+    c.rr_two_pi = hzf_refined_rcp(two_pi);
     c.rr_zrange = hzf_refined_rcp(c.zrange);
     c.rr_crange = hzf_refined_rcp(c.crange);
     return c;

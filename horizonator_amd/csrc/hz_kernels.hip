@@ -693,7 +693,7 @@ void k_big(unsigned long long* __restrict__ fb,
 #define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
 #define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
-#define MR_NEAR_CELLS 128            /* round 1 of a draw: strips within this many cells of the viewer */
+#define MR_NEAR_CELLS 64             /* round 1 of a draw: strips within this many cells of the viewer */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the
@@ -1349,6 +1349,81 @@ void k_resolve(unsigned long long* __restrict__ fb, const float* __restrict__ ta
                 r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);  /* = hypotf */
             }
             ranges[o] = r;
+        }
+    }
+}
+
+/* the same for sector widths that are a multiple of 4 and 16-byte aligned
+ * buffers (the normal case): a thread takes four neighbouring pixels of one
+ * row - two 16-byte loads, one store per output - and the row/column come from
+ * the launch grid instead of a 64-bit division per pixel */
+__device__ static inline float hz_range_from_z24(uint32_t zi, float tan_row, float znear, float zfar)
+{
+    /* reference horizonator-lib.c:1013-1025 */
+    const float depth = (float)((double)zi * (1.0/16777215.0));
+    const float len   = depth * (zfar-znear) + znear;
+    const float zt    = tan_row * len;
+    return (float)sqrt((double)len*(double)len + (double)zt*(double)zt);  /* = hypotf */
+}
+
+template<bool CLEAR>
+__global__ __launch_bounds__(256)
+void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
+                unsigned char* __restrict__ bgr, float* __restrict__ ranges,
+                int32_t* __restrict__ index, uint32_t* __restrict__ z24,
+                int SW, int H, float znear, float zfar)
+{
+    const int x = (int)(blockIdx.x*blockDim.x + threadIdx.x)*4;
+    if(x >= SW) return;
+    for(int yo = blockIdx.y; yo < H; yo += gridDim.y)
+    {
+        const int row = H-1 - yo;               /* GL row, reference horizonator-lib.c:949-958 */
+        ulonglong2* src = (ulonglong2*)(fb + (size_t)row*SW + x);
+        const ulonglong2 k01 = src[0], k23 = src[1];
+        if(CLEAR)
+        {
+            const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
+            if((k01.x & k01.y) != HZ_FB_CLEAR) src[0] = ones;
+            if((k23.x & k23.y) != HZ_FB_CLEAR) src[1] = ones;
+        }
+        const unsigned long long key[4] = { k01.x, k01.y, k23.x, k23.y };
+        uint32_t zi[4], pix[4];
+        #pragma unroll
+        for(int k=0; k<4; k++)
+        {
+            zi[k] = (uint32_t)(key[k] >> 40);
+            /* reference horizonator-lib.c:185 clear colour (0,0,1) -> B=255; fragment.glsl:15-16 terrain = (red,0,0) -> R;
+             * the three bytes B,G,R as the low 24 bits */
+            pix[k] = zi[k] == HZ_Z24_MAX ? 0x0000FFu : (((uint32_t)key[k] & 0xFFu) << 16);
+        }
+        const size_t o = (size_t)yo*SW + x;
+        if(bgr)
+        {
+            uint3 w;
+            w.x = pix[0] | (pix[1] << 24);
+            w.y = (pix[1] >> 8) | (pix[2] << 16);
+            w.z = (pix[2] >> 16) | (pix[3] << 8);
+            *(uint3*)(bgr + o*3) = w;
+        }
+        if(index)
+        {
+            int4 w;
+            w.x = zi[0] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[0] >> 8);
+            w.y = zi[1] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[1] >> 8);
+            w.z = zi[2] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[2] >> 8);
+            w.w = zi[3] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[3] >> 8);
+            *(int4*)(index + o) = w;
+        }
+        if(z24) { uint4 w = { zi[0], zi[1], zi[2], zi[3] }; *(uint4*)(z24 + o) = w; }
+        if(ranges)
+        {
+            const float tr = tanel[row];
+            float4 w;
+            w.x = zi[0] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[0], tr, znear, zfar);
+            w.y = zi[1] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[1], tr, znear, zfar);
+            w.z = zi[2] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[2], tr, znear, zfar);
+            w.w = zi[3] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[3], tr, znear, zfar);
+            *(float4*)(ranges + o) = w;
         }
     }
 }
@@ -2387,7 +2462,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
          * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms) */
         const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
         const bool want_two = e2 ? atoi(e2) != 0
-                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 12.0f*(float)near_cells);
+                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 24.0f*(float)near_cells);
         const bool two_pass = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
         const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
@@ -2527,7 +2602,18 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
     if(nblocks > 256*32) nblocks = 256*32;
     /* the textured resolve reads the framebuffer after this kernel: no fused clear then */
     const bool clears = d->resolve_clears && !(d->tex_on && bgr);
-    if(clears)
+    const bool wide = (SW % 4) == 0 && (((uintptr_t)bgr | (uintptr_t)ranges | (uintptr_t)index | (uintptr_t)z24 | (uintptr_t)d->d_fb) & 15u) == 0;
+    if(wide)
+    {
+        const dim3 grid((unsigned)((SW/4 + 255)/256), (unsigned)(d->H < 2048 ? d->H : 2048));
+        if(clears)
+            hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+        else
+            hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+    }
+    else if(clears)
         hipLaunchKernelGGL(k_resolve<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
                            d->d_fb, (const float*)d->d_tanel,
                            bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
