@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
 
 
+def test_rccl_library_exports_what_its_header_declares():
+    """include/horizonator_rccl.h -> libhorizonator_rccl.so (the exchange steps for a C caller; a
+    library of its own so that libhorizonator.so does not depend on RCCL)"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "horizonator_rccl.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(horizonator_rccl_[a-z0-9_]+)\s*\(", text))
+    assert declared == {"horizonator_rccl_broadcast_mosaic", "horizonator_rccl_gather_strips"}
+    _lib.load()                                     # libhorizonator.so first: the rccl library links against it
+    lib = C.CDLL(os.path.join(ROOT, "horizonator_amd", "libhorizonator_rccl.so"))
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_context_layout_matches_reference_abi():
     # numbers printed by a program compiled against the REFERENCE's own
     # horizonator.h / dem.h (gcc 11, x86-64): sizeof(ctx), offsetof program,
