@@ -103,10 +103,11 @@ struct hz_params_t
 };
 
 /* a set-up triangle as it travels between phases: through LDS inside
- * k_scatter (stride 19 dwords = odd, conflict-free), through HBM to k_big */
+ * k_scatter (stride 23 dwords = odd, conflict-free), through HBM to k_mid and
+ * k_big.  Coverage as hz_edges_t: what the pixel loops need, ready made. */
 struct hz_rec_t
 {
-    int32_t  xs[3], ys[3];
+    hz_edges_t e;
     float    z_org, dzdx, dzdy, r_org, drdx, drdy;
     int32_t  px0, py0, bw;
     float    inv_bw;
@@ -169,12 +170,39 @@ __device__ static inline uint32_t hz_big_chunks(int bw, int bh)
 /* ------------------------------------------------------------------------ */
 /* device helpers                                                            */
 
-__device__ static inline void hz_tri_from_rec(hz_tri_t& t, const hz_rec_t& r)
+/* record <- set-up triangle (planes + coverage); the box and the id are the caller's */
+__device__ static inline void hz_rec_from_tri(hz_rec_t& r, const hz_tri_t& t)
+{
+    hz_edges_of(&r.e, &t);
+    r.z_org = t.z_org; r.dzdx = t.dzdx; r.dzdy = t.dzdy;
+    r.r_org = t.r_org; r.drdx = t.drdx; r.drdy = t.drdy;
+}
+/* the planes of a record as a hz_tri_t for hz_tri_fragment() (which reads nothing else) */
+__device__ static inline void hz_planes_from_rec(hz_tri_t& t, const hz_rec_t& r)
 {
     #pragma unroll
-    for(int m=0; m<3; m++) { t.xs[m] = r.xs[m]; t.ys[m] = r.ys[m]; }
+    for(int m=0; m<3; m++) { t.xs[m] = 0; t.ys[m] = 0; }
     t.z_org = r.z_org; t.dzdx = r.dzdx; t.dzdy = r.dzdy;
     t.r_org = r.r_org; t.drdx = r.drdx; t.drdy = r.drdy;
+}
+/* one pixel centre of a record's triangle: coverage, depth, colour, framebuffer */
+template<bool PRETEST>
+__device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_params_t& p, const hz_rec_t& r, int px, int py)
+{
+    if(!hz_edges_cover(&r.e, px, py)) return;
+    hz_tri_t t;
+    hz_planes_from_rec(t, r);
+    uint32_t zi, r8;
+    if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
+    const unsigned long long key = hz_pack(zi, r.prim, r8);
+    unsigned long long* dst = &fb[(size_t)py*p.SW + (px - p.col0)];
+    if(PRETEST)
+    {
+        if(key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(dst, key);
+    }
+    else
+        atomicMin(dst, key);
 }
 
 /* PRETEST: read the word first and skip the atomic when the fragment cannot
@@ -268,10 +296,7 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
             continue;
         }
         hz_bigrec_t br;
-        #pragma unroll
-        for(int m=0; m<3; m++) { br.r.xs[m] = tri.xs[m]; br.r.ys[m] = tri.ys[m]; }
-        br.r.z_org = tri.z_org; br.r.dzdx = tri.dzdx; br.r.dzdy = tri.dzdy;
-        br.r.r_org = tri.r_org; br.r.drdx = tri.drdx; br.r.drdy = tri.drdy;
+        hz_rec_from_tri(br.r, tri);
         br.r.px0 = box.px0; br.r.py0 = box.py0; br.r.bw = box.px1 - box.px0 + 1;
         br.r.inv_bw = 1.0f / (float)br.r.bw;
         br.r.prim = prim;
@@ -340,7 +365,7 @@ void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__
 #define SC_VX (SC_CX+1)
 #define SC_VY (SC_CY+1)
 #define SC_THREADS (SC_CX*SC_CY)
-#define SC_REC_STRIDE 17
+#define SC_REC_STRIDE 23
 
 static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");
 
@@ -450,10 +475,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             hz_tri_t tri;
             hz_tri_planes(&tri, &a, &b, &c);
             hz_rec_t r;
-            #pragma unroll
-            for(int m=0; m<3; m++) { r.xs[m] = tri.xs[m]; r.ys[m] = tri.ys[m]; }
-            r.z_org = tri.z_org; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
-            r.r_org = tri.r_org; r.drdx = tri.drdx; r.drdy = tri.drdy;
+            hz_rec_from_tri(r, tri);
             r.px0 = box.px0; r.py0 = box.py0; r.bw = box.px1 - box.px0 + 1;
             r.inv_bw = 1.0f / (float)r.bw;
             r.prim = (uint32_t)(((size_t)(j0+cy)*(p.N-1) + (i0+cx))*2 + t);
@@ -537,9 +559,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             const uint32_t local = it - s_prefix[lo];
             const int ry = (int)(((float)local + 0.5f) * r.inv_bw);
             const int rx = (int)local - ry*r.bw;
-            hz_tri_t tri;
-            hz_tri_from_rec(tri, r);
-            hz_emit(fb, p, tri, r.prim, r.px0 + rx, r.py0 + ry);
+            hz_emit_rec<true>(fb, p, r, r.px0 + rx, r.py0 + ry);
         }
         __syncthreads();
     }
@@ -607,7 +627,7 @@ void k_big(unsigned long long* __restrict__ fb,
         const hz_bigrec_t  br   = rec_next;
         if(it + nwaves < nitems) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
         hz_tri_t tri;
-        hz_tri_from_rec(tri, br.r);
+        hz_planes_from_rec(tri, br.r);
         const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;
         const uint32_t prim = br.r.prim;
 
@@ -620,26 +640,23 @@ void k_big(unsigned long long* __restrict__ fb,
         #pragma unroll
         for(int m=0; m<3; m++)
         {
-            /* edge m (vertex m -> m+1), hz_edge():  E(px) = K - dy*256*px  with
-             * K = dx*(row*256 - ys[a]) + dy*xs[a];  covered <=> E >= c, c = 0 if the
-             * edge owns its zeros, else 1 (hz_tri_covers) */
-            const int a = m, b = (m == 2) ? 0 : m+1;
-            const int32_t dx = tri.xs[b] - tri.xs[a], dy = tri.ys[b] - tri.ys[a];       /* wave-uniform */
-            const int64_t K  = (int64_t)dx*(((int64_t)row << HZ_SUBPIXEL_BITS) - tri.ys[a]) + (int64_t)dy*(int64_t)tri.xs[a];
-            const int64_t num = K - (hz_edge_owns_zero(&tri, m) ? 0 : 1);
+            /* edge m covers px in this row iff g + dx*row - dy*px >= 0 (hz_edges_t), g and
+             * the deltas wave-uniform: a bound on px from one side, by an exact division */
+            const int32_t dx = br.r.e.dx[m], dy = -br.r.e.ndy[m];
+            const int64_t n8 = hz_edges_g(&br.r.e, m) + (int64_t)dx*(int64_t)row;
             if(dy > 0)
             {
-                /* px <= floor(num / (256*dy)) = floor(floor(num/256) / dy) */
-                const int32_t q = hz_floor_div(num >> HZ_SUBPIXEL_BITS, dy, 1.0/(double)dy);
+                /* dy*px <= n8  <=>  px <= floor(n8 / dy) */
+                const int32_t q = hz_floor_div(n8, dy, 1.0/(double)dy);
                 x1 = x1 < q ? x1 : q;
             }
             else if(dy < 0)
             {
-                /* 256*|dy|*px >= -num  <=>  px >= ceil(-num / (256*|dy|)) = -floor(num / (256*|dy|)) */
-                const int32_t q = hz_floor_div(num >> HZ_SUBPIXEL_BITS, -dy, 1.0/(double)(-dy));
+                /* |dy|*px >= -n8  <=>  px >= ceil(-n8 / |dy|) = -floor(n8 / |dy|) */
+                const int32_t q = hz_floor_div(n8, -dy, 1.0/(double)(-dy));
                 x0 = x0 > -q ? x0 : -q;
             }
-            else if(num < 0) any = false;               /* a horizontal edge: the whole row is on one side */
+            else if(n8 < 0) any = false;                /* a horizontal edge: the whole row is on one side */
         }
         const uint32_t count = (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
 
@@ -790,20 +807,16 @@ __device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
      * at least half the lanes still have a pixel left (boxes of similar size,
      * the common case inside one flush) */
     uint32_t done = 0;
+    for(;;)
     {
-        hz_tri_t own;
-        hz_tri_from_rec(own, r);
-        for(;;)
+        const bool more = npix > done;
+        if(__popcll(__ballot(more)) < 32) break;
+        if(more)
         {
-            const bool more = npix > done;
-            if(__popcll(__ballot(more)) < 32) break;
-            if(more)
-            {
-                const int ry = (int)(((float)done + 0.5f) * r.inv_bw);
-                const int rx = (int)done - ry*r.bw;
-                hz_emit_t<false>(fb, p, own, r.prim, r.px0 + rx, r.py0 + ry);
-                done++;
-            }
+            const int ry = (int)(((float)done + 0.5f) * r.inv_bw);
+            const int rx = (int)done - ry*r.bw;
+            hz_emit_rec<false>(fb, p, r, r.px0 + rx, r.py0 + ry);
+            done++;
         }
     }
 
@@ -823,21 +836,25 @@ __device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
             const uint32_t v = __shfl(excl, lo + step);
             if(v <= it) lo += step;
         }
-        hz_tri_t tri;
+        hz_rec_t o;
         #pragma unroll
-        for(int m=0; m<3; m++) { tri.xs[m] = __shfl(r.xs[m], lo); tri.ys[m] = __shfl(r.ys[m], lo); }
-        tri.z_org = __shfl(r.z_org, lo); tri.dzdx = __shfl(r.dzdx, lo); tri.dzdy = __shfl(r.dzdy, lo);
-        tri.r_org = __shfl(r.r_org, lo); tri.drdx = __shfl(r.drdx, lo); tri.drdy = __shfl(r.drdy, lo);
-        const int      opx0 = __shfl(r.px0, lo), opy0 = __shfl(r.py0, lo), obw = __shfl(r.bw, lo);
-        const float    oinv = __shfl(r.inv_bw, lo);
-        const uint32_t oprim = __shfl(r.prim, lo);
+        for(int m=0; m<3; m++)
+        {
+            o.e.dx[m]  = __shfl(r.e.dx[m], lo);  o.e.ndy[m] = __shfl(r.e.ndy[m], lo);
+            o.e.glo[m] = __shfl(r.e.glo[m], lo); o.e.ghi[m] = __shfl(r.e.ghi[m], lo);
+        }
+        o.z_org = __shfl(r.z_org, lo); o.dzdx = __shfl(r.dzdx, lo); o.dzdy = __shfl(r.dzdy, lo);
+        o.r_org = __shfl(r.r_org, lo); o.drdx = __shfl(r.drdx, lo); o.drdy = __shfl(r.drdy, lo);
+        o.px0 = __shfl(r.px0, lo); o.py0 = __shfl(r.py0, lo); o.bw = __shfl(r.bw, lo);
+        o.inv_bw = __shfl(r.inv_bw, lo);
+        o.prim = __shfl(r.prim, lo);
         const uint32_t oexcl = __shfl(excl, lo), odone = __shfl(done, lo);
         if(it < total)
         {
             const uint32_t local = it - oexcl + odone;
-            const int ry = (int)(((float)local + 0.5f) * oinv);
-            const int rx = (int)local - ry*obw;
-            hz_emit_t<false>(fb, p, tri, oprim, opx0 + rx, opy0 + ry);
+            const int ry = (int)(((float)local + 0.5f) * o.inv_bw);
+            const int rx = (int)local - ry*o.bw;
+            hz_emit_rec<false>(fb, p, o, o.px0 + rx, o.py0 + ry);
         }
     }
 }
@@ -936,10 +953,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     {
         hz_tri_t tri;
         hz_tri_planes(&tri, &a, &b, &c);
-        #pragma unroll
-        for(int m=0; m<3; m++) { r.xs[m] = tri.xs[m]; r.ys[m] = tri.ys[m]; }
-        r.z_org = tri.z_org; r.dzdx = tri.dzdx; r.dzdy = tri.dzdy;
-        r.r_org = tri.r_org; r.drdx = tri.drdx; r.drdy = tri.drdy;
+        hz_rec_from_tri(r, tri);
         r.px0 = box.px0; r.bw = box.px1 - box.px0 + 1;
         r.py0 = box.py0; bh   = box.py1 - box.py0 + 1;
         r.inv_bw = 1.0f / (float)r.bw;
@@ -949,7 +963,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     else
     {
         #pragma unroll
-        for(int m=0; m<3; m++) { r.xs[m] = 0; r.ys[m] = 0; }
+        for(int m=0; m<3; m++) { r.e.dx[m] = 0; r.e.ndy[m] = 0; r.e.glo[m] = 0; r.e.ghi[m] = 0; }
         r.z_org = r.dzdx = r.dzdy = r.r_org = r.drdx = r.drdy = 0.f;
         r.px0 = r.py0 = 0; r.bw = 1; r.inv_bw = 1.f; r.prim = 0;
     }
@@ -992,11 +1006,9 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             else
             {
                 /* queue full (capacities are sized for 32k-wide panoramas): slow but correct */
-                hz_tri_t tri;
-                hz_tri_from_rec(tri, r);
                 for(int py = r.py0; py < r.py0 + bh; py++)
                     for(int px = r.px0; px < r.px0 + r.bw; px++)
-                        hz_emit(fb, p, tri, r.prim, px, py);
+                        hz_emit_rec<true>(fb, p, r, px, py);
             }
             npix = 0;
         }
@@ -3213,8 +3225,8 @@ extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long se
 
 /* diagnostics: the large-triangle queue of the last draw (set 0: its only or
  * second round, set 1: the first round of a two-round draw): counters[6] and,
- * for the first min(max_rec, counters[0]) records, px0 py0 bw bh + the six
- * snapped vertex coordinates (10 int32 each) */
+ * for the first min(max_rec, counters[0]) records, px0 py0 bw bh + the three
+ * edge vectors dx, dy in 1/256 pixel (10 int32 each) */
 extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counters, int max_rec, int32_t* recs)
 {
     HZ_ON_DEVICE(d);
@@ -3231,7 +3243,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     {
         int32_t* o = recs + (size_t)r*10;
         o[0] = h[r].r.px0; o[1] = h[r].r.py0; o[2] = h[r].r.bw; o[3] = h[r].bh;
-        for(int m=0; m<3; m++) { o[4+m] = h[r].r.xs[m]; o[7+m] = h[r].r.ys[m]; }
+        for(int m=0; m<3; m++) { o[4+m] = h[r].r.e.dx[m]; o[7+m] = -h[r].r.e.ndy[m]; }
     }
     free(h);
     return 0;

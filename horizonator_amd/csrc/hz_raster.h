@@ -272,6 +272,39 @@ HZ_HD int hz_tri_covers(const hz_tri_t* t, int px, int py)
     return 1;
 }
 
+/* The coverage test once more, with everything that depends on the triangle
+ * alone taken out of it.  hz_edge() is
+ *     E = dx*(256*py - ya) - dy*(256*px - xa) = 256*(dx*py - dy*px) + (dy*xa - dx*ya)
+ * and a pixel centre is covered by edge m iff E >= c, c = 0 where the edge owns
+ * its zeros, else 1 (hz_tri_covers).  With F = dy*xa - dx*ya - c that is
+ * 256*T + F >= 0 for the integer T = dx*py - dy*px, i.e. T >= ceil(-F/256) =
+ * -floor(F/256):   covered  <=>  g + dx*py - dy*px >= 0,   g = F >> 8.
+ * Three edges: six 64-bit multiply-adds and a sign test per pixel. */
+typedef struct { int32_t dx[3], ndy[3]; uint32_t glo[3], ghi[3]; } hz_edges_t;
+
+HZ_HD void hz_edges_of(hz_edges_t* e, const hz_tri_t* t)
+{
+    #pragma unroll
+    for(int m=0; m<3; m++)
+    {
+        const int a = m, b = (m == 2) ? 0 : m+1;
+        const int32_t dx = t->xs[b] - t->xs[a], dy = t->ys[b] - t->ys[a];
+        const int64_t F = (int64_t)dy*(int64_t)t->xs[a] - (int64_t)dx*(int64_t)t->ys[a] - (hz_edge_owns_zero(t, m) ? 0 : 1);
+        const int64_t g = F >> HZ_SUBPIXEL_BITS;            /* arithmetic: floor */
+        e->dx[m] = dx; e->ndy[m] = -dy;
+        e->glo[m] = (uint32_t)(uint64_t)g; e->ghi[m] = (uint32_t)((uint64_t)g >> 32);
+    }
+}
+HZ_HD int64_t hz_edges_g(const hz_edges_t* e, int m) { return (int64_t)(((uint64_t)e->ghi[m] << 32) | (uint64_t)e->glo[m]); }
+HZ_HD int hz_edges_cover(const hz_edges_t* e, int px, int py)
+{
+    int64_t any = 0;
+    #pragma unroll
+    for(int m=0; m<3; m++)
+        any |= hz_edges_g(e, m) + (int64_t)e->dx[m]*(int64_t)py + (int64_t)e->ndy[m]*(int64_t)px;
+    return any >= 0;
+}
+
 /* depth + colour of a covered pixel; returns 0 if the fragment cannot beat the
  * cleared depth */
 HZ_HD int hz_tri_fragment(const hz_tri_t* t, int px, int py, uint32_t* zi, uint32_t* r8)

@@ -228,7 +228,7 @@ int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsign
 /* diagnostics (tools/bigqueue_stats.py): the queue of large triangles the last
  * draw left behind - set 0: its only or second round, 1: the first round of a
  * two-round draw.  counters: 6 words (mr_queue_t); recs: 10 int32 per record
- * (px0 py0 bw bh, snapped x of the three vertices, snapped y), at most max_rec */
+ * (px0 py0 bw bh, the three edge vectors' dx, then dy, in 1/256 pixel), at most max_rec */
 int  hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counters, int max_rec, int32_t* recs);
 
 const char* hz_hip_last_error(void);

@@ -34,6 +34,6 @@ with hzutil.HipDev(m, W, H, raster=2) as dev:
             *np.percentile(tiles, [10, 50, 90, 99, 100]), 100*(tiles <= 4).mean(), 100*(tiles <= 16).mean(), 100*(tiles <= 64).mean()))
         print("   box: width p50 %d p90 %d p99 %d; height p50 %d p90 %d p99 %d" % (*np.percentile(bw, [50, 90, 99]), *np.percentile(bh, [50, 90, 99])))
         # triangle area in pixels (snapped) vs box area: how much of a box is covered
-        xs, ys = r[:, 4:7], r[:, 7:10]
-        area = np.abs((xs[:, 1]-xs[:, 0])*(ys[:, 2]-ys[:, 0]) - (xs[:, 2]-xs[:, 0])*(ys[:, 1]-ys[:, 0])) / 2.0 / 65536.0
+        dx, dy = r[:, 4:7], r[:, 7:10]                          # edge vectors m -> m+1
+        area = np.abs(dx[:, 0]*dy[:, 1] - dx[:, 1]*dy[:, 0]) / 2.0 / 65536.0
         print("   triangle area (unclipped) / box area: mean %.3f; sum of areas %.1f Mpx vs boxes %.1f Mpx" % (np.mean(np.minimum(area/(bw*bh), 1)), area.sum()/1e6, (bw*bh).sum()/1e6))
