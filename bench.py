@@ -477,6 +477,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "k_scatter" if args.raster == 1 else "k_march", "kernel_ms": raster_ms,
+                "kernel_launch": ("second round of a two-round draw: every strip but those next to the viewer (the first round's "
+                                  "k_march is in other_kernels_ms.round1_near_viewer with its queue kernels)") if near_ms > 0.05 else "the draw's only k_march launch",
+                "frac_whole_render": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes": algo_bytes,
                 "other_kernels_ms": {"clear": clear_ms, "round1_near_viewer": near_ms, "queues_after": big_ms, "resolve": resolve_ms},
                 "device_ms_per_render_sum_of_stages": total_ms,

@@ -616,10 +616,15 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
      * samples (BASELINE configs[4]) would otherwise need 44 GB of vertices. */
     enum { BLK = 32 };
     typedef struct { float xn, yn, zn, wx, wy, zw, red; } pvert_t;
-    pvert_t* vert = malloc((size_t)(BLK+1)*N*sizeof(pvert_t));
-    float (*vst)[2] = tex ? malloc((size_t)(BLK+1)*N*sizeof(*vst)) : NULL;
+    /* cell rows per band: as many as ~2 GB of vertices allow (the whole grid up to
+     * BASELINE's 7x7-tile mosaic: one band, no barrier in between), a multiple of BLK */
+    int band = (int)(2000000000.0 / ((double)N*sizeof(pvert_t))) / BLK * BLK;
+    if(band < BLK) band = BLK;
+    if(band > N-1) band = ((N-1 + BLK-1)/BLK)*BLK;
+    pvert_t* vert = malloc((size_t)(band+1)*N*sizeof(pvert_t));
+    float (*vst)[2] = tex ? malloc((size_t)(band+1)*N*sizeof(*vst)) : NULL;
     float* tanel = malloc((size_t)H*sizeof(float));
-    const int nb = (N-1 + BLK-1)/BLK;
+    const int nbx = (N-1 + BLK-1)/BLK, nby = band/BLK, nb = nbx*nby;
     int* blk_lo = malloc((size_t)nb*sizeof(int));
     int* blk_hi = malloc((size_t)nb*sizeof(int));
     if(!fb.depth || !fb.prim || !fb.red || !vert || !tanel || !blk_lo || !blk_hi || (tex && (!fb.color || !vst)))
@@ -641,9 +646,9 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
     az_constants(v, &c, &k);
     const float halfW = (float)W*0.5f, halfH = (float)H*0.5f;
 
-    for(int jb=0; jb<N-1; jb+=BLK)
+    for(int jb=0; jb<N-1; jb+=band)
     {
-        const int jrows = (jb + BLK < N-1 ? BLK : N-1 - jb) + 1;        /* vertex rows of this band */
+        const int jrows = (jb + band < N-1 ? band : N-1 - jb) + 1;      /* vertex rows of this band */
         /* vertex stage + viewport transform (glViewport(0,0,W,H), reference
          * horizonator-lib.c:657; depth range 0..1) */
         #pragma omp parallel for schedule(static) num_threads(nthreads) collapse(2)
@@ -671,9 +676,10 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
         #pragma omp parallel for schedule(dynamic,8) num_threads(nthreads)
         for(int b=0; b<nb; b++)
         {
-            const int ib = b*BLK;
+            const int ib = (b%nbx)*BLK, jj0 = (b/nbx)*BLK;
+            if(jj0 >= jrows-1) { blk_lo[b] = INT32_MAX; blk_hi[b] = INT32_MIN; continue; }     /* beyond the last (short) band */
             float lo = INFINITY, hi = -INFINITY, nlo = INFINITY, nhi = -INFINITY;
-            for(int jj=0; jj<jrows; jj++)
+            for(int jj=jj0; jj<=jj0+BLK && jj<jrows; jj++)
                 for(int i=ib; i<=ib+BLK && i<N; i++)
                 {
                     const pvert_t* w = &vert[(size_t)jj*N + i];
@@ -699,9 +705,10 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
             if(x_lo <= x_hi)
                 for(int b=0; b<nb; b++)
                 {
+                    const int ib = (b%nbx)*BLK, jj0 = (b/nbx)*BLK;
+                    if(jj0 >= jrows-1) break;
                     if(blk_hi[b] < x_lo || blk_lo[b] > x_hi) continue;
-                    const int ib = b*BLK;
-                    for(int jj=0; jj<jrows-1; jj++)
+                    for(int jj=jj0; jj<jj0+BLK && jj<jrows-1; jj++)
                         for(int i=ib; i<ib+BLK && i<N-1; i++)
                         {
                             wvert_t q[4];               /* v00 v10 v01 v11 */
