@@ -100,7 +100,24 @@ struct hz_params_t
     int   quad_max_dx;                 /* k_march: 256*(W/16 - 1): see the cull of whole cells                  */
     int   debug;                       /* HZ_MARCH_DEBUG (timing splits, wrong pictures): 1 survivors are dropped,
                                         * 2 survivors are dropped after the early depth test */
+    /* one byte per HZ_SEG consecutive pixels of a framebuffer row (row stride
+     * seg_stride): nonzero once anything was drawn there.  Every write to the
+     * framebuffer sets it (hz_fb_min); the conversion skips reading - and
+     * clearing - segments nothing touched: the sky, 62 % of the benchmark's
+     * pixels.  A stale nonzero byte only costs the read. */
+    unsigned char* touched;
+    int   seg_stride;
 };
+#define HZ_SEG_LOG2 8
+#define HZ_SEG      (1 << HZ_SEG_LOG2)
+
+/* the one place fragments enter the framebuffer */
+__device__ static inline void hz_fb_min(unsigned long long* fb, const hz_params_t& p, int px, int py, unsigned long long key)
+{
+    const int x = px - p.col0;
+    p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1;
+    atomicMin(&fb[(size_t)py*p.SW + x], key);
+}
 
 /* a set-up triangle as it travels between phases: through LDS inside
  * k_scatter (stride 23 dwords = odd, conflict-free), through HBM to k_mid and
@@ -198,14 +215,13 @@ __device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_param
     uint32_t zi, r8;
     if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
     const unsigned long long key = hz_pack(zi, r.prim, r8);
-    unsigned long long* dst = &fb[(size_t)py*p.SW + (px - p.col0)];
     if(PRETEST)
     {
-        if(key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMin(dst, key);
+        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            hz_fb_min(fb, p, px, py, key);
     }
     else
-        atomicMin(dst, key);
+        hz_fb_min(fb, p, px, py, key);
 }
 
 /* PRETEST: read the word first and skip the atomic when the fragment cannot
@@ -220,14 +236,13 @@ __device__ static inline void hz_emit_t(unsigned long long* fb, const hz_params_
     uint32_t zi, r8;
     if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
     const unsigned long long key = hz_pack(zi, prim, r8);
-    unsigned long long* dst = &fb[(size_t)py*p.SW + (px - p.col0)];
     if(PRETEST)
     {
-        if(key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMin(dst, key);
+        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            hz_fb_min(fb, p, px, py, key);
     }
     else
-        atomicMin(dst, key);
+        hz_fb_min(fb, p, px, py, key);
 }
 __device__ static inline void hz_emit(unsigned long long* fb, const hz_params_t& p,
                                       const hz_tri_t& t, uint32_t prim, int px, int py)
@@ -319,28 +334,39 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
  * If the id queue overflowed (never with the default capacity) the ids that
  * did not fit are lost: the kernel then finds every triangle that needs the
  * clipper again, one thread per cell, and clips it on the spot.  Slow, correct. */
-__global__ __launch_bounds__(64)
+/* Resources matter more than speed here: the kernel of the first round runs
+ * beside the marching kernel of the panorama before, whose waves fill every
+ * SIMD's registers; a workgroup that wants 60 KB of contiguous LDS and half a
+ * SIMD's registers (what this kernel took with 64 clipping lanes per block)
+ * waited ~0.7 ms to be placed.  HZ_CLIP_LANES lanes of a block clip, the
+ * others leave at once. */
+#define HZ_CLIP_LANES 4
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
 {
-    __shared__ hz_cvert_t polygon[64][2][HZ_MAX_CLIPPED+1];
+    __shared__ hz_cvert_t polygon[HZ_CLIP_LANES][2][HZ_MAX_CLIPPED+1];
+    if(threadIdx.x >= HZ_CLIP_LANES) return;
+    hz_cvert_t* poly0 = polygon[threadIdx.x][0];
+    hz_cvert_t* poly1 = polygon[threadIdx.x][1];
     const unsigned int n = q.counters[4];
+    const unsigned int me = blockIdx.x*HZ_CLIP_LANES + threadIdx.x, stride = gridDim.x*HZ_CLIP_LANES;
     if(n <= q.clip_capacity)
     {
-        for(unsigned int k = blockIdx.x*blockDim.x + threadIdx.x; k < n; k += gridDim.x*blockDim.x)
-            hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
+        for(unsigned int k = me; k < n; k += stride)
+            hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, poly0, poly1);
         return;
     }
     const size_t ncells = (size_t)(p.N-1)*(p.N-1);
-    for(size_t cell = (size_t)blockIdx.x*blockDim.x + threadIdx.x; cell < ncells; cell += (size_t)gridDim.x*blockDim.x)
+    for(size_t cell = me; cell < ncells; cell += stride)
     {
         const int j = (int)(cell / (size_t)(p.N-1)), i = (int)(cell - (size_t)j*(p.N-1));
         const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i, j),   v10 = hz_vertex_at(p, mosaic, i+1, j);
         const hz_wvert_t v01 = hz_vertex_at(p, mosaic, i, j+1), v11 = hz_vertex_at(p, mosaic, i+1, j+1);
         hz_box_t box;
         if(hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, poly0, poly1);
         if(hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, polygon[threadIdx.x][0], polygon[threadIdx.x][1]);
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, poly0, poly1);
     }
 }
 
@@ -684,7 +710,7 @@ void k_big(unsigned long long* __restrict__ fb,
             {
                 uint32_t zi, r8;
                 if(hz_tri_fragment(&tri, px, py, &zi, &r8))
-                    atomicMin(&fb[(size_t)py*p.SW + (px - p.col0)], hz_pack(zi, prim, r8));
+                    hz_fb_min(fb, p, px, py, hz_pack(zi, prim, r8));
             }
         }
     }
@@ -1386,20 +1412,29 @@ __global__ __launch_bounds__(256)
 void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
                 unsigned char* __restrict__ bgr, float* __restrict__ ranges,
                 int32_t* __restrict__ index, uint32_t* __restrict__ z24,
-                int SW, int H, float znear, float zfar)
+                int SW, int H, float znear, float zfar,
+                unsigned char* __restrict__ touched, int seg_stride)
 {
+    /* a wave = 64 lanes x 4 pixels = one HZ_SEG-pixel segment of a row */
+    static_assert(HZ_SEG == 256, "k_resolve4: one wave converts one segment");
     const int x = (int)(blockIdx.x*blockDim.x + threadIdx.x)*4;
     if(x >= SW) return;
     for(int yo = blockIdx.y; yo < H; yo += gridDim.y)
     {
         const int row = H-1 - yo;               /* GL row, reference horizonator-lib.c:949-958 */
         ulonglong2* src = (ulonglong2*)(fb + (size_t)row*SW + x);
-        const ulonglong2 k01 = src[0], k23 = src[1];
-        if(CLEAR)
+        unsigned char* flag = touched + (size_t)row*seg_stride + (x >> HZ_SEG_LOG2);
+        ulonglong2 k01 = { HZ_FB_CLEAR, HZ_FB_CLEAR }, k23 = k01;
+        if(*flag)                               /* (the same byte for the whole wave) */
         {
-            const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
-            if((k01.x & k01.y) != HZ_FB_CLEAR) src[0] = ones;
-            if((k23.x & k23.y) != HZ_FB_CLEAR) src[1] = ones;
+            k01 = src[0]; k23 = src[1];
+            if(CLEAR)
+            {
+                const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
+                if((k01.x & k01.y) != HZ_FB_CLEAR) src[0] = ones;
+                if((k23.x & k23.y) != HZ_FB_CLEAR) src[1] = ones;
+                if((x & (HZ_SEG-1)) == 0) *flag = 0;
+            }
         }
         const unsigned long long key[4] = { k01.x, k01.y, k23.x, k23.y };
         uint32_t zi[4], pix[4];
@@ -1911,6 +1946,8 @@ struct hz_dev
     size_t              fb_used[HZ_NFB];    /* words of d_fbs[i] that may differ from all ones            */
     int                 fbi;            /* framebuffer of the last draw                                */
     unsigned long long* d_fb;           /* = d_fbs[fbi]                                               */
+    unsigned char*      d_touched[HZ_NFB];  /* hz_params_t::touched of each framebuffer: seg_stride*H bytes */
+    int                 seg_stride;         /* ceil(W / HZ_SEG)                                            */
     /* the queues between the marching kernel and the kernels that finish a draw
      * (clipped, medium, large triangles): two sets, like the framebuffers, so
      * that those kernels of panorama k (qstream) run beside k_march of k+1.
@@ -1975,7 +2012,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     if(d->qstream) (void)hipStreamSynchronize(d->qstream);
     if(d->rstream) (void)hipStreamSynchronize(d->rstream);
     (void)hipFree(d->d_mosaic);
-    for(int i=0; i<HZ_NFB; i++) (void)hipFree(d->d_fbs[i]);
+    for(int i=0; i<HZ_NFB; i++) { (void)hipFree(d->d_fbs[i]); (void)hipFree(d->d_touched[i]); }
     if(d->nstream) (void)hipStreamSynchronize(d->nstream);
     for(int i=0; i<2*HZ_NFB; i++)
     {
@@ -2036,11 +2073,14 @@ static int create_impl(hz_dev_t* d)
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_readers, hipEventDisableTiming));
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_tanel,   hipEventDisableTiming));
     HZ_CHECK(hipMalloc(&d->d_mosaic, (size_t)d->N*d->N*sizeof(int16_t)));
+    d->seg_stride = (d->W + HZ_SEG-1) / HZ_SEG;
     for(int i=0; i<HZ_NFB; i++)
     {
         /* glClear (reference horizonator-lib.c:896): depth = 1.0 -> all-ones words */
         HZ_CHECK(hipMalloc(&d->d_fbs[i], (size_t)d->W*d->H*sizeof(unsigned long long)));
         HZ_CHECK(hipMemsetAsync(d->d_fbs[i], 0xFF, (size_t)d->W*d->H*sizeof(unsigned long long), d->rstream));
+        HZ_CHECK(hipMalloc(&d->d_touched[i], (size_t)d->seg_stride*d->H));
+        HZ_CHECK(hipMemsetAsync(d->d_touched[i], 0, (size_t)d->seg_stride*d->H, d->rstream));
         HZ_CHECK(hipEventRecord(d->ev_free[i], d->rstream));
         d->fb_used[i] = 0;
     }
@@ -2331,6 +2371,7 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.halfH = (float)d->H * 0.5f;
     p.N = d->N; p.W = d->W; p.H = d->H;
     p.col0 = d->col0; p.col1 = d->col1; p.SW = d->col1 - d->col0;
+    p.touched = d->d_touched[d->fbi]; p.seg_stride = d->seg_stride;
     /* Whole panorama on one GPU: the marching waves keep everything up to 64
      * pixels (cheapest in total).  One azimuth sector of several: the waves next
      * to the viewer become the critical path, so medium boxes are handed to
@@ -2409,12 +2450,16 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
         HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));       /* the previous draw's last kernels (qstream) */
         if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->rstream));
         if(d->fb_used[prev])
+        {
             HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
+            HZ_CHECK(hipMemsetAsync(d->d_touched[prev], 0, (size_t)d->seg_stride*d->H, d->rstream));
+        }
         if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
         d->fb_used[prev] = 0;
         HZ_CHECK(hipEventRecord(d->ev_free[prev], d->rstream));
         d->fbi = next; d->d_fb = d->d_fbs[next];
         d->fb_used[next] = (size_t)p.SW*p.H;
+        p.touched = d->d_touched[next];
     }
 
     auto queue_set = [&](int k) -> mr_queue_t
@@ -2623,10 +2668,10 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
         const dim3 grid((unsigned)((SW/4 + 255)/256), (unsigned)(d->H < 2048 ? d->H : 2048));
         if(clears)
             hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
-                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride);
         else
             hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
-                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride);
     }
     else if(clears)
         hipLaunchKernelGGL(k_resolve<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
