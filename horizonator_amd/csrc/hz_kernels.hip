@@ -2004,6 +2004,16 @@ extern "C" int hz_hip_device_count(void)
     return n;
 }
 
+/* everything queued on any of the context's streams is done */
+static hipError_t sync_all(hz_dev_t* d)
+{
+    hipError_t rc = hipSuccess;
+    hipStream_t all[4] = { d->stream, d->nstream, d->qstream, d->rstream };
+    for(int k=0; k<4; k++)
+        if(all[k]) { const hipError_t e = hipStreamSynchronize(all[k]); if(e != hipSuccess) rc = e; }
+    return rc;
+}
+
 extern "C" void hz_hip_destroy(hz_dev_t* d)
 {
     if(!d) return;
@@ -2151,6 +2161,7 @@ extern "C" hz_dev_t* hz_hip_create(int device, int N, int width, int height)
 extern "C" int hz_hip_upload_mosaic(hz_dev_t* d, const int16_t* mosaic)
 {
     HZ_ON_DEVICE(d);
+    HZ_CHECK(sync_all(d));      /* draws in flight (first rounds run on a stream of their own) still read the old one */
     HZ_CHECK(hipMemcpyAsync(d->d_mosaic, mosaic, (size_t)d->N*d->N*sizeof(int16_t), hipMemcpyHostToDevice, d->stream));
     HZ_CHECK(hipStreamSynchronize(d->stream));
     return 0;
@@ -2200,6 +2211,7 @@ extern "C" int hz_hip_ingest_tiles(hz_dev_t* d, const unsigned char* const* tile
     unsigned char** d_ptrs = NULL;
     int rc = -1;
     if(!h_ptrs) return -1;
+    if(sync_all(d) != hipSuccess) { free(h_ptrs); return -1; }      /* draws in flight still read the old mosaic */
     do {
         bool ok = true;
         for(int k=0; k<nt && ok; k++)
@@ -2622,10 +2634,7 @@ static int upload_tanel(hz_dev_t* d, const float* tanel)
     if(d->tanel_resident && memcmp(d->h_tanel, tanel, bytes) == 0) return 0;
     /* a different table (the azimuth extents changed): nothing queued on either
      * stream may still read the old one, and both streams must see the new one */
-    HZ_CHECK(hipStreamSynchronize(d->stream));
-    HZ_CHECK(hipStreamSynchronize(d->nstream));
-    HZ_CHECK(hipStreamSynchronize(d->qstream));
-    HZ_CHECK(hipStreamSynchronize(d->rstream));
+    HZ_CHECK(sync_all(d));
     memcpy(d->h_tanel, tanel, bytes);
     HZ_CHECK(hipMemcpy(d->d_tanel, d->h_tanel, bytes, hipMemcpyHostToDevice));
     d->tanel_resident = 1;
@@ -3300,10 +3309,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
 extern "C" int hz_hip_sync(hz_dev_t* d)
 {
     HZ_ON_DEVICE(d);
-    HZ_CHECK(hipStreamSynchronize(d->stream));
-    HZ_CHECK(hipStreamSynchronize(d->nstream));
-    HZ_CHECK(hipStreamSynchronize(d->qstream));
-    HZ_CHECK(hipStreamSynchronize(d->rstream));
+    HZ_CHECK(sync_all(d));
     return 0;
 }
 
@@ -3312,10 +3318,7 @@ extern "C" int hz_hip_last_times(hz_dev_t* d, hz_times_t* t)
     memset(t, 0, sizeof(*t));
     if(!d->have_times) return -1;
     HZ_ON_DEVICE(d);
-    HZ_CHECK(hipStreamSynchronize(d->stream));
-    HZ_CHECK(hipStreamSynchronize(d->nstream));
-    HZ_CHECK(hipStreamSynchronize(d->qstream));
-    HZ_CHECK(hipStreamSynchronize(d->rstream));
+    HZ_CHECK(sync_all(d));
     /* clear_ms is the clear this draw queued: that of the OTHER framebuffer, which runs on
      * rstream beside the draw.  total_ms is the sum of the stages, not a latency. */
     HZ_CHECK(hipEventElapsedTime(&t->clear_ms,  d->ev[0], d->ev[1]));
