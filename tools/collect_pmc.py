@@ -3,7 +3,11 @@
 Run on the GPU box (see tools/collect_pmc.sh), FETCH_SIZE and WRITE_SIZE in
 separate passes as MI355X_MICROARCH.md prescribes.  On gfx950 FETCH_SIZE counts
 half the bytes of a streaming read; the factor is checked in the same run on
-k_resolve, whose traffic is known exactly (reads 8 B/pixel, writes 7 B/pixel)."""
+the conversion kernel, whose reads are known exactly: 8 B per pixel of every
+256-pixel row segment that holds terrain (tools/touched_segments.py counts them;
+argv[7] = that many bytes) - and its writes: 7 B/pixel + 8 B per terrain pixel
+cleared (argv[8] = terrain fraction).  The runtime's own fill/copy kernels are
+context creation, not part of a render: listed, not summed."""
 import collections
 import csv
 import glob
@@ -11,6 +15,8 @@ import json
 import sys
 
 indir, outpath, config, zfar, W, H = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+resolve_reads = float(sys.argv[7]) if len(sys.argv) > 7 else 8.0*W*H
+terrain_fraction = float(sys.argv[8]) if len(sys.argv) > 8 else None
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(indir + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -26,9 +32,10 @@ count = {k: max(len(v) for v in cs.values()) for k, cs in agg.items()}
 res = mean.get("k_resolve4<true>", mean.get("k_resolve<true>", mean.get("k_resolve", {})))
 read_factor = None
 if "FETCH_SIZE" in res:
-    read_factor = (8.0 * W * H) / (res["FETCH_SIZE"] * 1024.0)      # the conversion reads every 64-bit word once
+    read_factor = resolve_reads / (res["FETCH_SIZE"] * 1024.0)
 out = {"config": config, "zfar": zfar, "W": W, "H": H, "fetch_size_read_factor_measured_on_k_resolve": read_factor,
-       "write_size_check_on_k_resolve": (res.get("WRITE_SIZE", 0) * 1024.0) / (7.0 * W * H) if res else None, "kernels": {}}
+       "conversion_reads_bytes_expected": resolve_reads,
+       "write_size_check_on_k_resolve": (res.get("WRITE_SIZE", 0) * 1024.0) / ((7.0 + 8.0*(terrain_fraction or 0.0)) * W * H) if res else None, "kernels": {}}
 for k, cs in mean.items():
     if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
         continue
@@ -41,7 +48,7 @@ for k, cs in mean.items():
 dom = "k_march" if "k_march" in out["kernels"] else "k_scatter"
 out["kernel"] = dom
 out["hbm_bytes_per_launch"] = out["kernels"][dom]["hbm_bytes_per_launch"]
-out["hbm_bytes_per_render_all_kernels"] = sum(v["hbm_bytes_per_render"] for k, v in out["kernels"].items() if k.startswith(("k_", "__amd")))
+out["hbm_bytes_per_render_all_kernels"] = sum(v["hbm_bytes_per_render"] for k, v in out["kernels"].items() if k.startswith("k_"))
 json.dump(out, open(outpath, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
 for k, v in out["kernels"].items():

@@ -12,4 +12,6 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
          "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum"; do
   rocprofv3 --pmc $c --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-host "$@" >/dev/null 2>&1
 done
-python3 $GRAFT_REPO_ROOT/tools/collect_pmc.py $OUT $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG.json cfg3 600000 16000 4000
+cd $GRAFT_REPO_ROOT
+read SEGFRAC READS TERRAIN < <(python3 tools/touched_segments.py 2>/dev/null | tail -1)
+python3 tools/collect_pmc.py $OUT gpurun_out/pmc_$TAG.json cfg3 600000 16000 4000 $READS $TERRAIN
