@@ -9,9 +9,13 @@ names = [r["Kernel_Name"] for r in rows]
 res = [i for i, n in enumerate(names) if "k_resolve4" in n]
 mid = len(res)//2
 lo, hi = res[mid-2], res[mid+1]
+if len(sys.argv) > 2 and sys.argv[2] == "--last":      # the last N renders and the drain
+    lo, hi = res[-int(sys.argv[3])-1] + 8, len(rows) - 1
+if len(sys.argv) > 2 and sys.argv[2] == "--from":      # from the K-th conversion on
+    lo, hi = res[int(sys.argv[3])] + 8, res[int(sys.argv[3]) + int(sys.argv[4])]
 t0 = int(rows[lo]["Start_Timestamp"])
 qs = {}
-for r in rows[lo-8:hi+1]:
+for r in rows[max(lo-8, 0):hi+1]:
     q = r["Queue_Id"]; qs.setdefault(q, len(qs))
     n = r["Kernel_Name"].split("(")[0][:14]
     g = r.get("Grid_Size_X", r.get("Grid_Size", "?"))
