@@ -88,6 +88,7 @@ struct hz_params_t
     unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
     unsigned int big_min;              /* k_march: boxes above this many pixels go to k_big (tiles), between: k_mid  */
     float far_dd;                      /* k_march: squared horizontal distance beyond which a vertex is surely past zfar */
+    int   far_strips;                  /* some vertex of the mosaic lies beyond that: whole strips may (k_march asks) */
     /* two-pass draw (see hz_hip_draw): which strips a k_march launch takes, and
      * whether it tests its survivors against the depth already in the framebuffer */
     int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 all the others */
@@ -1143,6 +1144,21 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         if(rel < 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n_tab), rel));
         return hz_north(&p.u, (float)(jbeg + rel));
     };
+    /* A strip whose vertex rows all lie beyond zfar (the test the row loop
+     * makes per row, for the row nearest the viewer: rounding is monotonic, so
+     * min over rows of fl(fl(n^2) + fl(e^2)) = fl(min fl(n^2) + fl(e^2))) would
+     * walk its rows without transforming one: it leaves here.  With the API's
+     * default far clip of 40 km that is 90 % of the strips of a 7x7-tile mosaic. */
+    if(p.far_strips)
+    {
+        const int nrows = jend - jbeg;                  /* vertex rows 0..nrows */
+        float nn = lane <= nrows ? n_tab*n_tab : __builtin_inff();
+        if(nrows >= 64) { const float n64 = hz_north(&p.u, (float)(jbeg + 64)); nn = hz_min(nn, n64*n64); }
+        #pragma unroll
+        for(int m=32; m>=1; m>>=1) nn = hz_min(nn, __shfl_xor(nn, m));
+        if(__all(nn + e*e > p.far_dd)) return;
+    }
+
     /* abridged division / square-root sequences (hz_fast.h): allowed where the
      * operands are in range - the draw's uniforms (host), this strip's east
      * offsets, each row's north offset */
@@ -2390,6 +2406,13 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
      * k_mid, which spreads them over the chip (measured: 8 sectors 0.97 -> 0.58 ms). */
     p.inline_max = (p.SW == p.W) ? HZ_INLINE_MAX_PIX : 16;
     p.far_dd = (v->zfar*1.001f)*(v->zfar*1.001f);
+    {
+        /* the mosaic's corners are its most distant vertices */
+        const float e0 = hz_abs(hz_east(&p.u, 0.f)),  e1 = hz_abs(hz_east(&p.u, (float)(p.N-1)));
+        const float n0 = hz_abs(hz_north(&p.u, 0.f)), n1 = hz_abs(hz_north(&p.u, (float)(p.N-1)));
+        const float em = e0 > e1 ? e0 : e1, nm = n0 > n1 ? n0 : n1;
+        p.far_strips = !(nm*nm + em*em <= p.far_dd);
+    }
     p.big_min    = HZ_INLINE_MAX_PIX;
     p.z_guard = 1.0f/500.0f + (float)(d->W > d->H ? d->W : d->H) * (1.0f/4194304.0f);
     p.z_hide_k = 1.03f * p.z_guard * 16777215.f;

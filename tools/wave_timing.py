@@ -7,7 +7,8 @@ import hzutil, horizonator_amd
 LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
 R, W, H = 4200, 16000, 4000
 h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
-h.set_view(-180, 180, zfar=600000.0)
+ZFAR = float(os.environ.get("HZ_WT_ZFAR", "600000"))
+h.set_view(-180, 180, zfar=ZFAR)
 import torch
 img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda"); rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
 for _ in range(2):
@@ -21,7 +22,9 @@ t = a[:, :, 0].astype(np.float64) / 2400.0          # shader clock ~2.4 GHz -> u
 flushes = (a[:, :, 1] >> 32).astype(np.int64); tris = (a[:, :, 1] & 0xFFFFFFFF).astype(np.int64)
 big = (a[:, :, 2] >> 32).astype(np.int64); mid = (a[:, :, 2] & 0xFFFFFFFF).astype(np.int64)
 items = (a[:, :, 3] & 0xFFFFFFFF).astype(np.int64); hidden = (a[:, :, 3] >> 32).astype(np.int64)
-print("grid", gx, gy, "waves", gx*gy)
+print("zfar", ZFAR, "grid", gx, gy, "waves", gx*gy)
+busy = t > 3.0
+print("waves longer than 3 us: %d, their sum %.1f ms; the others: sum %.1f ms, median %.2f us" % (busy.sum(), t[busy].sum()/1e3, t[~busy].sum()/1e3, np.median(t[~busy]) if (~busy).any() else 0))
 q = np.percentile(t, [50, 90, 99, 99.9, 100])
 print("wave duration us: p50 %.1f p90 %.1f p99 %.1f p99.9 %.1f max %.1f; sum %.1f ms" % (*q, t.sum()/1e3))
 print("totals: flushes %d tris %d big %d mid %d inline items %d hidden by early-Z %d" % (flushes.sum(), tris.sum(), big.sum(), mid.sum(), items.sum(), hidden.sum()))
