@@ -147,6 +147,37 @@ def test_full_medium_queue_on_a_reused_context(monkeypatch):
                 hzutil.assert_same_render(got, ref, f"round {rounds} draw {k} sector [{c0},{c1})")
 
 
+@pytest.mark.parametrize("clears", ["1", "0"])
+def test_conversion_skips_only_what_nothing_was_drawn_into(clears, monkeypatch):
+    """the conversion does not read 256-pixel row segments whose `touched` byte is zero.  One context,
+    three framebuffers in turn: terrain that grows and shrinks between draws (viewer up, down, up), a
+    sector of odd width in between (its conversion is the one-pixel-per-thread kernel, which clears
+    words but leaves the bytes set), a draw that is never converted (cleared by memset before its
+    framebuffer comes round again) - every conversion equal to the oracle's render of that view."""
+    import ctypes as C
+    monkeypatch.setenv("HZ_RESOLVE_CLEARS", clears)
+    R, W, H = 200, 1500, 400
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    high = od.view(LAT, LON, W, H, -180, 180, viewer_z=6000.0, zfar=50000.0)
+    low = od.view(LAT, LON, W, H, -180, 180, zfar=50000.0)
+    zoom = od.view(LAT + 0.01, LON, W, H, 20, 75, zfar=30000.0)
+    seq = [(high, 0, W), (low, 0, W), (zoom, 123, 770), (high, 0, W), (low, 256, 1280), (high, 0, W), (zoom, 0, W), (high, 0, W)]
+    with hzutil.HipDev(m, W, H, raster=2) as dev:
+        for k, (v, c0, c1) in enumerate(seq):
+            if k == 4:
+                # a draw nobody converts: its framebuffer stays dirty until the memset before its next turn
+                vv = hzutil.hzlib.View()
+                for name, _ in hzutil.hzlib.View._fields_:
+                    setattr(vv, name, getattr(low, name))
+                assert dev.lib.hz_hip_set_sector(dev.dev, 0, W) == 0
+                assert dev.lib.hz_hip_draw(dev.dev, C.byref(vv)) == 0
+            got = dev.render(v, c0, c1)
+            ref = oracle.render(m, v, W, H, c0, c1)
+            hzutil.assert_same_render(got, ref, f"draw {k} sector [{c0},{c1}) HZ_RESOLVE_CLEARS={clears}")
+
+
 def test_two_round_draw_with_early_depth_test_changes_nothing(monkeypatch):
     """HZ_TWO_PASS=1: strips next to the viewer first, then everything else with the early
     depth test of mr_flush (hz_tri_depth_floor) - byte-identical to the one-round draw and to
