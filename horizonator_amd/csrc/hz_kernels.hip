@@ -1943,14 +1943,14 @@ struct hz_dev
     int col0, col1;
     int raster;
     int profiling;
-    int serial;                         /* HZ_SERIAL: the three streams are one */
+    int serial;                         /* HZ_SERIAL: the four streams are one */
 
-    /* Two streams, two framebuffers.  A draw (stream) fills one framebuffer; the
-     * readback conversion of that draw (rstream) reads it; the NEXT draw goes into
-     * the other framebuffer at once, while rstream is still converting and then
-     * clearing the first.  Back-to-back renders thereby overlap the
-     * bandwidth-bound stages (convert, clear) of panorama k with the
-     * instruction-bound rasterisation of panorama k+1.
+    /* Streams and HZ_NFB framebuffers.  A draw (stream, nstream, qstream) fills
+     * one framebuffer; the readback conversion of that draw (rstream) reads it
+     * and clears it behind itself; the NEXT draw goes into the next framebuffer
+     * at once, while rstream is still converting the first.  Back-to-back
+     * renders thereby overlap the bandwidth-bound conversion of panorama k with
+     * the instruction-bound rasterisation of panorama k+1 (see draw_impl).
      *   ev_drawn        stream:  the last draw is complete
      *   ev_free[i]      rstream: framebuffer i is all ones again
      *   ev_readers      stream:  everything queued on `stream` before the current draw
@@ -1965,9 +1965,9 @@ struct hz_dev
     unsigned char*      d_touched[HZ_NFB];  /* hz_params_t::touched of each framebuffer: seg_stride*H bytes */
     int                 seg_stride;         /* ceil(W / HZ_SEG)                                            */
     /* the queues between the marching kernel and the kernels that finish a draw
-     * (clipped, medium, large triangles): two sets, like the framebuffers, so
+     * (clipped, medium, large triangles): one set per framebuffer, so
      * that those kernels of panorama k (qstream) run beside k_march of k+1.
-     * A two-round draw (see hz_hip_draw) has a second pair of sets for its first
+     * A two-round draw (see hz_hip_draw) has as many sets again for its first
      * round, which runs on a stream of its own (nstream) beside the second round
      * of the panorama before. */
     hipStream_t         qstream, nstream;
@@ -2477,7 +2477,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words): its
      * conversion did that already (k_resolve<true>), or a memset does it now on
      * rstream, behind the conversions of that draw and behind whatever `stream`
-     * still had to read from it; this draw takes the other framebuffer. */
+     * still had to read from it; this draw takes the next framebuffer. */
     const int prev = d->fbi, next = (prev + 1) % HZ_NFB;
     {
         HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
