@@ -1,7 +1,7 @@
 #!/bin/bash
 # the measurements DESIGN.md and profiles/ quote: run on the GPU box, results under gpurun_out/final
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/final; rm -rf $O; mkdir -p $O
+O=gpurun_out/final; rm -rf $O; mkdir -p $O   # (gpurun merges into the local gpurun_out/: remove the local copy first as well)
 timeout 300 ./tools/build/valu_issue > $O/valu_issue.json 2> $O/valu_issue.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 HZ_TWO_PASS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host > $O/bench_one_round.json 2>> $O/bench.err
