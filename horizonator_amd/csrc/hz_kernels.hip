@@ -2034,12 +2034,9 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
 {
     if(!d) return;
     hz_device_guard device_guard_(d->device);
-    if(d->stream) (void)hipStreamSynchronize(d->stream);
-    if(d->qstream) (void)hipStreamSynchronize(d->qstream);
-    if(d->rstream) (void)hipStreamSynchronize(d->rstream);
+    (void)sync_all(d);          /* nothing of this context is still running when its memory goes */
     (void)hipFree(d->d_mosaic);
     for(int i=0; i<HZ_NFB; i++) { (void)hipFree(d->d_fbs[i]); (void)hipFree(d->d_touched[i]); }
-    if(d->nstream) (void)hipStreamSynchronize(d->nstream);
     for(int i=0; i<2*HZ_NFB; i++)
     {
         (void)hipFree(d->d_bigrec_s[i]);
