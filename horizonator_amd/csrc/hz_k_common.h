@@ -1,0 +1,301 @@
+/* hz_k_common.h - part of hz_kernels.hip (included there, in this order; one translation unit):
+ * kernel parameters, the records that travel between kernels, device helpers, k_clip. */
+#pragma once
+
+/* ------------------------------------------------------------------------ */
+/* kernel parameters                                                         */
+
+struct hz_params_t
+{
+    hz_xform_t u;
+    float halfW, halfH;
+    int   N;                /* samples per mosaic axis                  */
+    int   W, H;             /* full image size                          */
+    int   col0, col1;       /* sector [col0,col1)                       */
+    int   SW;               /* col1-col0, row stride of fb              */
+    unsigned long long* wave_cycles;   /* diagnostics: per-wave duration of k_march, or NULL */
+    unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
+    unsigned int big_min;              /* k_march: boxes above this many pixels go to k_big (tiles), between: k_mid  */
+    float far_dd;                      /* k_march: squared horizontal distance beyond which a vertex is surely past zfar */
+    int   far_strips;                  /* some vertex of the mosaic lies beyond that: whole strips may (k_march asks) */
+    /* two-pass draw (see hz_hip_draw): which strips a k_march launch takes, and
+     * whether it tests its survivors against the depth already in the framebuffer */
+    int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 all the others */
+    int   near_x0, near_x1;            /* strip columns [x0,x1] and                                             */
+    int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
+    int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
+    float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
+    float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
+    int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */
+    int   quad_max_dx;                 /* k_march: 256*(W/16 - 1): see the cull of whole cells                  */
+    int   debug;                       /* HZ_MARCH_DEBUG (timing splits, wrong pictures): 1 survivors are dropped,
+                                        * 2 survivors are dropped after the early depth test */
+    /* one byte per HZ_SEG consecutive pixels of a framebuffer row (row stride
+     * seg_stride): nonzero once anything was drawn there.  Every write to the
+     * framebuffer sets it (hz_fb_min); the conversion skips reading - and
+     * clearing - segments nothing touched: the sky, 62 % of the benchmark's
+     * pixels.  A stale nonzero byte only costs the read. */
+    unsigned char* touched;
+    int   seg_stride;
+};
+#define HZ_SEG_LOG2 8
+#define HZ_SEG      (1 << HZ_SEG_LOG2)
+
+/* the one place fragments enter the framebuffer */
+__device__ static inline void hz_fb_min(unsigned long long* fb, const hz_params_t& p, int px, int py, unsigned long long key)
+{
+    const int x = px - p.col0;
+    p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1;
+    atomicMin(&fb[(size_t)py*p.SW + x], key);
+}
+
+/* a set-up triangle as it travels between phases: through LDS inside
+ * k_scatter (stride 23 dwords = odd, conflict-free), through HBM to k_mid and
+ * k_big.  Coverage as hz_edges_t: what the pixel loops need, ready made. */
+struct hz_rec_t
+{
+    hz_edges_t e;
+    float    z_org, dzdx, dzdy, r_org, drdx, drdy;
+    int32_t  px0, py0, bw;
+    float    inv_bw;
+    uint32_t prim;
+};
+struct hz_bigrec_t { hz_rec_t r; int32_t bh; };
+
+/* work item of the large-triangle pass: 64 tiles of one triangle */
+struct hz_bigitem_t { uint32_t rec; uint32_t chunk; };
+
+/* the HBM queues between the kernels of one draw */
+struct mr_queue_t
+{
+    hz_bigrec_t*  bigrec;           /* set-up triangles for k_big                                */
+    hz_bigitem_t* bigitem;          /* ... and their work items                                  */
+    hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
+    uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
+    unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item
+                                     * [3] mid records [4] clip ids [5] first invalid mid record */
+    unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
+};
+
+/* triangles that cross a plane of the view volume: their ids go to k_clip.
+ * One atomic per wave.  Ids that do not fit are not stored, but still counted:
+ * counters[4] > capacity makes k_clip redo the job without the queue. */
+__device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint32_t prim, int lane)
+{
+    const unsigned long long m = __ballot(want);
+    if(!m) return;
+    uint32_t base = 0;
+    if(lane == (int)__builtin_ctzll(m)) base = atomicAdd(&q.counters[4], (uint32_t)__popcll(m));
+    base = __shfl(base, (int)__builtin_ctzll(m));
+    if(!want) return;
+    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if(at < q.clip_capacity) q.clip[at] = prim;
+}
+
+#define HZ_NCOUNTERS 6
+#ifndef HZ_NFB
+#define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
+#endif
+#define HZ_STAGE_SLOTS 4                /* pinned staging chunks in flight between device and caller memory */
+#define HZ_STAGE_BYTES ((size_t)32 << 20)
+#define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
+/* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
+ * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
+/* k_big walks a triangle's box in chunks of pixel rows, one wave per chunk
+ * (lane = row for the row's span of covered pixels, then lane = pixel): 64 rows,
+ * fewer for wide boxes so that a chunk holds at most ~8192 box pixels (the
+ * triangles next to the viewer reach thousands of pixels in width; a wave that
+ * had 64 such rows to itself would set the kernel's duration).  Producer
+ * (queueing) and consumer (k_big) derive the chunking from the box alone. */
+__device__ static inline int hz_big_rows_log2(int bw)
+{
+    return bw <= 128 ? 6 : bw <= 256 ? 5 : bw <= 512 ? 4 : bw <= 1024 ? 3 : bw <= 2048 ? 2 : bw <= 4096 ? 1 : 0;
+}
+__device__ static inline uint32_t hz_big_chunks(int bw, int bh)
+{
+    const int rl = hz_big_rows_log2(bw);
+    return ((uint32_t)bh + (1u << rl) - 1u) >> rl;
+}
+
+/* ------------------------------------------------------------------------ */
+/* device helpers                                                            */
+
+/* record <- set-up triangle (planes + coverage); the box and the id are the caller's */
+__device__ static inline void hz_rec_from_tri(hz_rec_t& r, const hz_tri_t& t)
+{
+    hz_edges_of(&r.e, &t);
+    r.z_org = t.z_org; r.dzdx = t.dzdx; r.dzdy = t.dzdy;
+    r.r_org = t.r_org; r.drdx = t.drdx; r.drdy = t.drdy;
+}
+/* the planes of a record as a hz_tri_t for hz_tri_fragment() (which reads nothing else) */
+__device__ static inline void hz_planes_from_rec(hz_tri_t& t, const hz_rec_t& r)
+{
+    #pragma unroll
+    for(int m=0; m<3; m++) { t.xs[m] = 0; t.ys[m] = 0; }
+    t.z_org = r.z_org; t.dzdx = r.dzdx; t.dzdy = r.dzdy;
+    t.r_org = r.r_org; t.drdx = r.drdx; t.drdy = r.drdy;
+}
+/* one pixel centre of a record's triangle: coverage, depth, colour, framebuffer */
+template<bool PRETEST>
+__device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_params_t& p, const hz_rec_t& r, int px, int py)
+{
+    if(!hz_edges_cover(&r.e, px, py)) return;
+    hz_tri_t t;
+    hz_planes_from_rec(t, r);
+    uint32_t zi, r8;
+    if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
+    const unsigned long long key = hz_pack(zi, r.prim, r8);
+    if(PRETEST)
+    {
+        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            hz_fb_min(fb, p, px, py, key);
+    }
+    else
+        hz_fb_min(fb, p, px, py, key);
+}
+
+/* PRETEST: read the word first and skip the atomic when the fragment cannot
+ * win (a stale, larger value only costs the atomic).  It saves atomics but puts
+ * a dependent HBM round trip into the loop that calls it; callers that walk
+ * many pixels per lane in sequence do better without. */
+template<bool PRETEST>
+__device__ static inline void hz_emit_t(unsigned long long* fb, const hz_params_t& p,
+                                        const hz_tri_t& t, uint32_t prim, int px, int py)
+{
+    if(!hz_tri_covers(&t, px, py)) return;
+    uint32_t zi, r8;
+    if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
+    const unsigned long long key = hz_pack(zi, prim, r8);
+    if(PRETEST)
+    {
+        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            hz_fb_min(fb, p, px, py, key);
+    }
+    else
+        hz_fb_min(fb, p, px, py, key);
+}
+__device__ static inline void hz_emit(unsigned long long* fb, const hz_params_t& p,
+                                      const hz_tri_t& t, uint32_t prim, int px, int py)
+{
+    hz_emit_t<true>(fb, p, t, prim, px, py);
+}
+
+__device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int16_t* mosaic, int i, int j)
+{
+    const float z = (float)mosaic[(size_t)j*p.N + i];
+    return hz_to_window(hz_transform(&p.u, (float)i, (float)j, z), p.halfW, p.halfH);
+}
+
+/* clip one triangle of the grid (by id) and hand its pieces on: to the k_big
+ * queue, or - `inline_ok` and no room - straight into the framebuffer */
+__device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long long* fb, const mr_queue_t& q,
+                                        const hz_params_t& p, uint32_t prim, bool inline_ok,
+                                        hz_cvert_t* bufa, hz_cvert_t* bufb)
+{
+    const uint32_t cell = prim >> 1;
+    const int t = prim & 1;
+    const int j = cell / (uint32_t)(p.N-1);
+    const int i = cell - (uint32_t)j*(uint32_t)(p.N-1);
+    /* reference horizonator-lib.c:500-506 */
+    const int ib = i+1,           jb = t == 0 ? j+1 : j;
+    const int ic = t == 0 ? i : i+1, jc = j+1;
+    const hz_cvert_t a = hz_cvert(hz_transform(&p.u, (float)i,  (float)j,  (float)mosaic[(size_t)j *p.N + i ]), p.halfW, p.halfH);
+    const hz_cvert_t b = hz_cvert(hz_transform(&p.u, (float)ib, (float)jb, (float)mosaic[(size_t)jb*p.N + ib]), p.halfW, p.halfH);
+    const hz_cvert_t c = hz_cvert(hz_transform(&p.u, (float)ic, (float)jc, (float)mosaic[(size_t)jc*p.N + ic]), p.halfW, p.halfH);
+
+    hz_cvert_t* poly;
+    const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
+    /* fan that keeps vertex 0 last (GL provoking-vertex convention).  First
+     * pass: which pieces draw anything, and how much queue they need - so that
+     * the whole triangle reserves its records and work items with two atomics
+     * (one round trip each) instead of two per piece: k_clip runs a handful of
+     * threads and its time is the length of this dependency chain. */
+    uint32_t npieces = 0, nchunks = 0;
+    for(int k=2; k<n; k++)
+    {
+        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
+        hz_box_t box;
+        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
+        npieces++;
+        nchunks += hz_big_chunks(box.px1 - box.px0 + 1, box.py1 - box.py0 + 1);
+    }
+    if(npieces == 0) return;
+    bool queued = false;
+    uint32_t ri = atomicAdd(&q.counters[0], npieces), ii = 0;
+    if(ri + npieces <= q.bigrec_capacity)
+    {
+        ii = atomicAdd(&q.counters[1], nchunks);
+        if(ii + nchunks <= q.bigitem_capacity) queued = true;
+        else atomicMin(&q.counters[2], ii);
+    }
+    if(!queued && !inline_ok) return;
+    for(int k=2; k<n; k++)
+    {
+        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
+        hz_box_t box;
+        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
+        hz_tri_t tri;
+        hz_tri_planes(&tri, &va, &vb, &vc);
+        if(!queued)
+        {
+            for(int py = box.py0; py <= box.py1; py++)
+                for(int px = box.px0; px <= box.px1; px++)
+                    hz_emit(fb, p, tri, prim, px, py);
+            continue;
+        }
+        hz_bigrec_t br;
+        hz_rec_from_tri(br.r, tri);
+        br.r.px0 = box.px0; br.r.py0 = box.py0; br.r.bw = box.px1 - box.px0 + 1;
+        br.r.inv_bw = 1.0f / (float)br.r.bw;
+        br.r.prim = prim;
+        br.bh = box.py1 - box.py0 + 1;
+        const uint32_t chunks = hz_big_chunks(br.r.bw, br.bh);
+        q.bigrec[ri] = br;
+        for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+        ri++; ii += chunks;
+    }
+}
+
+/* one thread per queued triangle id.  The clipper's two polygon buffers are
+ * indexed dynamically, which would put them into scratch memory: a handful of
+ * threads, each a chain of dependent scratch round trips, was 40 us of every
+ * draw.  They live in LDS instead (one 64-thread block per CU is plenty here).
+ *
+ * If the id queue overflowed (never with the default capacity) the ids that
+ * did not fit are lost: the kernel then finds every triangle that needs the
+ * clipper again, one thread per cell, and clips it on the spot.  Slow, correct. */
+/* Resources matter more than speed here: the kernel of the first round runs
+ * beside the marching kernel of the panorama before, whose waves fill every
+ * SIMD's registers; a workgroup that wants 60 KB of contiguous LDS and half a
+ * SIMD's registers (what this kernel took with 64 clipping lanes per block)
+ * waited ~0.7 ms to be placed.  HZ_CLIP_LANES lanes of a block clip, the
+ * others leave at once. */
+#define HZ_CLIP_LANES 4
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
+{
+    __shared__ hz_cvert_t polygon[HZ_CLIP_LANES][2][HZ_MAX_CLIPPED+1];
+    if(threadIdx.x >= HZ_CLIP_LANES) return;
+    hz_cvert_t* poly0 = polygon[threadIdx.x][0];
+    hz_cvert_t* poly1 = polygon[threadIdx.x][1];
+    const unsigned int n = q.counters[4];
+    const unsigned int me = blockIdx.x*HZ_CLIP_LANES + threadIdx.x, stride = gridDim.x*HZ_CLIP_LANES;
+    if(n <= q.clip_capacity)
+    {
+        for(unsigned int k = me; k < n; k += stride)
+            hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, poly0, poly1);
+        return;
+    }
+    const size_t ncells = (size_t)(p.N-1)*(p.N-1);
+    for(size_t cell = me; cell < ncells; cell += stride)
+    {
+        const int j = (int)(cell / (size_t)(p.N-1)), i = (int)(cell - (size_t)j*(p.N-1));
+        const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i, j),   v10 = hz_vertex_at(p, mosaic, i+1, j);
+        const hz_wvert_t v01 = hz_vertex_at(p, mosaic, i, j+1), v11 = hz_vertex_at(p, mosaic, i+1, j+1);
+        hz_box_t box;
+        if(hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, poly0, poly1);
+        if(hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
+            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, poly0, poly1);
+    }
+}

@@ -1,0 +1,646 @@
+/* hz_k_march.h - part of hz_kernels.hip (included there, in this order; one translation unit):
+ * the marching rasteriser: k_march, its flush, pixel spreading, k_mid. */
+#pragma once
+
+/* ------------------------------------------------------------------------ */
+/* marching rasteriser                                                       */
+/*
+ * One wave walks one strip of the DEM, 63 cells wide and 4..64 cell rows long
+ * (short near the viewer, where a cell covers many pixels and a wave would
+ * otherwise carry the whole near field; see mr_zones_t), from south to north,
+ * lane = grid column:
+ *   - the east offset e(i) is computed once per strip, the elevation of the
+ *     next row is in flight while the current row is transformed
+ *   - each vertex is transformed once (64 vertices per row for 63 cells);
+ *     a cell takes its right-hand vertices from the neighbouring lane
+ *     (cross-lane reads, no LDS staging, no workgroup barrier anywhere)
+ *   - triangles that survive every pixel-free rejection are appended to a
+ *     per-wave LDS ring (ballot compaction); whenever 64 are waiting they are
+ *     set up one per lane and their pixel centres are spread over the lanes
+ *     through a wave prefix sum, as in k_scatter
+ * Workgroup = one wave, so nothing ever waits for another wave.
+ */
+
+#define MR_COLS   63
+#define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
+#define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
+#define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
+#define MR_NEAR_CELLS 64             /* round 1 of a draw: strips within this many cells of the viewer */
+
+/* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
+ * conflict-free 256-byte store per field and row) and a ring of ids of the
+ * triangles waiting for set-up.  id = (cell row - first row of the segment)<<7
+ * | lane<<1 | t.  Only 6 + 2 LDS stores per row of 126 triangles. */
+struct mr_lds_t
+{
+    uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
+    uint32_t ids[MR_CAP];
+};
+
+__device__ static inline void mr_store_row(mr_lds_t& L, int slot, int lane, const hz_wvert_t& v)
+{
+    L.rows[slot][0][lane] = __float_as_uint(v.wx);  L.rows[slot][1][lane] = __float_as_uint(v.wy);
+    L.rows[slot][2][lane] = __float_as_uint(v.zw);  L.rows[slot][3][lane] = __float_as_uint(v.red);
+    L.rows[slot][4][lane] = (uint32_t)v.xs;         L.rows[slot][5][lane] = (uint32_t)v.ys;
+}
+__device__ static inline hz_wvert_t mr_load_vert(const mr_lds_t& L, int slot, int lane)
+{
+    hz_wvert_t v;
+    v.xn  = 0.f;
+    v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
+    v.zw  = __uint_as_float(L.rows[slot][2][lane]); v.red = __uint_as_float(L.rows[slot][3][lane]);
+    v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
+    v.cmask = 0;
+    return v;
+}
+
+/* ... without the colour */
+__device__ static inline hz_wvert_t mr_load_vert_pos(const mr_lds_t& L, int slot, int lane)
+{
+    hz_wvert_t v;
+    v.xn  = 0.f; v.red = 0.f; v.cmask = 0;
+    v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
+    v.zw  = __uint_as_float(L.rows[slot][2][lane]);
+    v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
+    return v;
+}
+
+/* The strips are cut into segments of rows; the segment length depends on the
+ * distance (in rows) from the viewer's row so that every wave gets a comparable
+ * amount of pixel work: zones south->north with 64, 16, 4, 2, 4, 16, 64 rows
+ * per segment.  Built on the host per draw (mr_make_zones).  Measured: with
+ * uniform 64-row segments the waves next to the viewer run 10-50x longer than
+ * the median and set the kernel time. */
+#define MR_NZONES 7
+struct mr_zones_t
+{
+    int row0[MR_NZONES+1];          /* first cell row of each zone; row0[MR_NZONES] = N-1 */
+    int rows[MR_NZONES];            /* cell rows per segment                              */
+    int seg0[MR_NZONES];            /* number of the zone's first segment                 */
+    int nseg[MR_NZONES];            /* segments in the zone                               */
+    int total;                      /* all segments = gridDim.y                           */
+    int near_first;                 /* dispatch order: segments nearest to the viewer's row first */
+};
+
+/* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
+ * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63
+ * gets an unspecified value; it has no cell. */
+__device__ static inline int32_t mr_from_east(int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+__device__ static inline float mr_from_east(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
+
+
+__device__ static inline int32_t hz_imin(int32_t a, int32_t b) { return a < b ? a : b; }
+__device__ static inline int32_t hz_imax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+/* what k_march keeps of a vertex row for the cells between it and the next */
+struct mr_rowstate_t
+{
+    float    xn;                        /* NDC x (discard rule)                              */
+    int32_t  xs, ys;                    /* snapped position                                  */
+    uint32_t cmask;                     /* clip mask (0 in rows that are wholly inside)      */
+    int32_t  c_x, f_x, c_y, f_y;        /* first / last pixel column and row at or beyond / up to the vertex, clipped to the scissor */
+    int32_t  h_c_x, h_f_x, h_c_y, h_f_y;        /* the same, over the vertex and its eastern neighbour */
+    int32_t  h_dx, h_dy;                /* eastern neighbour's snapped position minus this vertex's */
+};
+
+
+/* lane k holds triangle record r with npix pixel centres in its box (0 = none):
+ * spread all those pixel centres over the 64 lanes (wave prefix sum + search),
+ * so that every lane tests one pixel per pass whatever the mix of box sizes */
+__device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
+                                     unsigned long long* fb, const hz_params_t& p)
+{
+    /* rounds in which every lane tests the next pixel of ITS OWN triangle: no
+     * cross-lane traffic, no search, short dependency chains.  Worth it while
+     * at least half the lanes still have a pixel left (boxes of similar size,
+     * the common case inside one flush) */
+    uint32_t done = 0;
+    for(;;)
+    {
+        const bool more = npix > done;
+        if(__popcll(__ballot(more)) < 32) break;
+        if(more)
+        {
+            const int ry = (int)(((float)done + 0.5f) * r.inv_bw);
+            const int rx = (int)done - ry*r.bw;
+            hz_emit_rec<false>(fb, p, r, r.px0 + rx, r.py0 + ry);
+            done++;
+        }
+    }
+
+    /* what is left (a few larger boxes) is spread evenly over the lanes */
+    const uint32_t rest  = npix > done ? npix - done : 0;
+    const uint32_t incl  = mr_scan(rest, lane);
+    const uint32_t excl  = incl - rest;
+    const uint32_t total = __shfl(incl, 63);
+    for(uint32_t base = 0; base < total; base += 64)
+    {
+        const uint32_t it = base + lane;
+        /* owner = last lane whose exclusive prefix is <= it */
+        int lo = 0;
+        #pragma unroll
+        for(int step=32; step>=1; step>>=1)
+        {
+            const uint32_t v = __shfl(excl, lo + step);
+            if(v <= it) lo += step;
+        }
+        hz_rec_t o;
+        #pragma unroll
+        for(int m=0; m<3; m++)
+        {
+            o.e.dx[m]  = __shfl(r.e.dx[m], lo);  o.e.ndy[m] = __shfl(r.e.ndy[m], lo);
+            o.e.glo[m] = __shfl(r.e.glo[m], lo); o.e.ghi[m] = __shfl(r.e.ghi[m], lo);
+        }
+        o.z_org = __shfl(r.z_org, lo); o.dzdx = __shfl(r.dzdx, lo); o.dzdy = __shfl(r.dzdy, lo);
+        o.r_org = __shfl(r.r_org, lo); o.drdx = __shfl(r.drdx, lo); o.drdy = __shfl(r.drdy, lo);
+        o.px0 = __shfl(r.px0, lo); o.py0 = __shfl(r.py0, lo); o.bw = __shfl(r.bw, lo);
+        o.inv_bw = __shfl(r.inv_bw, lo);
+        o.prim = __shfl(r.prim, lo);
+        const uint32_t oexcl = __shfl(excl, lo), odone = __shfl(done, lo);
+        if(it < total)
+        {
+            const uint32_t local = it - oexcl + odone;
+            const int ry = (int)(((float)local + 0.5f) * o.inv_bw);
+            const int rx = (int)local - ry*o.bw;
+            hz_emit_rec<false>(fb, p, o, o.px0 + rx, o.py0 + ry);
+        }
+    }
+}
+
+/* medium triangles queued by k_march: one wave per 64 records */
+__global__ __launch_bounds__(64)
+void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ midrec,
+           const unsigned int* __restrict__ counters, unsigned int midrec_capacity, hz_params_t p)
+{
+    const int lane = threadIdx.x;
+    /* records from the first reservation that did not fit were not written
+     * (their triangles were rasterised by the marching wave instead) */
+    const unsigned int n = min(min(counters[3], counters[5]), midrec_capacity);
+    for(unsigned int base = blockIdx.x*64u; base < n; base += gridDim.x*64u)
+    {
+        hz_rec_t r = {};
+        uint32_t npix = 0;
+        if(base + lane < n)
+        {
+            r = midrec[base + lane];
+            /* queued records carry the pixel count of the box in the inv_bw
+             * slot (the reciprocal is cheaper to redo than to store) */
+            npix = __float_as_uint(r.inv_bw);
+            r.inv_bw = 1.0f / (float)r.bw;
+        }
+        mr_distribute(r, npix, lane, fb, p);
+    }
+}
+
+/* set up and rasterise the `n` (<= 64) oldest pending triangles */
+__device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned int n, int lane,
+                                int jbeg, int i0,
+                                unsigned long long* fb, const mr_queue_t& q, const hz_params_t& p,
+                                unsigned int* dbg = nullptr)
+{
+    hz_rec_t r;
+    uint32_t npix = 0;
+    int bh = 0;
+    bool live = (unsigned int)lane < n;
+    const bool valid = live;
+    hz_wvert_t a = {}, b = {}, c = {};
+    hz_box_t box = {};
+    int t = 0, l = 0, rowoff = 0;
+    int sa = 0, sb = 0, sc = 0, la = 0, lb = 0, lc = 0;      /* LDS row slot and lane of the three vertices */
+    if(valid)
+    {
+        const uint32_t id = L.ids[(head + lane) & (MR_CAP-1)];
+        t = id & 1; l = (id >> 1) & 63; rowoff = id >> 7;
+        const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
+        /* reference horizonator-lib.c:500-506 */
+        sa = s0;               la = l;
+        sb = t == 0 ? s1 : s0; lb = l+1;
+        sc = s1;               lc = t == 0 ? l : l+1;
+        /* position and depth now; the colour only for triangles that get drawn */
+        a = mr_load_vert_pos(L, sa, la);
+        b = mr_load_vert_pos(L, sb, lb);
+        c = mr_load_vert_pos(L, sc, lc);
+        hz_tri_box(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);
+    }
+    if(p.early_z)
+    {
+        /* early depth test (exact, see hz_tri_hidden): behind the ridges next to
+         * the viewer almost every survivor ends here, and a flush whose triangles
+         * are all hidden costs neither plane set-up nor pixel tests.  For boxes of
+         * at most 4 x 2 pixel centres - nearly all of the far field's, which is
+         * seen at grazing angles - and with the eight depths fetched at once (a
+         * narrower box fetches pixels twice). */
+        if(valid && box.px1 - box.px0 <= 3 && box.py1 - box.py0 <= 1)
+        {
+            const uint32_t* fbw = (const uint32_t*)fb;              /* depth = the upper 24 bits of the upper word */
+            const uint32_t* row0 = fbw + 2*((size_t)box.py0*p.SW) + 1;
+            const uint32_t* row1 = fbw + 2*((size_t)box.py1*p.SW) + 1;
+            const int c0 = box.px0 - p.col0, cl = box.px1 - p.col0;
+            const int c1 = min(c0+1, cl), c2 = min(c0+2, cl);
+            uint32_t z[8];
+            z[0] = row0[2*c0]; z[1] = row0[2*c1]; z[2] = row0[2*c2]; z[3] = row0[2*cl];
+            z[4] = row1[2*c0]; z[5] = row1[2*c1]; z[6] = row1[2*c2]; z[7] = row1[2*cl];
+            const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
+            if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
+        }
+        if(dbg) { dbg[5] += (unsigned int)__popcll(__ballot(valid && !live)); }
+        if(p.debug == 2) return;
+        if(!__any(live))
+        {
+            if(dbg) { dbg[0] += 1; dbg[1] += n; }
+            return;
+        }
+    }
+    if(live)
+    {
+        a.red = __uint_as_float(L.rows[sa][3][la]);
+        b.red = __uint_as_float(L.rows[sb][3][lb]);
+        c.red = __uint_as_float(L.rows[sc][3][lc]);
+    }
+    if(live)
+    {
+        hz_tri_t tri;
+        hz_tri_planes(&tri, &a, &b, &c);
+        hz_rec_from_tri(r, tri);
+        r.px0 = box.px0; r.bw = box.px1 - box.px0 + 1;
+        r.py0 = box.py0; bh   = box.py1 - box.py0 + 1;
+        r.inv_bw = 1.0f / (float)r.bw;
+        r.prim = (uint32_t)(((size_t)(jbeg + rowoff)*(p.N-1) + (i0 + l))*2 + t);
+        npix = (uint32_t)r.bw*(uint32_t)bh;
+    }
+    else
+    {
+        #pragma unroll
+        for(int m=0; m<3; m++) { r.e.dx[m] = 0; r.e.ndy[m] = 0; r.e.glo[m] = 0; r.e.ghi[m] = 0; }
+        r.z_org = r.dzdx = r.dzdy = r.r_org = r.drdx = r.drdy = 0.f;
+        r.px0 = r.py0 = 0; r.bw = 1; r.inv_bw = 1.f; r.prim = 0;
+    }
+
+    /* large boxes go to k_big: one record, ceil(tiles/64) work items */
+    const bool is_big = live && npix > p.big_min;
+    const unsigned long long bigmask = __ballot(is_big);
+    if(dbg) { dbg[0] += 1; dbg[1] += n; dbg[2] += (unsigned int)__popcll(bigmask); }
+    if(bigmask)
+    {
+        uint32_t chunks = 0;
+        if(is_big)
+        {
+            chunks = hz_big_chunks(r.bw, bh);
+        }
+        const uint32_t incl  = mr_scan(chunks, lane);
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t nb    = (uint32_t)__popcll(bigmask);
+        uint32_t rbase = 0, ibase = 0, ok = 0;
+        if(lane == 0)
+        {
+            rbase = atomicAdd(&q.counters[0], nb);
+            if(rbase + nb <= q.bigrec_capacity)
+            {
+                ibase = atomicAdd(&q.counters[1], total);
+                if(ibase + total <= q.bigitem_capacity) ok = 1;
+                else atomicMin(&q.counters[2], ibase);          /* items from here on are not valid */
+            }
+        }
+        rbase = __shfl(rbase, 0); ibase = __shfl(ibase, 0); ok = __shfl(ok, 0);
+        if(is_big)
+        {
+            if(ok)
+            {
+                const uint32_t ri = rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull));
+                const uint32_t ii = ibase + incl - chunks;
+                q.bigrec[ri].r = r; q.bigrec[ri].bh = bh;
+                for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+            }
+            else
+            {
+                /* queue full (capacities are sized for 32k-wide panoramas): slow but correct */
+                for(int py = r.py0; py < r.py0 + bh; py++)
+                    for(int px = r.px0; px < r.px0 + r.bw; px++)
+                        hz_emit_rec<true>(fb, p, r, px, py);
+            }
+            npix = 0;
+        }
+    }
+
+    /* medium boxes go to k_mid, which spreads them over the whole chip: left
+     * here they make the waves next to the viewer the critical path */
+    const bool is_mid = live && npix > p.inline_max;
+    const unsigned long long midmask = __ballot(is_mid);
+    if(dbg) { dbg[3] += (unsigned int)__popcll(midmask); }
+    if(midmask)
+    {
+        uint32_t mbase = 0;
+        if(lane == 0) mbase = atomicAdd(&q.counters[3], (uint32_t)__popcll(midmask));
+        mbase = __shfl(mbase, 0);
+        if(mbase + (uint32_t)__popcll(midmask) <= q.midrec_capacity)
+        {
+            if(is_mid)
+            {
+                hz_rec_t m = r;
+                m.inv_bw = __uint_as_float(npix);       /* see k_mid */
+                q.midrec[mbase + (uint32_t)__popcll(midmask & ((1ull << lane) - 1ull))] = m;
+                npix = 0;
+            }
+        }
+        /* else: queue full, they stay here; the slots from mbase on hold nothing
+         * of this draw and k_mid must not read them */
+        else if(lane == 0) atomicMin(&q.counters[5], mbase);
+    }
+
+    if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }
+    mr_distribute(r, npix, lane, fb, p);
+}
+
+__global__ __launch_bounds__(64)
+void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
+             mr_queue_t q, mr_zones_t zn, hz_params_t p)
+{
+    __shared__ mr_lds_t L;
+    const unsigned long long t_start = p.wave_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned int dbgv[6] = {0,0,0,0,0,0};
+    unsigned int* dbg = p.wave_cycles ? dbgv : nullptr;
+
+    const int lane = threadIdx.x;
+    const int sx   = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0);     /* strip column */
+    const int i0   = sx*MR_COLS;
+    const int i    = i0 + lane;
+    int zone = 0;
+    #pragma unroll
+    for(int z=1; z<MR_NZONES; z++)
+        if((int)blockIdx.y >= zn.seg0[z] && (int)blockIdx.y < zn.seg0[z] + zn.nseg[z]) zone = z;
+    int sseg = (int)blockIdx.y - zn.seg0[zone];
+    if(zn.near_first && zone < MR_NZONES/2) sseg = zn.nseg[zone]-1 - sseg;      /* south of the viewer: northernmost first */
+    const int jbeg = zn.row0[zone] + sseg*zn.rows[zone];
+    const int jend = min(jbeg + zn.rows[zone], zn.row0[zone+1]);   /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
+    if(p.pass)
+    {
+        const bool near = sx >= p.near_x0 && sx <= p.near_x1 && jbeg < p.near_j1 && jend > p.near_j0;
+        if(near != (p.pass == 1)) return;
+    }
+    const bool has_vertex = i < p.N;
+    const bool has_cell   = lane < MR_COLS && i < p.N-1;
+    const int  ic = has_vertex ? i : p.N-1;             /* clamped: idle lanes redo the last column */
+
+    /* azimuth-sector shard (multi-GPU): a segment that does not contain the
+     * viewer is a convex patch seen from outside, so its azimuth extent is that
+     * of its four corner vertices; if that lies outside this GPU's columns the
+     * whole wave has nothing to draw.  (The corners are real vertices: their x
+     * is computed exactly as the rasteriser computes it.) */
+    if(p.col0 > 0 || p.col1 < p.W)
+    {
+        const int ia = i0, ib = min(i0 + MR_COLS, p.N-1);
+        const bool viewer_inside = p.u.viewer_cell_i >= (float)(ia-1) && p.u.viewer_cell_i <= (float)(ib+1) &&
+                                   p.u.viewer_cell_j >= (float)(jbeg-1) && p.u.viewer_cell_j <= (float)(jend+1);
+        if(!viewer_inside)
+        {
+            /* lanes 0..3 take one corner each (the others repeat them): one
+             * transform's worth of instructions for the wave instead of four */
+            const hz_vertex_t v = hz_transform_en(&p.u, hz_east(&p.u, (float)((lane & 1) ? ib : ia)),
+                                                  hz_north(&p.u, (float)((lane & 2) ? jend : jbeg)), 0.f);
+            float xlo = 2.f, xhi = -2.f;
+            #pragma unroll
+            for(int c=0; c<4; c++)
+            {
+                const float xc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), c));
+                xlo = hz_min(xlo, xc); xhi = hz_max(xhi, xc);
+            }
+            if(xhi - xlo <= 1.0f)       /* not across the +-180 degree seam */
+            {
+                const float flo = (xlo*p.halfW + p.halfW) - 2.5f, fhi = (xhi*p.halfW + p.halfW) + 1.5f;
+                if(fhi < (float)p.col0 || flo > (float)p.col1) return;
+            }
+        }
+    }
+
+    const float e = hz_east(&p.u, (float)ic);
+    /* the north offset of vertex row jbeg+lane, computed once per strip: a row
+     * then takes its n with one v_readlane instead of redoing the (wave-uniform)
+     * arithmetic with its IEEE division 64 lanes wide in every row */
+    const float n_tab = hz_north(&p.u, (float)(jbeg + lane));
+    auto north_of = [&](int rel) -> float
+    {
+        if(rel < 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n_tab), rel));
+        return hz_north(&p.u, (float)(jbeg + rel));
+    };
+    /* A strip whose vertex rows all lie beyond zfar (the test the row loop
+     * makes per row, for the row nearest the viewer: rounding is monotonic, so
+     * min over rows of fl(fl(n^2) + fl(e^2)) = fl(min fl(n^2) + fl(e^2))) would
+     * walk its rows without transforming one: it leaves here.  With the API's
+     * default far clip of 40 km that is 90 % of the strips of a 7x7-tile mosaic. */
+    if(p.far_strips)
+    {
+        const int nrows = jend - jbeg;                  /* vertex rows 0..nrows */
+        float nn = lane <= nrows ? n_tab*n_tab : __builtin_inff();
+        if(nrows >= 64) { const float n64 = hz_north(&p.u, (float)(jbeg + 64)); nn = hz_min(nn, n64*n64); }
+        #pragma unroll
+        for(int m=32; m>=1; m>>=1) nn = hz_min(nn, __shfl_xor(nn, m));
+        if(__all(nn + e*e > p.far_dd)) return;
+    }
+
+    /* abridged division / square-root sequences (hz_fast.h): allowed where the
+     * operands are in range - the draw's uniforms (host), this strip's east
+     * offsets, each row's north offset */
+    const hzf_const_t fc = hzf_setup(&p.u);
+    const bool fast_strip = p.fast_ok && __all(hzf_in_range(e));
+    const unsigned long long fast_rows = __ballot(hzf_in_range(n_tab));
+
+    /* pending-triangle ring, wave-uniform state */
+    unsigned int head = 0, count = 0;
+    int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
+    /* what a row keeps of itself for the cells above it (the attributes of its
+     * vertices live in LDS, where mr_flush takes them from): per lane the
+     * vertex's NDC x, snapped position and clip mask, its pixel columns/rows
+     * (mr_vcull_t) and the same combined with the vertex one lane to the east */
+    mr_rowstate_t prev = {};
+    bool prev_simple = false;
+    int16_t z_next = mosaic[(size_t)jbeg*p.N + ic];
+    /* rows whose 64 vertices all lie safely beyond zfar (by horizontal distance
+     * alone, 0.1% margin): their triangles can only be far-clipped, so a vertex
+     * row is transformed only if it or a neighbouring row is not such a row.
+     * With the default zfar = 40 km this is most of a large mosaic. */
+    float n_cur = north_of(0);
+    bool far_prev = true;
+    bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
+    for(int j = jbeg; j <= jend; j++)
+    {
+        const int rel = j - jbeg;
+        const float z = (float)z_next;
+        if(j < jend) z_next = mosaic[(size_t)(j+1)*p.N + ic];
+        const float n_next   = (j == jend) ? 0.f : north_of(rel+1);
+        const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
+        const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
+        const bool  skip_cells = far_prev && far_cur;               /* cell row j-1 entirely clipped */
+        const float n = n_cur;
+        n_cur = n_next; far_prev = far_cur; far_cur = far_next;
+        if(skip_row) continue;
+
+        const bool fast = fast_strip && (rel >= 64 ? hzf_in_range(n) : (int)((fast_rows >> rel) & 1ull));
+        const hz_vertex_t vtx = fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z);
+
+        /* window position as hz_to_window() computes it.  Two facts about the
+         * whole row are established on the way, which decide how its cells are
+         * culled: every vertex inside the view volume (clip mask 0: with
+         * xn + 1 < 0 <=> xn < -1 for every float, "inside" is |x|,|y|,|z| <= 1)
+         * and every vertex inside the guard band. */
+        hz_wvert_t cur;
+        cur.xn  = vtx.x;
+        cur.wx  = vtx.x*p.halfW + p.halfW;
+        cur.wy  = vtx.y*p.halfH + p.halfH;
+        cur.zw  = vtx.z*0.5f + 0.5f;
+        cur.red = vtx.red;
+        const float fxw = cur.wx - 0.5f, fyw = cur.wy - 0.5f;
+        const bool  in_guard  = hz_abs(fxw) <= HZ_GUARD_PX && hz_abs(fyw) <= HZ_GUARD_PX;     /* a NaN is outside */
+        /* fmaxf skips a NaN, as the six comparisons of hz_clip_mask() do (all false) */
+        const bool  in_volume = __builtin_fmaxf(__builtin_fmaxf(hz_abs(vtx.x), hz_abs(vtx.y)), hz_abs(vtx.z)) <= 1.0f;
+        const bool  cur_simple = __all(in_guard && in_volume);
+        cur.xs = (int32_t)hz_roundeven(fxw*256.f);
+        cur.ys = (int32_t)hz_roundeven(fyw*256.f);
+        cur.cmask = 0;
+        if(!cur_simple)
+        {
+            cur.cmask = hz_clip_mask(vtx.x, vtx.y, vtx.z);
+            if(!in_guard) { cur.xs = HZ_OUTSIDE_GUARD; cur.ys = 0; }
+        }
+
+        /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
+         * still need it are set up now (happens where survivors are sparse) */
+        if(count && first_row <= rel - MR_RSLOTS)
+        {
+            __syncthreads();
+            mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+            __syncthreads();
+            head = (head + count) & (MR_CAP-1);
+            count = 0;
+        }
+        mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
+
+        mr_rowstate_t now;
+        now.xn = cur.xn; now.xs = cur.xs; now.ys = cur.ys; now.cmask = cur.cmask;
+        /* pixel columns/rows of the vertex: a triangle's pixel box is the min of
+         * its vertices' first and the max of their last (hz_tri_box: the shifts
+         * are monotone), clipped to the scissor here already (max and min
+         * distribute over it) */
+        now.c_x = hz_imax((cur.xs + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, p.col0);
+        now.f_x = hz_imin(cur.xs >> HZ_SUBPIXEL_BITS, p.col1-1);
+        now.c_y = hz_imax((cur.ys + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, 0);
+        now.f_y = hz_imin(cur.ys >> HZ_SUBPIXEL_BITS, p.H-1);
+        /* the same over this vertex and its eastern neighbour (one DPP-fused
+         * instruction each: the neighbour's value never lands in a register of
+         * its own), and the step to that neighbour */
+        now.h_c_x  = hz_imin(mr_from_east(now.c_x), now.c_x);
+        now.h_f_x  = hz_imax(mr_from_east(now.f_x), now.f_x);
+        now.h_c_y  = hz_imin(mr_from_east(now.c_y), now.c_y);
+        now.h_f_y  = hz_imax(mr_from_east(now.f_y), now.f_y);
+        now.h_dx   = (int32_t)((uint32_t)mr_from_east(cur.xs) - (uint32_t)cur.xs);     /* (wraps for guard-band markers; unused then) */
+        now.h_dy   = (int32_t)((uint32_t)mr_from_east(cur.ys) - (uint32_t)cur.ys);
+
+        if(j > jbeg && !skip_cells)
+        {
+            /* cell (i, j-1): v00 = prev, v01 = cur, v10 / v11 = those of the lane to
+             * the east; triangles t0 = (v00,v11,v01), t1 = (v00,v10,v11), reference
+             * horizonator-lib.c:500-506 */
+            bool keep0 = false, keep1 = false;
+            bool simple = cur_simple && prev_simple;
+            /* steps from v00 to the cell's other vertices, in 1/256 pixel */
+            const int32_t d01x = (int32_t)((uint32_t)cur.xs - (uint32_t)prev.xs);               /* v01 - v00 */
+            const int32_t d01y = (int32_t)((uint32_t)cur.ys - (uint32_t)prev.ys);
+            const int32_t d11x = (int32_t)((uint32_t)d01x + (uint32_t)now.h_dx);                /* v11 - v00 = (v01 - v00) + (v11 - v01) */
+            const int32_t d11y = (int32_t)((uint32_t)d01y + (uint32_t)now.h_dy);
+            const int32_t d10x = prev.h_dx, d10y = prev.h_dy;                                   /* v10 - v00 */
+            if(simple)
+            {
+                /* reference geometry.glsl:21-27 (a triangle spanning more than 0.5 in
+                 * NDC x = a quarter of the image is dropped) cannot apply to a cell
+                 * whose vertices are all within quad_max_dx of v00 in snapped x: any
+                 * two of them are then less than a quarter of the image minus two
+                 * pixels apart, and window x follows NDC x to within a hundredth
+                 * of a pixel.  A wider cell is rare (the +-180 degree seam, cells
+                 * next to the viewer) and sends the row the long way. */
+                const int32_t lo = hz_imin(hz_imin(d01x, d11x), d10x), hi = hz_imax(hz_imax(d01x, d11x), d10x);
+                if(__any(has_cell && !(lo > -p.quad_max_dx && hi < p.quad_max_dx))) simple = false;
+            }
+            if(simple)
+            {
+                /* all four vertices inside the view volume and the guard band, no
+                 * discard: what is left of hz_tri_cull() is the back-face test on
+                 * the snapped area and the pixel box */
+                const int64_t area0 = (int64_t)d11x*(int64_t)d01y - (int64_t)d01x*(int64_t)d11y;
+                const int64_t area1 = (int64_t)d10x*(int64_t)d11y - (int64_t)d11x*(int64_t)d10y;
+                /* t0 = the row's own edge v01-v11 plus v00; t1 = the lower edge v00-v10 plus v11 */
+                const int32_t px0_0 = hz_imin(now.h_c_x, prev.c_x), px1_0 = hz_imax(now.h_f_x, prev.f_x);
+                const int32_t py0_0 = hz_imin(now.h_c_y, prev.c_y), py1_0 = hz_imax(now.h_f_y, prev.f_y);
+                const int32_t px0_1 = hz_imin(mr_from_east(now.c_x), prev.h_c_x), px1_1 = hz_imax(mr_from_east(now.f_x), prev.h_f_x);
+                const int32_t py0_1 = hz_imin(mr_from_east(now.c_y), prev.h_c_y), py1_1 = hz_imax(mr_from_east(now.f_y), prev.h_f_y);
+                keep0 = has_cell && area0 > 0 && px0_0 <= px1_0 && py0_0 <= py1_0;
+                keep1 = has_cell && area1 > 0 && px0_1 <= px1_1 && py0_1 <= py1_1;
+            }
+            else
+            {
+                hz_wvert_t v00 = {}, v01 = {}, v10 = {}, v11 = {};
+                v00.xn = prev.xn; v00.xs = prev.xs; v00.ys = prev.ys; v00.cmask = prev.cmask;
+                v01.xn = cur.xn;  v01.xs = cur.xs;  v01.ys = cur.ys;  v01.cmask = cur.cmask;
+                /* (the neighbour's snapped position from the step to it: the DPP read of it stays fused into that subtraction) */
+                v10.xn = mr_from_east(prev.xn);
+                v10.xs = (int32_t)((uint32_t)prev.xs + (uint32_t)prev.h_dx); v10.ys = (int32_t)((uint32_t)prev.ys + (uint32_t)prev.h_dy);
+                v10.cmask = (uint32_t)mr_from_east((int32_t)prev.cmask);
+                v11.xn = mr_from_east(cur.xn);
+                v11.xs = (int32_t)((uint32_t)cur.xs + (uint32_t)now.h_dx);   v11.ys = (int32_t)((uint32_t)cur.ys + (uint32_t)now.h_dy);
+                v11.cmask = (uint32_t)mr_from_east((int32_t)cur.cmask);
+                hz_box_t box;
+                const int verdict0 = has_cell ? hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
+                const int verdict1 = has_cell ? hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
+                /* crossing the image border or the near/far sphere: k_clip */
+                const uint32_t prim0 = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2);
+                hz_queue_clip(q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
+                hz_queue_clip(q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
+                keep0 = verdict0 == HZ_TRI_DRAW; keep1 = verdict1 == HZ_TRI_DRAW;
+            }
+            #pragma unroll
+            for(int t=0; t<2; t++)
+            {
+                const bool keep = (t == 0 ? keep0 : keep1) && p.debug != 1;
+                const unsigned long long m = __ballot(keep);
+                if(m)
+                {
+                    if(count == 0) first_row = rel-1;
+                    if(keep)
+                    {
+                        const unsigned int at = (head + count + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & (MR_CAP-1);
+                        L.ids[at] = ((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t;
+                    }
+                    count += (unsigned int)__popcll(m);
+                    if(count >= 64)
+                    {
+                        __syncthreads();        /* one wave: orders the LDS writes before the reads */
+                        mr_flush(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
+                        head = (head + 64) & (MR_CAP-1);
+                        count -= 64;
+                        if(count) first_row = (int)(L.ids[head] >> 7);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        prev = now; prev_simple = cur_simple;
+    }
+    if(count)
+    {
+        __syncthreads();
+        mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+    }
+    if(p.wave_cycles && lane == 0)
+    {
+        unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];
+        o[0] = __builtin_amdgcn_s_memtime() - t_start;
+        o[1] = ((unsigned long long)dbgv[0] << 32) | dbgv[1];     /* flushes, triangles set up */
+        o[2] = ((unsigned long long)dbgv[2] << 32) | dbgv[3];     /* to k_big, to k_mid        */
+        o[3] = ((unsigned long long)dbgv[5] << 32) | dbgv[4];     /* hidden by the early depth test, pixel centres tested here */
+    }
+}

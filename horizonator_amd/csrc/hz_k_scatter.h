@@ -1,0 +1,349 @@
+/* hz_k_scatter.h - part of hz_kernels.hip (included there, in this order; one translation unit):
+ * k_scatter (first design, kept as the second rasteriser), wave prefix sum, exact span division, k_big. */
+#pragma once
+
+/* ------------------------------------------------------------------------ */
+/* scatter rasteriser                                                        */
+/*
+ * block = 64 x 4 DEM cells (one wave = one 128-byte row segment of the mosaic)
+ *   phase 0  the block's 65 x 5 vertices are transformed once into LDS (2-D
+ *            staging of the (i,j) (i+1,j) (i,j+1) (i+1,j+1) neighbourhood)
+ *   phase 1a thread = cell: the two triangles of the cell (reference
+ *            horizonator-lib.c:500-506) go through every pixel-free rejection
+ *            (discard rule, guard band, back face, empty pixel box, depth
+ *            range); ~78% of all triangles end here.  Survivors are compacted
+ *            into an LDS list with wave ballots.
+ *   phase 1b thread = surviving triangle: attribute planes; boxes above
+ *            HZ_INLINE_MAX_PIX pixels go to the HBM queue of k_big
+ *   phase 2  thread = one pixel centre of one survivor's box, found through a
+ *            block-wide prefix sum of the box sizes: every lane tests a pixel,
+ *            whatever the mix of box sizes (a per-triangle pixel loop ran at
+ *            ~15% lane utilisation here)
+ */
+
+#define SC_CX 64
+#define SC_CY 4
+#define SC_VX (SC_CX+1)
+#define SC_VY (SC_CY+1)
+#define SC_THREADS (SC_CX*SC_CY)
+#define SC_REC_STRIDE 23
+
+static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");
+
+__global__ __launch_bounds__(SC_THREADS)
+void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
+               mr_queue_t q, hz_params_t p)
+{
+    hz_bigrec_t* const bigrec = q.bigrec;
+    hz_bigitem_t* const bigitem = q.bigitem;
+    unsigned int* const big_counters = q.counters;
+    const unsigned int bigrec_capacity = q.bigrec_capacity, bigitem_capacity = q.bigitem_capacity;
+    __shared__ float   s_xn [SC_VY][SC_VX];
+    __shared__ float   s_fx [SC_VY][SC_VX];
+    __shared__ float   s_fy [SC_VY][SC_VX];
+    __shared__ float   s_zw [SC_VY][SC_VX];
+    __shared__ float   s_red[SC_VY][SC_VX];
+    __shared__ int32_t s_xs [SC_VY][SC_VX];
+    __shared__ int32_t s_ys [SC_VY][SC_VX];
+    __shared__ uint32_t s_cm[SC_VY][SC_VX];
+    __shared__ unsigned short s_cand[2*SC_THREADS];
+    __shared__ uint32_t s_rec[SC_THREADS*SC_REC_STRIDE];
+    __shared__ uint32_t s_prefix[SC_THREADS+1];
+    __shared__ uint32_t s_wavesum[SC_THREADS/64];
+    __shared__ uint32_t s_ncand;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i0   = blockIdx.x*SC_CX;
+    const int j0   = blockIdx.y*SC_CY;
+
+    /* ---- phase 0: vertices ------------------------------------------------ */
+    if(tid == 0) s_ncand = 0;
+    int some_not_near = 0, some_not_far = 0;
+    for(int v = tid; v < SC_VX*SC_VY; v += SC_THREADS)
+    {
+        const int vy = v / SC_VX, vx = v - vy*SC_VX;
+        const int i = i0 + vx, j = j0 + vy;
+        if(i < p.N && j < p.N)
+        {
+            const hz_wvert_t w = hz_vertex_at(p, mosaic, i, j);
+            s_xn [vy][vx] = w.xn;  s_fx [vy][vx] = w.wx;  s_fy[vy][vx] = w.wy;
+            s_zw [vy][vx] = w.zw;  s_red[vy][vx] = w.red;
+            s_xs [vy][vx] = w.xs;  s_ys [vy][vx] = w.ys;  s_cm[vy][vx] = w.cmask;
+            some_not_near |= !(w.zw < 0.f);
+            some_not_far  |= !(w.zw > 1.f);
+        }
+    }
+    /* block-wide early out: every vertex in front of the near sphere, or
+     * every vertex beyond the far one.  hz_tri_cull() drops exactly those
+     * triangles anyway (with the default zfar = 40 km most of a large mosaic
+     * goes this way). */
+    some_not_near = __syncthreads_or(some_not_near);
+    some_not_far  = __syncthreads_or(some_not_far);
+    if(!some_not_near || !some_not_far) return;
+
+    /* ---- phase 1a: pixel-free rejection, compaction ----------------------- */
+    {
+        const int cx = lane, cy = wave;
+        const int i = i0 + cx, j = j0 + cy;
+        int keep0 = 0, keep1 = 0;
+        if(i < p.N-1 && j < p.N-1)
+        {
+            #define LDV(vy,vx) hz_wvert_t{ s_xn[vy][vx], s_fx[vy][vx], s_fy[vy][vx], s_zw[vy][vx], s_red[vy][vx], s_xs[vy][vx], s_ys[vy][vx], s_cm[vy][vx] }
+            const hz_wvert_t v00 = LDV(cy,   cx  );
+            const hz_wvert_t v10 = LDV(cy,   cx+1);
+            const hz_wvert_t v01 = LDV(cy+1, cx  );
+            const hz_wvert_t v11 = LDV(cy+1, cx+1);
+            hz_box_t box;
+            keep0 = hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1);
+            keep1 = hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1);
+        }
+        /* triangles that cross the view volume's planes go through k_clip */
+        {
+            const uint32_t prim0 = (uint32_t)(((size_t)j*(p.N-1) + i)*2);
+            hz_queue_clip(q, keep0 == HZ_TRI_CLIP, prim0,   lane);
+            hz_queue_clip(q, keep1 == HZ_TRI_CLIP, prim0+1, lane);
+            keep0 = keep0 == HZ_TRI_DRAW; keep1 = keep1 == HZ_TRI_DRAW;
+        }
+        const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+        const unsigned int n0 = __popcll(m0), n1 = __popcll(m1);
+        unsigned int base = 0;
+        if(lane == 0 && n0+n1) base = atomicAdd(&s_ncand, n0+n1);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned short id = (unsigned short)((cy << 7) | (cx << 1));
+        if(keep0) s_cand[base      + __popcll(m0 & below)] = id;
+        if(keep1) s_cand[base + n0 + __popcll(m1 & below)] = id | 1;
+    }
+    __syncthreads();
+    const unsigned int ncand = s_ncand;
+
+    for(unsigned int batch = 0; batch < ncand; batch += SC_THREADS)
+    {
+        /* ---- phase 1b: attribute planes, one thread per survivor ----------- */
+        uint32_t npix = 0;
+        const unsigned int k = batch + tid;
+        if(k < ncand)
+        {
+            const unsigned int id = s_cand[k];
+            const int t = id & 1, cx = (id >> 1) & 63, cy = id >> 7;
+            const hz_wvert_t a = LDV(cy, cx);
+            const hz_wvert_t b = t == 0 ? LDV(cy+1, cx+1) : LDV(cy,   cx+1);
+            const hz_wvert_t c = t == 0 ? LDV(cy+1, cx  ) : LDV(cy+1, cx+1);
+            hz_box_t box;
+            hz_tri_cull_window(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);     /* known to pass: recomputes the box */
+            hz_tri_t tri;
+            hz_tri_planes(&tri, &a, &b, &c);
+            hz_rec_t r;
+            hz_rec_from_tri(r, tri);
+            r.px0 = box.px0; r.py0 = box.py0; r.bw = box.px1 - box.px0 + 1;
+            r.inv_bw = 1.0f / (float)r.bw;
+            r.prim = (uint32_t)(((size_t)(j0+cy)*(p.N-1) + (i0+cx))*2 + t);
+            const int bh = box.py1 - box.py0 + 1;
+            const long long n = (long long)r.bw*bh;
+            if(n <= HZ_INLINE_MAX_PIX)
+            {
+                npix = (uint32_t)n;
+                uint32_t* dst = &s_rec[tid*SC_REC_STRIDE];
+                const uint32_t* src = (const uint32_t*)&r;
+                #pragma unroll
+                for(int q=0; q<SC_REC_STRIDE; q++) dst[q] = src[q];
+            }
+            else
+            {
+                /* large: hand over to k_big, 64 tiles per work item */
+                const unsigned int chunks = hz_big_chunks(r.bw, bh);
+                unsigned int ri = atomicAdd(&big_counters[0], 1u), ii = 0;
+                bool queued = false;
+                if(ri < bigrec_capacity)
+                {
+                    ii = atomicAdd(&big_counters[1], chunks);
+                    if(ii + chunks <= bigitem_capacity) queued = true;
+                    else atomicMin(&big_counters[2], ii);      /* items from here on are not valid */
+                }
+                if(queued)
+                {
+                    bigrec[ri].r = r; bigrec[ri].bh = bh;
+                    for(unsigned int c2=0; c2<chunks; c2++) { bigitem[ii+c2].rec = ri; bigitem[ii+c2].chunk = c2; }
+                }
+                else
+                {
+                    /* queue full (never seen; the capacities are sized for 32k-wide
+                     * panoramas): rasterise here, slowly but correctly */
+                    for(int py = box.py0; py <= box.py1; py++)
+                        for(int px = box.px0; px <= box.px1; px++)
+                            hz_emit(fb, p, tri, r.prim, px, py);
+                }
+            }
+        }
+        #undef LDV
+
+        /* ---- exclusive prefix sum of the box sizes over the block ---------- */
+        uint32_t incl = npix;
+        #pragma unroll
+        for(int d=1; d<64; d<<=1)
+        {
+            const uint32_t up = __shfl_up(incl, d);
+            if(lane >= d) incl += up;
+        }
+        if(lane == 63) s_wavesum[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
+        #pragma unroll
+        for(int w=0; w<SC_THREADS/64; w++)
+        {
+            const uint32_t ws = s_wavesum[w];
+            if(w < wave) wave_base += ws;
+            total += ws;
+        }
+        s_prefix[tid] = wave_base + incl - npix;
+        if(tid == 0) s_prefix[SC_THREADS] = total;
+        __syncthreads();
+
+        /* ---- phase 2: one thread per pixel centre --------------------------- */
+        for(uint32_t it = tid; it < total; it += SC_THREADS)
+        {
+            /* record holding item `it`: last k with prefix[k] <= it */
+            int lo = 0, hi = SC_THREADS;
+            #pragma unroll
+            for(int step=0; step<9; step++)       /* the range [lo,hi) of 256 shrinks to empty in 9 halvings */
+            {
+                const int mid = (lo + hi) >> 1;
+                if(s_prefix[mid+1] <= it) lo = mid+1; else hi = mid;
+            }
+            const uint32_t* src = &s_rec[lo*SC_REC_STRIDE];
+            hz_rec_t r;
+            uint32_t* dst = (uint32_t*)&r;
+            #pragma unroll
+            for(int q=0; q<SC_REC_STRIDE; q++) dst[q] = src[q];
+            const uint32_t local = it - s_prefix[lo];
+            const int ry = (int)(((float)local + 0.5f) * r.inv_bw);
+            const int rx = (int)local - ry*r.bw;
+            hz_emit_rec<true>(fb, p, r, r.px0 + rx, r.py0 + ry);
+        }
+        __syncthreads();
+    }
+}
+
+/* inclusive prefix sum over the 64 lanes */
+__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
+{
+    #pragma unroll
+    for(int d=1; d<64; d<<=1)
+    {
+        const uint32_t up = __shfl_up(v, d);
+        if(lane >= d) v += up;
+    }
+    return v;
+}
+
+/* floor(n / d) for d > 0: a double-precision estimate (r = 1/d to full double
+ * accuracy, computed by the caller once per edge), then the remainder decides -
+ * exactly.  |n| < 2^55, d < 2^31; results beyond +-2^30 come back clamped (the
+ * caller only compares them with pixel columns). */
+__device__ static inline int32_t hz_floor_div(int64_t n, int32_t d, double r)
+{
+    double qd = __builtin_floor((double)n * r);
+    qd = qd < -1073741824.0 ? -1073741824.0 : (qd > 1073741824.0 ? 1073741824.0 : qd);
+    int32_t q = (int32_t)qd;
+    int64_t rem = n - (int64_t)q*(int64_t)d;
+    /* the estimate is off by one at most (two steps each way for good measure) */
+    if(rem < 0)  { q--; rem += d; }
+    if(rem < 0)  { q--; rem += d; }
+    if(rem >= d) { q++; rem -= d; }
+    if(rem >= d) { q++; rem -= d; }
+    return q;
+}
+
+/* large triangles: one wave per work item = 64 pixel rows of a queued triangle.
+ * Lane = row: the covered pixel centres of a row are a span [x0, x1] - each
+ * edge function is linear in px, so each edge bounds the span from one side, at
+ * a column that an integer division gives exactly (the ownership of zeros
+ * included).  Then lane = pixel: the spans of the 64 rows are laid end to end
+ * (wave prefix sum) and every lane takes one covered pixel per pass, whatever
+ * the shape of the triangle - the long thin slivers next to the viewer cover a
+ * quarter of their boxes. */
+__global__ __launch_bounds__(256)
+void k_big(unsigned long long* __restrict__ fb,
+           const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
+           const unsigned int* __restrict__ big_counters,
+           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
+{
+    /* items at and beyond the first overflow were rasterised inline by their producer */
+    const unsigned int nitems = min(big_counters[1], big_counters[2]);
+    (void)bigrec_capacity; (void)bigitem_capacity;
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
+    const unsigned int nwaves = gridDim.x*(blockDim.x/64);
+    /* item and record come through the scalar cache (wave-uniform addresses);
+     * the next item's are requested before the current one is rasterised, so
+     * their latency hides behind the pixel work */
+    hz_bigitem_t item_next = {};
+    hz_bigrec_t  rec_next  = {};
+    if(wave_global < nitems) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
+    for(unsigned int it = wave_global; it < nitems; it += nwaves)
+    {
+        const hz_bigitem_t item = item_next;
+        const hz_bigrec_t  br   = rec_next;
+        if(it + nwaves < nitems) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
+        hz_tri_t tri;
+        hz_planes_from_rec(tri, br.r);
+        const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;
+        const uint32_t prim = br.r.prim;
+
+        /* lane = row */
+        const int rows_log2 = hz_big_rows_log2(bw);
+        const int row_first = py0 + ((int)item.chunk << rows_log2);
+        const int row = row_first + lane;
+        int32_t x0 = px0, x1 = px0 + bw - 1;
+        bool any = lane < (1 << rows_log2) && row < py0 + bh;
+        #pragma unroll
+        for(int m=0; m<3; m++)
+        {
+            /* edge m covers px in this row iff g + dx*row - dy*px >= 0 (hz_edges_t), g and
+             * the deltas wave-uniform: a bound on px from one side, by an exact division */
+            const int32_t dx = br.r.e.dx[m], dy = -br.r.e.ndy[m];
+            const int64_t n8 = hz_edges_g(&br.r.e, m) + (int64_t)dx*(int64_t)row;
+            if(dy > 0)
+            {
+                /* dy*px <= n8  <=>  px <= floor(n8 / dy) */
+                const int32_t q = hz_floor_div(n8, dy, 1.0/(double)dy);
+                x1 = x1 < q ? x1 : q;
+            }
+            else if(dy < 0)
+            {
+                /* |dy|*px >= -n8  <=>  px >= ceil(-n8 / |dy|) = -floor(n8 / |dy|) */
+                const int32_t q = hz_floor_div(n8, -dy, 1.0/(double)(-dy));
+                x0 = x0 > -q ? x0 : -q;
+            }
+            else if(n8 < 0) any = false;                /* a horizontal edge: the whole row is on one side */
+        }
+        const uint32_t count = (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
+
+        /* lane = pixel */
+        const uint32_t incl  = mr_scan(count, lane);
+        const uint32_t excl  = incl - count;
+        const uint32_t total = __shfl(incl, 63);
+        for(uint32_t base = 0; base < total; base += 64)
+        {
+            const uint32_t k = base + lane;
+            /* the row that holds pixel k: last lane whose exclusive prefix is <= k */
+            int own = 0;
+            #pragma unroll
+            for(int step=32; step>=1; step>>=1)
+            {
+                const uint32_t v = __shfl(excl, own + step);
+                if(v <= k) own += step;
+            }
+            const int px = __shfl(x0, own) + (int)(k - __shfl(excl, own));
+            const int py = row_first + own;
+            if(k < total)
+            {
+                uint32_t zi, r8;
+                if(hz_tri_fragment(&tri, px, py, &zi, &r8))
+                    hz_fb_min(fb, p, px, py, hz_pack(zi, prim, r8));
+            }
+        }
+    }
+}

@@ -14,6 +14,11 @@
  *   mosaic  int16 [N][N], row j = constant latitude (south first), i fastest
  *   fb      uint64 [H][SW]  GL row order (row 0 = bottom), SW = sector width
  *           word = z24<<40 | primitive<<8 | red8, cleared to all ones
+ *
+ * One translation unit: the device code lives in hz_k_common.h (parameters,
+ * records, helpers, k_clip), hz_k_scatter.h (k_scatter, k_big), hz_k_march.h
+ * (k_march, k_mid), hz_k_resolve.h (conversions, strips), hz_k_tex.h (textured
+ * resolve); this file holds the context (hz_dev), the streams and the C-ABI.
  */
 #include <hip/hip_runtime.h>
 
@@ -73,1865 +78,11 @@ struct hz_device_guard
 };
 #define HZ_ON_DEVICE(d) hz_device_guard device_guard_((d)->device); if(!device_guard_.ok) return -1
 
-/* ------------------------------------------------------------------------ */
-/* kernel parameters                                                         */
-
-struct hz_params_t
-{
-    hz_xform_t u;
-    float halfW, halfH;
-    int   N;                /* samples per mosaic axis                  */
-    int   W, H;             /* full image size                          */
-    int   col0, col1;       /* sector [col0,col1)                       */
-    int   SW;               /* col1-col0, row stride of fb              */
-    unsigned long long* wave_cycles;   /* diagnostics: per-wave duration of k_march, or NULL */
-    unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
-    unsigned int big_min;              /* k_march: boxes above this many pixels go to k_big (tiles), between: k_mid  */
-    float far_dd;                      /* k_march: squared horizontal distance beyond which a vertex is surely past zfar */
-    int   far_strips;                  /* some vertex of the mosaic lies beyond that: whole strips may (k_march asks) */
-    /* two-pass draw (see hz_hip_draw): which strips a k_march launch takes, and
-     * whether it tests its survivors against the depth already in the framebuffer */
-    int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 all the others */
-    int   near_x0, near_x1;            /* strip columns [x0,x1] and                                             */
-    int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
-    int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
-    float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
-    float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
-    int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */
-    int   quad_max_dx;                 /* k_march: 256*(W/16 - 1): see the cull of whole cells                  */
-    int   debug;                       /* HZ_MARCH_DEBUG (timing splits, wrong pictures): 1 survivors are dropped,
-                                        * 2 survivors are dropped after the early depth test */
-    /* one byte per HZ_SEG consecutive pixels of a framebuffer row (row stride
-     * seg_stride): nonzero once anything was drawn there.  Every write to the
-     * framebuffer sets it (hz_fb_min); the conversion skips reading - and
-     * clearing - segments nothing touched: the sky, 62 % of the benchmark's
-     * pixels.  A stale nonzero byte only costs the read. */
-    unsigned char* touched;
-    int   seg_stride;
-};
-#define HZ_SEG_LOG2 8
-#define HZ_SEG      (1 << HZ_SEG_LOG2)
-
-/* the one place fragments enter the framebuffer */
-__device__ static inline void hz_fb_min(unsigned long long* fb, const hz_params_t& p, int px, int py, unsigned long long key)
-{
-    const int x = px - p.col0;
-    p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1;
-    atomicMin(&fb[(size_t)py*p.SW + x], key);
-}
-
-/* a set-up triangle as it travels between phases: through LDS inside
- * k_scatter (stride 23 dwords = odd, conflict-free), through HBM to k_mid and
- * k_big.  Coverage as hz_edges_t: what the pixel loops need, ready made. */
-struct hz_rec_t
-{
-    hz_edges_t e;
-    float    z_org, dzdx, dzdy, r_org, drdx, drdy;
-    int32_t  px0, py0, bw;
-    float    inv_bw;
-    uint32_t prim;
-};
-struct hz_bigrec_t { hz_rec_t r; int32_t bh; };
-
-/* work item of the large-triangle pass: 64 tiles of one triangle */
-struct hz_bigitem_t { uint32_t rec; uint32_t chunk; };
-
-/* the HBM queues between the kernels of one draw */
-struct mr_queue_t
-{
-    hz_bigrec_t*  bigrec;           /* set-up triangles for k_big                                */
-    hz_bigitem_t* bigitem;          /* ... and their work items                                  */
-    hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
-    uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
-    unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item
-                                     * [3] mid records [4] clip ids [5] first invalid mid record */
-    unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
-};
-
-/* triangles that cross a plane of the view volume: their ids go to k_clip.
- * One atomic per wave.  Ids that do not fit are not stored, but still counted:
- * counters[4] > capacity makes k_clip redo the job without the queue. */
-__device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint32_t prim, int lane)
-{
-    const unsigned long long m = __ballot(want);
-    if(!m) return;
-    uint32_t base = 0;
-    if(lane == (int)__builtin_ctzll(m)) base = atomicAdd(&q.counters[4], (uint32_t)__popcll(m));
-    base = __shfl(base, (int)__builtin_ctzll(m));
-    if(!want) return;
-    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if(at < q.clip_capacity) q.clip[at] = prim;
-}
-
-#define HZ_NCOUNTERS 6
-#ifndef HZ_NFB
-#define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
-#endif
-#define HZ_STAGE_SLOTS 4                /* pinned staging chunks in flight between device and caller memory */
-#define HZ_STAGE_BYTES ((size_t)32 << 20)
-#define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
-/* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
- * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
-/* k_big walks a triangle's box in chunks of pixel rows, one wave per chunk
- * (lane = row for the row's span of covered pixels, then lane = pixel): 64 rows,
- * fewer for wide boxes so that a chunk holds at most ~8192 box pixels (the
- * triangles next to the viewer reach thousands of pixels in width; a wave that
- * had 64 such rows to itself would set the kernel's duration).  Producer
- * (queueing) and consumer (k_big) derive the chunking from the box alone. */
-__device__ static inline int hz_big_rows_log2(int bw)
-{
-    return bw <= 128 ? 6 : bw <= 256 ? 5 : bw <= 512 ? 4 : bw <= 1024 ? 3 : bw <= 2048 ? 2 : bw <= 4096 ? 1 : 0;
-}
-__device__ static inline uint32_t hz_big_chunks(int bw, int bh)
-{
-    const int rl = hz_big_rows_log2(bw);
-    return ((uint32_t)bh + (1u << rl) - 1u) >> rl;
-}
-
-/* ------------------------------------------------------------------------ */
-/* device helpers                                                            */
-
-/* record <- set-up triangle (planes + coverage); the box and the id are the caller's */
-__device__ static inline void hz_rec_from_tri(hz_rec_t& r, const hz_tri_t& t)
-{
-    hz_edges_of(&r.e, &t);
-    r.z_org = t.z_org; r.dzdx = t.dzdx; r.dzdy = t.dzdy;
-    r.r_org = t.r_org; r.drdx = t.drdx; r.drdy = t.drdy;
-}
-/* the planes of a record as a hz_tri_t for hz_tri_fragment() (which reads nothing else) */
-__device__ static inline void hz_planes_from_rec(hz_tri_t& t, const hz_rec_t& r)
-{
-    #pragma unroll
-    for(int m=0; m<3; m++) { t.xs[m] = 0; t.ys[m] = 0; }
-    t.z_org = r.z_org; t.dzdx = r.dzdx; t.dzdy = r.dzdy;
-    t.r_org = r.r_org; t.drdx = r.drdx; t.drdy = r.drdy;
-}
-/* one pixel centre of a record's triangle: coverage, depth, colour, framebuffer */
-template<bool PRETEST>
-__device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_params_t& p, const hz_rec_t& r, int px, int py)
-{
-    if(!hz_edges_cover(&r.e, px, py)) return;
-    hz_tri_t t;
-    hz_planes_from_rec(t, r);
-    uint32_t zi, r8;
-    if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
-    const unsigned long long key = hz_pack(zi, r.prim, r8);
-    if(PRETEST)
-    {
-        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            hz_fb_min(fb, p, px, py, key);
-    }
-    else
-        hz_fb_min(fb, p, px, py, key);
-}
-
-/* PRETEST: read the word first and skip the atomic when the fragment cannot
- * win (a stale, larger value only costs the atomic).  It saves atomics but puts
- * a dependent HBM round trip into the loop that calls it; callers that walk
- * many pixels per lane in sequence do better without. */
-template<bool PRETEST>
-__device__ static inline void hz_emit_t(unsigned long long* fb, const hz_params_t& p,
-                                        const hz_tri_t& t, uint32_t prim, int px, int py)
-{
-    if(!hz_tri_covers(&t, px, py)) return;
-    uint32_t zi, r8;
-    if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
-    const unsigned long long key = hz_pack(zi, prim, r8);
-    if(PRETEST)
-    {
-        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            hz_fb_min(fb, p, px, py, key);
-    }
-    else
-        hz_fb_min(fb, p, px, py, key);
-}
-__device__ static inline void hz_emit(unsigned long long* fb, const hz_params_t& p,
-                                      const hz_tri_t& t, uint32_t prim, int px, int py)
-{
-    hz_emit_t<true>(fb, p, t, prim, px, py);
-}
-
-__device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int16_t* mosaic, int i, int j)
-{
-    const float z = (float)mosaic[(size_t)j*p.N + i];
-    return hz_to_window(hz_transform(&p.u, (float)i, (float)j, z), p.halfW, p.halfH);
-}
-
-/* clip one triangle of the grid (by id) and hand its pieces on: to the k_big
- * queue, or - `inline_ok` and no room - straight into the framebuffer */
-__device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long long* fb, const mr_queue_t& q,
-                                        const hz_params_t& p, uint32_t prim, bool inline_ok,
-                                        hz_cvert_t* bufa, hz_cvert_t* bufb)
-{
-    const uint32_t cell = prim >> 1;
-    const int t = prim & 1;
-    const int j = cell / (uint32_t)(p.N-1);
-    const int i = cell - (uint32_t)j*(uint32_t)(p.N-1);
-    /* reference horizonator-lib.c:500-506 */
-    const int ib = i+1,           jb = t == 0 ? j+1 : j;
-    const int ic = t == 0 ? i : i+1, jc = j+1;
-    const hz_cvert_t a = hz_cvert(hz_transform(&p.u, (float)i,  (float)j,  (float)mosaic[(size_t)j *p.N + i ]), p.halfW, p.halfH);
-    const hz_cvert_t b = hz_cvert(hz_transform(&p.u, (float)ib, (float)jb, (float)mosaic[(size_t)jb*p.N + ib]), p.halfW, p.halfH);
-    const hz_cvert_t c = hz_cvert(hz_transform(&p.u, (float)ic, (float)jc, (float)mosaic[(size_t)jc*p.N + ic]), p.halfW, p.halfH);
-
-    hz_cvert_t* poly;
-    const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
-    /* fan that keeps vertex 0 last (GL provoking-vertex convention).  First
-     * pass: which pieces draw anything, and how much queue they need - so that
-     * the whole triangle reserves its records and work items with two atomics
-     * (one round trip each) instead of two per piece: k_clip runs a handful of
-     * threads and its time is the length of this dependency chain. */
-    uint32_t npieces = 0, nchunks = 0;
-    for(int k=2; k<n; k++)
-    {
-        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
-        hz_box_t box;
-        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
-        npieces++;
-        nchunks += hz_big_chunks(box.px1 - box.px0 + 1, box.py1 - box.py0 + 1);
-    }
-    if(npieces == 0) return;
-    bool queued = false;
-    uint32_t ri = atomicAdd(&q.counters[0], npieces), ii = 0;
-    if(ri + npieces <= q.bigrec_capacity)
-    {
-        ii = atomicAdd(&q.counters[1], nchunks);
-        if(ii + nchunks <= q.bigitem_capacity) queued = true;
-        else atomicMin(&q.counters[2], ii);
-    }
-    if(!queued && !inline_ok) return;
-    for(int k=2; k<n; k++)
-    {
-        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
-        hz_box_t box;
-        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
-        hz_tri_t tri;
-        hz_tri_planes(&tri, &va, &vb, &vc);
-        if(!queued)
-        {
-            for(int py = box.py0; py <= box.py1; py++)
-                for(int px = box.px0; px <= box.px1; px++)
-                    hz_emit(fb, p, tri, prim, px, py);
-            continue;
-        }
-        hz_bigrec_t br;
-        hz_rec_from_tri(br.r, tri);
-        br.r.px0 = box.px0; br.r.py0 = box.py0; br.r.bw = box.px1 - box.px0 + 1;
-        br.r.inv_bw = 1.0f / (float)br.r.bw;
-        br.r.prim = prim;
-        br.bh = box.py1 - box.py0 + 1;
-        const uint32_t chunks = hz_big_chunks(br.r.bw, br.bh);
-        q.bigrec[ri] = br;
-        for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
-        ri++; ii += chunks;
-    }
-}
-
-/* one thread per queued triangle id.  The clipper's two polygon buffers are
- * indexed dynamically, which would put them into scratch memory: a handful of
- * threads, each a chain of dependent scratch round trips, was 40 us of every
- * draw.  They live in LDS instead (one 64-thread block per CU is plenty here).
- *
- * If the id queue overflowed (never with the default capacity) the ids that
- * did not fit are lost: the kernel then finds every triangle that needs the
- * clipper again, one thread per cell, and clips it on the spot.  Slow, correct. */
-/* Resources matter more than speed here: the kernel of the first round runs
- * beside the marching kernel of the panorama before, whose waves fill every
- * SIMD's registers; a workgroup that wants 60 KB of contiguous LDS and half a
- * SIMD's registers (what this kernel took with 64 clipping lanes per block)
- * waited ~0.7 ms to be placed.  HZ_CLIP_LANES lanes of a block clip, the
- * others leave at once. */
-#define HZ_CLIP_LANES 4
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
-void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
-{
-    __shared__ hz_cvert_t polygon[HZ_CLIP_LANES][2][HZ_MAX_CLIPPED+1];
-    if(threadIdx.x >= HZ_CLIP_LANES) return;
-    hz_cvert_t* poly0 = polygon[threadIdx.x][0];
-    hz_cvert_t* poly1 = polygon[threadIdx.x][1];
-    const unsigned int n = q.counters[4];
-    const unsigned int me = blockIdx.x*HZ_CLIP_LANES + threadIdx.x, stride = gridDim.x*HZ_CLIP_LANES;
-    if(n <= q.clip_capacity)
-    {
-        for(unsigned int k = me; k < n; k += stride)
-            hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, poly0, poly1);
-        return;
-    }
-    const size_t ncells = (size_t)(p.N-1)*(p.N-1);
-    for(size_t cell = me; cell < ncells; cell += stride)
-    {
-        const int j = (int)(cell / (size_t)(p.N-1)), i = (int)(cell - (size_t)j*(p.N-1));
-        const hz_wvert_t v00 = hz_vertex_at(p, mosaic, i, j),   v10 = hz_vertex_at(p, mosaic, i+1, j);
-        const hz_wvert_t v01 = hz_vertex_at(p, mosaic, i, j+1), v11 = hz_vertex_at(p, mosaic, i+1, j+1);
-        hz_box_t box;
-        if(hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2),     true, poly0, poly1);
-        if(hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_CLIP)
-            hz_clip_and_draw(mosaic, fb, q, p, (uint32_t)(cell*2 + 1), true, poly0, poly1);
-    }
-}
-
-/* ------------------------------------------------------------------------ */
-/* scatter rasteriser                                                        */
-/*
- * block = 64 x 4 DEM cells (one wave = one 128-byte row segment of the mosaic)
- *   phase 0  the block's 65 x 5 vertices are transformed once into LDS (2-D
- *            staging of the (i,j) (i+1,j) (i,j+1) (i+1,j+1) neighbourhood)
- *   phase 1a thread = cell: the two triangles of the cell (reference
- *            horizonator-lib.c:500-506) go through every pixel-free rejection
- *            (discard rule, guard band, back face, empty pixel box, depth
- *            range); ~78% of all triangles end here.  Survivors are compacted
- *            into an LDS list with wave ballots.
- *   phase 1b thread = surviving triangle: attribute planes; boxes above
- *            HZ_INLINE_MAX_PIX pixels go to the HBM queue of k_big
- *   phase 2  thread = one pixel centre of one survivor's box, found through a
- *            block-wide prefix sum of the box sizes: every lane tests a pixel,
- *            whatever the mix of box sizes (a per-triangle pixel loop ran at
- *            ~15% lane utilisation here)
- */
-
-#define SC_CX 64
-#define SC_CY 4
-#define SC_VX (SC_CX+1)
-#define SC_VY (SC_CY+1)
-#define SC_THREADS (SC_CX*SC_CY)
-#define SC_REC_STRIDE 23
-
-static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");
-
-__global__ __launch_bounds__(SC_THREADS)
-void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
-               mr_queue_t q, hz_params_t p)
-{
-    hz_bigrec_t* const bigrec = q.bigrec;
-    hz_bigitem_t* const bigitem = q.bigitem;
-    unsigned int* const big_counters = q.counters;
-    const unsigned int bigrec_capacity = q.bigrec_capacity, bigitem_capacity = q.bigitem_capacity;
-    __shared__ float   s_xn [SC_VY][SC_VX];
-    __shared__ float   s_fx [SC_VY][SC_VX];
-    __shared__ float   s_fy [SC_VY][SC_VX];
-    __shared__ float   s_zw [SC_VY][SC_VX];
-    __shared__ float   s_red[SC_VY][SC_VX];
-    __shared__ int32_t s_xs [SC_VY][SC_VX];
-    __shared__ int32_t s_ys [SC_VY][SC_VX];
-    __shared__ uint32_t s_cm[SC_VY][SC_VX];
-    __shared__ unsigned short s_cand[2*SC_THREADS];
-    __shared__ uint32_t s_rec[SC_THREADS*SC_REC_STRIDE];
-    __shared__ uint32_t s_prefix[SC_THREADS+1];
-    __shared__ uint32_t s_wavesum[SC_THREADS/64];
-    __shared__ uint32_t s_ncand;
-
-    const int tid  = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int i0   = blockIdx.x*SC_CX;
-    const int j0   = blockIdx.y*SC_CY;
-
-    /* ---- phase 0: vertices ------------------------------------------------ */
-    if(tid == 0) s_ncand = 0;
-    int some_not_near = 0, some_not_far = 0;
-    for(int v = tid; v < SC_VX*SC_VY; v += SC_THREADS)
-    {
-        const int vy = v / SC_VX, vx = v - vy*SC_VX;
-        const int i = i0 + vx, j = j0 + vy;
-        if(i < p.N && j < p.N)
-        {
-            const hz_wvert_t w = hz_vertex_at(p, mosaic, i, j);
-            s_xn [vy][vx] = w.xn;  s_fx [vy][vx] = w.wx;  s_fy[vy][vx] = w.wy;
-            s_zw [vy][vx] = w.zw;  s_red[vy][vx] = w.red;
-            s_xs [vy][vx] = w.xs;  s_ys [vy][vx] = w.ys;  s_cm[vy][vx] = w.cmask;
-            some_not_near |= !(w.zw < 0.f);
-            some_not_far  |= !(w.zw > 1.f);
-        }
-    }
-    /* block-wide early out: every vertex in front of the near sphere, or
-     * every vertex beyond the far one.  hz_tri_cull() drops exactly those
-     * triangles anyway (with the default zfar = 40 km most of a large mosaic
-     * goes this way). */
-    some_not_near = __syncthreads_or(some_not_near);
-    some_not_far  = __syncthreads_or(some_not_far);
-    if(!some_not_near || !some_not_far) return;
-
-    /* ---- phase 1a: pixel-free rejection, compaction ----------------------- */
-    {
-        const int cx = lane, cy = wave;
-        const int i = i0 + cx, j = j0 + cy;
-        int keep0 = 0, keep1 = 0;
-        if(i < p.N-1 && j < p.N-1)
-        {
-            #define LDV(vy,vx) hz_wvert_t{ s_xn[vy][vx], s_fx[vy][vx], s_fy[vy][vx], s_zw[vy][vx], s_red[vy][vx], s_xs[vy][vx], s_ys[vy][vx], s_cm[vy][vx] }
-            const hz_wvert_t v00 = LDV(cy,   cx  );
-            const hz_wvert_t v10 = LDV(cy,   cx+1);
-            const hz_wvert_t v01 = LDV(cy+1, cx  );
-            const hz_wvert_t v11 = LDV(cy+1, cx+1);
-            hz_box_t box;
-            keep0 = hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1);
-            keep1 = hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1);
-        }
-        /* triangles that cross the view volume's planes go through k_clip */
-        {
-            const uint32_t prim0 = (uint32_t)(((size_t)j*(p.N-1) + i)*2);
-            hz_queue_clip(q, keep0 == HZ_TRI_CLIP, prim0,   lane);
-            hz_queue_clip(q, keep1 == HZ_TRI_CLIP, prim0+1, lane);
-            keep0 = keep0 == HZ_TRI_DRAW; keep1 = keep1 == HZ_TRI_DRAW;
-        }
-        const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
-        const unsigned int n0 = __popcll(m0), n1 = __popcll(m1);
-        unsigned int base = 0;
-        if(lane == 0 && n0+n1) base = atomicAdd(&s_ncand, n0+n1);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const unsigned short id = (unsigned short)((cy << 7) | (cx << 1));
-        if(keep0) s_cand[base      + __popcll(m0 & below)] = id;
-        if(keep1) s_cand[base + n0 + __popcll(m1 & below)] = id | 1;
-    }
-    __syncthreads();
-    const unsigned int ncand = s_ncand;
-
-    for(unsigned int batch = 0; batch < ncand; batch += SC_THREADS)
-    {
-        /* ---- phase 1b: attribute planes, one thread per survivor ----------- */
-        uint32_t npix = 0;
-        const unsigned int k = batch + tid;
-        if(k < ncand)
-        {
-            const unsigned int id = s_cand[k];
-            const int t = id & 1, cx = (id >> 1) & 63, cy = id >> 7;
-            const hz_wvert_t a = LDV(cy, cx);
-            const hz_wvert_t b = t == 0 ? LDV(cy+1, cx+1) : LDV(cy,   cx+1);
-            const hz_wvert_t c = t == 0 ? LDV(cy+1, cx  ) : LDV(cy+1, cx+1);
-            hz_box_t box;
-            hz_tri_cull_window(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);     /* known to pass: recomputes the box */
-            hz_tri_t tri;
-            hz_tri_planes(&tri, &a, &b, &c);
-            hz_rec_t r;
-            hz_rec_from_tri(r, tri);
-            r.px0 = box.px0; r.py0 = box.py0; r.bw = box.px1 - box.px0 + 1;
-            r.inv_bw = 1.0f / (float)r.bw;
-            r.prim = (uint32_t)(((size_t)(j0+cy)*(p.N-1) + (i0+cx))*2 + t);
-            const int bh = box.py1 - box.py0 + 1;
-            const long long n = (long long)r.bw*bh;
-            if(n <= HZ_INLINE_MAX_PIX)
-            {
-                npix = (uint32_t)n;
-                uint32_t* dst = &s_rec[tid*SC_REC_STRIDE];
-                const uint32_t* src = (const uint32_t*)&r;
-                #pragma unroll
-                for(int q=0; q<SC_REC_STRIDE; q++) dst[q] = src[q];
-            }
-            else
-            {
-                /* large: hand over to k_big, 64 tiles per work item */
-                const unsigned int chunks = hz_big_chunks(r.bw, bh);
-                unsigned int ri = atomicAdd(&big_counters[0], 1u), ii = 0;
-                bool queued = false;
-                if(ri < bigrec_capacity)
-                {
-                    ii = atomicAdd(&big_counters[1], chunks);
-                    if(ii + chunks <= bigitem_capacity) queued = true;
-                    else atomicMin(&big_counters[2], ii);      /* items from here on are not valid */
-                }
-                if(queued)
-                {
-                    bigrec[ri].r = r; bigrec[ri].bh = bh;
-                    for(unsigned int c2=0; c2<chunks; c2++) { bigitem[ii+c2].rec = ri; bigitem[ii+c2].chunk = c2; }
-                }
-                else
-                {
-                    /* queue full (never seen; the capacities are sized for 32k-wide
-                     * panoramas): rasterise here, slowly but correctly */
-                    for(int py = box.py0; py <= box.py1; py++)
-                        for(int px = box.px0; px <= box.px1; px++)
-                            hz_emit(fb, p, tri, r.prim, px, py);
-                }
-            }
-        }
-        #undef LDV
-
-        /* ---- exclusive prefix sum of the box sizes over the block ---------- */
-        uint32_t incl = npix;
-        #pragma unroll
-        for(int d=1; d<64; d<<=1)
-        {
-            const uint32_t up = __shfl_up(incl, d);
-            if(lane >= d) incl += up;
-        }
-        if(lane == 63) s_wavesum[wave] = incl;
-        __syncthreads();
-        uint32_t wave_base = 0, total = 0;
-        #pragma unroll
-        for(int w=0; w<SC_THREADS/64; w++)
-        {
-            const uint32_t ws = s_wavesum[w];
-            if(w < wave) wave_base += ws;
-            total += ws;
-        }
-        s_prefix[tid] = wave_base + incl - npix;
-        if(tid == 0) s_prefix[SC_THREADS] = total;
-        __syncthreads();
-
-        /* ---- phase 2: one thread per pixel centre --------------------------- */
-        for(uint32_t it = tid; it < total; it += SC_THREADS)
-        {
-            /* record holding item `it`: last k with prefix[k] <= it */
-            int lo = 0, hi = SC_THREADS;
-            #pragma unroll
-            for(int step=0; step<9; step++)       /* the range [lo,hi) of 256 shrinks to empty in 9 halvings */
-            {
-                const int mid = (lo + hi) >> 1;
-                if(s_prefix[mid+1] <= it) lo = mid+1; else hi = mid;
-            }
-            const uint32_t* src = &s_rec[lo*SC_REC_STRIDE];
-            hz_rec_t r;
-            uint32_t* dst = (uint32_t*)&r;
-            #pragma unroll
-            for(int q=0; q<SC_REC_STRIDE; q++) dst[q] = src[q];
-            const uint32_t local = it - s_prefix[lo];
-            const int ry = (int)(((float)local + 0.5f) * r.inv_bw);
-            const int rx = (int)local - ry*r.bw;
-            hz_emit_rec<true>(fb, p, r, r.px0 + rx, r.py0 + ry);
-        }
-        __syncthreads();
-    }
-}
-
-/* inclusive prefix sum over the 64 lanes */
-__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
-{
-    #pragma unroll
-    for(int d=1; d<64; d<<=1)
-    {
-        const uint32_t up = __shfl_up(v, d);
-        if(lane >= d) v += up;
-    }
-    return v;
-}
-
-/* floor(n / d) for d > 0: a double-precision estimate (r = 1/d to full double
- * accuracy, computed by the caller once per edge), then the remainder decides -
- * exactly.  |n| < 2^55, d < 2^31; results beyond +-2^30 come back clamped (the
- * caller only compares them with pixel columns). */
-__device__ static inline int32_t hz_floor_div(int64_t n, int32_t d, double r)
-{
-    double qd = __builtin_floor((double)n * r);
-    qd = qd < -1073741824.0 ? -1073741824.0 : (qd > 1073741824.0 ? 1073741824.0 : qd);
-    int32_t q = (int32_t)qd;
-    int64_t rem = n - (int64_t)q*(int64_t)d;
-    /* the estimate is off by one at most (two steps each way for good measure) */
-    if(rem < 0)  { q--; rem += d; }
-    if(rem < 0)  { q--; rem += d; }
-    if(rem >= d) { q++; rem -= d; }
-    if(rem >= d) { q++; rem -= d; }
-    return q;
-}
-
-/* large triangles: one wave per work item = 64 pixel rows of a queued triangle.
- * Lane = row: the covered pixel centres of a row are a span [x0, x1] - each
- * edge function is linear in px, so each edge bounds the span from one side, at
- * a column that an integer division gives exactly (the ownership of zeros
- * included).  Then lane = pixel: the spans of the 64 rows are laid end to end
- * (wave prefix sum) and every lane takes one covered pixel per pass, whatever
- * the shape of the triangle - the long thin slivers next to the viewer cover a
- * quarter of their boxes. */
-__global__ __launch_bounds__(256)
-void k_big(unsigned long long* __restrict__ fb,
-           const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
-           const unsigned int* __restrict__ big_counters,
-           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
-{
-    /* items at and beyond the first overflow were rasterised inline by their producer */
-    const unsigned int nitems = min(big_counters[1], big_counters[2]);
-    (void)bigrec_capacity; (void)bigitem_capacity;
-    const int lane = threadIdx.x & 63;
-    const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
-    const unsigned int nwaves = gridDim.x*(blockDim.x/64);
-    /* item and record come through the scalar cache (wave-uniform addresses);
-     * the next item's are requested before the current one is rasterised, so
-     * their latency hides behind the pixel work */
-    hz_bigitem_t item_next = {};
-    hz_bigrec_t  rec_next  = {};
-    if(wave_global < nitems) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
-    for(unsigned int it = wave_global; it < nitems; it += nwaves)
-    {
-        const hz_bigitem_t item = item_next;
-        const hz_bigrec_t  br   = rec_next;
-        if(it + nwaves < nitems) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
-        hz_tri_t tri;
-        hz_planes_from_rec(tri, br.r);
-        const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;
-        const uint32_t prim = br.r.prim;
-
-        /* lane = row */
-        const int rows_log2 = hz_big_rows_log2(bw);
-        const int row_first = py0 + ((int)item.chunk << rows_log2);
-        const int row = row_first + lane;
-        int32_t x0 = px0, x1 = px0 + bw - 1;
-        bool any = lane < (1 << rows_log2) && row < py0 + bh;
-        #pragma unroll
-        for(int m=0; m<3; m++)
-        {
-            /* edge m covers px in this row iff g + dx*row - dy*px >= 0 (hz_edges_t), g and
-             * the deltas wave-uniform: a bound on px from one side, by an exact division */
-            const int32_t dx = br.r.e.dx[m], dy = -br.r.e.ndy[m];
-            const int64_t n8 = hz_edges_g(&br.r.e, m) + (int64_t)dx*(int64_t)row;
-            if(dy > 0)
-            {
-                /* dy*px <= n8  <=>  px <= floor(n8 / dy) */
-                const int32_t q = hz_floor_div(n8, dy, 1.0/(double)dy);
-                x1 = x1 < q ? x1 : q;
-            }
-            else if(dy < 0)
-            {
-                /* |dy|*px >= -n8  <=>  px >= ceil(-n8 / |dy|) = -floor(n8 / |dy|) */
-                const int32_t q = hz_floor_div(n8, -dy, 1.0/(double)(-dy));
-                x0 = x0 > -q ? x0 : -q;
-            }
-            else if(n8 < 0) any = false;                /* a horizontal edge: the whole row is on one side */
-        }
-        const uint32_t count = (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
-
-        /* lane = pixel */
-        const uint32_t incl  = mr_scan(count, lane);
-        const uint32_t excl  = incl - count;
-        const uint32_t total = __shfl(incl, 63);
-        for(uint32_t base = 0; base < total; base += 64)
-        {
-            const uint32_t k = base + lane;
-            /* the row that holds pixel k: last lane whose exclusive prefix is <= k */
-            int own = 0;
-            #pragma unroll
-            for(int step=32; step>=1; step>>=1)
-            {
-                const uint32_t v = __shfl(excl, own + step);
-                if(v <= k) own += step;
-            }
-            const int px = __shfl(x0, own) + (int)(k - __shfl(excl, own));
-            const int py = row_first + own;
-            if(k < total)
-            {
-                uint32_t zi, r8;
-                if(hz_tri_fragment(&tri, px, py, &zi, &r8))
-                    hz_fb_min(fb, p, px, py, hz_pack(zi, prim, r8));
-            }
-        }
-    }
-}
-
-/* ------------------------------------------------------------------------ */
-/* marching rasteriser                                                       */
-/*
- * One wave walks one strip of the DEM, 63 cells wide and 4..64 cell rows long
- * (short near the viewer, where a cell covers many pixels and a wave would
- * otherwise carry the whole near field; see mr_zones_t), from south to north,
- * lane = grid column:
- *   - the east offset e(i) is computed once per strip, the elevation of the
- *     next row is in flight while the current row is transformed
- *   - each vertex is transformed once (64 vertices per row for 63 cells);
- *     a cell takes its right-hand vertices from the neighbouring lane
- *     (cross-lane reads, no LDS staging, no workgroup barrier anywhere)
- *   - triangles that survive every pixel-free rejection are appended to a
- *     per-wave LDS ring (ballot compaction); whenever 64 are waiting they are
- *     set up one per lane and their pixel centres are spread over the lanes
- *     through a wave prefix sum, as in k_scatter
- * Workgroup = one wave, so nothing ever waits for another wave.
- */
-
-#define MR_COLS   63
-#define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
-#define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
-#define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
-#define MR_NEAR_CELLS 64             /* round 1 of a draw: strips within this many cells of the viewer */
-
-/* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
- * conflict-free 256-byte store per field and row) and a ring of ids of the
- * triangles waiting for set-up.  id = (cell row - first row of the segment)<<7
- * | lane<<1 | t.  Only 6 + 2 LDS stores per row of 126 triangles. */
-struct mr_lds_t
-{
-    uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
-    uint32_t ids[MR_CAP];
-};
-
-__device__ static inline void mr_store_row(mr_lds_t& L, int slot, int lane, const hz_wvert_t& v)
-{
-    L.rows[slot][0][lane] = __float_as_uint(v.wx);  L.rows[slot][1][lane] = __float_as_uint(v.wy);
-    L.rows[slot][2][lane] = __float_as_uint(v.zw);  L.rows[slot][3][lane] = __float_as_uint(v.red);
-    L.rows[slot][4][lane] = (uint32_t)v.xs;         L.rows[slot][5][lane] = (uint32_t)v.ys;
-}
-__device__ static inline hz_wvert_t mr_load_vert(const mr_lds_t& L, int slot, int lane)
-{
-    hz_wvert_t v;
-    v.xn  = 0.f;
-    v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
-    v.zw  = __uint_as_float(L.rows[slot][2][lane]); v.red = __uint_as_float(L.rows[slot][3][lane]);
-    v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
-    v.cmask = 0;
-    return v;
-}
-
-/* ... without the colour */
-__device__ static inline hz_wvert_t mr_load_vert_pos(const mr_lds_t& L, int slot, int lane)
-{
-    hz_wvert_t v;
-    v.xn  = 0.f; v.red = 0.f; v.cmask = 0;
-    v.wx  = __uint_as_float(L.rows[slot][0][lane]); v.wy  = __uint_as_float(L.rows[slot][1][lane]);
-    v.zw  = __uint_as_float(L.rows[slot][2][lane]);
-    v.xs  = (int32_t)L.rows[slot][4][lane];         v.ys  = (int32_t)L.rows[slot][5][lane];
-    return v;
-}
-
-/* The strips are cut into segments of rows; the segment length depends on the
- * distance (in rows) from the viewer's row so that every wave gets a comparable
- * amount of pixel work: zones south->north with 64, 16, 4, 2, 4, 16, 64 rows
- * per segment.  Built on the host per draw (mr_make_zones).  Measured: with
- * uniform 64-row segments the waves next to the viewer run 10-50x longer than
- * the median and set the kernel time. */
-#define MR_NZONES 7
-struct mr_zones_t
-{
-    int row0[MR_NZONES+1];          /* first cell row of each zone; row0[MR_NZONES] = N-1 */
-    int rows[MR_NZONES];            /* cell rows per segment                              */
-    int seg0[MR_NZONES];            /* number of the zone's first segment                 */
-    int nseg[MR_NZONES];            /* segments in the zone                               */
-    int total;                      /* all segments = gridDim.y                           */
-    int near_first;                 /* dispatch order: segments nearest to the viewer's row first */
-};
-
-/* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
- * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63
- * gets an unspecified value; it has no cell. */
-__device__ static inline int32_t mr_from_east(int32_t v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-}
-__device__ static inline float mr_from_east(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
-}
-
-
-
-__device__ static inline int32_t hz_imin(int32_t a, int32_t b) { return a < b ? a : b; }
-__device__ static inline int32_t hz_imax(int32_t a, int32_t b) { return a > b ? a : b; }
-
-/* what k_march keeps of a vertex row for the cells between it and the next */
-struct mr_rowstate_t
-{
-    float    xn;                        /* NDC x (discard rule)                              */
-    int32_t  xs, ys;                    /* snapped position                                  */
-    uint32_t cmask;                     /* clip mask (0 in rows that are wholly inside)      */
-    int32_t  c_x, f_x, c_y, f_y;        /* first / last pixel column and row at or beyond / up to the vertex, clipped to the scissor */
-    int32_t  h_c_x, h_f_x, h_c_y, h_f_y;        /* the same, over the vertex and its eastern neighbour */
-    int32_t  h_dx, h_dy;                /* eastern neighbour's snapped position minus this vertex's */
-};
-
-
-/* lane k holds triangle record r with npix pixel centres in its box (0 = none):
- * spread all those pixel centres over the 64 lanes (wave prefix sum + search),
- * so that every lane tests one pixel per pass whatever the mix of box sizes */
-__device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
-                                     unsigned long long* fb, const hz_params_t& p)
-{
-    /* rounds in which every lane tests the next pixel of ITS OWN triangle: no
-     * cross-lane traffic, no search, short dependency chains.  Worth it while
-     * at least half the lanes still have a pixel left (boxes of similar size,
-     * the common case inside one flush) */
-    uint32_t done = 0;
-    for(;;)
-    {
-        const bool more = npix > done;
-        if(__popcll(__ballot(more)) < 32) break;
-        if(more)
-        {
-            const int ry = (int)(((float)done + 0.5f) * r.inv_bw);
-            const int rx = (int)done - ry*r.bw;
-            hz_emit_rec<false>(fb, p, r, r.px0 + rx, r.py0 + ry);
-            done++;
-        }
-    }
-
-    /* what is left (a few larger boxes) is spread evenly over the lanes */
-    const uint32_t rest  = npix > done ? npix - done : 0;
-    const uint32_t incl  = mr_scan(rest, lane);
-    const uint32_t excl  = incl - rest;
-    const uint32_t total = __shfl(incl, 63);
-    for(uint32_t base = 0; base < total; base += 64)
-    {
-        const uint32_t it = base + lane;
-        /* owner = last lane whose exclusive prefix is <= it */
-        int lo = 0;
-        #pragma unroll
-        for(int step=32; step>=1; step>>=1)
-        {
-            const uint32_t v = __shfl(excl, lo + step);
-            if(v <= it) lo += step;
-        }
-        hz_rec_t o;
-        #pragma unroll
-        for(int m=0; m<3; m++)
-        {
-            o.e.dx[m]  = __shfl(r.e.dx[m], lo);  o.e.ndy[m] = __shfl(r.e.ndy[m], lo);
-            o.e.glo[m] = __shfl(r.e.glo[m], lo); o.e.ghi[m] = __shfl(r.e.ghi[m], lo);
-        }
-        o.z_org = __shfl(r.z_org, lo); o.dzdx = __shfl(r.dzdx, lo); o.dzdy = __shfl(r.dzdy, lo);
-        o.r_org = __shfl(r.r_org, lo); o.drdx = __shfl(r.drdx, lo); o.drdy = __shfl(r.drdy, lo);
-        o.px0 = __shfl(r.px0, lo); o.py0 = __shfl(r.py0, lo); o.bw = __shfl(r.bw, lo);
-        o.inv_bw = __shfl(r.inv_bw, lo);
-        o.prim = __shfl(r.prim, lo);
-        const uint32_t oexcl = __shfl(excl, lo), odone = __shfl(done, lo);
-        if(it < total)
-        {
-            const uint32_t local = it - oexcl + odone;
-            const int ry = (int)(((float)local + 0.5f) * o.inv_bw);
-            const int rx = (int)local - ry*o.bw;
-            hz_emit_rec<false>(fb, p, o, o.px0 + rx, o.py0 + ry);
-        }
-    }
-}
-
-/* medium triangles queued by k_march: one wave per 64 records */
-__global__ __launch_bounds__(64)
-void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ midrec,
-           const unsigned int* __restrict__ counters, unsigned int midrec_capacity, hz_params_t p)
-{
-    const int lane = threadIdx.x;
-    /* records from the first reservation that did not fit were not written
-     * (their triangles were rasterised by the marching wave instead) */
-    const unsigned int n = min(min(counters[3], counters[5]), midrec_capacity);
-    for(unsigned int base = blockIdx.x*64u; base < n; base += gridDim.x*64u)
-    {
-        hz_rec_t r = {};
-        uint32_t npix = 0;
-        if(base + lane < n)
-        {
-            r = midrec[base + lane];
-            /* queued records carry the pixel count of the box in the inv_bw
-             * slot (the reciprocal is cheaper to redo than to store) */
-            npix = __float_as_uint(r.inv_bw);
-            r.inv_bw = 1.0f / (float)r.bw;
-        }
-        mr_distribute(r, npix, lane, fb, p);
-    }
-}
-
-/* set up and rasterise the `n` (<= 64) oldest pending triangles */
-__device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned int n, int lane,
-                                int jbeg, int i0,
-                                unsigned long long* fb, const mr_queue_t& q, const hz_params_t& p,
-                                unsigned int* dbg = nullptr)
-{
-    hz_rec_t r;
-    uint32_t npix = 0;
-    int bh = 0;
-    bool live = (unsigned int)lane < n;
-    const bool valid = live;
-    hz_wvert_t a = {}, b = {}, c = {};
-    hz_box_t box = {};
-    int t = 0, l = 0, rowoff = 0;
-    int sa = 0, sb = 0, sc = 0, la = 0, lb = 0, lc = 0;      /* LDS row slot and lane of the three vertices */
-    if(valid)
-    {
-        const uint32_t id = L.ids[(head + lane) & (MR_CAP-1)];
-        t = id & 1; l = (id >> 1) & 63; rowoff = id >> 7;
-        const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
-        /* reference horizonator-lib.c:500-506 */
-        sa = s0;               la = l;
-        sb = t == 0 ? s1 : s0; lb = l+1;
-        sc = s1;               lc = t == 0 ? l : l+1;
-        /* position and depth now; the colour only for triangles that get drawn */
-        a = mr_load_vert_pos(L, sa, la);
-        b = mr_load_vert_pos(L, sb, lb);
-        c = mr_load_vert_pos(L, sc, lc);
-        hz_tri_box(&box, &a, &b, &c, p.col0, p.col1-1, 0, p.H-1);
-    }
-    if(p.early_z)
-    {
-        /* early depth test (exact, see hz_tri_hidden): behind the ridges next to
-         * the viewer almost every survivor ends here, and a flush whose triangles
-         * are all hidden costs neither plane set-up nor pixel tests.  For boxes of
-         * at most 4 x 2 pixel centres - nearly all of the far field's, which is
-         * seen at grazing angles - and with the eight depths fetched at once (a
-         * narrower box fetches pixels twice). */
-        if(valid && box.px1 - box.px0 <= 3 && box.py1 - box.py0 <= 1)
-        {
-            const uint32_t* fbw = (const uint32_t*)fb;              /* depth = the upper 24 bits of the upper word */
-            const uint32_t* row0 = fbw + 2*((size_t)box.py0*p.SW) + 1;
-            const uint32_t* row1 = fbw + 2*((size_t)box.py1*p.SW) + 1;
-            const int c0 = box.px0 - p.col0, cl = box.px1 - p.col0;
-            const int c1 = min(c0+1, cl), c2 = min(c0+2, cl);
-            uint32_t z[8];
-            z[0] = row0[2*c0]; z[1] = row0[2*c1]; z[2] = row0[2*c2]; z[3] = row0[2*cl];
-            z[4] = row1[2*c0]; z[5] = row1[2*c1]; z[6] = row1[2*c2]; z[7] = row1[2*cl];
-            const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
-            if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
-        }
-        if(dbg) { dbg[5] += (unsigned int)__popcll(__ballot(valid && !live)); }
-        if(p.debug == 2) return;
-        if(!__any(live))
-        {
-            if(dbg) { dbg[0] += 1; dbg[1] += n; }
-            return;
-        }
-    }
-    if(live)
-    {
-        a.red = __uint_as_float(L.rows[sa][3][la]);
-        b.red = __uint_as_float(L.rows[sb][3][lb]);
-        c.red = __uint_as_float(L.rows[sc][3][lc]);
-    }
-    if(live)
-    {
-        hz_tri_t tri;
-        hz_tri_planes(&tri, &a, &b, &c);
-        hz_rec_from_tri(r, tri);
-        r.px0 = box.px0; r.bw = box.px1 - box.px0 + 1;
-        r.py0 = box.py0; bh   = box.py1 - box.py0 + 1;
-        r.inv_bw = 1.0f / (float)r.bw;
-        r.prim = (uint32_t)(((size_t)(jbeg + rowoff)*(p.N-1) + (i0 + l))*2 + t);
-        npix = (uint32_t)r.bw*(uint32_t)bh;
-    }
-    else
-    {
-        #pragma unroll
-        for(int m=0; m<3; m++) { r.e.dx[m] = 0; r.e.ndy[m] = 0; r.e.glo[m] = 0; r.e.ghi[m] = 0; }
-        r.z_org = r.dzdx = r.dzdy = r.r_org = r.drdx = r.drdy = 0.f;
-        r.px0 = r.py0 = 0; r.bw = 1; r.inv_bw = 1.f; r.prim = 0;
-    }
-
-    /* large boxes go to k_big: one record, ceil(tiles/64) work items */
-    const bool is_big = live && npix > p.big_min;
-    const unsigned long long bigmask = __ballot(is_big);
-    if(dbg) { dbg[0] += 1; dbg[1] += n; dbg[2] += (unsigned int)__popcll(bigmask); }
-    if(bigmask)
-    {
-        uint32_t chunks = 0;
-        if(is_big)
-        {
-            chunks = hz_big_chunks(r.bw, bh);
-        }
-        const uint32_t incl  = mr_scan(chunks, lane);
-        const uint32_t total = __shfl(incl, 63);
-        const uint32_t nb    = (uint32_t)__popcll(bigmask);
-        uint32_t rbase = 0, ibase = 0, ok = 0;
-        if(lane == 0)
-        {
-            rbase = atomicAdd(&q.counters[0], nb);
-            if(rbase + nb <= q.bigrec_capacity)
-            {
-                ibase = atomicAdd(&q.counters[1], total);
-                if(ibase + total <= q.bigitem_capacity) ok = 1;
-                else atomicMin(&q.counters[2], ibase);          /* items from here on are not valid */
-            }
-        }
-        rbase = __shfl(rbase, 0); ibase = __shfl(ibase, 0); ok = __shfl(ok, 0);
-        if(is_big)
-        {
-            if(ok)
-            {
-                const uint32_t ri = rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull));
-                const uint32_t ii = ibase + incl - chunks;
-                q.bigrec[ri].r = r; q.bigrec[ri].bh = bh;
-                for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
-            }
-            else
-            {
-                /* queue full (capacities are sized for 32k-wide panoramas): slow but correct */
-                for(int py = r.py0; py < r.py0 + bh; py++)
-                    for(int px = r.px0; px < r.px0 + r.bw; px++)
-                        hz_emit_rec<true>(fb, p, r, px, py);
-            }
-            npix = 0;
-        }
-    }
-
-    /* medium boxes go to k_mid, which spreads them over the whole chip: left
-     * here they make the waves next to the viewer the critical path */
-    const bool is_mid = live && npix > p.inline_max;
-    const unsigned long long midmask = __ballot(is_mid);
-    if(dbg) { dbg[3] += (unsigned int)__popcll(midmask); }
-    if(midmask)
-    {
-        uint32_t mbase = 0;
-        if(lane == 0) mbase = atomicAdd(&q.counters[3], (uint32_t)__popcll(midmask));
-        mbase = __shfl(mbase, 0);
-        if(mbase + (uint32_t)__popcll(midmask) <= q.midrec_capacity)
-        {
-            if(is_mid)
-            {
-                hz_rec_t m = r;
-                m.inv_bw = __uint_as_float(npix);       /* see k_mid */
-                q.midrec[mbase + (uint32_t)__popcll(midmask & ((1ull << lane) - 1ull))] = m;
-                npix = 0;
-            }
-        }
-        /* else: queue full, they stay here; the slots from mbase on hold nothing
-         * of this draw and k_mid must not read them */
-        else if(lane == 0) atomicMin(&q.counters[5], mbase);
-    }
-
-    if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }
-    mr_distribute(r, npix, lane, fb, p);
-}
-
-__global__ __launch_bounds__(64)
-void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
-             mr_queue_t q, mr_zones_t zn, hz_params_t p)
-{
-    __shared__ mr_lds_t L;
-    const unsigned long long t_start = p.wave_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
-    unsigned int dbgv[6] = {0,0,0,0,0,0};
-    unsigned int* dbg = p.wave_cycles ? dbgv : nullptr;
-
-    const int lane = threadIdx.x;
-    const int sx   = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0);     /* strip column */
-    const int i0   = sx*MR_COLS;
-    const int i    = i0 + lane;
-    int zone = 0;
-    #pragma unroll
-    for(int z=1; z<MR_NZONES; z++)
-        if((int)blockIdx.y >= zn.seg0[z] && (int)blockIdx.y < zn.seg0[z] + zn.nseg[z]) zone = z;
-    int sseg = (int)blockIdx.y - zn.seg0[zone];
-    if(zn.near_first && zone < MR_NZONES/2) sseg = zn.nseg[zone]-1 - sseg;      /* south of the viewer: northernmost first */
-    const int jbeg = zn.row0[zone] + sseg*zn.rows[zone];
-    const int jend = min(jbeg + zn.rows[zone], zn.row0[zone+1]);   /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
-    if(p.pass)
-    {
-        const bool near = sx >= p.near_x0 && sx <= p.near_x1 && jbeg < p.near_j1 && jend > p.near_j0;
-        if(near != (p.pass == 1)) return;
-    }
-    const bool has_vertex = i < p.N;
-    const bool has_cell   = lane < MR_COLS && i < p.N-1;
-    const int  ic = has_vertex ? i : p.N-1;             /* clamped: idle lanes redo the last column */
-
-    /* azimuth-sector shard (multi-GPU): a segment that does not contain the
-     * viewer is a convex patch seen from outside, so its azimuth extent is that
-     * of its four corner vertices; if that lies outside this GPU's columns the
-     * whole wave has nothing to draw.  (The corners are real vertices: their x
-     * is computed exactly as the rasteriser computes it.) */
-    if(p.col0 > 0 || p.col1 < p.W)
-    {
-        const int ia = i0, ib = min(i0 + MR_COLS, p.N-1);
-        const bool viewer_inside = p.u.viewer_cell_i >= (float)(ia-1) && p.u.viewer_cell_i <= (float)(ib+1) &&
-                                   p.u.viewer_cell_j >= (float)(jbeg-1) && p.u.viewer_cell_j <= (float)(jend+1);
-        if(!viewer_inside)
-        {
-            /* lanes 0..3 take one corner each (the others repeat them): one
-             * transform's worth of instructions for the wave instead of four */
-            const hz_vertex_t v = hz_transform_en(&p.u, hz_east(&p.u, (float)((lane & 1) ? ib : ia)),
-                                                  hz_north(&p.u, (float)((lane & 2) ? jend : jbeg)), 0.f);
-            float xlo = 2.f, xhi = -2.f;
-            #pragma unroll
-            for(int c=0; c<4; c++)
-            {
-                const float xc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), c));
-                xlo = hz_min(xlo, xc); xhi = hz_max(xhi, xc);
-            }
-            if(xhi - xlo <= 1.0f)       /* not across the +-180 degree seam */
-            {
-                const float flo = (xlo*p.halfW + p.halfW) - 2.5f, fhi = (xhi*p.halfW + p.halfW) + 1.5f;
-                if(fhi < (float)p.col0 || flo > (float)p.col1) return;
-            }
-        }
-    }
-
-    const float e = hz_east(&p.u, (float)ic);
-    /* the north offset of vertex row jbeg+lane, computed once per strip: a row
-     * then takes its n with one v_readlane instead of redoing the (wave-uniform)
-     * arithmetic with its IEEE division 64 lanes wide in every row */
-    const float n_tab = hz_north(&p.u, (float)(jbeg + lane));
-    auto north_of = [&](int rel) -> float
-    {
-        if(rel < 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n_tab), rel));
-        return hz_north(&p.u, (float)(jbeg + rel));
-    };
-    /* A strip whose vertex rows all lie beyond zfar (the test the row loop
-     * makes per row, for the row nearest the viewer: rounding is monotonic, so
-     * min over rows of fl(fl(n^2) + fl(e^2)) = fl(min fl(n^2) + fl(e^2))) would
-     * walk its rows without transforming one: it leaves here.  With the API's
-     * default far clip of 40 km that is 90 % of the strips of a 7x7-tile mosaic. */
-    if(p.far_strips)
-    {
-        const int nrows = jend - jbeg;                  /* vertex rows 0..nrows */
-        float nn = lane <= nrows ? n_tab*n_tab : __builtin_inff();
-        if(nrows >= 64) { const float n64 = hz_north(&p.u, (float)(jbeg + 64)); nn = hz_min(nn, n64*n64); }
-        #pragma unroll
-        for(int m=32; m>=1; m>>=1) nn = hz_min(nn, __shfl_xor(nn, m));
-        if(__all(nn + e*e > p.far_dd)) return;
-    }
-
-    /* abridged division / square-root sequences (hz_fast.h): allowed where the
-     * operands are in range - the draw's uniforms (host), this strip's east
-     * offsets, each row's north offset */
-    const hzf_const_t fc = hzf_setup(&p.u);
-    const bool fast_strip = p.fast_ok && __all(hzf_in_range(e));
-    const unsigned long long fast_rows = __ballot(hzf_in_range(n_tab));
-
-    /* pending-triangle ring, wave-uniform state */
-    unsigned int head = 0, count = 0;
-    int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
-    /* what a row keeps of itself for the cells above it (the attributes of its
-     * vertices live in LDS, where mr_flush takes them from): per lane the
-     * vertex's NDC x, snapped position and clip mask, its pixel columns/rows
-     * (mr_vcull_t) and the same combined with the vertex one lane to the east */
-    mr_rowstate_t prev = {};
-    bool prev_simple = false;
-    int16_t z_next = mosaic[(size_t)jbeg*p.N + ic];
-    /* rows whose 64 vertices all lie safely beyond zfar (by horizontal distance
-     * alone, 0.1% margin): their triangles can only be far-clipped, so a vertex
-     * row is transformed only if it or a neighbouring row is not such a row.
-     * With the default zfar = 40 km this is most of a large mosaic. */
-    float n_cur = north_of(0);
-    bool far_prev = true;
-    bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
-    for(int j = jbeg; j <= jend; j++)
-    {
-        const int rel = j - jbeg;
-        const float z = (float)z_next;
-        if(j < jend) z_next = mosaic[(size_t)(j+1)*p.N + ic];
-        const float n_next   = (j == jend) ? 0.f : north_of(rel+1);
-        const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
-        const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
-        const bool  skip_cells = far_prev && far_cur;               /* cell row j-1 entirely clipped */
-        const float n = n_cur;
-        n_cur = n_next; far_prev = far_cur; far_cur = far_next;
-        if(skip_row) continue;
-
-        const bool fast = fast_strip && (rel >= 64 ? hzf_in_range(n) : (int)((fast_rows >> rel) & 1ull));
-        const hz_vertex_t vtx = fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z);
-
-        /* window position as hz_to_window() computes it.  Two facts about the
-         * whole row are established on the way, which decide how its cells are
-         * culled: every vertex inside the view volume (clip mask 0: with
-         * xn + 1 < 0 <=> xn < -1 for every float, "inside" is |x|,|y|,|z| <= 1)
-         * and every vertex inside the guard band. */
-        hz_wvert_t cur;
-        cur.xn  = vtx.x;
-        cur.wx  = vtx.x*p.halfW + p.halfW;
-        cur.wy  = vtx.y*p.halfH + p.halfH;
-        cur.zw  = vtx.z*0.5f + 0.5f;
-        cur.red = vtx.red;
-        const float fxw = cur.wx - 0.5f, fyw = cur.wy - 0.5f;
-        const bool  in_guard  = hz_abs(fxw) <= HZ_GUARD_PX && hz_abs(fyw) <= HZ_GUARD_PX;     /* a NaN is outside */
-        /* fmaxf skips a NaN, as the six comparisons of hz_clip_mask() do (all false) */
-        const bool  in_volume = __builtin_fmaxf(__builtin_fmaxf(hz_abs(vtx.x), hz_abs(vtx.y)), hz_abs(vtx.z)) <= 1.0f;
-        const bool  cur_simple = __all(in_guard && in_volume);
-        cur.xs = (int32_t)hz_roundeven(fxw*256.f);
-        cur.ys = (int32_t)hz_roundeven(fyw*256.f);
-        cur.cmask = 0;
-        if(!cur_simple)
-        {
-            cur.cmask = hz_clip_mask(vtx.x, vtx.y, vtx.z);
-            if(!in_guard) { cur.xs = HZ_OUTSIDE_GUARD; cur.ys = 0; }
-        }
-
-        /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
-         * still need it are set up now (happens where survivors are sparse) */
-        if(count && first_row <= rel - MR_RSLOTS)
-        {
-            __syncthreads();
-            mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
-            __syncthreads();
-            head = (head + count) & (MR_CAP-1);
-            count = 0;
-        }
-        mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
-
-        mr_rowstate_t now;
-        now.xn = cur.xn; now.xs = cur.xs; now.ys = cur.ys; now.cmask = cur.cmask;
-        /* pixel columns/rows of the vertex: a triangle's pixel box is the min of
-         * its vertices' first and the max of their last (hz_tri_box: the shifts
-         * are monotone), clipped to the scissor here already (max and min
-         * distribute over it) */
-        now.c_x = hz_imax((cur.xs + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, p.col0);
-        now.f_x = hz_imin(cur.xs >> HZ_SUBPIXEL_BITS, p.col1-1);
-        now.c_y = hz_imax((cur.ys + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, 0);
-        now.f_y = hz_imin(cur.ys >> HZ_SUBPIXEL_BITS, p.H-1);
-        /* the same over this vertex and its eastern neighbour (one DPP-fused
-         * instruction each: the neighbour's value never lands in a register of
-         * its own), and the step to that neighbour */
-        now.h_c_x  = hz_imin(mr_from_east(now.c_x), now.c_x);
-        now.h_f_x  = hz_imax(mr_from_east(now.f_x), now.f_x);
-        now.h_c_y  = hz_imin(mr_from_east(now.c_y), now.c_y);
-        now.h_f_y  = hz_imax(mr_from_east(now.f_y), now.f_y);
-        now.h_dx   = (int32_t)((uint32_t)mr_from_east(cur.xs) - (uint32_t)cur.xs);     /* (wraps for guard-band markers; unused then) */
-        now.h_dy   = (int32_t)((uint32_t)mr_from_east(cur.ys) - (uint32_t)cur.ys);
-
-        if(j > jbeg && !skip_cells)
-        {
-            /* cell (i, j-1): v00 = prev, v01 = cur, v10 / v11 = those of the lane to
-             * the east; triangles t0 = (v00,v11,v01), t1 = (v00,v10,v11), reference
-             * horizonator-lib.c:500-506 */
-            bool keep0 = false, keep1 = false;
-            bool simple = cur_simple && prev_simple;
-            /* steps from v00 to the cell's other vertices, in 1/256 pixel */
-            const int32_t d01x = (int32_t)((uint32_t)cur.xs - (uint32_t)prev.xs);               /* v01 - v00 */
-            const int32_t d01y = (int32_t)((uint32_t)cur.ys - (uint32_t)prev.ys);
-            const int32_t d11x = (int32_t)((uint32_t)d01x + (uint32_t)now.h_dx);                /* v11 - v00 = (v01 - v00) + (v11 - v01) */
-            const int32_t d11y = (int32_t)((uint32_t)d01y + (uint32_t)now.h_dy);
-            const int32_t d10x = prev.h_dx, d10y = prev.h_dy;                                   /* v10 - v00 */
-            if(simple)
-            {
-                /* reference geometry.glsl:21-27 (a triangle spanning more than 0.5 in
-                 * NDC x = a quarter of the image is dropped) cannot apply to a cell
-                 * whose vertices are all within quad_max_dx of v00 in snapped x: any
-                 * two of them are then less than a quarter of the image minus two
-                 * pixels apart, and window x follows NDC x to within a hundredth
-                 * of a pixel.  A wider cell is rare (the +-180 degree seam, cells
-                 * next to the viewer) and sends the row the long way. */
-                const int32_t lo = hz_imin(hz_imin(d01x, d11x), d10x), hi = hz_imax(hz_imax(d01x, d11x), d10x);
-                if(__any(has_cell && !(lo > -p.quad_max_dx && hi < p.quad_max_dx))) simple = false;
-            }
-            if(simple)
-            {
-                /* all four vertices inside the view volume and the guard band, no
-                 * discard: what is left of hz_tri_cull() is the back-face test on
-                 * the snapped area and the pixel box */
-                const int64_t area0 = (int64_t)d11x*(int64_t)d01y - (int64_t)d01x*(int64_t)d11y;
-                const int64_t area1 = (int64_t)d10x*(int64_t)d11y - (int64_t)d11x*(int64_t)d10y;
-                /* t0 = the row's own edge v01-v11 plus v00; t1 = the lower edge v00-v10 plus v11 */
-                const int32_t px0_0 = hz_imin(now.h_c_x, prev.c_x), px1_0 = hz_imax(now.h_f_x, prev.f_x);
-                const int32_t py0_0 = hz_imin(now.h_c_y, prev.c_y), py1_0 = hz_imax(now.h_f_y, prev.f_y);
-                const int32_t px0_1 = hz_imin(mr_from_east(now.c_x), prev.h_c_x), px1_1 = hz_imax(mr_from_east(now.f_x), prev.h_f_x);
-                const int32_t py0_1 = hz_imin(mr_from_east(now.c_y), prev.h_c_y), py1_1 = hz_imax(mr_from_east(now.f_y), prev.h_f_y);
-                keep0 = has_cell && area0 > 0 && px0_0 <= px1_0 && py0_0 <= py1_0;
-                keep1 = has_cell && area1 > 0 && px0_1 <= px1_1 && py0_1 <= py1_1;
-            }
-            else
-            {
-                hz_wvert_t v00 = {}, v01 = {}, v10 = {}, v11 = {};
-                v00.xn = prev.xn; v00.xs = prev.xs; v00.ys = prev.ys; v00.cmask = prev.cmask;
-                v01.xn = cur.xn;  v01.xs = cur.xs;  v01.ys = cur.ys;  v01.cmask = cur.cmask;
-                /* (the neighbour's snapped position from the step to it: the DPP read of it stays fused into that subtraction) */
-                v10.xn = mr_from_east(prev.xn);
-                v10.xs = (int32_t)((uint32_t)prev.xs + (uint32_t)prev.h_dx); v10.ys = (int32_t)((uint32_t)prev.ys + (uint32_t)prev.h_dy);
-                v10.cmask = (uint32_t)mr_from_east((int32_t)prev.cmask);
-                v11.xn = mr_from_east(cur.xn);
-                v11.xs = (int32_t)((uint32_t)cur.xs + (uint32_t)now.h_dx);   v11.ys = (int32_t)((uint32_t)cur.ys + (uint32_t)now.h_dy);
-                v11.cmask = (uint32_t)mr_from_east((int32_t)cur.cmask);
-                hz_box_t box;
-                const int verdict0 = has_cell ? hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
-                const int verdict1 = has_cell ? hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
-                /* crossing the image border or the near/far sphere: k_clip */
-                const uint32_t prim0 = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2);
-                hz_queue_clip(q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
-                hz_queue_clip(q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
-                keep0 = verdict0 == HZ_TRI_DRAW; keep1 = verdict1 == HZ_TRI_DRAW;
-            }
-            #pragma unroll
-            for(int t=0; t<2; t++)
-            {
-                const bool keep = (t == 0 ? keep0 : keep1) && p.debug != 1;
-                const unsigned long long m = __ballot(keep);
-                if(m)
-                {
-                    if(count == 0) first_row = rel-1;
-                    if(keep)
-                    {
-                        const unsigned int at = (head + count + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & (MR_CAP-1);
-                        L.ids[at] = ((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t;
-                    }
-                    count += (unsigned int)__popcll(m);
-                    if(count >= 64)
-                    {
-                        __syncthreads();        /* one wave: orders the LDS writes before the reads */
-                        mr_flush(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
-                        head = (head + 64) & (MR_CAP-1);
-                        count -= 64;
-                        if(count) first_row = (int)(L.ids[head] >> 7);
-                        __syncthreads();
-                    }
-                }
-            }
-        }
-        prev = now; prev_simple = cur_simple;
-    }
-    if(count)
-    {
-        __syncthreads();
-        mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
-    }
-    if(p.wave_cycles && lane == 0)
-    {
-        unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];
-        o[0] = __builtin_amdgcn_s_memtime() - t_start;
-        o[1] = ((unsigned long long)dbgv[0] << 32) | dbgv[1];     /* flushes, triangles set up */
-        o[2] = ((unsigned long long)dbgv[2] << 32) | dbgv[3];     /* to k_big, to k_mid        */
-        o[3] = ((unsigned long long)dbgv[5] << 32) | dbgv[4];     /* hidden by the early depth test, pixel centres tested here */
-    }
-}
-
-/* ------------------------------------------------------------------------ */
-/* resolve: framebuffer words -> BGR8, range, primitive id, z24; flips rows  */
-
-/* CLEAR: the kernel is the last reader of this draw: it leaves the framebuffer
- * as glClear would (reference horizonator-lib.c:896), storing all ones behind
- * itself where a triangle had written - the words of the sky (62 % of the
- * benchmark image) are all ones already and are not written again */
-template<bool CLEAR>
-__global__ __launch_bounds__(256)
-void k_resolve(unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
-               unsigned char* __restrict__ bgr, float* __restrict__ ranges,
-               int32_t* __restrict__ index, uint32_t* __restrict__ z24,
-               int SW, int H, float znear, float zfar)
-{
-    const size_t npix = (size_t)SW*H;
-    for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
-    {
-        const int yo  = (int)(o / SW);          /* output row, 0 = top            */
-        const int x   = (int)(o - (size_t)yo*SW);
-        const int row = H-1 - yo;               /* GL row, reference horizonator-lib.c:949-958 */
-        const unsigned long long key = fb[(size_t)row*SW + x];
-        if(CLEAR && key != HZ_FB_CLEAR) fb[(size_t)row*SW + x] = HZ_FB_CLEAR;
-        const uint32_t zi = (uint32_t)(key >> 40);
-        const bool sky = (zi == HZ_Z24_MAX);
-        if(bgr)
-        {
-            /* reference horizonator-lib.c:185 clear colour (0,0,1) -> B=255;
-             * reference fragment.glsl:15-16 terrain = (red,0,0) -> R */
-            bgr[o*3+0] = sky ? 255 : 0;
-            bgr[o*3+1] = 0;
-            bgr[o*3+2] = sky ? 0 : (unsigned char)(key & 0xFF);
-        }
-        if(index) index[o] = sky ? -1 : (int32_t)(uint32_t)((key >> 8) & 0xFFFFFFFFull);
-        if(z24)   z24[o]   = zi;
-        if(ranges)
-        {
-            /* reference horizonator-lib.c:1013-1025 */
-            float r = -1.0f;
-            if(!sky)
-            {
-                const float depth = (float)((double)zi * (1.0/16777215.0));
-                const float len   = depth * (zfar-znear) + znear;
-                const float zt    = tanel[row] * len;
-                r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);  /* = hypotf */
-            }
-            ranges[o] = r;
-        }
-    }
-}
-
-/* the same for sector widths that are a multiple of 4 and 16-byte aligned
- * buffers (the normal case): a thread takes four neighbouring pixels of one
- * row - two 16-byte loads, one store per output - and the row/column come from
- * the launch grid instead of a 64-bit division per pixel */
-__device__ static inline float hz_range_from_z24(uint32_t zi, float tan_row, float znear, float zfar)
-{
-    /* reference horizonator-lib.c:1013-1025 */
-    const float depth = (float)((double)zi * (1.0/16777215.0));
-    const float len   = depth * (zfar-znear) + znear;
-    const float zt    = tan_row * len;
-    return (float)sqrt((double)len*(double)len + (double)zt*(double)zt);  /* = hypotf */
-}
-
-template<bool CLEAR>
-__global__ __launch_bounds__(256)
-void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
-                unsigned char* __restrict__ bgr, float* __restrict__ ranges,
-                int32_t* __restrict__ index, uint32_t* __restrict__ z24,
-                int SW, int H, float znear, float zfar,
-                unsigned char* __restrict__ touched, int seg_stride)
-{
-    /* a wave = 64 lanes x 4 pixels = one HZ_SEG-pixel segment of a row */
-    static_assert(HZ_SEG == 256, "k_resolve4: one wave converts one segment");
-    const int x = (int)(blockIdx.x*blockDim.x + threadIdx.x)*4;
-    if(x >= SW) return;
-    for(int yo = blockIdx.y; yo < H; yo += gridDim.y)
-    {
-        const int row = H-1 - yo;               /* GL row, reference horizonator-lib.c:949-958 */
-        ulonglong2* src = (ulonglong2*)(fb + (size_t)row*SW + x);
-        unsigned char* flag = touched + (size_t)row*seg_stride + (x >> HZ_SEG_LOG2);
-        ulonglong2 k01 = { HZ_FB_CLEAR, HZ_FB_CLEAR }, k23 = k01;
-        if(*flag)                               /* (the same byte for the whole wave) */
-        {
-            k01 = src[0]; k23 = src[1];
-            if(CLEAR)
-            {
-                const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
-                if((k01.x & k01.y) != HZ_FB_CLEAR) src[0] = ones;
-                if((k23.x & k23.y) != HZ_FB_CLEAR) src[1] = ones;
-                if((x & (HZ_SEG-1)) == 0) *flag = 0;
-            }
-        }
-        const unsigned long long key[4] = { k01.x, k01.y, k23.x, k23.y };
-        uint32_t zi[4], pix[4];
-        #pragma unroll
-        for(int k=0; k<4; k++)
-        {
-            zi[k] = (uint32_t)(key[k] >> 40);
-            /* reference horizonator-lib.c:185 clear colour (0,0,1) -> B=255; fragment.glsl:15-16 terrain = (red,0,0) -> R;
-             * the three bytes B,G,R as the low 24 bits */
-            pix[k] = zi[k] == HZ_Z24_MAX ? 0x0000FFu : (((uint32_t)key[k] & 0xFFu) << 16);
-        }
-        const size_t o = (size_t)yo*SW + x;
-        if(bgr)
-        {
-            uint3 w;
-            w.x = pix[0] | (pix[1] << 24);
-            w.y = (pix[1] >> 8) | (pix[2] << 16);
-            w.z = (pix[2] >> 16) | (pix[3] << 8);
-            *(uint3*)(bgr + o*3) = w;
-        }
-        if(index)
-        {
-            int4 w;
-            w.x = zi[0] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[0] >> 8);
-            w.y = zi[1] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[1] >> 8);
-            w.z = zi[2] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[2] >> 8);
-            w.w = zi[3] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[3] >> 8);
-            *(int4*)(index + o) = w;
-        }
-        if(z24) { uint4 w = { zi[0], zi[1], zi[2], zi[3] }; *(uint4*)(z24 + o) = w; }
-        if(ranges)
-        {
-            const float tr = tanel[row];
-            float4 w;
-            w.x = zi[0] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[0], tr, znear, zfar);
-            w.y = zi[1] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[1], tr, znear, zfar);
-            w.z = zi[2] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[2], tr, znear, zfar);
-            w.w = zi[3] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[3], tr, znear, zfar);
-            *(float4*)(ranges + o) = w;
-        }
-    }
-}
-
-/* ------------------------------------------------------------------------ */
-/* packed strips for the multi-GPU gather                                    */
-/*
- * A finished strip as BGR8 + float32 range is 7 bytes per pixel, and with N
- * GPUs (N-1)/N of the panorama has to reach the gathering rank through its
- * xGMI links: at N = 2 that is 224 MB over ONE link per panorama, more time
- * than the render itself.  Everything the readback conversion needs is the
- * 24-bit depth and the 8-bit shade, so a rank ships z24<<8 | red8 (4 bytes per
- * pixel, top row first) and the gathering rank runs the conversion
- * (reference horizonator-lib.c:936-1048) on what arrives: same bytes out.
- */
-template<bool CLEAR>
-__global__ __launch_bounds__(256)
-void k_pack(unsigned long long* __restrict__ fb, uint32_t* __restrict__ packed, int SW, int H)
-{
-    const size_t npix = (size_t)SW*H;
-    for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
-    {
-        const int yo = (int)(o / SW), x = (int)(o - (size_t)yo*SW);
-        const unsigned long long key = fb[(size_t)(H-1 - yo)*SW + x];
-        if(CLEAR && key != HZ_FB_CLEAR) fb[(size_t)(H-1 - yo)*SW + x] = HZ_FB_CLEAR;
-        packed[o] = ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
-    }
-}
-
-/* packed[H][stride] (columns 0..ncols-1 used) -> columns out_col0.. of the
- * full-width outputs bgr[H][out_W][3], ranges[H][out_W]; rows top first */
-__global__ __launch_bounds__(256)
-void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols,
-                      const float* __restrict__ tanel,
-                      unsigned char* __restrict__ bgr, float* __restrict__ ranges,
-                      int out_W, int out_col0, int H, float znear, float zfar)
-{
-    const size_t npix = (size_t)ncols*H;
-    for(size_t k = (size_t)blockIdx.x*blockDim.x + threadIdx.x; k < npix; k += (size_t)gridDim.x*blockDim.x)
-    {
-        const int yo = (int)(k / ncols), x = (int)(k - (size_t)yo*ncols);
-        const uint32_t w  = packed[(size_t)yo*stride + x];
-        const uint32_t zi = w >> 8;
-        const bool sky = (zi == HZ_Z24_MAX);
-        const size_t o = (size_t)yo*out_W + out_col0 + x;
-        if(bgr)
-        {
-            bgr[o*3+0] = sky ? 255 : 0;
-            bgr[o*3+1] = 0;
-            bgr[o*3+2] = sky ? 0 : (unsigned char)(w & 0xFF);
-        }
-        if(ranges)
-        {
-            /* reference horizonator-lib.c:1013-1025, as k_resolve */
-            float r = -1.0f;
-            if(!sky)
-            {
-                const float depth = (float)((double)zi * (1.0/16777215.0));
-                const float len   = depth * (zfar-znear) + znear;
-                const float zt    = tanel[H-1 - yo] * len;
-                r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
-            }
-            ranges[o] = r;
-        }
-    }
-}
-
-/* Sparse strips: most of a panorama is sky (62 % of the benchmark image), and a
- * sky pixel carries no information.  A strip as a stream of uint32:
- *   [0]                    number of terrain pixels T
- *   [1 .. 1+H)             row_base[yo]: where row yo's words start in the data
- *   [1+H .. HDR)           terrain mask, mask_stride words per row, bit c%32 of word c/32
- *   [HDR .. HDR+T)         z24<<8 | red8 of the terrain pixels, row by row, left to right
- * with HDR = 1 + H + H*mask_stride, rows top first.  Rows may be laid out in
- * any order in the data (row_base says where): one block per row, one atomic
- * per row for its base.  The buffer must hold HDR + H*SW words; [0] must be 0
- * on entry. */
-template<bool CLEAR>
-__global__ __launch_bounds__(256)
-void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
-                   int SW, int H, int mask_stride)
-{
-    __shared__ uint32_t wave_count[4];
-    __shared__ uint32_t row_base_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
-    for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
-    {
-        unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
-        uint32_t* mask = out + 1 + H + (size_t)yo*mask_stride;
-        /* pass 1: mask and count */
-        uint32_t mine = 0;
-        for(int c0 = 0; c0 < SW; c0 += 256)
-        {
-            const int c = c0 + threadIdx.x;
-            const bool terrain = c < SW && (uint32_t)(row[c] >> 40) != HZ_Z24_MAX;
-            const unsigned long long b = __ballot(terrain);
-            if(lane == 0  && c0 + wave*64      < SW) mask[(c0 >> 5) + wave*2]     = (uint32_t)b;
-            if(lane == 32 && c0 + wave*64 + 32 < SW) mask[(c0 >> 5) + wave*2 + 1] = (uint32_t)(b >> 32);
-            mine += (uint32_t)__popcll(b);                  /* the same in every lane of the wave */
-        }
-        if(lane == 0) wave_count[wave] = mine;
-        __syncthreads();
-        if(threadIdx.x == 0)
-        {
-            const uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-            const uint32_t base = atomicAdd(&out[0], total);
-            out[1 + yo] = base;
-            row_base_s = base;
-        }
-        __syncthreads();
-        /* pass 2: the words (the row is in L2 now) */
-        uint32_t run = row_base_s;
-        for(int c0 = 0; c0 < SW; c0 += 256)
-        {
-            const int c = c0 + threadIdx.x;
-            unsigned long long key = 0;
-            bool terrain = false;
-            if(c < SW)
-            {
-                key = row[c];
-                terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX;
-                if(CLEAR && key != HZ_FB_CLEAR) row[c] = HZ_FB_CLEAR;
-            }
-            const unsigned long long b = __ballot(terrain);
-            __syncthreads();
-            if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
-            __syncthreads();
-            uint32_t before = 0;
-            for(int w=0; w<wave; w++) before += wave_count[w];
-            if(terrain)
-                out[HDR + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] =
-                    ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
-            run += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-        }
-        __syncthreads();
-    }
-}
-
-/* the readback conversion on a sparse strip: columns [0,ncols) of the strip go
- * to columns out_col0.. of the full-width outputs */
-__global__ __launch_bounds__(256)
-void k_resolve_sparse(const uint32_t* __restrict__ in, int mask_stride, int ncols,
-                      const float* __restrict__ tanel,
-                      unsigned char* __restrict__ bgr, float* __restrict__ ranges,
-                      int out_W, int out_col0, int H, float znear, float zfar)
-{
-    __shared__ uint32_t wave_count[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
-    for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
-    {
-        const uint32_t* mask = in + 1 + H + (size_t)yo*mask_stride;
-        uint32_t run = in[1 + yo];
-        const float tan_row = tanel[H-1 - yo];
-        for(int c0 = 0; c0 < ncols; c0 += 256)
-        {
-            const int c = c0 + threadIdx.x;
-            const bool terrain = c < ncols && ((mask[c >> 5] >> (c & 31)) & 1u);
-            const unsigned long long b = __ballot(terrain);
-            __syncthreads();
-            if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
-            __syncthreads();
-            uint32_t before = 0;
-            for(int w=0; w<wave; w++) before += wave_count[w];
-            if(c < ncols)
-            {
-                const size_t o = (size_t)yo*out_W + out_col0 + c;
-                uint32_t w = 0;
-                if(terrain) w = in[HDR + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))];
-                if(bgr)
-                {
-                    bgr[o*3+0] = terrain ? 0 : 255;
-                    bgr[o*3+1] = 0;
-                    bgr[o*3+2] = terrain ? (unsigned char)(w & 0xFF) : 0;
-                }
-                if(ranges)
-                {
-                    float r = -1.0f;
-                    if(terrain)
-                    {
-                        const float depth = (float)((double)(w >> 8) * (1.0/16777215.0));
-                        const float len   = depth * (zfar-znear) + znear;
-                        const float zt    = tan_row * len;
-                        r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
-                    }
-                    ranges[o] = r;
-                }
-            }
-            run += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-        }
-        __syncthreads();
-    }
-}
-
-/* ------------------------------------------------------------------------ */
-/* textured resolve ("next" row N4): deferred shading                         */
-/*
- * The rasteriser kernels do not know about the texture: the framebuffer word
- * says which triangle won each pixel, and that is all the reference's fragment
- * stage needs beyond the triangle itself.  So for every terrain pixel this
- * kernel builds the winning triangle again (three vertices through the same
- * transform, plus their texture coordinates), sets up the planes of shade, s
- * and t with hz_tri_planes() arithmetic, evaluates them at the pixel, samples
- * the texture and blends (hz_tex.h).  A triangle the clipper cut is clipped
- * again, and the piece that covers the pixel with the stored depth supplies the
- * planes.  This path is not the benchmark's.
- */
-__device__ __noinline__ static bool hz_shade_clipped(const hz_cvert_t& a, const hz_cvert_t& b, const hz_cvert_t& c,
-                                                     const hz_params_t& p, int px, int py, uint32_t zi,
-                                                     hz_texplanes_t* planes)
-{
-    hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1], *poly;
-    const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
-    for(int k=2; k<n; k++)
-    {
-        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
-        hz_box_t box;
-        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
-        if(px < box.px0 || px > box.px1 || py < box.py0 || py > box.py1) continue;
-        hz_tri_t tri;
-        hz_tri_planes(&tri, &va, &vb, &vc);
-        if(!hz_tri_covers(&tri, px, py)) continue;
-        uint32_t z2, r8;
-        if(!hz_tri_fragment(&tri, px, py, &z2, &r8) || z2 != zi) continue;
-        hz_tri_planes_tex(planes, &poly[k-1], &poly[k], &poly[0]);
-        return true;
-    }
-    return false;
-}
-
-/* the three vertices of grid triangle `prim` with their texture coordinates */
-__device__ static inline void hz_prim_cverts(const int16_t* __restrict__ mosaic, const hz_texparams_t& tp,
-                                             const hz_params_t& p, uint32_t prim,
-                                             hz_cvert_t* a, hz_cvert_t* b, hz_cvert_t* c)
-{
-    const uint32_t cell = prim >> 1;
-    const int t = prim & 1;
-    const int j = cell / (uint32_t)(p.N-1);
-    const int i = cell - (uint32_t)j*(uint32_t)(p.N-1);
-    /* reference horizonator-lib.c:500-506 */
-    const int ib = i+1,              jb = t == 0 ? j+1 : j;
-    const int ic = t == 0 ? i : i+1, jc = j+1;
-    *a = hz_cvert(hz_transform(&p.u, (float)i,  (float)j,  (float)mosaic[(size_t)j *p.N + i ]), p.halfW, p.halfH);
-    *b = hz_cvert(hz_transform(&p.u, (float)ib, (float)jb, (float)mosaic[(size_t)jb*p.N + ib]), p.halfW, p.halfH);
-    *c = hz_cvert(hz_transform(&p.u, (float)ic, (float)jc, (float)mosaic[(size_t)jc*p.N + ic]), p.halfW, p.halfH);
-    hz_vertex_tex(&tp, p.u.deg_per_cell, (float)i,  (float)j,  &a->s, &a->t);
-    hz_vertex_tex(&tp, p.u.deg_per_cell, (float)ib, (float)jb, &b->s, &b->t);
-    hz_vertex_tex(&tp, p.u.deg_per_cell, (float)ic, (float)jc, &c->s, &c->t);
-}
-
-/* One wave shades TX_CHUNK consecutive output pixels at a time.  Neighbouring
- * pixels mostly belong to the same triangle, and the expensive part - building
- * the triangle again and setting up its planes - depends on the triangle only:
- *   A  the chunk's pixels are cut into runs of equal primitive id (ballot + popcount)
- *   B  lane = run: vertices, planes of shade/s/t into LDS (a triangle the clipper
- *      cut is flagged: its planes depend on the piece that covers the pixel)
- *   C  lane = pixel: planes of its run from LDS, evaluate, sample, blend, store
- * Next to the viewer a chunk holds a handful of runs; at the skyline every pixel
- * is its own run and the scheme falls back to one set-up per pixel. */
-#define TX_SUB   4                      /* sub-spans of 64 pixels per chunk */
-#define TX_CHUNK (64*TX_SUB)
-#define TX_MAXCLIP 4                    /* clipped triangles per chunk whose pieces are kept in LDS */
-#define TX_PIECES  (HZ_MAX_CLIPPED-2)
-struct tx_lds_t
-{
-    uint32_t run_prim[TX_CHUNK];
-    float    planes[9][TX_CHUNK];       /* r_org drdx drdy s_org dsdx dsdy t_org dtdx dtdy;
-                                         * r_org = NaN: clipped, drdx then holds the slot below (-1: none) */
-    /* The few triangles next to the viewer that cross the image border cover a
-     * large share of the picture (9 triangles, 18% of the terrain pixels in the
-     * benchmark scene): their clipped pieces are set up once per chunk.  Per
-     * piece: snapped vertices (6), depth plane (3), the nine texture planes. */
-    int32_t  npieces[TX_MAXCLIP];
-    uint32_t piece[TX_MAXCLIP][TX_PIECES][18];
-};
-
-/* B, for a triangle the clipper cuts: all its pieces into LDS slot `slot` */
-__device__ __noinline__ static void tx_store_pieces(tx_lds_t& L, int slot, const hz_cvert_t& a, const hz_cvert_t& b,
-                                                    const hz_cvert_t& c, const hz_params_t& p)
-{
-    hz_cvert_t bufa[HZ_MAX_CLIPPED+1], bufb[HZ_MAX_CLIPPED+1], *poly;
-    const int n = hz_clip_triangle(bufa, bufb, &poly, &a, &b, &c, p.halfW, p.halfH);
-    int count = 0;
-    for(int k=2; k<n && count < TX_PIECES; k++)
-    {
-        const hz_wvert_t va = hz_wvert_of(&poly[k-1]), vb = hz_wvert_of(&poly[k]), vc = hz_wvert_of(&poly[0]);
-        hz_box_t box;
-        if(!hz_tri_cull_window(&box, &va, &vb, &vc, p.col0, p.col1-1, 0, p.H-1)) continue;
-        hz_tri_t tri;
-        hz_tri_planes(&tri, &va, &vb, &vc);
-        hz_texplanes_t pl;
-        hz_tri_planes_tex(&pl, &poly[k-1], &poly[k], &poly[0]);
-        uint32_t* o = L.piece[slot][count++];
-        #pragma unroll
-        for(int m=0; m<3; m++) { o[m] = (uint32_t)tri.xs[m]; o[3+m] = (uint32_t)tri.ys[m]; }
-        o[6] = __float_as_uint(tri.z_org); o[7] = __float_as_uint(tri.dzdx); o[8] = __float_as_uint(tri.dzdy);
-        o[9]  = __float_as_uint(pl.r_org); o[10] = __float_as_uint(pl.drdx); o[11] = __float_as_uint(pl.drdy);
-        o[12] = __float_as_uint(pl.s_org); o[13] = __float_as_uint(pl.dsdx); o[14] = __float_as_uint(pl.dsdy);
-        o[15] = __float_as_uint(pl.t_org); o[16] = __float_as_uint(pl.dtdx); o[17] = __float_as_uint(pl.dtdy);
-    }
-    L.npieces[slot] = count;
-}
-/* C, for a pixel of such a triangle: the piece that covers it with the stored depth */
-__device__ static inline bool tx_find_piece(const tx_lds_t& L, int slot, int px, int py, uint32_t zi, hz_texplanes_t* pl)
-{
-    const int n = L.npieces[slot];
-    for(int k=0; k<n; k++)
-    {
-        const uint32_t* o = L.piece[slot][k];
-        hz_tri_t tri;
-        #pragma unroll
-        for(int m=0; m<3; m++) { tri.xs[m] = (int32_t)o[m]; tri.ys[m] = (int32_t)o[3+m]; }
-        tri.z_org = __uint_as_float(o[6]); tri.dzdx = __uint_as_float(o[7]); tri.dzdy = __uint_as_float(o[8]);
-        tri.r_org = tri.drdx = tri.drdy = 0.f;
-        if(!hz_tri_covers(&tri, px, py)) continue;
-        uint32_t z2, r8;
-        if(!hz_tri_fragment(&tri, px, py, &z2, &r8) || z2 != zi) continue;
-        pl->r_org = __uint_as_float(o[9]);  pl->drdx = __uint_as_float(o[10]); pl->drdy = __uint_as_float(o[11]);
-        pl->s_org = __uint_as_float(o[12]); pl->dsdx = __uint_as_float(o[13]); pl->dsdy = __uint_as_float(o[14]);
-        pl->t_org = __uint_as_float(o[15]); pl->dtdx = __uint_as_float(o[16]); pl->dtdy = __uint_as_float(o[17]);
-        return true;
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(64)
-void k_shade_tex(const unsigned long long* __restrict__ fb, const int16_t* __restrict__ mosaic,
-                 const uint32_t* __restrict__ texels, hz_texparams_t tp,
-                 unsigned char* __restrict__ bgr, hz_params_t p)
-{
-    __shared__ tx_lds_t L;
-    const int lane = threadIdx.x;
-    const size_t npix = (size_t)p.SW*p.H;
-    const size_t nchunks = (npix + TX_CHUNK-1)/TX_CHUNK;
-    for(size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x)
-    {
-        /* A: runs */
-        uint32_t zi_k[TX_SUB], run_k[TX_SUB];
-        uint32_t nruns = 0, prev_last = 0xFFFFFFFFu;
-        /* output position of this lane's pixel in sub-span 0 (one 64-bit division per
-         * chunk), then stepped by 64 pixels */
-        const size_t o0 = chunk*TX_CHUNK + lane;
-        const int yo0 = (int)(o0 / p.SW), x0 = (int)(o0 - (size_t)yo0*p.SW);
-        int yo = yo0, x = x0;
-        #pragma unroll
-        for(int k=0; k<TX_SUB; k++)
-        {
-            const size_t o = o0 + (size_t)k*64;
-            uint32_t prim = 0xFFFFFFFFu, zi = HZ_Z24_MAX;
-            if(o < npix)
-            {
-                const unsigned long long key = fb[(size_t)(p.H-1 - yo)*p.SW + x];
-                zi = (uint32_t)(key >> 40);
-                if(zi != HZ_Z24_MAX) prim = (uint32_t)((key >> 8) & 0xFFFFFFFFull);
-            }
-            uint32_t left = __shfl_up(prim, 1);
-            if(lane == 0) left = prev_last;
-            prev_last = __shfl(prim, 63);
-            const bool is_start = prim != 0xFFFFFFFFu && prim != left;
-            const unsigned long long starts = __ballot(is_start);
-            const uint32_t upto = (uint32_t)__popcll(starts & ((2ull << lane) - 1ull));   /* starts at lanes <= lane */
-            run_k[k] = nruns + upto - 1u;           /* a sky pixel gets a meaningless index it never uses */
-            zi_k[k]  = zi;
-            if(is_start) L.run_prim[run_k[k]] = prim;
-            nruns += (uint32_t)__popcll(starts);
-            x += 64;
-            while(x >= p.SW) { x -= p.SW; yo++; }
-        }
-        if(nruns == 0) continue;                    /* sky only */
-        __syncthreads();
-
-        /* B: planes per run */
-        int clip_slots = 0;
-        for(uint32_t r0 = 0; r0 < nruns; r0 += 64)
-        {
-            const uint32_t r = r0 + lane;
-            hz_cvert_t a = {}, b = {}, c = {};
-            bool clipped = false;
-            if(r < nruns)
-            {
-                hz_prim_cverts(mosaic, tp, p, L.run_prim[r], &a, &b, &c);
-                clipped = (hz_clip_mask(a.xn, a.yn, a.zn) | hz_clip_mask(b.xn, b.yn, b.zn) | hz_clip_mask(c.xn, c.yn, c.zn)) != 0;
-            }
-            const unsigned long long cm = __ballot(clipped);
-            hz_texplanes_t pl = {};
-            if(clipped)
-            {
-                /* one LDS slot per clipped run, while they last (the same triangle may
-                 * start several runs of a chunk: row after row) */
-                const int slot = clip_slots + (int)__popcll(cm & ((1ull << lane) - 1ull));
-                pl.r_org = __uint_as_float(0x7FC00000u);
-                pl.drdx  = (float)(slot < TX_MAXCLIP ? slot : -1);
-                if(slot < TX_MAXCLIP) tx_store_pieces(L, slot, a, b, c, p);
-            }
-            else if(r < nruns)
-                hz_tri_planes_tex(&pl, &a, &b, &c);
-            clip_slots += (int)__popcll(cm);
-            if(r >= nruns) continue;
-            L.planes[0][r] = pl.r_org; L.planes[1][r] = pl.drdx; L.planes[2][r] = pl.drdy;
-            L.planes[3][r] = pl.s_org; L.planes[4][r] = pl.dsdx; L.planes[5][r] = pl.dsdy;
-            L.planes[6][r] = pl.t_org; L.planes[7][r] = pl.dtdx; L.planes[8][r] = pl.dtdy;
-        }
-        __syncthreads();
-
-        /* C: pixels */
-        yo = yo0; x = x0;
-        #pragma unroll
-        for(int k=0; k<TX_SUB; k++)
-        {
-            const size_t o = o0 + (size_t)k*64;
-            const int py = p.H-1 - yo, px = x + p.col0;
-            x += 64;
-            while(x >= p.SW) { x -= p.SW; yo++; }
-            if(o >= npix || zi_k[k] == HZ_Z24_MAX) continue;       /* sky: k_resolve wrote the clear colour */
-            const uint32_t r = run_k[k];
-            hz_texplanes_t pl;
-            pl.r_org = L.planes[0][r]; pl.drdx = L.planes[1][r]; pl.drdy = L.planes[2][r];
-            pl.s_org = L.planes[3][r]; pl.dsdx = L.planes[4][r]; pl.dsdy = L.planes[5][r];
-            pl.t_org = L.planes[6][r]; pl.dtdx = L.planes[7][r]; pl.dtdy = L.planes[8][r];
-            if(!(pl.r_org == pl.r_org))
-            {
-                /* the clipper cut this triangle: the piece that covers this pixel with the stored depth */
-                const int slot = (int)pl.drdx;
-                if(slot < 0 || !tx_find_piece(L, slot, px, py, zi_k[k], &pl))
-                {
-                    hz_cvert_t a, b, c;
-                    hz_prim_cverts(mosaic, tp, p, L.run_prim[r], &a, &b, &c);
-                    if(!hz_shade_clipped(a, b, c, p, px, py, zi_k[k], &pl)) continue;   /* cannot happen; keeps the untextured colour */
-                }
-            }
-            const float shade = hz_plane_at(pl.r_org, pl.drdx, pl.drdy, px, py);
-            const float s     = hz_plane_at(pl.s_org, pl.dsdx, pl.dsdy, px, py);
-            const float tt    = hz_plane_at(pl.t_org, pl.dtdx, pl.dtdy, px, py);
-            const uint32_t col = hz_fragment_textured(hz_tex_sample(texels, tp.tex_w, tp.tex_h, s, tt), shade);
-            bgr[o*3+0] = (unsigned char)(col & 255u);
-            bgr[o*3+1] = (unsigned char)((col >> 8) & 255u);
-            bgr[o*3+2] = (unsigned char)((col >> 16) & 255u);
-        }
-        __syncthreads();                            /* the next chunk reuses the LDS tables */
-    }
-}
+#include "hz_k_common.h"
+#include "hz_k_scatter.h"
+#include "hz_k_march.h"
+#include "hz_k_resolve.h"
+#include "hz_k_tex.h"
 
 /* ------------------------------------------------------------------------ */
 /* host side of the C-ABI                                                    */
