@@ -239,14 +239,20 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
          * narrower box fetches pixels twice). */
         if(valid && box.px1 - box.px0 <= 3 && box.py1 - box.py0 <= 1)
         {
-            const uint32_t* fbw = (const uint32_t*)fb;              /* depth = the upper 24 bits of the upper word */
-            const uint32_t* row0 = fbw + 2*((size_t)box.py0*p.SW) + 1;
-            const uint32_t* row1 = fbw + 2*((size_t)box.py1*p.SW) + 1;
+            /* depth = the upper 24 bits of a word's upper half.  Byte offsets in 32 bits
+             * (the test is only switched on for framebuffers below 4 GB: draw_impl): one scalar base and a
+             * 32-bit offset per load instead of eight 64-bit address computations */
+            const char* hi = (const char*)fb + 4;
+            const uint32_t rowbytes = (uint32_t)p.SW*8u;
+            const uint32_t o0 = (uint32_t)box.py0*rowbytes, o1 = box.py1 > box.py0 ? o0 + rowbytes : o0;
             const int c0 = box.px0 - p.col0, cl = box.px1 - p.col0;
             const int c1 = min(c0+1, cl), c2 = min(c0+2, cl);
+            const uint32_t b0 = 8u*(uint32_t)c0, b1 = 8u*(uint32_t)c1, b2 = 8u*(uint32_t)c2, bl = 8u*(uint32_t)cl;
             uint32_t z[8];
-            z[0] = row0[2*c0]; z[1] = row0[2*c1]; z[2] = row0[2*c2]; z[3] = row0[2*cl];
-            z[4] = row1[2*c0]; z[5] = row1[2*c1]; z[6] = row1[2*c2]; z[7] = row1[2*cl];
+            z[0] = *(const uint32_t*)(hi + (o0 + b0)); z[1] = *(const uint32_t*)(hi + (o0 + b1));
+            z[2] = *(const uint32_t*)(hi + (o0 + b2)); z[3] = *(const uint32_t*)(hi + (o0 + bl));
+            z[4] = *(const uint32_t*)(hi + (o1 + b0)); z[5] = *(const uint32_t*)(hi + (o1 + b1));
+            z[6] = *(const uint32_t*)(hi + (o1 + b2)); z[7] = *(const uint32_t*)(hi + (o1 + bl));
             const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
             if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }

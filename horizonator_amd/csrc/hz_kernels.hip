@@ -726,7 +726,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             HZ_CHECK(hipEventRecord(d->ev_nqfree[next], d->nstream));
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
-            p.pass = 2; p.early_z = 1;
+            /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
+            p.pass = 2; p.early_z = ((unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32)) ? 1 : 0;
         }
         else if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
