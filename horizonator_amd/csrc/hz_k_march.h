@@ -193,7 +193,7 @@ void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ mid
             /* queued records carry the pixel count of the box in the inv_bw
              * slot (the reciprocal is cheaper to redo than to store) */
             npix = __float_as_uint(r.inv_bw);
-            r.inv_bw = 1.0f / (float)r.bw;
+            r.inv_bw = 1.0f / (float)r.bw;      /* (boxes of up to big_min pixels, which a test may set to anything) */
         }
         mr_distribute(r, npix, lane, fb, p);
     }
@@ -273,9 +273,14 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         hz_rec_from_tri(r, tri);
         r.px0 = box.px0; r.bw = box.px1 - box.px0 + 1;
         r.py0 = box.py0; bh   = box.py1 - box.py0 + 1;
-        r.inv_bw = 1.0f / (float)r.bw;
         r.prim = (uint32_t)(((size_t)(jbeg + rowoff)*(p.N-1) + (i0 + l))*2 + t);
         npix = live ? (uint32_t)r.bw*(uint32_t)bh : 0u;       /* the others own no pixel: mr_distribute never reads their record */
+        /* inv_bw turns a pixel's number k inside the box into its row, floor((k + 0.5)/bw).
+         * For boxes of at most 64 pixels - every box of nearly every flush - v_rcp_f32's
+         * 1 ulp is plenty: the quotient is off by < 64 * 3 * 2^-24 and lies at least
+         * 0.5/64 away from an integer.  (Larger boxes are rasterised here only when
+         * a queue is full.) */
+        r.inv_bw = __all(npix <= 64u) ? __builtin_amdgcn_rcpf((float)r.bw) : 1.0f / (float)r.bw;
     }
 
     /* large boxes go to k_big: one record, ceil(tiles/64) work items */
