@@ -386,6 +386,22 @@ def main():
         except Exception:
             traffic = None
 
+    # what actually bounds the dominant kernel: the SIMDs' vector issue slots.
+    # Recorded counters of the same workload (profiles/), set against the duration measured now.
+    valu = None
+    mix = os.path.join(ROOT, "profiles", "pmc_r2_instruction_mix_cfg3.json")
+    if args.config == "cfg3" and args.zfar == 600000.0 and world == 1 and args.raster in (0, 2) and os.path.exists(mix):
+        try:
+            rec = json.load(open(mix))
+            far = max((v for k, v in rec.items() if k.startswith("k_march grid")), key=lambda v: v["SQ_INSTS_VALU"])
+            busy_ms = far["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3     # quad-cycles -> cycles, 1024 SIMDs at 2.4 GHz
+            valu = {"wave_instructions": far["SQ_INSTS_VALU"], "active_quad_cycles": far["SQ_ACTIVE_INST_VALU"],
+                    "cycles_per_instruction": 4.0 * far["SQ_ACTIVE_INST_VALU"] / far["SQ_INSTS_VALU"],
+                    "issue_busy_ms": busy_ms, "frac_of_kernel_ms": busy_ms / raster_ms,
+                    "source": "profiles/pmc_r2_instruction_mix_cfg3.json (recorded), profiles/valu_issue.json (issue rates per instruction kind)"}
+        except Exception:
+            valu = None
+
     extra = {}
     if not args.no_extra and abs(args.zfar - 40000.0) > 1:
         dt40, k40 = timed(40000.0, max(3, args.steps // 2), 1)
@@ -484,6 +500,7 @@ def main():
                 "other_kernels_ms": {"clear": clear_ms, "round1_near_viewer": near_ms, "queues_after": big_ms, "resolve": resolve_ms},
                 "device_ms_per_render_sum_of_stages": total_ms,
                 "achieved_whole_render": algo_bytes / (ms_per_step * 1e-3) / 1e9,
+                "valu_issue": valu,
             },
             "cpu_baseline": cpu,
             "reference_llvmpipe_recorded": ref_rec,
