@@ -238,20 +238,31 @@ __device__ static inline uint32_t mr_scan(uint32_t v, int lane)
     return v;
 }
 
-/* floor(n / d) for d > 0: a double-precision estimate (r = 1/d to full double
- * accuracy, computed by the caller once per edge), then the remainder decides -
- * exactly.  |n| < 2^55, d < 2^31; results beyond +-2^30 come back clamped (the
- * caller only compares them with pixel columns). */
+/* 1/d for 1 <= d < 2^31 to within 2^-50 relative: v_rcp_f64's estimate and two
+ * Newton steps (each squares the relative error; the estimate is good to 2^-20
+ * at the very least).  Not the correctly rounded quotient - hz_floor_div() does
+ * not need it - and a third of the instructions of 1.0/d. */
+__device__ static inline double hz_rcp_f64(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+/* floor(n / d) for d > 0: a double-precision estimate (r = hz_rcp_f64(d),
+ * computed by the caller once per edge), then the remainder decides - exactly.
+ * |n| < 2^55, d < 2^31; results beyond +-2^30 come back clamped (the caller
+ * only compares them with pixel columns).  Inside that range the estimate
+ * n*r differs from n/d by less than 2^30 * (2^-50 + 2 * 2^-53) < 2^-19, so its
+ * floor is the true one or a neighbour of it: one step each way. */
 __device__ static inline int32_t hz_floor_div(int64_t n, int32_t d, double r)
 {
     double qd = __builtin_floor((double)n * r);
     qd = qd < -1073741824.0 ? -1073741824.0 : (qd > 1073741824.0 ? 1073741824.0 : qd);
     int32_t q = (int32_t)qd;
     int64_t rem = n - (int64_t)q*(int64_t)d;
-    /* the estimate is off by one at most (two steps each way for good measure) */
     if(rem < 0)  { q--; rem += d; }
-    if(rem < 0)  { q--; rem += d; }
-    if(rem >= d) { q++; rem -= d; }
     if(rem >= d) { q++; rem -= d; }
     return q;
 }
@@ -308,13 +319,13 @@ void k_big(unsigned long long* __restrict__ fb,
             if(dy > 0)
             {
                 /* dy*px <= n8  <=>  px <= floor(n8 / dy) */
-                const int32_t q = hz_floor_div(n8, dy, 1.0/(double)dy);
+                const int32_t q = hz_floor_div(n8, dy, hz_rcp_f64((double)dy));
                 x1 = x1 < q ? x1 : q;
             }
             else if(dy < 0)
             {
                 /* |dy|*px >= -n8  <=>  px >= ceil(-n8 / |dy|) = -floor(n8 / |dy|) */
-                const int32_t q = hz_floor_div(n8, -dy, 1.0/(double)(-dy));
+                const int32_t q = hz_floor_div(n8, -dy, hz_rcp_f64((double)(-dy)));
                 x0 = x0 > -q ? x0 : -q;
             }
             else if(n8 < 0) any = false;                /* a horizontal edge: the whole row is on one side */

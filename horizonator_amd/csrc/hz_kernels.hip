@@ -1412,6 +1412,31 @@ void k_check_fastmath(int what, unsigned long long seed, unsigned long long n, u
             if((r1 >> 60) == 0) a = 0.0f;            /* +0 */
             want = a / b; got = hzf_div(a, b);
         }
+        else if(what == 4)                  /* hz_rcp_f64: every divisor 1 <= d < 2^31 (k = d - 1): within 2^-50 of 1/d? */
+        {
+            const double dd = (double)(k + 1);
+            const double r = hz_rcp_f64(dd);
+            /* d*r - 1 is the relative error of r; the fma gives it without cancellation */
+            const double rel = __builtin_fabs(__builtin_fma(dd, r, -1.0));
+            a = (float)dd; b = (float)rel; want = 0.f; got = rel < 8.8817841970012523e-16 ? 0.f : 1.f;      /* 2^-50 */
+        }
+        else if(what == 5)                  /* hz_floor_div against 64-bit integer division: seeded n (|n| < 2^55), d (1 <= d < 2^31) */
+        {
+            const unsigned long long r1 = hz_mix64(seed + 2*k), r2 = hz_mix64(seed + 2*k + 1);
+            /* divisors of every magnitude; numerators of every magnitude and both signs, and the
+             * hard ones: multiples of d and their neighbours */
+            const int32_t d = (int32_t)(((r2 >> 8) & 0x7FFFFFFFull) >> (r2 & 31)) | 1;
+            int64_t n = (int64_t)(r1 >> 9) >> ((r1 >> 3) & 63);
+            if(r1 & 1) n = -n;
+            if((r1 & 6) == 2) n = (n / d)*(int64_t)d + (int64_t)((r2 >> 40) % 3) - 1;
+            int64_t q = n / d;                                  /* truncates */
+            if((n % d) != 0 && n < 0) q--;                      /* floor */
+            const int32_t f = hz_floor_div(n, d, hz_rcp_f64((double)d));
+            a = (float)n; b = (float)d;
+            /* beyond +-2^30 any value beyond is right (see hz_floor_div) */
+            const bool ok = (q > 1073741824ll) ? f >= 1073741824 : (q < -1073741824ll) ? f <= -1073741824 : (int64_t)f == q;
+            want = 0.f; got = ok ? 0.f : 1.f;
+        }
         else                                /* division by a per-draw constant through hzf_div_by: k = numerator pattern */
         {
             b = __uint_as_float((uint32_t)seed);
@@ -1435,8 +1460,9 @@ extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long se
 {
     hz_device_guard device_guard_(device);
     if(!device_guard_.ok) return -1;
-    if(what < 0 || what > 3) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
+    if(what < 0 || what > 5) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
     if(what == 0 || what == 1 || what == 3) n = 1ull << 32;
+    if(what == 4) n = (1ull << 31) - 1;
     unsigned long long* d_bad = NULL; float* d_first = NULL;
     HZ_CHECK(hipMalloc(&d_bad, 2*sizeof(unsigned long long)));
     HZ_CHECK(hipMalloc(&d_first, 4*sizeof(float)));

@@ -220,7 +220,10 @@ int   hz_hip_wait_for(hz_dev_t* d, void* stream);
  * sqrtf, bit for bit.  what: 0 reciprocal, every float32 pattern in the
  * sequences' operand range; 1 square root, every pattern from 2^-96 up; 2
  * division, n seeded pairs; 3 division by the constant whose bit pattern is
- * `seed`, every numerator pattern.  *mismatches = how many differed (0 is the
+ * `seed`, every numerator pattern; 4 k_big's double reciprocal (hz_rcp_f64),
+ * every divisor 1 <= d < 2^31: within 2^-50 of 1/d; 5 k_big's exact floor
+ * division (hz_floor_div), n seeded (numerator, divisor) pairs against 64-bit
+ * integer division.  *mismatches = how many differed (0 is the
  * only acceptable answer); first_bad (4 floats: a, b, want, got) may be NULL. */
 int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsigned long long n,
                            unsigned long long* mismatches, float* first_bad);

@@ -43,6 +43,18 @@ def test_division_by_a_draw_constant_every_numerator(divisor):
     _check(3, seed=bits)
 
 
+def test_double_reciprocal_of_every_divisor_is_within_2_pow_minus_50():
+    """hz_rcp_f64 (k_big's span division): v_rcp_f64 + two Newton steps, every d in [1, 2^31)"""
+    _check(4)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_floor_division_against_64_bit_integer_division(seed):
+    """hz_floor_div (the exact first/last covered column of a row): 2^30 seeded (n, d) per seed, all magnitudes,
+    both signs, multiples of d and their neighbours - against the device's own int64 division"""
+    _check(5, seed=seed * 0x2000000000, n=1 << 30)
+
+
 def test_abridged_transform_renders_the_same_bytes(monkeypatch):
     import oracle
     LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
