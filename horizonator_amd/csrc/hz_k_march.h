@@ -83,15 +83,15 @@ struct mr_zones_t
 };
 
 /* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
- * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63
- * gets an unspecified value; it has no cell. */
+ * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63,
+ * which has no source and no cell, reads 0 (bound_ctrl: no `old` operand to set up). */
 __device__ static inline int32_t mr_from_east(int32_t v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
 __device__ static inline float mr_from_east(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
 
