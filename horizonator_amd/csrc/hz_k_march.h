@@ -358,14 +358,19 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     mr_distribute(r, npix, lane, fb, p);
 }
 
+/* COUNTERS: the diagnostics instance (HZ_WAVE_TIMING: per-wave duration and
+ * counters into p.wave_cycles).  The production instance carries none of it -
+ * no scratch memory for the counters, none of their branches, fewer scalar
+ * registers held. */
+template<bool COUNTERS>
 __global__ __launch_bounds__(64)
 void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
              mr_queue_t q, mr_zones_t zn, hz_params_t p)
 {
     __shared__ mr_lds_t L;
-    const unsigned long long t_start = p.wave_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_start = COUNTERS ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned int dbgv[6] = {0,0,0,0,0,0};
-    unsigned int* dbg = p.wave_cycles ? dbgv : nullptr;
+    unsigned int* dbg = COUNTERS ? dbgv : nullptr;
 
     const int lane = threadIdx.x;
     const int sx   = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0);     /* strip column */
@@ -635,7 +640,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         __syncthreads();
         mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
     }
-    if(p.wave_cycles && lane == 0)
+    if(COUNTERS && p.wave_cycles && lane == 0)
     {
         unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];
         o[0] = __builtin_amdgcn_s_memtime() - t_start;

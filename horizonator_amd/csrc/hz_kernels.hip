@@ -718,7 +718,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->nstream, qn.counters);
             hz_params_t p1 = p;
             p1.pass = 1; p1.early_z = 0;
-            hipLaunchKernelGGL(k_march, dim3(p.near_x1 - p.near_x0 + 1, zn.total), dim3(64), 0, d->nstream,
+            hipLaunchKernelGGL(k_march<false>, dim3(p.near_x1 - p.near_x0 + 1, zn.total), dim3(64), 0, d->nstream,
                                (const int16_t*)d->d_mosaic, d->d_fb, qn, zn, p1);
             HZ_CHECK(hipGetLastError());
             if(queue_kernels(qn, p1, d->nstream) != 0) return -1;
@@ -747,8 +747,12 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             HZ_CHECK(hipMemsetAsync(d_cycles, 0, (size_t)grid.x*grid.y*4*sizeof(unsigned long long), d->stream));
             pm.wave_cycles = d_cycles;
         }
-        hipLaunchKernelGGL(k_march, grid, dim3(64), 0, d->stream,
-                           (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+        if(timing_path)
+            hipLaunchKernelGGL(k_march<true>, grid, dim3(64), 0, d->stream,
+                               (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+        else
+            hipLaunchKernelGGL(k_march<false>, grid, dim3(64), 0, d->stream,
+                               (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
         if(timing_path)
         {
             const size_t n = (size_t)grid.x*grid.y*4;
