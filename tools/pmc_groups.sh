@@ -19,7 +19,10 @@ for f in glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         # a kernel launched with different grids in one render (k_march: the strips next to the viewer,
         # then all the others) is kept apart by its grid size
-        agg[r["Kernel_Name"].split("(")[0] + " grid " + str(r.get("Grid_Size", "?"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name.startswith("k_march<"):          # k_march<false>: the production instance (no per-wave counters)
+            name = "k_march"
+        agg[name + " grid " + str(r.get("Grid_Size", "?"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, launches_seen=max(len(v) for v in cs.values())) for k, cs in agg.items()}
 json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
