@@ -705,7 +705,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
          * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms) */
         const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
         const bool want_two = e2 ? atoi(e2) != 0
-                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 24.0f*(float)near_cells);
+                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 1536.0f && cells_to_zfar >= 12.0f*(float)near_cells);
         const bool two_pass = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
         const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
