@@ -1,0 +1,57 @@
+"""What fits beside k_march is part of the design: the marching kernel holds
+four waves on every SIMD and most of every CU's LDS while panoramas overlap, and a kernel of
+another stream that does not fit into what is left waits for a marching wave to retire - k_clip
+once waited 0.7 ms of every panorama that way, and a k_march with 8 registers more cost 7 %.
+The footprints are read from the code object inside the built library (no GPU needed)."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernels():
+    lib = os.path.join(ROOT, "horizonator_amd", "libhorizonator.so")
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(lib) and os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("library or llvm tools not present")
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, copy)                      # (the tool writes the bundles next to its input)
+        subprocess.run([objdump, "--offloading", copy], check=True, capture_output=True)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert len(co) == 1, os.listdir(tmp)
+        notes = subprocess.run([readelf, "--notes", os.path.join(tmp, co[0])], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for block in notes.split("- .agpr_count")[1:]:
+        f = {k: v for k, v in re.findall(r"\.(name|vgpr_count|sgpr_count|group_segment_fixed_size|private_segment_fixed_size):\s+(\S+)", block)}
+        out[f["name"]] = {k: int(v) for k, v in f.items() if k != "name"}
+    return out
+
+
+def _one(kernels, fragment):
+    hit = [v for k, v in kernels.items() if fragment in k]
+    assert len(hit) == 1, (fragment, [k for k in kernels if fragment in k])
+    return hit[0]
+
+
+def test_what_runs_beside_the_marching_kernel_fits_beside_it():
+    k = _kernels()
+    march = _one(k, "k_marchILb0E")                 # the production instance (no per-wave counters)
+    assert march["private_segment_fixed_size"] == 0, "k_march<false> must not use scratch memory"
+    assert march["vgpr_count"] <= 112, "four marching waves + one wave of k_big / the conversion per SIMD: 4*112 + 48 <= 512"
+    assert march["group_segment_fixed_size"] <= 7168
+    left_vgprs = 512 - 4*((march["vgpr_count"] + 7)//8*8)
+    left_lds = 160*1024 - 16*march["group_segment_fixed_size"]
+    for name in ("k_bigPy", "k_resolve4ILb1E", "k_resolve4ILb0E", "k_clipPKs"):
+        other = _one(k, name)
+        assert other["private_segment_fixed_size"] == 0, name
+        assert (other["vgpr_count"] + 7)//8*8 <= max(left_vgprs, 96 if name.startswith("k_clip") else 0), (name, other, left_vgprs)
+        assert other["group_segment_fixed_size"] <= 4096 and other["group_segment_fixed_size"] <= left_lds, (name, other)
+    # k_clip is a 64-thread workgroup that is placed when one marching wave has gone: 96 registers at most
+    assert _one(k, "k_clipPKs")["vgpr_count"] <= 96
