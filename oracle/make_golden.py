@@ -209,11 +209,11 @@ def texture_fixtures():
 
 
 def random_checksum_fixtures():
-    """24 seeded random configurations (hzutil.random_view_case): SHA-256 of the reference's draw"""
+    """64 seeded random configurations (hzutil.random_view_case): SHA-256 of the reference's draw"""
     import hashlib
     import json
     out = {}
-    for seed in range(24):
+    for seed in range(64):
         c = hzutil.random_view_case(seed)
         d = hzutil.dem_dir_for(LAT, LON, c["R"], rough=c["rough"])
         od = oracle.Dem(LAT, LON, d, radius_cells=c["R"])

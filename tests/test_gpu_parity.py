@@ -303,7 +303,7 @@ def test_sparse_strips_resolve_to_the_same_panorama():
 RANDOM_GOLD = json.load(open(os.path.join(GOLD, "random_checksums.json")))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(64))
 def test_random_views_bit_exact_vs_oracle_and_vs_reference(seed):
     """seeded random viewpoints, azimuth extents (narrow, wide, wrapped, exactly 360), image
     sizes, depth/colour extents, viewer heights, sectors and rasterisers: every output equal to
