@@ -140,7 +140,7 @@ def batch_checksum_fixtures():
     out = {"R": R, "W": W, "H": H, "lat": LAT, "lon": LON, "az_deg0": -180.0, "az_deg1": 180.0,
            "znear": 100.0, "zfar": zfar, "mosaic_sha256": hashlib.sha256(m.tobytes()).hexdigest(),
            "viewpoints": {}}
-    for vp in (0, 37, 136, 255):
+    for vp in (0, 15, 37, 68, 85, 102, 119, 136, 153, 170, 187, 204, 221, 240, 250, 255):
         v = od.view(float(lats[vp]), float(lons[vp]), W, H, -180.0, 180.0, zfar=zfar)
         g = glsl_run.render(m, v, W, H)
         out["viewpoints"][str(vp)] = {

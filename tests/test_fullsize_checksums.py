@@ -14,7 +14,7 @@ import hzutil
 import oracle
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "render_checksums.json")))
-# BASELINE.json configs[3]: four of the 256 viewpoints over the 5x5-tile window, same provenance
+# BASELINE.json configs[3]: sixteen of the 256 viewpoints over the 5x5-tile window, same provenance
 BATCH = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "batch_checksums.json")))
 
 
@@ -134,7 +134,7 @@ def test_hip_all_256_viewpoints_batch_equals_one_render_each():
     """BASELINE.json configs[3] whole: the 16x16 lattice of viewpoints over the 5x5-tile window,
     8000x2000 each, queued as ONE batch without a wait in between - and every image and range
     image of the batch equal to what the same viewpoint gives when rendered on its own and
-    waited for (the four pinned viewpoints are also hashed against the reference above)"""
+    waited for (the sixteen pinned viewpoints are also hashed against the reference above)"""
     import torch
     import horizonator_amd
     c = BATCH
