@@ -108,22 +108,29 @@ def checksum_fixtures():
     import hashlib
     import json
     out = {}
-    for name, R, W, H, zfar in [("cfg2_3x3_8000x2000", 1800, 8000, 2000, 600000.0),
-                                ("cfg3_7x7_16000x4000", 4200, 16000, 4000, 600000.0),
-                                ("cfg3_7x7_16000x4000_zfar40km", 4200, 16000, 4000, 40000.0)]:
+    # name, R, W, H, azimuth extents, viewpoint offset from the window's centre (degrees), view keywords
+    for name, R, W, H, az0, az1, dlat, dlon, kw in [
+            ("cfg2_3x3_8000x2000", 1800, 8000, 2000, -180.0, 180.0, 0.0, 0.0, dict(zfar=600000.0)),
+            ("cfg3_7x7_16000x4000", 4200, 16000, 4000, -180.0, 180.0, 0.0, 0.0, dict(zfar=600000.0)),
+            ("cfg3_7x7_16000x4000_zfar40km", 4200, 16000, 4000, -180.0, 180.0, 0.0, 0.0, dict(zfar=40000.0)),
+            # the benchmark's image and mosaic with other views: a 45 degree zoom, a viewer 4.5 km up, a moved viewpoint
+            ("cfg3_7x7_16000x4000_zoom45deg", 4200, 16000, 4000, 30.0, 75.0, 0.0, 0.0, dict(zfar=150000.0)),
+            ("cfg3_7x7_16000x4000_viewer_4500m", 4200, 16000, 4000, -180.0, 180.0, 0.0, 0.0, dict(zfar=600000.0, viewer_z=4500.0)),
+            ("cfg2_3x3_8000x2000_moved_wide", 1800, 8000, 2000, -100.0, 140.0, 0.3, -0.2, dict(znear=10.0, zfar=200000.0))]:
         d = hzutil.dem_dir_for(LAT, LON, R)
         od = oracle.Dem(LAT, LON, d, radius_cells=R)
         m = od.mosaic()
-        v = od.view(LAT, LON, W, H, -180.0, 180.0, zfar=zfar)
+        v = od.view(LAT + dlat, LON + dlon, W, H, az0, az1, **kw)
         g = glsl_run.render(m, v, W, H)
-        out[name] = {"R": R, "W": W, "H": H, "lat": LAT, "lon": LON, "az_deg0": -180.0, "az_deg1": 180.0,
-                     "znear": 100.0, "zfar": zfar,
+        out[name] = {"R": R, "W": W, "H": H, "lat": LAT, "lon": LON, "az_deg0": az0, "az_deg1": az1,
+                     "view_lat": LAT + dlat, "view_lon": LON + dlon, "kw": kw,
+                     "znear": float(kw.get("znear", 100.0)), "zfar": float(kw["zfar"]),
                      "view": {k: float(np.float32(x)) for k, x in v.as_dict().items()},
                      "mosaic_sha256": hashlib.sha256(m.tobytes()).hexdigest(),
                      "bgr_sha256": hashlib.sha256(g["bgr"].tobytes()).hexdigest(),
                      "z24_sha256": hashlib.sha256(g["z24"].tobytes()).hexdigest(),
                      "terrain_fraction": float((g["z24"] != 0xFFFFFF).mean())}
-        print(f"checksum {name}: terrain fraction {out[name]['terrain_fraction']:.3f}")
+        print(f"checksum {name}: terrain fraction {out[name]['terrain_fraction']:.3f}", flush=True)
     json.dump(out, open(os.path.join(OUT, "render_checksums.json"), "w"), indent=1)
 
 
@@ -256,6 +263,9 @@ def main():
     if not glsl_run.available() or oracle.load_ref_dem() is None:
         sys.exit("needs /root/reference and oracle/_ref (run `make -C oracle` first)")
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["checksums"]:           # only tests/golden/render_checksums.json
+        checksum_fixtures()
+        return
     if sys.argv[1:] == ["batch"]:               # only tests/golden/batch_checksums.json
         batch_checksum_fixtures()
         return

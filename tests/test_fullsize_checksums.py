@@ -1,6 +1,7 @@
 """Full-size scenes against the reference: tests/golden/render_checksums.json
 holds the SHA-256 of what the reference's own shaders drew on Mesa llvmpipe for
-BASELINE's 3x3-tile / 8000x2000 and 7x7-tile / 16000x4000 panoramas (made by
+BASELINE's 3x3-tile / 8000x2000 and 7x7-tile / 16000x4000 panoramas and for other views at those
+sizes (a 45 degree zoom, a viewer 4.5 km up, a moved viewpoint with a 240 degree span; made by
 oracle/make_golden.py; the images themselves are too large to commit).  Equal
 hashes = every byte of the BGR image and of the 24-bit depth is the reference's."""
 import hashlib
@@ -35,7 +36,8 @@ def _inputs(c):
     m = od.mosaic()
     if hashlib.sha256(m.tobytes()).hexdigest() != c["mosaic_sha256"]:
         _dem_differs()
-    v = od.view(c["lat"], c["lon"], c["W"], c["H"], c["az_deg0"], c["az_deg1"], znear=c["znear"], zfar=c["zfar"])
+    v = od.view(c.get("view_lat", c["lat"]), c.get("view_lon", c["lon"]), c["W"], c["H"], c["az_deg0"], c["az_deg1"],
+                **dict(dict(znear=c["znear"], zfar=c["zfar"]), **c.get("kw", {})))
     assert {k: float(np.float32(x)) for k, x in v.as_dict().items()} == c["view"]
     return m, v
 
@@ -44,8 +46,9 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def test_oracle_cfg2_is_the_reference_render():
-    c = GOLD["cfg2_3x3_8000x2000"]
+@pytest.mark.parametrize("name", ["cfg2_3x3_8000x2000", "cfg2_3x3_8000x2000_moved_wide"])
+def test_oracle_cfg2_is_the_reference_render(name):
+    c = GOLD[name]
     m, v = _inputs(c)
     o = oracle.render(m, v, c["W"], c["H"], want=("bgr", "z24"))
     assert _sha(o["bgr"]) == c["bgr_sha256"]
