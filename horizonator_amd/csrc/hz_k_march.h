@@ -212,12 +212,14 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     bool live = (unsigned int)lane < n;
     const bool valid = live;
     /* Every lane goes through the whole set-up, the lanes beyond `n` as copies
-     * of lane 0 (n >= 1: the callers see to that): all their values are defined,
+     * of lane 0 (n >= 1: the callers see to that; v_readlane_b32 with the lane
+     * spelled out - the compiler moves a v_readfirstlane_b32 into the branch of
+     * the idle lanes, where the first active lane is one of them): all their values are defined,
      * none is used - `valid` / `live` guard everything that leaves the wave -
      * and the wave saves the ~50 instructions that gave those lanes zeros
      * (3.5 % of k_march's instructions went there). */
     const uint32_t id_own = L.ids[(head + lane) & (MR_CAP-1)];
-    const uint32_t id = valid ? id_own : (uint32_t)__builtin_amdgcn_readfirstlane((int)id_own);
+    const uint32_t id = valid ? id_own : (uint32_t)__builtin_amdgcn_readlane((int)id_own, 0);
     const int t = id & 1, l = (id >> 1) & 63, rowoff = id >> 7;
     const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
     /* LDS row slot and lane of the three vertices, reference horizonator-lib.c:500-506 */

@@ -10,7 +10,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for c in "${GROUPS_[@]}"; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" >/dev/null 2>>$OUT/err.log
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" >/dev/null 2>>$OUT/err.log
 done
 python3 - "$OUT" "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG.json" <<'PY'
 import collections, csv, glob, json, sys
