@@ -670,6 +670,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     };
 
     const mr_queue_t q = queue_set(next);           /* one-round draw, or second round */
+    bool near_beside_far = false;                   /* the second round did not wait for the first */
 
     if(d->raster == HZ_RASTER_SCATTER)
     {
@@ -732,6 +733,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
              * hidden whenever it looks (depths only decrease), so the bytes are the same. */
             if(getenv("HZ_ALWAYS_WAIT_NEAR") || hipEventQuery(d->ev_marched) != hipSuccess)
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
+            else
+                near_beside_far = true;         /* "drawn" then has to wait for both rounds: see qstream below */
             (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
             /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
             p.pass = 2; p.early_z = ((unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32)) ? 1 : 0;
@@ -778,6 +781,9 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * marching kernel can start beside them */
     HZ_CHECK(hipEventRecord(d->ev_marched, d->stream));
     HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_marched, 0));
+    /* ev_drawn (below) tells the conversion that the draw is complete: that is the end of the
+     * second round's queue kernels only as long as the second round itself waited for the first */
+    if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
     if(queue_kernels(q, p, d->qstream) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));

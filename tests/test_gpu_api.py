@@ -324,3 +324,37 @@ def test_contexts_from_several_threads():
     assert not errors, errors
     for image, ranges in results:
         assert np.array_equal(image, ref["bgr"]) and np.array_equal(ranges, ref["ranges"])
+
+
+@pytest.mark.parametrize("two_pass", ["1", "0"])
+def test_single_renders_through_the_api_with_the_round_count_forced(two_pass, monkeypatch):
+    """One render at a time, each converted at once, through horizonator.h's calls - with two
+    rounds forced on a scene far below the size where they are chosen, so that the first round is
+    the longer one: a draw that finds the chip idle runs its second round beside its first, and
+    the conversion has to wait for both (it once waited for the second only).  Repeated, on a
+    fresh and on a used context, with moves in between: every output against the oracle."""
+    import horizonator_amd
+    monkeypatch.setenv("HZ_TWO_PASS", two_pass)
+    R, W, H = 300, 1200, 300
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    used = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+    try:
+        views = [(LAT, LON, -180, 180, 20000.0), (LAT + 0.031, LON - 0.027, -180, 180, 20000.0), (LAT - 0.02, LON + 0.015, -60, 95, 60000.0)]
+        want = []
+        for lat, lon, a0, a1, zfar in views:
+            v = od.view(lat, lon, W, H, a0, a1, zfar=zfar)
+            want.append(oracle.render(m, v, W, H))
+        for rep in range(6):
+            fresh = horizonator_amd.horizonator.from_mosaic(LAT, LON, W, H, used.window(), m)
+            try:
+                for h in (fresh, used):
+                    for (lat, lon, a0, a1, zfar), o in zip(views, want):
+                        image, ranges, index, z24 = h.render_full(a0, a1, lat=lat, lon=lon, zfar=zfar)
+                        assert np.array_equal(index, o["index"]) and np.array_equal(z24, o["z24"]), (rep, lat, lon)
+                        assert np.array_equal(image, o["bgr"]) and np.array_equal(ranges, o["ranges"]), (rep, lat, lon)
+            finally:
+                fresh.close()
+    finally:
+        used.close()
