@@ -703,10 +703,14 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
          * strips: a large image (many pixel tests to save) and a far clip well
          * beyond them - with the API's default 40 km far clip most of a large
          * mosaic is never transformed at all and one round is faster (measured:
-         * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms) */
+         * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms).  An azimuth sector of such an image
+         * (one GPU of several) draws in two rounds as well: its renders overlap just the
+         * same, and the rank that also converts everybody's strips gains most (own sector
+         * + conversion of all strips, 2 / 4 / 8 sectors: 1.37 -> 1.18, 0.99 -> 0.81,
+         * 0.80 -> 0.66 ms per panorama; tools/sector_timing.py) */
         const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
         const bool want_two = e2 ? atoi(e2) != 0
-                                 : (p.SW == p.W && (double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 1536.0f && cells_to_zfar >= 12.0f*(float)near_cells);
+                                 : ((double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 1536.0f && cells_to_zfar >= 12.0f*(float)near_cells);
         const bool two_pass = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
         const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
