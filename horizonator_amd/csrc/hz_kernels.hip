@@ -715,6 +715,10 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
         const mr_zones_t zn = mr_make_zones(p, two_pass);
         if(two_pass)
         {
+            /* (a sector that draws in two rounds keeps boxes of up to 64 pixels in the marching
+             * waves like a whole image does; k_mid was the remedy for one-round sector draws.
+             * Gathering rank, 2 / 4 / 8 sectors: 1.19 -> 1.03, 0.82 -> 0.75, 0.69 -> 0.64 ms) */
+            p.inline_max = HZ_INLINE_MAX_PIX;
             /* round 1, on its own stream */
             const mr_queue_t qn = queue_set(HZ_NFB + next);
             HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_free[next], 0));
