@@ -20,6 +20,8 @@ struct hz_params_t
     int   far_strips;                  /* some vertex of the mosaic lies beyond that: whole strips may (k_march asks) */
     /* two-pass draw (see hz_hip_draw): which strips a k_march launch takes, and
      * whether it tests its survivors against the depth already in the framebuffer */
+    const uint32_t* worklist;          /* k_march: the (segment, strip column) pairs of this launch, one per workgroup; NULL = the launch grid says it */
+    int   cull_strips;                 /* k_march: strips whose four corners lie outside the drawn columns leave at once (sectors, views < 360 degrees) */
     int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 all the others */
     int   near_x0, near_x1;            /* strip columns [x0,x1] and                                             */
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
@@ -92,7 +94,14 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
     if(at < q.clip_capacity) q.clip[at] = prim;
 }
 
-#define HZ_NCOUNTERS 6
+#define HZ_NCOUNTERS 16
+#define HZ_CNT_DONE  6                  /* workgroups of k_big that have finished            */
+#define HZ_CNT_LAST  8                  /* [8..14): the counters as the round left them      */
+/* an empty queue set: what a round finds (hz_hip_create once, then k_big's last workgroup) */
+__host__ __device__ static inline void hz_counters_reset(unsigned int* c)
+{
+    c[0] = 0u; c[1] = 0u; c[2] = 0xFFFFFFFFu; c[3] = 0u; c[4] = 0u; c[5] = 0xFFFFFFFFu; c[HZ_CNT_DONE] = 0u;
+}
 #ifndef HZ_NFB
 #define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
 #endif

@@ -28,6 +28,8 @@
 #define MR_NEAR_CELLS 128            /* round 1 of a draw: strips within this many cells of the viewer (32: 1.085 ms per
                                       * 16000x4000 render, 64: 1.063, 96: 1.056, 128: 1.052, 192: 1.064, 256: 1.12) */
 
+#define HZ_NEAR_CELLS_MAX 256       /* the first rounds' queue sets are sized for a reach of this many cells (or HZ_NEAR_CELLS, if larger) */
+
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the
  * triangles waiting for set-up.  id = (cell row - first row of the segment)<<7
@@ -82,6 +84,27 @@ struct mr_zones_t
     int total;                      /* all segments = gridDim.y                           */
     int near_first;                 /* dispatch order: segments nearest to the viewer's row first */
 };
+
+/* cell rows [jbeg, jend) of segment `seg` (= blockIdx.y of a grid launch, or the
+ * segment field of a work-list item); vertex rows jbeg..jend.  Device and host
+ * (the work lists of draw_impl) use the same function. */
+HZ_HD void mr_segment_rows(const mr_zones_t& zn, int seg, int* jbeg, int* jend)
+{
+    int zone = 0;
+    #pragma unroll
+    for(int z=1; z<MR_NZONES; z++)
+        if(seg >= zn.seg0[z] && seg < zn.seg0[z] + zn.nseg[z]) zone = z;
+    int sseg = seg - zn.seg0[zone];
+    if(zn.near_first && zone < MR_NZONES/2) sseg = zn.nseg[zone]-1 - sseg;      /* south of the viewer: northernmost first */
+    const int jb = zn.row0[zone] + sseg*zn.rows[zone];
+    const int je = jb + zn.rows[zone];
+    *jbeg = jb;
+    *jend = je < zn.row0[zone+1] ? je : zn.row0[zone+1];
+}
+
+/* a work-list item: one marching wave = (segment, strip column) */
+#define MR_ITEM_SX_BITS 12
+#define MR_ITEM(seg, sx) (((uint32_t)(seg) << MR_ITEM_SX_BITS) | (uint32_t)(sx))
 
 /* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
  * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63,
@@ -376,17 +399,21 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     unsigned int* dbg = COUNTERS ? dbgv : nullptr;
 
     const int lane = threadIdx.x;
-    const int sx   = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0);     /* strip column */
+    /* which strip: from the launch grid (whole panoramas: every strip has work),
+     * or from the draw's work list (azimuth sectors and views of less than 360
+     * degrees: the host lists the strips that can reach the drawn columns, so a
+     * sector launches - and pays for - its own share of the waves only) */
+    int sx, seg;
+    if(p.worklist)
+    {
+        const uint32_t item = p.worklist[blockIdx.x];
+        sx = (int)(item & ((1u << MR_ITEM_SX_BITS) - 1u)); seg = (int)(item >> MR_ITEM_SX_BITS);
+    }
+    else { sx = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0); seg = (int)blockIdx.y; }
     const int i0   = sx*MR_COLS;
     const int i    = i0 + lane;
-    int zone = 0;
-    #pragma unroll
-    for(int z=1; z<MR_NZONES; z++)
-        if((int)blockIdx.y >= zn.seg0[z] && (int)blockIdx.y < zn.seg0[z] + zn.nseg[z]) zone = z;
-    int sseg = (int)blockIdx.y - zn.seg0[zone];
-    if(zn.near_first && zone < MR_NZONES/2) sseg = zn.nseg[zone]-1 - sseg;      /* south of the viewer: northernmost first */
-    const int jbeg = zn.row0[zone] + sseg*zn.rows[zone];
-    const int jend = min(jbeg + zn.rows[zone], zn.row0[zone+1]);   /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
+    int jbeg, jend;                                     /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
+    mr_segment_rows(zn, seg, &jbeg, &jend);
     if(p.pass)
     {
         const bool near = sx >= p.near_x0 && sx <= p.near_x1 && jbeg < p.near_j1 && jend > p.near_j0;
@@ -401,7 +428,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
      * of its four corner vertices; if that lies outside this GPU's columns the
      * whole wave has nothing to draw.  (The corners are real vertices: their x
      * is computed exactly as the rasteriser computes it.) */
-    if(p.col0 > 0 || p.col1 < p.W)
+    if(p.cull_strips)
     {
         const int ia = i0, ib = min(i0 + MR_COLS, p.N-1);
         const bool viewer_inside = p.u.viewer_cell_i >= (float)(ia-1) && p.u.viewer_cell_i <= (float)(ib+1) &&
@@ -645,7 +672,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     }
     if(COUNTERS && p.wave_cycles && lane == 0)
     {
-        unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];
+        unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];     /* (grid launches) */
         o[0] = __builtin_amdgcn_s_memtime() - t_start;
         o[1] = ((unsigned long long)dbgv[0] << 32) | dbgv[1];     /* flushes, triangles set up */
         o[2] = ((unsigned long long)dbgv[2] << 32) | dbgv[3];     /* to k_big, to k_mid        */

@@ -87,14 +87,68 @@ struct hz_device_guard
 /* ------------------------------------------------------------------------ */
 /* host side of the C-ABI                                                    */
 
+/* the HZ_* environment switches (diagnostics, tests), read once when a context is created */
+struct hz_env_t
+{
+    int    serial;                  /* HZ_SERIAL=1: the four streams are one (per-kernel times of a trace are then those of each kernel alone) */
+    int    queue_capacity;          /* HZ_QUEUE_CAPACITY: tests shrink the queues to exercise the overflow paths; 0 = default sizes */
+    int    resolve_clears;          /* HZ_RESOLVE_CLEARS=0 switches the fused clear of the conversion off */
+    int    march_debug;             /* HZ_MARCH_DEBUG: timing splits (wrong pictures), see hz_params_t::debug */
+    int    no_fast_math;            /* HZ_NO_FAST_MATH=1: the unabridged transform everywhere */
+    int    two_pass;                /* HZ_TWO_PASS=0/1 forces one / two rounds; -1: the draw decides */
+    int    near_cells;              /* HZ_NEAR_CELLS: the first round's reach in cells; -1: MR_NEAR_CELLS */
+    double two_pass_min_mpix;       /* HZ_TWO_PASS_MIN_MPIX (default 24) */
+    int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
+    int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
+    int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
+};
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static hz_env_t read_env(void)
+{
+    hz_env_t e;
+    e.serial           = env_int("HZ_SERIAL", 0) != 0;
+    e.queue_capacity   = env_int("HZ_QUEUE_CAPACITY", 0);
+    e.resolve_clears   = env_int("HZ_RESOLVE_CLEARS", 1) != 0;
+    e.march_debug      = env_int("HZ_MARCH_DEBUG", 0);
+    e.no_fast_math     = env_int("HZ_NO_FAST_MATH", 0) != 0;
+    e.two_pass         = getenv("HZ_TWO_PASS") ? (env_int("HZ_TWO_PASS", 0) != 0) : -1;
+    e.near_cells       = getenv("HZ_NEAR_CELLS") ? env_int("HZ_NEAR_CELLS", 0) : -1;
+    e.two_pass_min_mpix= getenv("HZ_TWO_PASS_MIN_MPIX") ? atof(getenv("HZ_TWO_PASS_MIN_MPIX")) : 24.0;
+    e.always_wait_near = getenv("HZ_ALWAYS_WAIT_NEAR") != NULL;
+    e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
+    e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
+    return e;
+}
+
+/* what decides a draw's work lists */
+struct hz_listkey_t
+{
+    hz_view_t view; int col0, col1, two_pass, near_x0, near_x1, near_j0, near_j1, far_rows;
+};
+/* the work lists of sector draws (see strips_behind_columns): [0] first round, [1] second or only round */
+struct hz_worklists_t
+{
+    uint32_t*    d_items[2];
+    uint32_t*    h_items[2];            /* pinned */
+    size_t       cap[2];
+    unsigned int n[2];
+    hipEvent_t   ev_copied[2];
+    int          valid;                 /* the resident lists are those of `key` */
+    hz_listkey_t key;
+    std::vector<uint32_t>* scratch;
+};
+
 struct hz_dev
 {
     int device;
+    hz_env_t env;
     int N, W, H;
     int col0, col1;
     int raster;
     int profiling;
-    int serial;                         /* HZ_SERIAL: the four streams are one */
+    hz_worklists_t lists;
+    /* diagnostics (hz_hip_debug_wave_timing): where the next draw's marching waves leave their counters */
+    struct { unsigned long long* d_cycles; size_t capacity; unsigned int grid_x, grid_y; } wave_timing;
 
     /* Streams and HZ_NFB framebuffers.  A draw (stream, nstream, qstream) fills
      * one framebuffer; the readback conversion of that draw (rstream) reads it
@@ -129,13 +183,13 @@ struct hz_dev
     uint32_t*           d_clip_s[2*HZ_NFB];
     unsigned int*       d_big_counters_s[2*HZ_NFB];    /* HZ_NCOUNTERS each, see mr_queue_t */
     unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
+    unsigned int        near_bigrec_capacity, near_bigitem_capacity, near_clip_capacity;    /* first rounds' sets: no medium queue */
     /* the last draw: a conversion that clears the framebuffer behind itself
      * (k_resolve<true>) consumes it; whoever wants to read it after that gets it
      * drawn again first (fb_refill) */
     hz_view_t           last_view;
     int                 have_view;
     int                 fb_consumed;
-    int                 resolve_clears;         /* HZ_RESOLVE_CLEARS=0 switches the fused clear off */
     float*              d_tanel;
     float*              h_tanel;        /* the table d_tanel holds (or is about to, in stream order) */
     int                 tanel_resident;
@@ -203,6 +257,13 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     }
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
+    for(int k=0; k<2; k++)
+    {
+        (void)hipFree(d->lists.d_items[k]);
+        if(d->lists.h_items[k])   (void)hipHostFree(d->lists.h_items[k]);
+        if(d->lists.ev_copied[k]) (void)hipEventDestroy(d->lists.ev_copied[k]);
+    }
+    delete d->lists.scratch;
     (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
@@ -230,17 +291,15 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     free(d);
 }
 
+static mr_queue_t queue_set(const hz_dev_t* d, int k);
+
 static int create_impl(hz_dev_t* d)
 {
     HZ_ON_DEVICE(d);
-    /* HZ_SERIAL=1 (profiling): one stream, nothing overlaps - per-kernel times
-     * of a trace are then those of each kernel alone on the chip */
-    {
-        const char* ser = getenv("HZ_SERIAL");
-        d->serial = ser && atoi(ser) != 0;
-    }
+    d->env = read_env();
+    d->lists.scratch = new std::vector<uint32_t>();
     HZ_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    if(d->serial) d->rstream = d->stream;
+    if(d->env.serial) d->rstream = d->stream;
     else HZ_CHECK(hipStreamCreateWithFlags(&d->rstream, hipStreamNonBlocking));
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_drawn,   hipEventDisableTiming));
     for(int i=0; i<HZ_NFB; i++) HZ_CHECK(hipEventCreateWithFlags(&d->ev_free[i], hipEventDisableTiming));
@@ -259,19 +318,29 @@ static int create_impl(hz_dev_t* d)
         d->fb_used[i] = 0;
     }
     d->fbi = HZ_NFB-1; d->d_fb = d->d_fbs[HZ_NFB-1];
-    /* queue of triangles too large for k_scatter's in-block pass.  cfg3
-     * (16000x4000) produces ~0.3 M records and ~0.4 M items; sized for 32k-wide */
-    d->bigrec_capacity  = 1u<<21;
-    d->bigitem_capacity = 1u<<22;
-    d->midrec_capacity  = 1u<<21;
-    d->clip_capacity    = 1u<<21;
+    /* queues of triangles too large for the marching wave (k_scatter: for the in-block
+     * pass).  cfg3 (16000x4000) produces ~0.3 M records and ~0.4 M work items; the sizes
+     * follow the image, 2^21 records for 64 Mpix and more (a full queue is correct,
+     * only slow: the producer then rasterises on the spot).  A first round only sees
+     * the triangles of the strips next to the viewer - at most 2*(2r+2)*(2r+126)
+     * for a reach of r cells - and never queues medium boxes. */
     {
-        /* tests shrink the queues to exercise the overflow paths */
-        const char* cap = getenv("HZ_QUEUE_CAPACITY");
-        if(cap && atoi(cap) > 0)
-            d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = d->clip_capacity = (unsigned int)atoi(cap);
+        const size_t mpix64 = (size_t)d->W*d->H/64;
+        unsigned int rec = mpix64 > (1u<<21) ? (1u<<21) : mpix64 < (1u<<15) ? (1u<<15) : (unsigned int)mpix64;
+        d->bigrec_capacity  = rec;
+        d->bigitem_capacity = 2*rec;
+        d->midrec_capacity  = rec;
+        d->clip_capacity    = rec;
+        const size_t r = (size_t)(d->env.near_cells > HZ_NEAR_CELLS_MAX ? d->env.near_cells : HZ_NEAR_CELLS_MAX);
+        const size_t near_tris = 2*(2*r + 2)*(2*r + 2*MR_COLS);
+        d->near_bigrec_capacity  = near_tris < rec ? (unsigned int)near_tris : rec;
+        d->near_bigitem_capacity = 2*rec;
+        d->near_clip_capacity    = d->near_bigrec_capacity;
+        if(d->env.queue_capacity > 0)
+            d->bigrec_capacity = d->bigitem_capacity = d->midrec_capacity = d->clip_capacity =
+            d->near_bigrec_capacity = d->near_bigitem_capacity = d->near_clip_capacity = (unsigned int)d->env.queue_capacity;
     }
-    if(d->serial) d->qstream = d->nstream = d->stream;
+    if(d->env.serial) d->qstream = d->nstream = d->stream;
     else
     {
         HZ_CHECK(hipStreamCreateWithFlags(&d->qstream, hipStreamNonBlocking));
@@ -281,11 +350,15 @@ static int create_impl(hz_dev_t* d)
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_near,    hipEventDisableTiming));
     for(int i=0; i<2*HZ_NFB; i++)
     {
-        HZ_CHECK(hipMalloc(&d->d_bigrec_s[i],  (size_t)d->bigrec_capacity*sizeof(hz_bigrec_t)));
-        HZ_CHECK(hipMalloc(&d->d_bigitem_s[i], (size_t)d->bigitem_capacity*sizeof(hz_bigitem_t)));
-        HZ_CHECK(hipMalloc(&d->d_midrec_s[i],  (size_t)d->midrec_capacity*sizeof(hz_rec_t)));
-        HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)d->clip_capacity*sizeof(uint32_t)));
+        const mr_queue_t q = queue_set(d, i);       /* (for the capacities of set i) */
+        HZ_CHECK(hipMalloc(&d->d_bigrec_s[i],  (size_t)q.bigrec_capacity*sizeof(hz_bigrec_t)));
+        HZ_CHECK(hipMalloc(&d->d_bigitem_s[i], (size_t)q.bigitem_capacity*sizeof(hz_bigitem_t)));
+        if(q.midrec_capacity) HZ_CHECK(hipMalloc(&d->d_midrec_s[i], (size_t)q.midrec_capacity*sizeof(hz_rec_t)));
+        HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)q.clip_capacity*sizeof(uint32_t)));
         HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], HZ_NCOUNTERS*sizeof(unsigned int)));
+        unsigned int empty[HZ_NCOUNTERS] = {0};
+        hz_counters_reset(empty);
+        HZ_CHECK(hipMemcpy(d->d_big_counters_s[i], empty, sizeof(empty), hipMemcpyHostToDevice));
     }
     for(int i=0; i<HZ_NFB; i++)
     {
@@ -295,10 +368,6 @@ static int create_impl(hz_dev_t* d)
         HZ_CHECK(hipEventRecord(d->ev_nqfree[i], d->nstream));
     }
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
-    {
-        const char* rc = getenv("HZ_RESOLVE_CLEARS");
-        d->resolve_clears = !(rc && atoi(rc) == 0);
-    }
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
     d->tanel_resident = 0;
@@ -565,20 +634,151 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.z_guard = 1.0f/500.0f + (float)(d->W > d->H ? d->W : d->H) * (1.0f/4194304.0f);
     p.z_hide_k = 1.03f * p.z_guard * 16777215.f;
     p.quad_max_dx = d->W >= 64 && d->W <= (1<<20) ? 256*(d->W/16 - 1) : 0;
-    {
-        const char* dbg = getenv("HZ_MARCH_DEBUG");
-        p.debug = dbg ? atoi(dbg) : 0;
-        const char* nf = getenv("HZ_NO_FAST_MATH");         /* diagnostics: the unabridged transform everywhere */
-        p.fast_ok = hzf_draw_ok(&p.u) && !(nf && atoi(nf) != 0);
-    }
+    p.debug   = d->env.march_debug;
+    p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
     return p;
 }
 
-/* start of a round: empty its queues */
-__global__ void k_reset_counters(unsigned int* counters)
+/* ---- which strips can reach the drawn columns -----------------------------------
+ * A draw that does not cover the full circle - one GPU's azimuth sector of a
+ * panorama, or a view of less than 360 degrees - needs only the strips of the
+ * DEM that lie in the wedge of azimuths behind its columns.  Launching every
+ * strip and letting the others leave (k_march's corner test) costs a sector the
+ * whole grid's launch plus a vertex transform per wave: 0.3 ms of a 0.4 ms
+ * sector at 8 sectors.  So the host lists, per draw, the (segment, strip column)
+ * pairs worth launching: per segment - a band of rows, i.e. of north offsets -
+ * the east extent of wedge x band, in double precision with margins (4 pixels of
+ * azimuth, a cell in every direction).  The list only has to be a superset: the
+ * corner test stays in the kernel and decides with the rasteriser's own arithmetic. */
+
+/* east extent [lo,hi] of { t*(sin a, cos a) : t >= 0, a in [a0,a1] } intersected with
+ * the band n_lo <= n <= n_hi; a1 - a0 <= pi (convex).  false: empty. */
+static bool wedge_band_extent(double a0, double a1, double n_lo, double n_hi, double* lo, double* hi)
 {
-    counters[0] = 0u; counters[1] = 0u; counters[2] = 0xFFFFFFFFu; counters[3] = 0u;
-    counters[4] = 0u; counters[5] = 0xFFFFFFFFu;
+    const double inf = 1e300;
+    double e_lo = inf, e_hi = -inf;
+    auto add = [&](double e) { if(e < e_lo) e_lo = e; if(e > e_hi) e_hi = e; };
+    if(n_lo <= 0.0 && 0.0 <= n_hi) add(0.0);                   /* the apex */
+    const double rays[2] = { a0, a1 };
+    for(int r=0; r<2; r++)
+    {
+        const double s = sin(rays[r]), c = cos(rays[r]);
+        if(fabs(c) < 1e-12)
+        {
+            if(n_lo <= 0.0 && 0.0 <= n_hi) add(s > 0 ? inf : -inf);
+            continue;
+        }
+        const double bounds[2] = { n_lo, n_hi };
+        for(int b=0; b<2; b++)
+        {
+            const double t = bounds[b]/c;
+            if(t >= 0.0) add(t*s);
+        }
+    }
+    if(e_lo > e_hi) return false;
+    /* unbounded towards east / west: the wedge contains that direction */
+    auto contains = [&](double dir) { double x = fmod(dir - a0, 2.0*M_PI); if(x < 0) x += 2.0*M_PI; return x <= a1 - a0; };
+    if(contains( 0.5*M_PI)) e_hi =  inf;
+    if(contains(-0.5*M_PI)) e_lo = -inf;
+    *lo = e_lo; *hi = e_hi;
+    return true;
+}
+
+/* strip columns [x0,x1] of the band of cell rows jbeg..jend that can reach the
+ * azimuths [a0,a1] (radians, a1 - a0 < 2 pi); false: none */
+static bool strips_behind_columns(const hz_params_t& p, double a0, double a1, int jbeg, int jend, int nsx, int* x0, int* x1)
+{
+    const double m_per_cell_n = (double)HZ_REARTH_PI * (double)p.u.deg_per_cell / 180.0;
+    const double m_per_cell_e = m_per_cell_n * (double)p.u.cos_viewer_lat;
+    const double n_lo = ((double)(jbeg-1) - (double)p.u.viewer_cell_j) * m_per_cell_n;
+    const double n_hi = ((double)(jend+1) - (double)p.u.viewer_cell_j) * m_per_cell_n;
+    double lo = 0, hi = 0;
+    bool any = false;
+    const int parts = (a1 - a0 > M_PI) ? 2 : 1;               /* a wedge of more than 180 degrees: two convex halves */
+    for(int k=0; k<parts; k++)
+    {
+        const double b0 = a0 + (a1 - a0)*k/parts, b1 = a0 + (a1 - a0)*(k+1)/parts;
+        double l, h;
+        if(!wedge_band_extent(b0, b1, n_lo, n_hi, &l, &h)) continue;
+        if(!any) { lo = l; hi = h; any = true; }
+        else { if(l < lo) lo = l; if(h > hi) hi = h; }
+    }
+    if(!any) return false;
+    /* cells, then strip columns; a strip reaches MR_COLS cells east of its first column */
+    double i_lo = lo/m_per_cell_e + (double)p.u.viewer_cell_i - 2.0, i_hi = hi/m_per_cell_e + (double)p.u.viewer_cell_i + 2.0;
+    if(!(i_lo > -1e9)) i_lo = -1e9;
+    if(!(i_hi <  1e9)) i_hi =  1e9;
+    int a = (int)floor(i_lo/(double)MR_COLS) - 1, b = (int)floor(i_hi/(double)MR_COLS);
+    if(a < 0) a = 0;
+    if(b > nsx-1) b = nsx-1;
+    if(a > b) return false;
+    *x0 = a; *x1 = b;
+    return true;
+}
+
+/* the azimuths behind image columns [col0,col1) +- 4 pixels; false: (nearly) the full circle */
+static bool azimuths_of_columns(const hz_params_t& p, double* a0, double* a1)
+{
+    const double k = (double)p.u.az_ndc_per_rad, c = (double)p.u.az_center, hw = (double)p.halfW;
+    const double lo = c + (((double)p.col0 - 4.0)/hw - 1.0)/k, hi = c + (((double)p.col1 + 4.0)/hw - 1.0)/k;
+    if(!(hi - lo < 2.0*M_PI - 1e-3) || !(hi > lo)) return false;
+    *a0 = lo; *a1 = hi;
+    return true;
+}
+
+/* the (segment, strip column) items of one k_march launch (p.pass says which
+ * round's) into `out`, in dispatch order: segments as mr_make_zones numbered
+ * them, strip columns west to east */
+static void list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, double a1, std::vector<uint32_t>& out, bool every_strip = false)
+{
+    const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
+    out.clear();
+    for(int seg=0; seg<zn.total; seg++)
+    {
+        int jbeg, jend;
+        mr_segment_rows(zn, seg, &jbeg, &jend);
+        int x0 = 0, x1 = nsx-1;
+        if(!every_strip && !strips_behind_columns(p, a0, a1, jbeg, jend, nsx, &x0, &x1)) continue;
+        const bool near_rows = jbeg < p.near_j1 && jend > p.near_j0;
+        for(int sx=x0; sx<=x1; sx++)
+        {
+            if(p.pass)
+            {
+                const bool near = near_rows && sx >= p.near_x0 && sx <= p.near_x1;
+                if(near != (p.pass == 1)) continue;
+            }
+            out.push_back(MR_ITEM(seg, sx));
+        }
+    }
+}
+
+/* the list of round `which` (0: first round, on nstream; 1: second or only round, on
+ * `stream`) resident in d_list[which], uploaded on the stream that consumes it */
+static int upload_list(hz_dev_t* d, int which, hipStream_t st, const std::vector<uint32_t>& items)
+{
+    hz_worklists_t& wl = d->lists;
+    const size_t n = items.size();
+    if(n > wl.cap[which])
+    {
+        /* (rare: the first sector draw of a context, a much wider sector) kernels in flight may still read the old one */
+        HZ_CHECK(sync_all(d));
+        (void)hipFree(wl.d_items[which]); (void)hipHostFree(wl.h_items[which]);
+        wl.d_items[which] = NULL; wl.h_items[which] = NULL; wl.cap[which] = 0;
+        const size_t cap = n + n/4 + 1024;
+        HZ_CHECK(hipMalloc(&wl.d_items[which], cap*sizeof(uint32_t)));
+        HZ_CHECK(hipHostMalloc((void**)&wl.h_items[which], cap*sizeof(uint32_t), hipHostMallocDefault));
+        wl.cap[which] = cap;
+    }
+    if(!wl.ev_copied[which]) HZ_CHECK(hipEventCreateWithFlags(&wl.ev_copied[which], hipEventDisableTiming));
+    else HZ_CHECK(hipEventSynchronize(wl.ev_copied[which]));      /* the copy engine is done with the pinned buffer */
+    if(n)
+    {
+        memcpy(wl.h_items[which], items.data(), n*sizeof(uint32_t));
+        HZ_CHECK(hipMemcpyAsync(wl.d_items[which], wl.h_items[which], n*sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    HZ_CHECK(hipEventRecord(wl.ev_copied[which], st));
+    wl.n[which] = (unsigned int)n;
+    return 0;
 }
 
 /* One draw = (clear: see below), then one or two rounds of
@@ -604,8 +804,11 @@ __global__ void k_reset_counters(unsigned int* counters)
  *   qstream |             clip mid big of k (waits ev_marched)
  *   rstream |             resolve k-1 (clears behind itself)      | resolve k
  *
- * HZ_TWO_PASS=0/1 forces one / two rounds; otherwise full-width contexts of at
- * least HZ_TWO_PASS_MIN_MPIX (default 24) megapixels whose far clip lies well
+ * A round's queues are empty when it starts: the last workgroup of the k_big
+ * that consumed them emptied them (no launch for that in front of k_march).
+ *
+ * HZ_TWO_PASS=0/1 forces one / two rounds; otherwise contexts of at least
+ * HZ_TWO_PASS_MIN_MPIX (default 24) megapixels whose far clip lies well
  * beyond the first round's strips draw in two rounds. */
 static int draw_impl(hz_dev_t* d, const hz_view_t* view);
 
@@ -615,70 +818,133 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     return draw_impl(d, view);
 }
 
+/* The framebuffer of the previous draw goes back to "cleared" (glClear,
+ * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words): its
+ * conversion did that already (k_resolve<true>), or a memset does it now on
+ * rstream, behind the conversions of that draw and behind whatever `stream`
+ * still had to read from it; this draw takes the next framebuffer. */
+static int next_framebuffer(hz_dev_t* d, hz_params_t& p)
+{
+    const bool prof = d->profiling != 0;
+    const int prev = d->fbi, next = (prev + 1) % HZ_NFB;
+    HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
+    HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
+    HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));       /* the previous draw's last kernels (qstream) */
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->rstream));
+    if(d->fb_used[prev])
+    {
+        HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
+        HZ_CHECK(hipMemsetAsync(d->d_touched[prev], 0, (size_t)d->seg_stride*d->H, d->rstream));
+    }
+    if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
+    d->fb_used[prev] = 0;
+    HZ_CHECK(hipEventRecord(d->ev_free[prev], d->rstream));
+    d->fbi = next; d->d_fb = d->d_fbs[next];
+    d->fb_used[next] = (size_t)p.SW*p.H;
+    p.touched = d->d_touched[next];
+    return 0;
+}
+
+static mr_queue_t queue_set(const hz_dev_t* d, int k)
+{
+    const bool first_round = k >= HZ_NFB;
+    mr_queue_t q = { d->d_bigrec_s[k], d->d_bigitem_s[k], d->d_midrec_s[k], d->d_clip_s[k], d->d_big_counters_s[k],
+                     first_round ? d->near_bigrec_capacity  : d->bigrec_capacity,
+                     first_round ? d->near_bigitem_capacity : d->bigitem_capacity,
+                     first_round ? 0u : d->midrec_capacity,
+                     first_round ? d->near_clip_capacity : d->clip_capacity };
+    return q;
+}
+
+/* what the marching waves queued: clipper, medium boxes, large boxes */
+static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
+    HZ_CHECK(hipGetLastError());
+    if(d->raster != HZ_RASTER_SCATTER && pp.inline_max < pp.big_min)      /* else nothing is ever queued for it */
+    {
+        hipLaunchKernelGGL(k_mid, dim3(2048), dim3(64), 0, st,
+                           d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)q.counters,
+                           q.midrec_capacity, pp);
+        HZ_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, st,
+                       d->d_fb, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
+                       q.counters, q.bigrec_capacity, q.bigitem_capacity, pp);
+    HZ_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* one k_march launch: over the grid (every strip, or pass 1's columns next to the
+ * viewer), or over a work list */
+static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const mr_zones_t& zn, hz_params_t pm,
+                        const uint32_t* d_list, unsigned int nlist)
+{
+    const int nsx = (pm.N-1 + MR_COLS-1)/MR_COLS;
+    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : nsx, zn.total);
+    pm.worklist = NULL;
+    if(d_list)
+    {
+        if(nlist == 0) return 0;                    /* nothing of the DEM lies behind these columns */
+        pm.worklist = d_list;
+        grid = dim3(nlist, 1);
+    }
+    /* diagnostics (hz_hip_debug_wave_timing): the instance with per-wave counters */
+    if(d->wave_timing.d_cycles && pm.pass != 1)
+    {
+        if((size_t)grid.x*grid.y*4 > d->wave_timing.capacity) { snprintf(g_last_error, sizeof(g_last_error), "wave timing buffer too small"); return -1; }
+        pm.wave_cycles = d->wave_timing.d_cycles;
+        d->wave_timing.grid_x = grid.x; d->wave_timing.grid_y = grid.y;
+        hipLaunchKernelGGL(k_march<true>, grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+    }
+    else
+        hipLaunchKernelGGL(k_march<false>, grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+    HZ_CHECK(hipGetLastError());
+    return 0;
+}
+
+/* the draw's plan: one or two rounds, which strips are "next to the viewer" */
+static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
+{
+    const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
+    const int near_cells = d->env.near_cells >= 0 ? d->env.near_cells : MR_NEAR_CELLS;
+    p.near_x0 = (int)floorf((p.u.viewer_cell_i - (float)near_cells)/(float)MR_COLS);
+    p.near_x1 = (int)floorf((p.u.viewer_cell_i + (float)near_cells)/(float)MR_COLS);
+    if(p.near_x0 < 0) p.near_x0 = 0;
+    if(p.near_x1 > nsx-1) p.near_x1 = nsx-1;
+    p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
+    p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
+    /* two rounds pay where there is a lot of terrain behind the first round's
+     * strips: a large image (many pixel tests to save) and a far clip well
+     * beyond them - with the API's default 40 km far clip most of a large
+     * mosaic is never transformed at all and one round is faster (measured:
+     * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms).  An azimuth sector of such an image
+     * (one GPU of several) draws in two rounds as well: its renders overlap just the
+     * same, and the rank that also converts everybody's strips gains most (own sector
+     * + conversion of all strips, 2 / 4 / 8 sectors: 1.37 -> 1.18, 0.99 -> 0.81,
+     * 0.80 -> 0.66 ms per panorama; tools/sector_timing.py) */
+    const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
+    const bool want_two = d->env.two_pass >= 0 ? d->env.two_pass != 0
+                             : ((double)p.W*(double)p.H >= d->env.two_pass_min_mpix*1e6 && cells_to_zfar >= 1536.0f && cells_to_zfar >= 12.0f*(float)near_cells);
+    return want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
+}
+
 static int draw_impl(hz_dev_t* d, const hz_view_t* view)
 {
     hz_params_t p = make_params(d, view);
     const bool prof = d->profiling != 0;
     d->last_view = *view; d->have_view = 1; d->fb_consumed = 0;
+    if(next_framebuffer(d, p) != 0) return -1;
+    const int next = d->fbi;
 
-    /* The framebuffer of the previous draw goes back to "cleared" (glClear,
-     * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words): its
-     * conversion did that already (k_resolve<true>), or a memset does it now on
-     * rstream, behind the conversions of that draw and behind whatever `stream`
-     * still had to read from it; this draw takes the next framebuffer. */
-    const int prev = d->fbi, next = (prev + 1) % HZ_NFB;
-    {
-        HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
-        HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
-        HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));       /* the previous draw's last kernels (qstream) */
-        if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->rstream));
-        if(d->fb_used[prev])
-        {
-            HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
-            HZ_CHECK(hipMemsetAsync(d->d_touched[prev], 0, (size_t)d->seg_stride*d->H, d->rstream));
-        }
-        if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
-        d->fb_used[prev] = 0;
-        HZ_CHECK(hipEventRecord(d->ev_free[prev], d->rstream));
-        d->fbi = next; d->d_fb = d->d_fbs[next];
-        d->fb_used[next] = (size_t)p.SW*p.H;
-        p.touched = d->d_touched[next];
-    }
-
-    auto queue_set = [&](int k) -> mr_queue_t
-    {
-        mr_queue_t q = { d->d_bigrec_s[k], d->d_bigitem_s[k], d->d_midrec_s[k], d->d_clip_s[k], d->d_big_counters_s[k],
-                         d->bigrec_capacity, d->bigitem_capacity, d->midrec_capacity, d->clip_capacity };
-        return q;
-    };
-    auto queue_kernels = [&](const mr_queue_t& q, const hz_params_t& pp, hipStream_t st) -> int
-    {
-        hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
-        HZ_CHECK(hipGetLastError());
-        if(d->raster != HZ_RASTER_SCATTER && pp.inline_max < pp.big_min)      /* else nothing is ever queued for it */
-        {
-            hipLaunchKernelGGL(k_mid, dim3(2048), dim3(64), 0, st,
-                               d->d_fb, (const hz_rec_t*)q.midrec, (const unsigned int*)q.counters,
-                               d->midrec_capacity, pp);
-            HZ_CHECK(hipGetLastError());
-        }
-        hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, st,
-                           d->d_fb, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
-                           (const unsigned int*)q.counters, d->bigrec_capacity, d->bigitem_capacity, pp);
-        HZ_CHECK(hipGetLastError());
-        return 0;
-    };
-
-    const mr_queue_t q = queue_set(next);           /* one-round draw, or second round */
+    const mr_queue_t q = queue_set(d, next);        /* one-round draw, or second round */
     bool near_beside_far = false;                   /* the second round did not wait for the first */
 
     if(d->raster == HZ_RASTER_SCATTER)
     {
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
-        if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
-        hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, q.counters);
-        if(prof) HZ_CHECK(hipEventRecord(d->ev[9], d->stream));
+        if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); HZ_CHECK(hipEventRecord(d->ev[9], d->stream)); }
         dim3 grid((p.N-1 + SC_CX-1)/SC_CX, (p.N-1 + SC_CY-1)/SC_CY);
         hipLaunchKernelGGL(k_scatter, grid, dim3(SC_THREADS), 0, d->stream,
                            (const int16_t*)d->d_mosaic, d->d_fb, q, p);
@@ -686,33 +952,23 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     }
     else
     {
-        const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
-        /* the strips next to the viewer: within near_cells cells of the viewer's cell */
-        const char* e2 = getenv("HZ_TWO_PASS");
-        const char* en = getenv("HZ_NEAR_CELLS");
-        const char* em = getenv("HZ_TWO_PASS_MIN_MPIX");
-        const int near_cells = en ? atoi(en) : MR_NEAR_CELLS;
-        p.near_x0 = (int)floorf((p.u.viewer_cell_i - (float)near_cells)/(float)MR_COLS);
-        p.near_x1 = (int)floorf((p.u.viewer_cell_i + (float)near_cells)/(float)MR_COLS);
-        if(p.near_x0 < 0) p.near_x0 = 0;
-        if(p.near_x1 > nsx-1) p.near_x1 = nsx-1;
-        p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
-        p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
-        const double min_mpix = em ? atof(em) : 24.0;
-        /* two rounds pay where there is a lot of terrain behind the first round's
-         * strips: a large image (many pixel tests to save) and a far clip well
-         * beyond them - with the API's default 40 km far clip most of a large
-         * mosaic is never transformed at all and one round is faster (measured:
-         * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms).  An azimuth sector of such an image
-         * (one GPU of several) draws in two rounds as well: its renders overlap just the
-         * same, and the rank that also converts everybody's strips gains most (own sector
-         * + conversion of all strips, 2 / 4 / 8 sectors: 1.37 -> 1.18, 0.99 -> 0.81,
-         * 0.80 -> 0.66 ms per panorama; tools/sector_timing.py) */
-        const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
-        const bool want_two = e2 ? atoi(e2) != 0
-                                 : ((double)p.W*(double)p.H >= min_mpix*1e6 && cells_to_zfar >= 1536.0f && cells_to_zfar >= 12.0f*(float)near_cells);
-        const bool two_pass = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
+        const bool two_pass = plan_rounds(d, view, p);
         const mr_zones_t zn = mr_make_zones(p, two_pass);
+        /* sectors and views of less than the full circle: only the strips behind the drawn columns */
+        double a0 = 0, a1 = 0;
+        const bool listed = !d->env.no_worklist && azimuths_of_columns(p, &a0, &a1) && zn.total < (1 << (32 - MR_ITEM_SX_BITS))
+                            && (p.N-1 + MR_COLS-1)/MR_COLS <= (1 << MR_ITEM_SX_BITS);
+        p.cull_strips = (p.col0 > 0 || p.col1 < p.W || listed) ? 1 : 0;
+        bool fresh_lists = false;
+        if(listed)
+        {
+            hz_listkey_t key;
+            memset(&key, 0, sizeof(key));
+            key.view = *view; key.col0 = p.col0; key.col1 = p.col1; key.two_pass = two_pass ? 1 : 0;
+            key.near_x0 = p.near_x0; key.near_x1 = p.near_x1; key.near_j0 = p.near_j0; key.near_j1 = p.near_j1; key.far_rows = zn.rows[0];
+            fresh_lists = !d->lists.valid || memcmp(&key, &d->lists.key, sizeof(key)) != 0;
+            if(fresh_lists) { d->lists.valid = 0; d->lists.key = key; }
+        }
         if(two_pass)
         {
             /* (a sector that draws in two rounds keeps boxes of up to 64 pixels in the marching
@@ -720,17 +976,19 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
              * Gathering rank, 2 / 4 / 8 sectors: 1.19 -> 1.03, 0.82 -> 0.75, 0.69 -> 0.64 ms) */
             p.inline_max = HZ_INLINE_MAX_PIX;
             /* round 1, on its own stream */
-            const mr_queue_t qn = queue_set(HZ_NFB + next);
+            const mr_queue_t qn = queue_set(d, HZ_NFB + next);
             HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_free[next], 0));
             HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_nqfree[next], 0));
-            if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
-            hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->nstream, qn.counters);
             hz_params_t p1 = p;
             p1.pass = 1; p1.early_z = 0;
-            hipLaunchKernelGGL(k_march<false>, dim3(p.near_x1 - p.near_x0 + 1, zn.total), dim3(64), 0, d->nstream,
-                               (const int16_t*)d->d_mosaic, d->d_fb, qn, zn, p1);
-            HZ_CHECK(hipGetLastError());
-            if(queue_kernels(qn, p1, d->nstream) != 0) return -1;
+            if(fresh_lists)
+            {
+                list_items(p1, zn, a0, a1, *d->lists.scratch);
+                if(upload_list(d, 0, d->nstream, *d->lists.scratch) != 0) return -1;
+            }
+            if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
+            if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
+            if(queue_kernels(d, qn, p1, d->nstream) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
             HZ_CHECK(hipEventRecord(d->ev_nqfree[next], d->nstream));
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
@@ -739,7 +997,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
              * the first of a series) starts its second round at once, beside its first.  The
              * early depth test then sees fewer occluders and skips less; what it skips is
              * hidden whenever it looks (depths only decrease), so the bytes are the same. */
-            if(getenv("HZ_ALWAYS_WAIT_NEAR") || hipEventQuery(d->ev_marched) != hipSuccess)
+            if(d->env.always_wait_near || hipEventQuery(d->ev_marched) != hipSuccess)
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
             else
                 near_beside_far = true;         /* "drawn" then has to wait for both rounds: see qstream below */
@@ -750,39 +1008,14 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
         else if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
-        hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, d->stream, q.counters);
+        if(fresh_lists)
+        {
+            list_items(p, zn, a0, a1, *d->lists.scratch);
+            if(upload_list(d, 1, d->stream, *d->lists.scratch) != 0) return -1;
+            d->lists.valid = 1;
+        }
         if(prof) HZ_CHECK(hipEventRecord(d->ev[9], d->stream));
-
-        dim3 grid(nsx, zn.total);
-        /* diagnostics: HZ_WAVE_TIMING=<file> dumps the duration (shader clock
-         * cycles) of every k_march wave of this launch as uint64[grid.y][grid.x][4] */
-        const char* timing_path = getenv("HZ_WAVE_TIMING");
-        hz_params_t pm = p;
-        unsigned long long* d_cycles = NULL;
-        if(timing_path)
-        {
-            HZ_CHECK(hipMalloc(&d_cycles, (size_t)grid.x*grid.y*4*sizeof(unsigned long long)));
-            HZ_CHECK(hipMemsetAsync(d_cycles, 0, (size_t)grid.x*grid.y*4*sizeof(unsigned long long), d->stream));
-            pm.wave_cycles = d_cycles;
-        }
-        if(timing_path)
-            hipLaunchKernelGGL(k_march<true>, grid, dim3(64), 0, d->stream,
-                               (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
-        else
-            hipLaunchKernelGGL(k_march<false>, grid, dim3(64), 0, d->stream,
-                               (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
-        if(timing_path)
-        {
-            const size_t n = (size_t)grid.x*grid.y*4;
-            unsigned long long* h = (unsigned long long*)malloc(n*sizeof(*h));
-            HZ_CHECK(hipMemcpyAsync(h, d_cycles, n*sizeof(*h), hipMemcpyDeviceToHost, d->stream));
-            HZ_CHECK(hipStreamSynchronize(d->stream));
-            FILE* f = fopen(timing_path, "wb");
-            if(f) { unsigned int hdr[2] = { grid.x, grid.y }; fwrite(hdr, 4, 2, f); fwrite(h, sizeof(*h), n, f); fclose(f); }
-            free(h);
-            (void)hipFree(d_cycles);
-        }
-        HZ_CHECK(hipGetLastError());
+        if(launch_march(d, d->stream, q, zn, p, listed ? d->lists.d_items[1] : NULL, d->lists.n[1]) != 0) return -1;
     }
     if(prof) HZ_CHECK(hipEventRecord(d->ev[2], d->stream));
     /* the kernels that finish the draw run on qstream, so that the next draw's
@@ -793,7 +1026,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * second round's queue kernels only as long as the second round itself waited for the first */
     if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
-    if(queue_kernels(q, p, d->qstream) != 0) return -1;
+    if(queue_kernels(d, q, p, d->qstream) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     HZ_CHECK(hipEventRecord(d->ev_qfree[next], d->qstream));
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
@@ -867,7 +1100,7 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
     /* the textured resolve reads the framebuffer after this kernel: no fused clear then */
-    const bool clears = d->resolve_clears && !(d->tex_on && bgr);
+    const bool clears = d->env.resolve_clears && !(d->tex_on && bgr);
     const bool wide = (SW % 4) == 0 && (((uintptr_t)bgr | (uintptr_t)ranges | (uintptr_t)index | (uintptr_t)z24 | (uintptr_t)d->d_fb) & 15u) == 0;
     if(wide)
     {
@@ -926,7 +1159,7 @@ extern "C" int hz_hip_pack(hz_dev_t* d, uint32_t* d_packed)
     const size_t npix = (size_t)SW*d->H;
     size_t nblocks = (npix + 255)/256;
     if(nblocks > 256*32) nblocks = 256*32;
-    if(d->resolve_clears)
+    if(d->env.resolve_clears)
     {
         hipLaunchKernelGGL(k_pack<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H);
         HZ_CHECK(hipGetLastError());
@@ -983,7 +1216,7 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
     if(rstream_after_draw(d) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[4], d->rstream));
     HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->rstream));
-    if(d->resolve_clears)
+    if(d->env.resolve_clears)
     {
         hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride);
         HZ_CHECK(hipGetLastError());
@@ -1165,8 +1398,7 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
     if(ranges) { dst[nbuf] = (unsigned char*)ranges; src[nbuf] = (const unsigned char*)d->d_ranges;   bytes[nbuf++] = npix*sizeof(float); }
     if(index)  { dst[nbuf] = (unsigned char*)index;  src[nbuf] = (const unsigned char*)d->d_index;    bytes[nbuf++] = npix*sizeof(int32_t); }
     if(z24)    { dst[nbuf] = (unsigned char*)z24;    src[nbuf] = (const unsigned char*)d->d_z24;      bytes[nbuf++] = npix*sizeof(uint32_t); }
-    const char* plain = getenv("HZ_PLAIN_COPY");        /* diagnostics: hipMemcpy into the caller's memory as it is */
-    if(plain && atoi(plain) != 0)
+    if(d->env.plain_copy)                               /* diagnostics: hipMemcpy into the caller's memory as it is */
     {
         for(int b=0; b<nbuf; b++) HZ_CHECK(hipMemcpyAsync(dst[b], src[b], bytes[b], hipMemcpyDeviceToHost, d->rstream));
         HZ_CHECK(hipStreamSynchronize(d->rstream));
@@ -1512,7 +1744,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     HZ_ON_DEVICE(d);
     if(hz_hip_sync(d) != 0) return -1;
     const int k = (set ? HZ_NFB : 0) + d->fbi;
-    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k], HZ_NCOUNTERS*sizeof(unsigned int), hipMemcpyDeviceToHost));
+    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k] + HZ_CNT_LAST, 6*sizeof(unsigned int), hipMemcpyDeviceToHost));     /* as the round left them: k_big */
     unsigned int n = counters[0] < d->bigrec_capacity ? counters[0] : d->bigrec_capacity;
     if((int)n > max_rec) n = (unsigned int)max_rec;
     if(n == 0 || recs == NULL) return 0;
@@ -1527,6 +1759,62 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     }
     free(h);
     return 0;
+}
+
+/* diagnostics / tests, no device needed: the work list draw_impl would build for a context of
+ * N samples per axis and a W x H image drawing columns [col0,col1) of `view`.  round: 0 the
+ * only round of a one-round draw, 1 / 2 the rounds of a two-round draw.  out: 3 int32 per
+ * item (strip column, first cell row, cell row behind the last); returns the number of items
+ * (also when capacity_items is smaller: then only that many were written), -1 if such a
+ * draw would launch the whole grid instead (full circle). */
+extern "C" long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view, int col0, int col1, int round,
+                                      int32_t* out, size_t capacity_items)
+{
+    hz_dev_t* d = (hz_dev_t*)calloc(1, sizeof(*d));
+    if(!d) return -1;
+    d->env = read_env();
+    d->N = N; d->W = W; d->H = H; d->col0 = col0; d->col1 = col1;
+    d->seg_stride = (W + HZ_SEG-1)/HZ_SEG;
+    hz_params_t p = make_params(d, view);
+    (void)plan_rounds(d, view, p);
+    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0);
+    free(d);
+    p.pass = round & 3;
+    double a0 = 0, a1 = 0;
+    const bool every_strip = (round & 256) != 0;
+    if(!every_strip && !azimuths_of_columns(p, &a0, &a1)) return -1;
+    std::vector<uint32_t> items;
+    list_items(p, zn, a0, a1, items, every_strip);
+    for(size_t k=0; k<items.size() && k<capacity_items; k++)
+    {
+        int jbeg, jend;
+        mr_segment_rows(zn, (int)(items[k] >> MR_ITEM_SX_BITS), &jbeg, &jend);
+        out[3*k] = (int32_t)(items[k] & ((1u << MR_ITEM_SX_BITS) - 1u)); out[3*k+1] = jbeg; out[3*k+2] = jend;
+    }
+    return (long)items.size();
+}
+
+/* diagnostics (tools/wave_timing.py): draws `view` once more with the instance of k_march
+ * that counts, and returns, per wave of its second (or only) round's launch, 4 words:
+ * duration in shader clock cycles, flushes<<32 | triangles set up, to k_big<<32 | to k_mid,
+ * hidden by the early depth test<<32 | pixel centres tested in the wave.  out: room for
+ * capacity_words; grid[2] = the launch grid (a work-list launch is grid[0] x 1). */
+extern "C" int hz_hip_debug_wave_timing(hz_dev_t* d, const hz_view_t* view, unsigned long long* out, size_t capacity_words, unsigned int* grid)
+{
+    HZ_ON_DEVICE(d);
+    HZ_CHECK(sync_all(d));
+    unsigned long long* d_cycles = NULL;
+    HZ_CHECK(hipMalloc(&d_cycles, capacity_words*sizeof(unsigned long long)));
+    HZ_CHECK(hipMemset(d_cycles, 0, capacity_words*sizeof(unsigned long long)));
+    d->wave_timing.d_cycles = d_cycles; d->wave_timing.capacity = capacity_words;
+    d->wave_timing.grid_x = d->wave_timing.grid_y = 0;
+    int rc = draw_impl(d, view);
+    d->wave_timing.d_cycles = NULL; d->wave_timing.capacity = 0;
+    if(rc == 0 && sync_all(d) != hipSuccess) rc = -1;
+    grid[0] = d->wave_timing.grid_x; grid[1] = d->wave_timing.grid_y;
+    if(rc == 0 && hipMemcpy(out, d_cycles, (size_t)grid[0]*grid[1]*4*sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    (void)hipFree(d_cycles);
+    return rc;
 }
 
 extern "C" int hz_hip_sync(hz_dev_t* d)

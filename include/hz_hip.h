@@ -11,6 +11,7 @@
  */
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -233,6 +234,23 @@ int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsign
  * two-round draw.  counters: 6 words (mr_queue_t); recs: 10 int32 per record
  * (px0 py0 bw bh, the three edge vectors' dx, then dy, in 1/256 pixel), at most max_rec */
 int  hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counters, int max_rec, int32_t* recs);
+
+/* diagnostics / tests (no device needed): the list of marching waves a draw of columns
+ * [col0,col1) of `view` launches on a context of N samples per axis and a W x H image -
+ * azimuth sectors and views of less than 360 degrees launch only the strips of the DEM
+ * that can reach their columns.  round: 0 = a one-round draw, 1 / 2 = the rounds of a
+ * two-round draw; + 256: every strip of the grid, no azimuth test.  out: 3 int32 per wave (strip column, first cell row, cell row behind
+ * the last).  Returns the number of waves (only capacity_items of them written if that
+ * is less), -1 for a draw that launches the whole grid (the full circle). */
+long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view, int col0, int col1, int round,
+                           int32_t* out, size_t capacity_items);
+
+/* diagnostics (tools/wave_timing.py): `view` drawn once more by the instance of the
+ * marching kernel that counts; per wave of its second (or only) round 4 words: duration
+ * in shader clock cycles, flushes<<32 | triangles set up, to k_big<<32 | to k_mid,
+ * hidden by the early depth test<<32 | pixel centres tested by the wave itself.
+ * grid[2] = the launch grid; out holds grid[0]*grid[1]*4 words (capacity_words: its size) */
+int  hz_hip_debug_wave_timing(hz_dev_t* d, const hz_view_t* view, unsigned long long* out, size_t capacity_words, unsigned int* grid);
 
 const char* hz_hip_last_error(void);
 

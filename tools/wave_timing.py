@@ -13,11 +13,17 @@ import torch
 img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda"); rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
 for _ in range(2):
     h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
-os.environ["HZ_WAVE_TIMING"] = "/tmp/wt.bin"
-h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
-raw = open("/tmp/wt.bin", "rb").read()
-gx, gy = np.frombuffer(raw[:8], np.uint32)
-a = np.frombuffer(raw[8:], np.uint64).reshape(gy, gx, 4)
+import ctypes as C
+lib = horizonator_amd._lib.load()
+v = horizonator_amd.View()
+for k, x in h.view().items():
+    setattr(v, k, x)
+cap = 4 * 4 * 1024 * 1024
+buf = np.zeros(cap, np.uint64)
+grid = (C.c_uint * 2)()
+assert lib.hz_hip_debug_wave_timing(lib.horizonator_amd_device(C.byref(h._ctx)), C.byref(v), buf.ctypes.data, cap, grid) == 0
+gx, gy = int(grid[0]), int(grid[1])
+a = buf[:gx * gy * 4].reshape(gy, gx, 4)
 t = a[:, :, 0].astype(np.float64) / 2400.0          # shader clock ~2.4 GHz -> us
 flushes = (a[:, :, 1] >> 32).astype(np.int64); tris = (a[:, :, 1] & 0xFFFFFFFF).astype(np.int64)
 big = (a[:, :, 2] >> 32).astype(np.int64); mid = (a[:, :, 2] & 0xFFFFFFFF).astype(np.int64)
