@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--exchange-anyway", action="store_true",
                     help="diagnostics, 1 GPU: run the N > 1 loop (sparse strip, device-side stream ordering, exchange, "
                          "conversion of the 'gathered' strips) with the one rank there is")
+    ap.add_argument("--gather", default="rotate", choices=["rotate", "root0"],
+                    help="N > 1: which rank gathers and converts a panorama's strips - rotate: panorama k goes to rank "
+                         "k mod N (every rank converts 1/N of the panoramas; the outputs stay on the rank that assembled "
+                         "them); root0: always rank 0, which then draws a narrower sector")
     ap.add_argument("--wire", default="sparse", choices=["sparse", "packed"],
                     help="N > 1: what a rank sends to rank 0 - sparse: terrain pixels only + mask (default); "
                          "packed: every pixel, 4 bytes")
@@ -148,7 +152,8 @@ def main():
     NBUF = 2 if multi else 1
     sparse = args.wire == "sparse"
     cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
-    weights = gatherer_weights(world, 1.77, 0.08) if world > 1 else None
+    rotate = args.gather == "rotate"
+    weights = gatherer_weights(world, 1.77, 0.08) if world > 1 and not rotate else None
     S = {}                                                               # the current layout and its buffers
 
     def apply_layout(layout):
@@ -165,7 +170,9 @@ def main():
             if sparse:
                 # a sparse strip: header + one word per TERRAIN pixel; room for the worst case (no sky at all)
                 S["FULL"] = S["HDR"] + H * S["SW_max"]
-                S["d_pk"] = [torch.zeros(S["FULL"], dtype=torch.int32, device=dev) for _ in range(NBUF)]
+                # (torch.empty: the library zeroes a strip's count word itself, on its own stream; a fill on
+                # torch's stream would be unordered against the render that writes the buffer)
+                S["d_pk"] = [torch.empty(S["FULL"], dtype=torch.int32, device=dev) for _ in range(NBUF)]
             else:
                 S["d_pk"] = [torch.empty((H, S["SW"]), dtype=torch.int32, device=dev) for _ in range(NBUF)]
 
@@ -174,11 +181,11 @@ def main():
     else:
         cos_lat = float(np.cos(np.radians(LAT)))
         apply_layout(balanced_layout(azimuth_density(W, -180.0, 180.0, cos_lat, floor=0.1), world, weights))
-    if world == 1 or rank == 0:
+    if world == 1 or rank == 0 or rotate:
         d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     pending = [None] * NBUF
-    state = {"k": 0, "wire_words": 0, "keep": None}
+    state = {"k": 0, "wire_words": 0, "keep": None, "converted": 0}
     on_gpu = args.backend == "nccl"
 
     def my_stream():
@@ -232,7 +239,7 @@ def main():
                 h.sync()
                 words += int(S["d_pk"][0][0].item())
             cap = agree_on_capacity(words, S["HDR"], S["FULL"], cdev)
-            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF)
+            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF, any_dst=rotate)
             S["sent"] = [None] * NBUF
             state["wire_words"] = S["ex"].cap
         return S["ex"]
@@ -248,6 +255,7 @@ def main():
                                   S["MSTRIDE"], d_img.data_ptr(), d_rng.data_ptr())
         if not on_gpu:
             h.sync()                                    # the uploaded copies go away with this frame
+        state["converted"] += 1
 
     def finish(slot):
         """complete the exchange that still reads buffer set `slot`; rank 0: turn the strips
@@ -271,10 +279,12 @@ def main():
                 parts = [(t.to(dev), c0, n) for t, c0, n in parts]
             h.resolve_gathered(parts, d_img.data_ptr(), d_rng.data_ptr())
             h.sync()                                     # ... before the strips are released
+            state["converted"] += 1
         pending[slot] = None
 
     def step():
         slot = state["k"] % NBUF
+        dst = state["k"] % world if rotate else 0      # the rank that gathers and converts this panorama
         state["k"] += 1
         if not multi:
             # no wait in between: the library overlaps the readback conversion and the clear of
@@ -295,7 +305,7 @@ def main():
                 h.sync()
                 send = d_pk[slot].cpu()                 # gloo (diagnostics): through host memory
             S["sent"][slot] = send
-            ex.post(slot, send)
+            ex.post(slot, send, dst=dst)
             pending[slot] = True
             return
         if S["SW"] > 0:
@@ -303,7 +313,7 @@ def main():
             h.sync()
         # the one exchange of the path: strips -> rank 0 over RCCL/xGMI
         pending[slot] = gather_strips_async(d_pk[slot] if args.backend == "nccl" else d_pk[slot].cpu(), W,
-                                            layout=S["layout"])
+                                            dst=dst, layout=S["layout"])
 
     def drain():
         for slot in range(NBUF):
@@ -318,19 +328,28 @@ def main():
         torch.cuda.synchronize()
 
     def verify():
-        """N > 1: the panorama rank 0 assembled from the gathered strips must be, byte for byte,
-        what one GPU renders on its own"""
-        if not multi or rank != 0:
+        """N > 1: the panorama a rank assembled from the gathered strips must be, byte for byte,
+        what one GPU renders on its own.  Every rank that converted a panorama checks its last one."""
+        if not multi:
             return None
-        got_img, got_rng = d_img.clone(), d_rng.clone()
-        h.set_sector(0, W)
-        one_img = torch.empty_like(d_img)
-        one_rng = torch.empty_like(d_rng)
-        h.render_device(one_img.data_ptr(), one_rng.data_ptr())
-        h.sync()
-        if S["SW"] > 0:
-            h.set_sector(S["col0"], S["col1"])
-        return bool(torch.equal(got_img, one_img) and torch.equal(got_rng, one_rng))
+        ok = 1
+        if state["converted"] > 0:
+            got_img, got_rng = d_img.clone(), d_rng.clone()
+            h.set_sector(0, W)
+            one_img = torch.empty_like(d_img)
+            one_rng = torch.empty_like(d_rng)
+            h.render_device(one_img.data_ptr(), one_rng.data_ptr())
+            h.sync()
+            if S["SW"] > 0:
+                h.set_sector(S["col0"], S["col1"])
+            ok = int(bool(torch.equal(got_img, one_img) and torch.equal(got_rng, one_rng)))
+            del got_img, got_rng, one_img, one_rng
+        if world > 1:
+            t = torch.tensor([ok, state["converted"]], dtype=torch.int64, device=cdev)
+            lo = t.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            ok = int(lo[0].item())
+        return bool(ok)
 
     def timed(zfar, steps, warmup):
         h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=zfar)
@@ -484,7 +503,8 @@ def main():
                 "sector_widths": [c1 - c0 for c0, c1 in S["layout"]],
                 "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * S["SW_max"]) if multi else 0,
                 "strip_resends": (S["ex"].resends if multi and sparse and S.get("ex") is not None else 0),
-                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to rank 0, overlapped with the next render; rank 0 converts them to BGR8 + float32 range" if world > 1 else ""),
+                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to " + ("rank k mod N for panorama k" if rotate else "rank 0") + ", overlapped with the next render; the gathering rank converts them to BGR8 + float32 range" if world > 1 else ""),
+                "gather": args.gather if multi else None,
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",
                 "init_s": init_s,

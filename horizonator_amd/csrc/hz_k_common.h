@@ -74,8 +74,8 @@ struct mr_queue_t
     hz_bigitem_t* bigitem;          /* ... and their work items                                  */
     hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
     uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
-    unsigned int* counters;         /* [0] big records [1] big items [2] first invalid big item
-                                     * [3] mid records [4] clip ids [5] first invalid mid record */
+    unsigned int* counters;         /* [0] big records [1] big items [2] ~(first invalid big item)
+                                     * [3] mid records [4] clip ids [5] ~(first invalid mid record) */
     unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
 };
 
@@ -95,12 +95,18 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
 }
 
 #define HZ_NCOUNTERS 16
-#define HZ_CNT_DONE  6                  /* workgroups of k_big that have finished            */
-#define HZ_CNT_LAST  8                  /* [8..14): the counters as the round left them      */
-/* an empty queue set: what a round finds (hz_hip_create once, then k_big's last workgroup) */
-__host__ __device__ static inline void hz_counters_reset(unsigned int* c)
+#define HZ_CNT_LAST  8                  /* [8..14): the counters as the last draw left them (diagnostics) */
+/* An empty queue set is all zeros ([2] and [5] hold the COMPLEMENT of the first
+ * invalid index, raised with atomicMax).  The queue sets of a framebuffer are
+ * emptied together with it: by the conversion that clears behind itself (one
+ * thread, hz_counters_consume) or by the memset that clears it otherwise - no
+ * launch of its own in front of every marching kernel (on that stream it was
+ * 40-90 us between consecutive panoramas), and no arrival counter in k_big
+ * (4096 atomics on one address: + 40 us per launch, measured). */
+__device__ static inline void hz_counters_consume(unsigned int* a, unsigned int* b)
 {
-    c[0] = 0u; c[1] = 0u; c[2] = 0xFFFFFFFFu; c[3] = 0u; c[4] = 0u; c[5] = 0xFFFFFFFFu; c[HZ_CNT_DONE] = 0u;
+    #pragma unroll
+    for(int k=0; k<6; k++) { a[HZ_CNT_LAST + k] = a[k]; a[k] = 0u; b[HZ_CNT_LAST + k] = b[k]; b[k] = 0u; }
 }
 #ifndef HZ_NFB
 #define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
@@ -235,7 +241,7 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
     {
         ii = atomicAdd(&q.counters[1], nchunks);
         if(ii + nchunks <= q.bigitem_capacity) queued = true;
-        else atomicMin(&q.counters[2], ii);
+        else atomicMax(&q.counters[2], ~ii);
     }
     if(!queued && !inline_ok) return;
     for(int k=2; k<n; k++)

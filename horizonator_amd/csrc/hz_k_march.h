@@ -206,7 +206,7 @@ void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ mid
     const int lane = threadIdx.x;
     /* records from the first reservation that did not fit were not written
      * (their triangles were rasterised by the marching wave instead) */
-    const unsigned int n = min(min(counters[3], counters[5]), midrec_capacity);
+    const unsigned int n = min(min(counters[3], ~counters[5]), midrec_capacity);
     for(unsigned int base = blockIdx.x*64u; base < n; base += gridDim.x*64u)
     {
         hz_rec_t r = {};
@@ -331,7 +331,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             {
                 ibase = atomicAdd(&q.counters[1], total);
                 if(ibase + total <= q.bigitem_capacity) ok = 1;
-                else atomicMin(&q.counters[2], ibase);          /* items from here on are not valid */
+                else atomicMax(&q.counters[2], ~ibase);         /* items from here on are not valid */
             }
         }
         rbase = __shfl(rbase, 0); ibase = __shfl(ibase, 0); ok = __shfl(ok, 0);
@@ -377,7 +377,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         }
         /* else: queue full, they stay here; the slots from mbase on hold nothing
          * of this draw and k_mid must not read them */
-        else if(lane == 0) atomicMin(&q.counters[5], mbase);
+        else if(lane == 0) atomicMax(&q.counters[5], ~mbase);
     }
 
     if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }

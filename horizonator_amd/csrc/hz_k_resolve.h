@@ -14,8 +14,10 @@ __global__ __launch_bounds__(256)
 void k_resolve(unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
                unsigned char* __restrict__ bgr, float* __restrict__ ranges,
                int32_t* __restrict__ index, uint32_t* __restrict__ z24,
-               int SW, int H, float znear, float zfar)
+               int SW, int H, float znear, float zfar, unsigned int* qa, unsigned int* qb)
 {
+    /* (the framebuffer's queue sets are emptied with it: hz_counters_consume) */
+    if(CLEAR && blockIdx.x == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     const size_t npix = (size_t)SW*H;
     for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
     {
@@ -71,8 +73,9 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
                 unsigned char* __restrict__ bgr, float* __restrict__ ranges,
                 int32_t* __restrict__ index, uint32_t* __restrict__ z24,
                 int SW, int H, float znear, float zfar,
-                unsigned char* __restrict__ touched, int seg_stride)
+                unsigned char* __restrict__ touched, int seg_stride, unsigned int* qa, unsigned int* qb)
 {
+    if(CLEAR && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     /* a wave = 64 lanes x 4 pixels = one HZ_SEG-pixel segment of a row */
     static_assert(HZ_SEG == 256, "k_resolve4: one wave converts one segment");
     const int x = (int)(blockIdx.x*blockDim.x + threadIdx.x)*4;
@@ -149,8 +152,9 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
  */
 template<bool CLEAR>
 __global__ __launch_bounds__(256)
-void k_pack(unsigned long long* __restrict__ fb, uint32_t* __restrict__ packed, int SW, int H)
+void k_pack(unsigned long long* __restrict__ fb, uint32_t* __restrict__ packed, int SW, int H, unsigned int* qa, unsigned int* qb)
 {
+    if(CLEAR && blockIdx.x == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     const size_t npix = (size_t)SW*H;
     for(size_t o = (size_t)blockIdx.x*blockDim.x + threadIdx.x; o < npix; o += (size_t)gridDim.x*blockDim.x)
     {
@@ -212,10 +216,11 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
 template<bool CLEAR>
 __global__ __launch_bounds__(256)
 void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
-                   int SW, int H, int mask_stride)
+                   int SW, int H, int mask_stride, unsigned int* qa, unsigned int* qb)
 {
     __shared__ uint32_t wave_count[4];
     __shared__ uint32_t row_base_s;
+    if(CLEAR && blockIdx.x == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
     for(int yo = blockIdx.x; yo < H; yo += gridDim.x)

@@ -160,7 +160,7 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
                 {
                     ii = atomicAdd(&big_counters[1], chunks);
                     if(ii + chunks <= bigitem_capacity) queued = true;
-                    else atomicMin(&big_counters[2], ii);      /* items from here on are not valid */
+                    else atomicMax(&big_counters[2], ~ii);     /* items from here on are not valid */
                 }
                 if(queued)
                 {
@@ -278,14 +278,11 @@ __device__ static inline int32_t hz_floor_div(int64_t n, int32_t d, double r)
 __global__ __launch_bounds__(256)
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
-           unsigned int* __restrict__ big_counters,
+           const unsigned int* __restrict__ big_counters,
            unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
 {
-    __shared__ unsigned int s_nitems;
     /* items at and beyond the first overflow were rasterised inline by their producer */
-    if(threadIdx.x == 0) s_nitems = min(big_counters[1], big_counters[2]);
-    __syncthreads();
-    const unsigned int nitems = s_nitems;
+    const unsigned int nitems = min(big_counters[1], ~big_counters[2]);
     (void)bigrec_capacity; (void)bigitem_capacity;
     const int lane = threadIdx.x & 63;
     const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
@@ -358,22 +355,6 @@ void k_big(unsigned long long* __restrict__ fb,
                 if(hz_tri_fragment(&tri, px, py, &zi, &r8))
                     hz_fb_min(fb, p, px, py, hz_pack(zi, prim, r8));
             }
-        }
-    }
-    /* k_big is the last kernel of a round to look at the round's queues: the
-     * workgroup that finishes last empties them for the draw that takes this
-     * queue set next (no k_reset_counters launch in front of every k_march: on the
-     * marching kernels' stream that was 40-90 us between consecutive panoramas).
-     * Every workgroup read the counters before it arrives here (s_nitems). */
-    __syncthreads();
-    if(threadIdx.x == 0)
-    {
-        __threadfence();
-        if(atomicAdd(&big_counters[HZ_CNT_DONE], 1u) == gridDim.x - 1u)
-        {
-            #pragma unroll
-            for(int k=0; k<6; k++) big_counters[HZ_CNT_LAST + k] = big_counters[k];     /* diagnostics: hz_hip_debug_bigqueue */
-            hz_counters_reset(big_counters);
         }
     }
 }

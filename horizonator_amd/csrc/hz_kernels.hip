@@ -356,9 +356,7 @@ static int create_impl(hz_dev_t* d)
         if(q.midrec_capacity) HZ_CHECK(hipMalloc(&d->d_midrec_s[i], (size_t)q.midrec_capacity*sizeof(hz_rec_t)));
         HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)q.clip_capacity*sizeof(uint32_t)));
         HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], HZ_NCOUNTERS*sizeof(unsigned int)));
-        unsigned int empty[HZ_NCOUNTERS] = {0};
-        hz_counters_reset(empty);
-        HZ_CHECK(hipMemcpy(d->d_big_counters_s[i], empty, sizeof(empty), hipMemcpyHostToDevice));
+        HZ_CHECK(hipMemset(d->d_big_counters_s[i], 0, HZ_NCOUNTERS*sizeof(unsigned int)));
     }
     for(int i=0; i<HZ_NFB; i++)
     {
@@ -804,8 +802,8 @@ static int upload_list(hz_dev_t* d, int which, hipStream_t st, const std::vector
  *   qstream |             clip mid big of k (waits ev_marched)
  *   rstream |             resolve k-1 (clears behind itself)      | resolve k
  *
- * A round's queues are empty when it starts: the last workgroup of the k_big
- * that consumed them emptied them (no launch for that in front of k_march).
+ * A round's queues are empty when it starts: they are emptied together with
+ * their framebuffer (hz_counters_consume; no launch for that in front of k_march).
  *
  * HZ_TWO_PASS=0/1 forces one / two rounds; otherwise contexts of at least
  * HZ_TWO_PASS_MIN_MPIX (default 24) megapixels whose far clip lies well
@@ -835,6 +833,9 @@ static int next_framebuffer(hz_dev_t* d, hz_params_t& p)
     {
         HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
         HZ_CHECK(hipMemsetAsync(d->d_touched[prev], 0, (size_t)d->seg_stride*d->H, d->rstream));
+        /* ... and its queue sets with it (the clearing conversions do that themselves) */
+        HZ_CHECK(hipMemsetAsync(d->d_big_counters_s[prev], 0, 6*sizeof(unsigned int), d->rstream));
+        HZ_CHECK(hipMemsetAsync(d->d_big_counters_s[HZ_NFB + prev], 0, 6*sizeof(unsigned int), d->rstream));
     }
     if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
     d->fb_used[prev] = 0;
@@ -1101,25 +1102,26 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
     if(nblocks > 256*32) nblocks = 256*32;
     /* the textured resolve reads the framebuffer after this kernel: no fused clear then */
     const bool clears = d->env.resolve_clears && !(d->tex_on && bgr);
+    unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];    /* emptied with the framebuffer */
     const bool wide = (SW % 4) == 0 && (((uintptr_t)bgr | (uintptr_t)ranges | (uintptr_t)index | (uintptr_t)z24 | (uintptr_t)d->d_fb) & 15u) == 0;
     if(wide)
     {
         const dim3 grid((unsigned)((SW/4 + 255)/256), (unsigned)(d->H < 2048 ? d->H : 2048));
         if(clears)
             hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
-                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride);
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride, qa, qb);
         else
             hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
-                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride);
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride, qa, qb);
     }
     else if(clears)
         hipLaunchKernelGGL(k_resolve<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
                            d->d_fb, (const float*)d->d_tanel,
-                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, qa, qb);
     else
         hipLaunchKernelGGL(k_resolve<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
                            d->d_fb, (const float*)d->d_tanel,
-                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar);
+                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, qa, qb);
     HZ_CHECK(hipGetLastError());
     if(clears && fb_mark_consumed(d) != 0) return -1;
     if(d->tex_on && bgr)
@@ -1161,12 +1163,13 @@ extern "C" int hz_hip_pack(hz_dev_t* d, uint32_t* d_packed)
     if(nblocks > 256*32) nblocks = 256*32;
     if(d->env.resolve_clears)
     {
-        hipLaunchKernelGGL(k_pack<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H);
+        hipLaunchKernelGGL(k_pack<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H,
+                           d->d_big_counters_s[d->fbi], d->d_big_counters_s[HZ_NFB + d->fbi]);
         HZ_CHECK(hipGetLastError());
         if(fb_mark_consumed(d) != 0) return -1;
     }
     else
-        hipLaunchKernelGGL(k_pack<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H);
+        hipLaunchKernelGGL(k_pack<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream, d->d_fb, d_packed, SW, d->H, (unsigned int*)NULL, (unsigned int*)NULL);
     HZ_CHECK(hipGetLastError());
     if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
     return 0;
@@ -1218,12 +1221,13 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
     HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->rstream));
     if(d->env.resolve_clears)
     {
-        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride);
+        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
+                           d->d_big_counters_s[d->fbi], d->d_big_counters_s[HZ_NFB + d->fbi]);
         HZ_CHECK(hipGetLastError());
         if(fb_mark_consumed(d) != 0) return -1;
     }
     else
-        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride);
+        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride, (unsigned int*)NULL, (unsigned int*)NULL);
     HZ_CHECK(hipGetLastError());
     if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
     return 0;
@@ -1744,7 +1748,9 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     HZ_ON_DEVICE(d);
     if(hz_hip_sync(d) != 0) return -1;
     const int k = (set ? HZ_NFB : 0) + d->fbi;
-    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k] + HZ_CNT_LAST, 6*sizeof(unsigned int), hipMemcpyDeviceToHost));     /* as the round left them: k_big */
+    /* (a conversion that cleared the framebuffer emptied the queues too and left a copy of the counters) */
+    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k] + (d->fb_consumed ? HZ_CNT_LAST : 0), 6*sizeof(unsigned int), hipMemcpyDeviceToHost));
+    counters[2] = ~counters[2]; counters[5] = ~counters[5];     /* as documented: the first invalid index */
     unsigned int n = counters[0] < d->bigrec_capacity ? counters[0] : d->bigrec_capacity;
     if((int)n > max_rec) n = (unsigned int)max_rec;
     if(n == 0 || recs == NULL) return 0;

@@ -26,10 +26,22 @@ int horizonator_rccl_gather_strips(const horizonator_context_t* ctx, void* comm,
     /* the strip is written by the context's conversion stream */
     if(ctx != NULL && !horizonator_amd_stream_waits_for_outputs(ctx, stream)) return -1;
     NCCL_TRY(ncclGroupStart());
+    /* a failure inside the group must still close it: an open group swallows every later
+     * RCCL call of this thread (queued, never launched - a hang, not an error) */
+    ncclResult_t first = ncclSuccess, r;
     if(rank == root)
-        for(int r=0; r<world; r++)
-            NCCL_TRY(ncclRecv(d_recv[r], words, ncclUint32, r, (ncclComm_t)comm, (hipStream_t)stream));
-    NCCL_TRY(ncclSend(d_send, words, ncclUint32, root, (ncclComm_t)comm, (hipStream_t)stream));
-    NCCL_TRY(ncclGroupEnd());
+        for(int k=0; k<world && first == ncclSuccess; k++)
+        {
+            r = ncclRecv(d_recv[k], words, ncclUint32, k, (ncclComm_t)comm, (hipStream_t)stream);
+            if(r != ncclSuccess) { MSG("ncclRecv from rank %d -> %s", k, ncclGetErrorString(r)); first = r; }
+        }
+    if(first == ncclSuccess)
+    {
+        r = ncclSend(d_send, words, ncclUint32, root, (ncclComm_t)comm, (hipStream_t)stream);
+        if(r != ncclSuccess) { MSG("ncclSend to rank %d -> %s", root, ncclGetErrorString(r)); first = r; }
+    }
+    r = ncclGroupEnd();
+    if(first != ncclSuccess) return -1;
+    if(r != ncclSuccess) { MSG("ncclGroupEnd -> %s", ncclGetErrorString(r)); return -1; }
     return 0;
 }

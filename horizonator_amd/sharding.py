@@ -255,53 +255,80 @@ class StripExchange:
     A strip's length (header + one word per terrain pixel) is only known on the device once it is
     drawn.  Reading it back, agreeing on the longest with an all_reduce and reading that back too
     puts two host round trips and a collective on the critical path of every panorama.  Instead
-    the ranks agree ONCE on a capacity (`cap_words`: the longest strip seen so far plus a margin)
+    the ranks agree ONCE on a capacity (`cap`: the longest strip seen so far plus a margin)
     and every panorama sends exactly that many words: the strip's own first word says how many of
     them mean anything.  Buffers - send side and the gathering rank's bins - are allocated once per
     slot and reused.  Whether any strip did not fit travels beside the strips as one flag word,
     all-reduced asynchronously; it is looked at when the exchange is completed, a panorama
     later and off the critical path, and grow() then redoes that one exchange with more room.
 
+    The gathering rank is chosen per exchange (post(..., dst=r)): with `any_dst` every rank keeps
+    bins, and consecutive panoramas can be gathered - and converted - by different ranks, so that
+    no rank has the conversion of every panorama to do on top of its own sector.
+
         ex = StripExchange(cap_words, full_words, header_words, device, nslots=2)
         ex.post(slot, d_strip)      # d_strip: the rank's full-size strip buffer (int32, 1-D), drawn on
                                     # the current stream or ordered before it; no host wait
         bins, overflow = ex.complete(slot)      # waits; bins on dst (one 1-D tensor per rank), else None
         if overflow: bins = ex.grow(slot, d_strip)
+
+    Capacity, bins and flag are per slot: grow() gives `slot` more room and redoes its exchange
+    while the exchanges of the other slots - still in flight, a panorama behind - keep the bins
+    they were posted with; those slots take the new capacity over when they are posted next.
     """
 
-    def __init__(self, cap_words, full_words, header_words, device, nslots=2, group=None, dst=0):
+    def __init__(self, cap_words, full_words, header_words, device, nslots=2, group=None, dst=0, any_dst=False):
         self.world, self.rank = _world_and_rank(group)
         self.group, self.dst, self.device = group, dst, device
+        self.any_dst = bool(any_dst)
         self.full, self.hdr = int(full_words), int(header_words)
         self.nslots = nslots
-        self._alloc(cap_words)
-        self.resends = 0
-
-    def _alloc(self, cap_words):
-        self.cap = int(min(max(cap_words, self.hdr + 1), self.full))
-        self.bins = [[torch.empty(self.cap, dtype=torch.int32, device=self.device) for _ in range(self.world)]
-                     if self.rank == self.dst else None for _ in range(self.nslots)]
-        self.flags = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.nslots)]
-        self.work = [None] * self.nslots
+        self.cap = self._clamp(cap_words)
+        self.slot_cap = [0] * nslots
+        self.bins = [None] * nslots
+        self.slot_dst = [dst] * nslots
+        self.flags = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(nslots)]
+        self.work = [None] * nslots
         # on a GPU the flag reaches the host through a stream of its own, so that looking at it
         # waits for that exchange only - not for whatever the caller has queued since
         self.cuda = torch.device(self.device).type == "cuda"
         if self.cuda:
             self.side = torch.cuda.Stream(device=self.device)
-            self.flag_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(self.nslots)]
-            self.flag_ready = [torch.cuda.Event() for _ in range(self.nslots)]
+            self.flag_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(nslots)]
+            self.flag_ready = [torch.cuda.Event() for _ in range(nslots)]
+        self.resends = 0
 
-    def post(self, slot, strip):
-        """start the exchange of `strip` (this rank's strip buffer, full_words long) in `slot`"""
+    def _clamp(self, cap_words):
+        return int(min(max(int(cap_words), self.hdr + 1), self.full))
+
+    def _holds_bins(self):
+        return self.any_dst or self.rank == self.dst
+
+    def _fit_slot(self, slot):
+        """the slot's bins at the agreed capacity (only ever called with no exchange of the slot in flight)"""
+        if self.slot_cap[slot] == self.cap:
+            return
+        self.slot_cap[slot] = self.cap
+        self.bins[slot] = [torch.empty(self.cap, dtype=torch.int32, device=self.device) for _ in range(self.world)] \
+            if self._holds_bins() else None
+
+    def post(self, slot, strip, dst=None):
+        """start the exchange of `strip` (this rank's strip buffer, full_words long) in `slot`;
+        dst: the rank that gathers this one (default: the exchange's)"""
         assert self.work[slot] is None, "complete() the slot's previous exchange first"
+        dst = self.dst if dst is None else int(dst)
+        assert dst == self.dst or self.any_dst, "a gathering rank other than the default needs any_dst=True"
+        self._fit_slot(slot)
+        cap = self.slot_cap[slot]
+        self.slot_dst[slot] = dst
         # does this rank's strip fit?  (device-side: no value leaves the device here)
-        self.flags[slot].copy_((strip[0:1] > (self.cap - self.hdr)).to(torch.int32))
-        send = strip[:self.cap]
+        self.flags[slot].copy_((strip[0:1] > (cap - self.hdr)).to(torch.int32))
+        send = strip[:cap]
         if self.world == 1:
             self.bins[slot][0].copy_(send)
             w1 = w2 = None
         else:
-            w1 = dist.gather(send, self.bins[slot], dst=self.dst, group=self.group, async_op=True)
+            w1 = dist.gather(send, self.bins[slot] if self.rank == dst else None, dst=dst, group=self.group, async_op=True)
             w2 = dist.all_reduce(self.flags[slot], op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
@@ -315,7 +342,7 @@ class StripExchange:
         self.work[slot] = (w1, w2)
 
     def complete(self, slot):
-        """the slot's exchange is over: (bins on the gathering rank else None, did a strip not fit).
+        """the slot's exchange is over: (bins on its gathering rank else None, did a strip not fit).
         On a GPU the caller's current stream waits for the strips (the host does not); the host waits
         for the flag word of THIS exchange only."""
         if self.work[slot] is None:
@@ -331,19 +358,20 @@ class StripExchange:
             if w2 is not None:
                 w2.wait()
             overflow = bool(int(self.flags[slot][0]))
-        return self.bins[slot], overflow
+        return (self.bins[slot] if self.rank == self.slot_dst[slot] else None), overflow
 
     def grow(self, slot, strip):
-        """a strip did not fit: agree on a new capacity (every rank calls this - they all saw the
-        same flag), reallocate, and redo the slot's exchange, waiting for it"""
+        """a strip of `slot`'s exchange did not fit: agree on a new capacity (every rank calls this -
+        they all saw the same flag) and redo that exchange with it, waiting for it.  Only `slot` is
+        reallocated: exchanges of other slots that are still in flight keep their bins and adopt
+        the new capacity at their next post()."""
+        assert self.work[slot] is None, "grow() follows complete() of the same slot"
         n = torch.tensor([self.hdr + int(strip[0].item())], dtype=torch.int64, device=self.device)
         if self.world > 1:
             dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
-        for k in range(self.nslots):                        # exchanges still in flight use the old bins: finish them first
-            assert self.work[k] is None or k == slot
-        self._alloc(int(int(n.item()) * 1.1) + 1024)
+        self.cap = self._clamp(int(int(n.item()) * 1.1) + 1024)
         self.resends += 1
-        self.post(slot, strip)
+        self.post(slot, strip, dst=self.slot_dst[slot])
         bins, overflow = self.complete(slot)
         assert not overflow
         return bins
@@ -378,7 +406,10 @@ def gather_viewpoints(images, n, group=None, dst=0, chunk=16, out=None):
     concatenation).  out: the [n, ...] result tensor on `dst`, if the caller has one."""
     world, rank = _world_and_rank(group)
     if world == 1:
-        return images
+        if out is None:
+            return images
+        out.copy_(images)
+        return out
     longest = -(-n // world)
     chunk = max(1, min(int(chunk), longest))
     item_shape = list(images.shape[1:])

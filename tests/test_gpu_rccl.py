@@ -47,7 +47,9 @@ def test_strips_through_rccl_convert_to_the_same_panorama():
         hdr = sparse_header_words(H, ms)
         dev = torch.device("cuda:0")
         stream = torch.cuda.current_stream().cuda_stream
-        d_send = torch.zeros(hdr + H * W, dtype=torch.int32, device=dev)
+        # (torch.empty: the library zeroes the strip's count word itself, on its own stream; a torch.zeros would
+        # fill the buffer on torch's stream, unordered against the render that writes it)
+        d_send = torch.empty(hdr + H * W, dtype=torch.int32, device=dev)
         d_recv = torch.full((hdr + H * W,), -1, dtype=torch.int32, device=dev)
         h.render_sparse(d_send.data_ptr(), ms)
         bins = (C.c_void_p * 1)(d_recv.data_ptr())

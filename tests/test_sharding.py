@@ -167,6 +167,45 @@ def _worker(rank, world, port, q):
         if rank == 0:
             for r, t in enumerate((200, 3000)):
                 assert np.array_equal(bins[r][:HDR + t].numpy(), strip_of(r, t, 3)[:HDR + t].numpy())
+        # ... and the way bench.py runs it: the OTHER slot's exchange is still in flight (posted, completed a
+        # panorama later) when a strip outgrows the capacity.  grow() reallocates its own slot only; the
+        # exchange in flight keeps its bins and arrives intact, and its slot adopts the capacity when posted next.
+        ex2 = StripExchange(HDR + 600, FULL, HDR, torch.device("cpu"), nslots=2)
+        inflight = strip_of(rank, 500, 4)
+        ex2.post(1, inflight)
+        huge = strip_of(rank, 3500 if rank == 0 else 100, 5)
+        ex2.post(0, huge)
+        bins0, overflow = ex2.complete(0)
+        assert overflow
+        old_cap = ex2.cap
+        bins0 = ex2.grow(0, huge)                           # slot 1 is posted and not completed
+        assert ex2.cap > old_cap and ex2.slot_cap == [ex2.cap, old_cap]
+        bins1, overflow1 = ex2.complete(1)
+        assert not overflow1
+        if rank == 0:
+            for r, t in enumerate((3500, 100)):
+                assert np.array_equal(bins0[r][:HDR + t].numpy(), strip_of(r, t, 5)[:HDR + t].numpy())
+            for r in range(world):
+                assert bins1[r].numel() == old_cap
+                assert np.array_equal(bins1[r][:HDR + 500].numpy(), strip_of(r, 500, 4)[:HDR + 500].numpy())
+        ex2.post(1, huge)                                   # the slot takes the new capacity over
+        bins1, overflow1 = ex2.complete(1)
+        assert not overflow1 and ex2.slot_cap == [ex2.cap, ex2.cap]
+        if rank == 0:
+            assert np.array_equal(bins1[0][:HDR + 3500].numpy(), strip_of(0, 3500, 5)[:HDR + 3500].numpy())
+        # the gathering rank rotates from panorama to panorama (bench.py --gather rotate): every rank keeps bins
+        ex3 = StripExchange(HDR + 600, FULL, HDR, torch.device("cpu"), nslots=2, any_dst=True)
+        for k in range(4):
+            slot, dst = k % 2, k % world
+            ex3.post(slot, strip_of(rank, 200 + 10 * rank + k, 6 + k), dst=dst)
+            binsk, overflowk = ex3.complete(slot)
+            assert not overflowk
+            if rank == dst:
+                for r in range(world):
+                    t = 200 + 10 * r + k
+                    assert np.array_equal(binsk[r][:HDR + t].numpy(), strip_of(r, t, 6 + k)[:HDR + t].numpy())
+            else:
+                assert binsk is None
         # unequal sectors, rank 0 drawing nothing at all
         wts = [0.0, 1.0]
         d0, d1 = sector_columns(W, world, rank, wts)

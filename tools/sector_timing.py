@@ -13,6 +13,7 @@ R, W, H = 4200, 16000, int(os.environ.get('HZ_H', '4000'))
 h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
 h.set_view(-180, 180, zfar=600000.0)
 h.set_profiling(True)
+fit = []
 for G in (1, 2, 4, 8):
     worst = 0
     for r in range(G):
@@ -58,5 +59,34 @@ for G in (1, 2, 4, 8):
                                           ms, full_img.data_ptr(), full_rng.data_ptr())
                 h.sync(); tt.append((time.perf_counter() - t0) * 1e3)
             rank0s = float(np.median(tt[1:]))
-    extra = f"; rank 0 (own sector + conversion of all {G} strips): packed {rank0:.3f} ms, sparse {rank0s:.3f} ms wall" if G > 1 else ""
-    print(f"G={G}: slowest sector {worst:.3f} ms device time -> {W*H/worst/1e3:.0f} Mpix/s if perfectly overlapped{extra}")
+            # a rank of bench.py --gather rotate: its own sector for every panorama, the conversion of all G
+            # strips for every G-th
+            strips = [(sp[q].data_ptr(), sector_columns(W, G, q)[0], sector_columns(W, G, q)[1] - sector_columns(W, G, q)[0]) for q in range(G)]
+            tt = []
+            for k in range(5):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for j in range(2 * G):
+                    h.render_sparse(sp[0].data_ptr(), ms)
+                    if j % G == 0:
+                        h.resolve_sparse_gathered(strips, ms, full_img.data_ptr(), full_rng.data_ptr())
+                h.sync(); tt.append((time.perf_counter() - t0) * 1e3 / (2 * G))
+            rot = float(np.median(tt[1:]))
+            # ... and its sector alone, queued back to back (what a rank does between its conversions)
+            tt = []
+            for k in range(5):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for j in range(16):
+                    h.render_sparse(sp[0].data_ptr(), ms)
+                h.sync(); tt.append((time.perf_counter() - t0) * 1e3 / 16)
+            alone = float(np.median(tt[1:]))
+    extra = (f"; rank 0 (own sector + conversion of all {G} strips): packed {rank0:.3f} ms, sparse {rank0s:.3f} ms wall; "
+             f"a rank of --gather rotate (sector every panorama, conversion every {G}th, back to back): {rot:.3f} ms per panorama; "
+             f"sector alone back to back: {alone:.3f} ms") if G > 1 else ""
+    print(f"G={G}: slowest sector {worst:.3f} ms device time (sum of stages, one render waited for){extra}")
+    fit.append((1.0 / G, worst, alone if G > 1 else None))
+xs = np.array([f[0] for f in fit]); ys = np.array([f[1] for f in fit])
+b, a = np.polyfit(xs, ys, 1)
+print(f"sum of stages ~ {a:.3f} ms fixed + {b:.3f} ms * share of the panorama")
+xs2 = np.array([f[0] for f in fit if f[2] is not None]); ys2 = np.array([f[2] for f in fit if f[2] is not None])
+b2, a2 = np.polyfit(xs2, ys2, 1)
+print(f"sector back to back ~ {a2:.3f} ms fixed + {b2:.3f} ms * share of the panorama")
