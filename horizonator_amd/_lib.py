@@ -166,6 +166,7 @@ def load():
     sig("hz_hip_resolve_packed", i, vp, P(View), vp, vp, i, i, i, vp, vp)
     sig("hz_hip_pack_sparse", i, vp, vp, i)
     sig("hz_hip_resolve_sparse", i, vp, P(View), vp, vp, i, i, i, vp, vp)
+    sig("hz_hip_resolve_sparse_strips", i, vp, P(View), vp, i, vp, i, vp, vp, vp, vp)
     sig("hz_hip_draw", i, vp, P(View))
     sig("hz_hip_resolve", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_resolve_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
@@ -212,7 +213,7 @@ DECLARED_SYMBOLS = [
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
-    "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
+    "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
     "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_check_fastmath", "hz_hip_debug_bigqueue", "hz_hip_debug_wave_timing", "hz_hip_debug_worklist", "hz_hip_last_error",
 ]
 

@@ -866,15 +866,11 @@ bool horizonator_amd_resolve_sparse_strips(const horizonator_context_t* ctx, int
     hz_state_t* s = live_state(ctx);
     if(s == NULL || nstrips < 0 || d_in == NULL || ncols == NULL || out_col0 == NULL) return false;
     if(d_ranges != NULL) fill_tanel(s);
-    for(int k=0; k<nstrips; k++)
+    if(0 != hz_hip_resolve_sparse_strips(s->dev, &s->view, s->tanel, nstrips, d_in, mask_stride, ncols, out_col0,
+                                         d_image, d_ranges))
     {
-        if(ncols[k] == 0) continue;
-        if(0 != hz_hip_resolve_sparse(s->dev, &s->view, s->tanel, d_in[k], mask_stride, ncols[k], out_col0[k],
-                                      d_image, d_ranges))
-        {
-            MSG("resolve of sparse strip %d failed: %s", k, hz_hip_last_error());
-            return false;
-        }
+        MSG("resolve of sparse strips failed: %s", hz_hip_last_error());
+        return false;
     }
     return true;
 }

@@ -213,120 +213,186 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
  * any order in the data (row_base says where): one block per row, one atomic
  * per row for its base.  The buffer must hold HDR + H*SW words; [0] must be 0
  * on entry. */
+/* One workgroup packs SP_ROWS consecutive rows and takes their place in the data
+ * with ONE atomic: a row's base used to be an atomic of its own, 4000 of them on
+ * one address per strip - they are serialised at ~10 ns each, 40 of the kernel's
+ * 65 us for a 2000 x 4000 strip.  First pass: mask and per-wave counts of every
+ * row (LDS); the segments nothing was drawn into (`touched`, as in k_resolve4) are
+ * sky without being read.  Second pass: the words, re-read from L2. */
+#define SP_ROWS   8
+#define SP_MAXIT  64                    /* 256-pixel steps per row: sectors up to 16384 columns */
 template<bool CLEAR>
 __global__ __launch_bounds__(256)
 void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
-                   int SW, int H, int mask_stride, unsigned int* qa, unsigned int* qb)
+                   int SW, int H, int mask_stride, unsigned char* __restrict__ touched, int seg_stride,
+                   unsigned int* qa, unsigned int* qb)
 {
-    __shared__ uint32_t wave_count[4];
-    __shared__ uint32_t row_base_s;
+    static_assert(HZ_SEG == 256, "k_pack_sparse: one step of the workgroup = one segment");
+    __shared__ uint32_t cnt[SP_ROWS*SP_MAXIT*4];        /* terrain pixels per (row, step, wave); then their exclusive prefix */
+    __shared__ uint32_t base_s;
     if(CLEAR && blockIdx.x == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
-    for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
+    const int nit = (SW + 255) >> 8;
+    for(int y0 = blockIdx.x*SP_ROWS; y0 < H; y0 += gridDim.x*SP_ROWS)
     {
-        unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
-        uint32_t* mask = out + 1 + H + (size_t)yo*mask_stride;
-        /* pass 1: mask and count */
-        uint32_t mine = 0;
-        for(int c0 = 0; c0 < SW; c0 += 256)
+        const int nrows = min(SP_ROWS, H - y0);
+        /* pass 1: masks and counts */
+        for(int r=0; r<nrows; r++)
         {
-            const int c = c0 + threadIdx.x;
-            const bool terrain = c < SW && (uint32_t)(row[c] >> 40) != HZ_Z24_MAX;
-            const unsigned long long b = __ballot(terrain);
-            if(lane == 0  && c0 + wave*64      < SW) mask[(c0 >> 5) + wave*2]     = (uint32_t)b;
-            if(lane == 32 && c0 + wave*64 + 32 < SW) mask[(c0 >> 5) + wave*2 + 1] = (uint32_t)(b >> 32);
-            mine += (uint32_t)__popcll(b);                  /* the same in every lane of the wave */
-        }
-        if(lane == 0) wave_count[wave] = mine;
-        __syncthreads();
-        if(threadIdx.x == 0)
-        {
-            const uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-            const uint32_t base = atomicAdd(&out[0], total);
-            out[1 + yo] = base;
-            row_base_s = base;
-        }
-        __syncthreads();
-        /* pass 2: the words (the row is in L2 now) */
-        uint32_t run = row_base_s;
-        for(int c0 = 0; c0 < SW; c0 += 256)
-        {
-            const int c = c0 + threadIdx.x;
-            unsigned long long key = 0;
-            bool terrain = false;
-            if(c < SW)
+            const int yo = y0 + r;
+            const unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
+            const unsigned char* flags = touched + (size_t)(H-1 - yo)*seg_stride;
+            uint32_t* mask = out + 1 + H + (size_t)yo*mask_stride;
+            for(int it=0; it<nit; it++)
             {
-                key = row[c];
-                terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX;
-                if(CLEAR && key != HZ_FB_CLEAR) row[c] = HZ_FB_CLEAR;
+                const int c = (it << 8) + threadIdx.x;
+                const bool terrain = c < SW && flags[it] && (uint32_t)(row[c] >> 40) != HZ_Z24_MAX;
+                const unsigned long long b = __ballot(terrain);
+                if(lane == 0  && (it << 8) + wave*64      < SW) mask[(it << 3) + wave*2]     = (uint32_t)b;
+                if(lane == 32 && (it << 8) + wave*64 + 32 < SW) mask[(it << 3) + wave*2 + 1] = (uint32_t)(b >> 32);
+                if(lane == 0) cnt[(r*nit + it)*4 + wave] = (uint32_t)__popcll(b);
             }
-            const unsigned long long b = __ballot(terrain);
-            __syncthreads();
-            if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
-            __syncthreads();
-            uint32_t before = 0;
-            for(int w=0; w<wave; w++) before += wave_count[w];
-            if(terrain)
-                out[HDR + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] =
-                    ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
-            run += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
         }
+        __syncthreads();
+        /* exclusive prefix over the counts in data order (row, step, wave), by the first wave: every
+         * lane sums a run of consecutive entries, the runs are scanned across the lanes */
+        const int n = nrows*nit*4, per = (n + 63) >> 6;
+        if(wave == 0)
+        {
+            uint32_t mine = 0;
+            for(int k=lane*per; k<min((lane+1)*per, n); k++) mine += cnt[k];
+            const uint32_t incl = mr_scan(mine, lane);
+            uint32_t run = incl - mine;
+            for(int k=lane*per; k<min((lane+1)*per, n); k++) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
+            if(lane == 63) base_s = atomicAdd(&out[0], incl);       /* (lane 63 holds the total) */
+        }
+        __syncthreads();
+        const uint32_t base = base_s;
+        if((int)threadIdx.x < nrows) out[1 + y0 + threadIdx.x] = base + cnt[threadIdx.x*nit*4];
+        /* pass 2: the words */
+        for(int r=0; r<nrows; r++)
+        {
+            const int yo = y0 + r;
+            unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
+            unsigned char* flags = touched + (size_t)(H-1 - yo)*seg_stride;
+            for(int it=0; it<nit; it++)
+            {
+                if(!flags[it]) continue;                            /* (the same byte for the whole workgroup) */
+                const int c = (it << 8) + threadIdx.x;
+                unsigned long long key = HZ_FB_CLEAR;
+                if(c < SW)
+                {
+                    key = row[c];
+                    if(CLEAR && key != HZ_FB_CLEAR) row[c] = HZ_FB_CLEAR;
+                }
+                const bool terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX;
+                const unsigned long long b = __ballot(terrain);
+                if(terrain)
+                    out[HDR + base + cnt[(r*nit + it)*4 + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] =
+                        ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
+            }
+        }
+        __syncthreads();                                            /* every wave has read the flags and the prefixes */
+        if(CLEAR)
+            for(int k=threadIdx.x; k<nrows*nit; k+=256)
+                touched[(size_t)(H-1 - (y0 + k/nit))*seg_stride + (k % nit)] = 0;
         __syncthreads();
     }
 }
 
-/* the readback conversion on a sparse strip: columns [0,ncols) of the strip go
- * to columns out_col0.. of the full-width outputs */
+/* the readback conversion on sparse strips: columns [0,ncols) of strip k go to
+ * columns col0[k].. of the full-width outputs.  All strips of a panorama in one
+ * launch (blockIdx.y = strip); a thread takes four neighbouring OUTPUT pixels
+ * whose first column is a multiple of four, so that its results leave as one
+ * 12-byte and one 16-byte store whatever column the strip starts at. */
+#define HZ_MAX_STRIPS 16
+struct hz_strips_t
+{
+    const uint32_t* in[HZ_MAX_STRIPS];
+    int ncols[HZ_MAX_STRIPS], col0[HZ_MAX_STRIPS];
+};
+
 __global__ __launch_bounds__(256)
-void k_resolve_sparse(const uint32_t* __restrict__ in, int mask_stride, int ncols,
+void k_resolve_sparse(hz_strips_t st, int mask_stride,
                       const float* __restrict__ tanel,
                       unsigned char* __restrict__ bgr, float* __restrict__ ranges,
-                      int out_W, int out_col0, int H, float znear, float zfar)
+                      int out_W, int H, float znear, float zfar)
 {
-    __shared__ uint32_t wave_count[4];
+    __shared__ uint32_t wave_count[2][4];
+    const uint32_t* __restrict__ in = st.in[blockIdx.y];
+    const int ncols = st.ncols[blockIdx.y], out_col0 = st.col0[blockIdx.y];
+    if(ncols <= 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
+    const bool aligned = (out_W & 3) == 0 && (((uintptr_t)bgr | (uintptr_t)ranges) & 15u) == 0;
+    const int shift = out_col0 & 3;             /* strip column of a thread's first pixel = 4*k - shift */
     for(int yo = blockIdx.x; yo < H; yo += gridDim.x)
     {
         const uint32_t* mask = in + 1 + H + (size_t)yo*mask_stride;
         uint32_t run = in[1 + yo];
         const float tan_row = tanel[H-1 - yo];
-        for(int c0 = 0; c0 < ncols; c0 += 256)
+        int flip = 0;
+        for(int c0 = -shift; c0 < ncols; c0 += 1024, flip ^= 1)
         {
-            const int c = c0 + threadIdx.x;
-            const bool terrain = c < ncols && ((mask[c >> 5] >> (c & 31)) & 1u);
-            const unsigned long long b = __ballot(terrain);
-            __syncthreads();
-            if(lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
-            __syncthreads();
-            uint32_t before = 0;
-            for(int w=0; w<wave; w++) before += wave_count[w];
-            if(c < ncols)
+            const int c = c0 + 4*(int)threadIdx.x;
+            /* which of the four are columns of the strip, which of those are terrain */
+            uint32_t valid = 0, terrain = 0;
+            #pragma unroll
+            for(int k=0; k<4; k++)
             {
-                const size_t o = (size_t)yo*out_W + out_col0 + c;
-                uint32_t w = 0;
-                if(terrain) w = in[HDR + run + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))];
-                if(bgr)
+                const int col = c + k;
+                if(col >= 0 && col < ncols)
                 {
-                    bgr[o*3+0] = terrain ? 0 : 255;
-                    bgr[o*3+1] = 0;
-                    bgr[o*3+2] = terrain ? (unsigned char)(w & 0xFF) : 0;
-                }
-                if(ranges)
-                {
-                    float r = -1.0f;
-                    if(terrain)
-                    {
-                        const float depth = (float)((double)(w >> 8) * (1.0/16777215.0));
-                        const float len   = depth * (zfar-znear) + znear;
-                        const float zt    = tan_row * len;
-                        r = (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
-                    }
-                    ranges[o] = r;
+                    valid |= 1u << k;
+                    terrain |= ((mask[col >> 5] >> (col & 31)) & 1u) << k;
                 }
             }
-            run += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            const uint32_t mine = (uint32_t)__popc(terrain);
+            const uint32_t incl = mr_scan(mine, lane);
+            if(lane == 63) wave_count[flip][wave] = incl;
+            __syncthreads();                                            /* (two sets of counts in turn: one barrier per step) */
+            uint32_t before = 0, total = 0;
+            #pragma unroll
+            for(int w=0; w<4; w++) { const uint32_t v = wave_count[flip][w]; total += v; if(w < wave) before += v; }
+            uint32_t at = (uint32_t)HDR + run + before + incl - mine;
+            run += total;
+            if(!valid) continue;
+            uint32_t pix[4]; float rng[4];
+            #pragma unroll
+            for(int k=0; k<4; k++)
+            {
+                pix[k] = 0x0000FFu; rng[k] = -1.0f;                    /* sky: B = 255 (reference horizonator-lib.c:185), range -1 */
+                if((terrain >> k) & 1u)
+                {
+                    const uint32_t w = in[at++];
+                    pix[k] = (w & 0xFFu) << 16;                         /* terrain: R = shade (fragment.glsl:15-16) */
+                    rng[k] = hz_range_from_z24(w >> 8, tan_row, znear, zfar);
+                }
+            }
+            const size_t o = (size_t)yo*out_W + out_col0 + c;
+            if(valid == 0xFu && aligned)
+            {
+                if(bgr)
+                {
+                    uint3 w;
+                    w.x = pix[0] | (pix[1] << 24);
+                    w.y = (pix[1] >> 8) | (pix[2] << 16);
+                    w.z = (pix[2] >> 16) | (pix[3] << 8);
+                    *(uint3*)(bgr + o*3) = w;
+                }
+                if(ranges) { const float4 w = { rng[0], rng[1], rng[2], rng[3] }; *(float4*)(ranges + o) = w; }
+            }
+            else
+            {
+                #pragma unroll
+                for(int k=0; k<4; k++)
+                    if((valid >> k) & 1u)
+                    {
+                        if(bgr) { bgr[(o+k)*3+0] = (unsigned char)pix[k]; bgr[(o+k)*3+1] = 0; bgr[(o+k)*3+2] = (unsigned char)(pix[k] >> 16); }
+                        if(ranges) ranges[o+k] = rng[k];
+                    }
+            }
         }
         __syncthreads();
     }

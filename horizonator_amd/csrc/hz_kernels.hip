@@ -1208,9 +1208,10 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
 {
     HZ_ON_DEVICE(d);
     const int SW = d->col1 - d->col0;
-    if(d->tex_on || mask_stride < (SW + 31)/32)
+    if(d->tex_on || mask_stride < (SW + 31)/32 || SW > SP_MAXIT*256)
     {
         snprintf(g_last_error, sizeof(g_last_error), d->tex_on ? "hz_hip_pack_sparse: strips carry the shade only, not a textured colour"
+                                                    : SW > SP_MAXIT*256 ? "hz_hip_pack_sparse: sectors of up to 16384 columns"
                                                                : "hz_hip_pack_sparse: mask stride too small");
         return -1;
     }
@@ -1221,15 +1222,47 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
     HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->rstream));
     if(d->env.resolve_clears)
     {
-        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
-                           d->d_big_counters_s[d->fbi], d->d_big_counters_s[HZ_NFB + d->fbi]);
+        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)((d->H + SP_ROWS-1)/SP_ROWS)), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
+                           d->d_touched[d->fbi], d->seg_stride, d->d_big_counters_s[d->fbi], d->d_big_counters_s[HZ_NFB + d->fbi]);
         HZ_CHECK(hipGetLastError());
         if(fb_mark_consumed(d) != 0) return -1;
     }
     else
-        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)d->H), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride, (unsigned int*)NULL, (unsigned int*)NULL);
+        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)((d->H + SP_ROWS-1)/SP_ROWS)), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
+                           d->d_touched[d->fbi], d->seg_stride, (unsigned int*)NULL, (unsigned int*)NULL);
     HZ_CHECK(hipGetLastError());
     if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
+    return 0;
+}
+
+extern "C" int hz_hip_resolve_sparse_strips(hz_dev_t* d, const hz_view_t* view, const float* tanel, int nstrips,
+                                            const uint32_t* const* d_in, int mask_stride, const int* ncols, const int* out_col0,
+                                            unsigned char* d_bgr, float* d_ranges)
+{
+    HZ_ON_DEVICE(d);
+    if(nstrips < 0 || (nstrips > 0 && (!d_in || !ncols || !out_col0)))
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_sparse_strips: bad arguments");
+        return -1;
+    }
+    for(int k=0; k<nstrips; k++)
+        if(ncols[k] < 0 || (ncols[k] > 0 && (mask_stride < (ncols[k] + 31)/32 || out_col0[k] < 0 || out_col0[k] + ncols[k] > d->W || !d_in[k])))
+        {
+            snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_sparse_strips: columns [%d,%d) of strip %d do not fit a %d-wide image",
+                     out_col0[k], out_col0[k] + ncols[k], k, d->W);
+            return -1;
+        }
+    if(d_ranges && upload_tanel(d, tanel) != 0) return -1;
+    for(int k0=0; k0<nstrips; k0+=HZ_MAX_STRIPS)
+    {
+        hz_strips_t st;
+        memset(&st, 0, sizeof(st));
+        const int n = nstrips - k0 < HZ_MAX_STRIPS ? nstrips - k0 : HZ_MAX_STRIPS;
+        for(int k=0; k<n; k++) { st.in[k] = d_in[k0+k]; st.ncols[k] = ncols[k0+k]; st.col0[k] = out_col0[k0+k]; }
+        hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)d->H, (unsigned)n), dim3(256), 0, d->rstream,
+                           st, mask_stride, (const float*)d->d_tanel, d_bgr, d_ranges, d->W, d->H, view->znear, view->zfar);
+        HZ_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1237,19 +1270,13 @@ extern "C" int hz_hip_resolve_sparse(hz_dev_t* d, const hz_view_t* view, const f
                                      const uint32_t* d_in, int mask_stride, int ncols, int out_col0,
                                      unsigned char* d_bgr, float* d_ranges)
 {
-    HZ_ON_DEVICE(d);
-    if(ncols <= 0 || mask_stride < (ncols + 31)/32 || out_col0 < 0 || out_col0 + ncols > d->W)
+    if(ncols <= 0)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_sparse: columns [%d,%d) do not fit a %d-wide image",
                  out_col0, out_col0 + ncols, d->W);
         return -1;
     }
-    if(d_ranges && upload_tanel(d, tanel) != 0) return -1;
-    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)d->H), dim3(256), 0, d->rstream,
-                       d_in, mask_stride, ncols, (const float*)d->d_tanel, d_bgr, d_ranges,
-                       d->W, out_col0, d->H, view->znear, view->zfar);
-    HZ_CHECK(hipGetLastError());
-    return 0;
+    return hz_hip_resolve_sparse_strips(d, view, tanel, 1, &d_in, mask_stride, &ncols, &out_col0, d_bgr, d_ranges);
 }
 
 static int ensure_out_buffers(hz_dev_t* d, bool bgr, bool ranges, bool index, bool z24)

@@ -178,6 +178,11 @@ int  hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride);
 int  hz_hip_resolve_sparse(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                            const uint32_t* d_in, int mask_stride, int ncols, int out_col0,
                            unsigned char* d_bgr, float* d_ranges);
+/* ... all strips of a panorama in one launch: strip k = d_in[k] (DEVICE), ncols[k] columns
+ * (0: skipped) that go to out_col0[k] */
+int  hz_hip_resolve_sparse_strips(hz_dev_t* d, const hz_view_t* view, const float* tanel, int nstrips,
+                                  const uint32_t* const* d_in, int mask_stride, const int* ncols, const int* out_col0,
+                                  unsigned char* d_bgr, float* d_ranges);
 
 /* uniforms of the texture half of the reference's vertex shader
  * (vertex.glsl:16-21; values as horizonator-lib.c:577-588,801-809 sets them)
