@@ -213,91 +213,170 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
  * any order in the data (row_base says where): one block per row, one atomic
  * per row for its base.  The buffer must hold HDR + H*SW words; [0] must be 0
  * on entry. */
-/* One workgroup packs SP_ROWS consecutive rows and takes their place in the data
- * with ONE atomic: a row's base used to be an atomic of its own, 4000 of them on
- * one address per strip - they are serialised at ~10 ns each, 40 of the kernel's
- * 65 us for a 2000 x 4000 strip.  First pass: mask and per-wave counts of every
- * row (LDS); the segments nothing was drawn into (`touched`, as in k_resolve4) are
- * sky without being read.  Second pass: the words, re-read from L2. */
-#define SP_ROWS   8
-#define SP_MAXIT  64                    /* 256-pixel steps per row: sectors up to 16384 columns */
+/* One WAVE packs one row, four pixels per lane and step (a step = one 256-pixel
+ * segment, as in k_resolve4): all loads of a row of up to 2048 pixels are in
+ * flight at once and the words stay in registers between the count and the
+ * write-out - a kernel that walked a row 256 pixels at a time, one pixel per
+ * thread, with a dependent load and two barriers per step, took 65 us for a
+ * 2000 x 4000 strip (1 TB/s); wider rows are read twice (the second time from
+ * L2).  Segments nothing was drawn into (`touched`) are sky without being read.
+ * The four rows of a workgroup take their place in the data with ONE atomic
+ * (same-address atomics are serialised at ~10 ns each). */
+#define SP_WAVES  4                     /* rows per workgroup                            */
+#define SP_STEPS  8                     /* steps whose words stay in registers           */
+#define SP_MAXIT  64                    /* steps per row: sectors up to 16384 columns    */
+
+/* one step of one row: loads, terrain bits (nibble per lane), mask words */
+__device__ static inline uint32_t sp_step(const unsigned long long* row, int SW, int it, int lane, bool flagged,
+                                          unsigned long long key[4], uint32_t* mask)
+{
+    const int c = (it << 8) + 4*lane;
+    key[0] = key[1] = key[2] = key[3] = HZ_FB_CLEAR;
+    if(flagged)
+    {
+        if(c + 3 < SW && (SW & 3) == 0)
+        {
+            const ulonglong2 a = *(const ulonglong2*)(row + c), b = *(const ulonglong2*)(row + c + 2);
+            key[0] = a.x; key[1] = a.y; key[2] = b.x; key[3] = b.y;
+        }
+        else
+        {
+            #pragma unroll
+            for(int k=0; k<4; k++) if(c + k < SW) key[k] = row[c + k];
+        }
+    }
+    uint32_t nib = 0;
+    #pragma unroll
+    for(int k=0; k<4; k++) nib |= ((uint32_t)(key[k] >> 40) != HZ_Z24_MAX ? 1u : 0u) << k;
+    /* mask word w of the segment = the nibbles of lanes 8w..8w+7 */
+    uint32_t v = nib << (4*(lane & 7));
+    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
+    if((lane & 7) == 0 && (it << 8) + 4*lane < SW) mask[(it << 3) + (lane >> 3)] = v;
+    return nib;
+}
+
+/* the words of one step: `at` = where the step's first word goes */
 template<bool CLEAR>
-__global__ __launch_bounds__(256)
+__device__ static inline uint32_t sp_emit(unsigned long long* row, int SW, int it, int lane, uint32_t nib,
+                                          const unsigned long long key[4], uint32_t* data, uint32_t at)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long b[4];
+    #pragma unroll
+    for(int k=0; k<4; k++) b[k] = __ballot((nib >> k) & 1u);
+    uint32_t o = at + (uint32_t)(__popcll(b[0] & lt) + __popcll(b[1] & lt) + __popcll(b[2] & lt) + __popcll(b[3] & lt));
+    #pragma unroll
+    for(int k=0; k<4; k++)
+        if((nib >> k) & 1u) data[o++] = ((uint32_t)(key[k] >> 40) << 8) | (uint32_t)(key[k] & 0xFF);
+    if(CLEAR)
+    {
+        const int c = (it << 8) + 4*lane;
+        if(c + 3 < SW && (SW & 3) == 0)
+        {
+            const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
+            if((key[0] & key[1]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c)     = ones;
+            if((key[2] & key[3]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c + 2) = ones;
+        }
+        else
+        {
+            #pragma unroll
+            for(int k=0; k<4; k++) if(c + k < SW && key[k] != HZ_FB_CLEAR) row[c + k] = HZ_FB_CLEAR;
+        }
+    }
+    return at + (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+}
+
+template<bool CLEAR>
+__global__ __launch_bounds__(64*SP_WAVES)
 void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ out,
                    int SW, int H, int mask_stride, unsigned char* __restrict__ touched, int seg_stride,
                    unsigned int* qa, unsigned int* qb)
 {
-    static_assert(HZ_SEG == 256, "k_pack_sparse: one step of the workgroup = one segment");
-    __shared__ uint32_t cnt[SP_ROWS*SP_MAXIT*4];        /* terrain pixels per (row, step, wave); then their exclusive prefix */
-    __shared__ uint32_t base_s;
+    static_assert(HZ_SEG == 256, "k_pack_sparse: one step of a wave = one segment");
+    __shared__ uint32_t row_count[SP_WAVES], row_base[SP_WAVES];
     if(CLEAR && blockIdx.x == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t HDR = 1 + (size_t)H + (size_t)H*mask_stride;
+    uint32_t* data = out + 1 + (size_t)H + (size_t)H*mask_stride;
     const int nit = (SW + 255) >> 8;
-    for(int y0 = blockIdx.x*SP_ROWS; y0 < H; y0 += gridDim.x*SP_ROWS)
+    const bool cached = nit <= SP_STEPS;
+    for(int y0 = blockIdx.x*SP_WAVES; y0 < H; y0 += gridDim.x*SP_WAVES)
     {
-        const int nrows = min(SP_ROWS, H - y0);
-        /* pass 1: masks and counts */
-        for(int r=0; r<nrows; r++)
+        const int yo = y0 + wave;
+        const bool have = yo < H;
+        unsigned long long* row = fb + (size_t)(H-1 - (have ? yo : 0))*SW;
+        unsigned char* flags = touched + (size_t)(H-1 - (have ? yo : 0))*seg_stride;
+        uint32_t* mask = out + 1 + H + (size_t)(have ? yo : 0)*mask_stride;
+        unsigned long long key[SP_STEPS][4];
+        uint32_t nibs = 0;                                  /* the nibbles of the cached steps */
+        unsigned long long flagged = 0;                     /* bit it: segment `it` of the row has been drawn into */
+        uint32_t count = 0;
+        if(have)
         {
-            const int yo = y0 + r;
-            const unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
-            const unsigned char* flags = touched + (size_t)(H-1 - yo)*seg_stride;
-            uint32_t* mask = out + 1 + H + (size_t)yo*mask_stride;
-            for(int it=0; it<nit; it++)
+            for(int it=lane; it<nit; it+=64) if(flags[it]) flagged |= 1ull << it;
+            #pragma unroll
+            for(int m=32; m>=1; m>>=1) flagged |= __shfl_xor(flagged, m);
+            if(cached)
             {
-                const int c = (it << 8) + threadIdx.x;
-                const bool terrain = c < SW && flags[it] && (uint32_t)(row[c] >> 40) != HZ_Z24_MAX;
-                const unsigned long long b = __ballot(terrain);
-                if(lane == 0  && (it << 8) + wave*64      < SW) mask[(it << 3) + wave*2]     = (uint32_t)b;
-                if(lane == 32 && (it << 8) + wave*64 + 32 < SW) mask[(it << 3) + wave*2 + 1] = (uint32_t)(b >> 32);
-                if(lane == 0) cnt[(r*nit + it)*4 + wave] = (uint32_t)__popcll(b);
+                #pragma unroll
+                for(int it=0; it<SP_STEPS; it++)
+                    if(it < nit)
+                    {
+                        const uint32_t nib = sp_step(row, SW, it, lane, (flagged >> it) & 1ull, key[it], mask);
+                        nibs |= nib << (4*it);
+                    }
+                count = (uint32_t)__popc(nibs);
             }
-        }
-        __syncthreads();
-        /* exclusive prefix over the counts in data order (row, step, wave), by the first wave: every
-         * lane sums a run of consecutive entries, the runs are scanned across the lanes */
-        const int n = nrows*nit*4, per = (n + 63) >> 6;
-        if(wave == 0)
-        {
-            uint32_t mine = 0;
-            for(int k=lane*per; k<min((lane+1)*per, n); k++) mine += cnt[k];
-            const uint32_t incl = mr_scan(mine, lane);
-            uint32_t run = incl - mine;
-            for(int k=lane*per; k<min((lane+1)*per, n); k++) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
-            if(lane == 63) base_s = atomicAdd(&out[0], incl);       /* (lane 63 holds the total) */
-        }
-        __syncthreads();
-        const uint32_t base = base_s;
-        if((int)threadIdx.x < nrows) out[1 + y0 + threadIdx.x] = base + cnt[threadIdx.x*nit*4];
-        /* pass 2: the words */
-        for(int r=0; r<nrows; r++)
-        {
-            const int yo = y0 + r;
-            unsigned long long* row = fb + (size_t)(H-1 - yo)*SW;
-            unsigned char* flags = touched + (size_t)(H-1 - yo)*seg_stride;
-            for(int it=0; it<nit; it++)
-            {
-                if(!flags[it]) continue;                            /* (the same byte for the whole workgroup) */
-                const int c = (it << 8) + threadIdx.x;
-                unsigned long long key = HZ_FB_CLEAR;
-                if(c < SW)
+            else
+                for(int it=0; it<nit; it++)
                 {
-                    key = row[c];
-                    if(CLEAR && key != HZ_FB_CLEAR) row[c] = HZ_FB_CLEAR;
+                    unsigned long long k4[4];
+                    count += (uint32_t)__popc(sp_step(row, SW, it, lane, (flagged >> it) & 1ull, k4, mask));
                 }
-                const bool terrain = (uint32_t)(key >> 40) != HZ_Z24_MAX;
-                const unsigned long long b = __ballot(terrain);
-                if(terrain)
-                    out[HDR + base + cnt[(r*nit + it)*4 + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] =
-                        ((uint32_t)(key >> 40) << 8) | (uint32_t)(key & 0xFF);
-            }
+            #pragma unroll
+            for(int m=32; m>=1; m>>=1) count += __shfl_xor(count, m);
         }
-        __syncthreads();                                            /* every wave has read the flags and the prefixes */
-        if(CLEAR)
-            for(int k=threadIdx.x; k<nrows*nit; k+=256)
-                touched[(size_t)(H-1 - (y0 + k/nit))*seg_stride + (k % nit)] = 0;
+        if(lane == 0) row_count[wave] = count;
         __syncthreads();
+        if(threadIdx.x == 0)
+        {
+            uint32_t total = 0;
+            #pragma unroll
+            for(int w=0; w<SP_WAVES; w++) { row_base[w] = total; total += row_count[w]; }
+            const uint32_t base = atomicAdd(&out[0], total);
+            #pragma unroll
+            for(int w=0; w<SP_WAVES; w++) row_base[w] += base;
+        }
+        __syncthreads();
+        if(have)
+        {
+            uint32_t at = row_base[wave];
+            if(lane == 0) out[1 + yo] = at;
+            if(cached)
+            {
+                #pragma unroll
+                for(int it=0; it<SP_STEPS; it++)
+                    if(it < nit && ((flagged >> it) & 1ull))
+                        at = sp_emit<CLEAR>(row, SW, it, lane, (nibs >> (4*it)) & 0xFu, key[it], data, at);
+            }
+            else
+                for(int it=0; it<nit; it++)
+                    if((flagged >> it) & 1ull)
+                    {
+                        /* (read again: the row has just been through this XCD's L2) */
+                        unsigned long long k4[4];
+                        const int c = (it << 8) + 4*lane;
+                        uint32_t nib = 0;
+                        #pragma unroll
+                        for(int k=0; k<4; k++)
+                        {
+                            k4[k] = c + k < SW ? row[c + k] : HZ_FB_CLEAR;
+                            nib |= ((uint32_t)(k4[k] >> 40) != HZ_Z24_MAX ? 1u : 0u) << k;
+                        }
+                        at = sp_emit<CLEAR>(row, SW, it, lane, nib, k4, data, at);
+                    }
+            if(CLEAR) for(int it=lane; it<nit; it+=64) if((flagged >> it) & 1ull) flags[it] = 0;
+        }
+        __syncthreads();                                    /* row_count / row_base are reused */
     }
 }
 

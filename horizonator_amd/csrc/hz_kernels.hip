@@ -1222,13 +1222,13 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
     HZ_CHECK(hipMemsetAsync(d_out, 0, sizeof(uint32_t), d->rstream));
     if(d->env.resolve_clears)
     {
-        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)((d->H + SP_ROWS-1)/SP_ROWS)), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
+        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)((d->H + SP_WAVES-1)/SP_WAVES)), dim3(64*SP_WAVES), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
                            d->d_touched[d->fbi], d->seg_stride, d->d_big_counters_s[d->fbi], d->d_big_counters_s[HZ_NFB + d->fbi]);
         HZ_CHECK(hipGetLastError());
         if(fb_mark_consumed(d) != 0) return -1;
     }
     else
-        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)((d->H + SP_ROWS-1)/SP_ROWS)), dim3(256), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
+        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)((d->H + SP_WAVES-1)/SP_WAVES)), dim3(64*SP_WAVES), 0, d->rstream, d->d_fb, d_out, SW, d->H, mask_stride,
                            d->d_touched[d->fbi], d->seg_stride, (unsigned int*)NULL, (unsigned int*)NULL);
     HZ_CHECK(hipGetLastError());
     if(prof) { HZ_CHECK(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
