@@ -101,6 +101,7 @@ struct hz_env_t
     int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
     int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
+    int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static hz_env_t read_env(void)
@@ -117,6 +118,7 @@ static hz_env_t read_env(void)
     e.always_wait_near = getenv("HZ_ALWAYS_WAIT_NEAR") != NULL;
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
+    e.far_rows         = env_int("HZ_FAR_ROWS", 0);
     return e;
 }
 
@@ -546,7 +548,7 @@ extern "C" int hz_hip_wait_for(hz_dev_t* d, void* stream)
 
 /* segment zones of k_march for this view: a cell `r` rows away from the viewer
  * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
-static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first)
+static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first, int far_rows_forced = 0)
 {
     const float ppr = p.halfW * p.u.az_ndc_per_rad;
     const int   ncr = p.N-1;                                /* cell rows */
@@ -570,6 +572,7 @@ static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first)
     int far_rows = 64*p.SW/p.W;
     if(far_rows < 16) far_rows = 16;
     if(far_rows > 64) far_rows = 64;
+    if(far_rows_forced >= 2 && far_rows_forced <= 64) far_rows = far_rows_forced;
     const int rows[MR_NZONES] = { far_rows, 16, 4, 2, 4, 16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
@@ -954,7 +957,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     else
     {
         const bool two_pass = plan_rounds(d, view, p);
-        const mr_zones_t zn = mr_make_zones(p, two_pass);
+        const mr_zones_t zn = mr_make_zones(p, two_pass, d->env.far_rows);
         /* sectors and views of less than the full circle: only the strips behind the drawn columns */
         double a0 = 0, a1 = 0;
         const bool listed = !d->env.no_worklist && azimuths_of_columns(p, &a0, &a1) && zn.total < (1 << (32 - MR_ITEM_SX_BITS))
@@ -1810,7 +1813,7 @@ extern "C" long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view
     d->seg_stride = (W + HZ_SEG-1)/HZ_SEG;
     hz_params_t p = make_params(d, view);
     (void)plan_rounds(d, view, p);
-    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0);
+    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0, d->env.far_rows);
     free(d);
     p.pass = round & 3;
     double a0 = 0, a1 = 0;
