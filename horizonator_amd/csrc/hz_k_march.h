@@ -25,9 +25,8 @@
 #define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
 #define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
-#define MR_NEAR_CELLS 128            /* round 1 of a draw: strips within this many cells of the viewer (32: 1.085 ms per
-                                      * 16000x4000 render, 64: 1.063, 96: 1.056, 128: 1.052, 192: 1.064, 256: 1.12) */
-
+/* round 1 of a draw takes the strips within ppr/20 cells of the viewer (draw_impl: plan_rounds); timed at 16000x4000,
+ * round 2: 32 cells 1.085 ms per render, 64: 1.063, 96: 1.056, 128: 1.052, 192: 1.064, 256: 1.12 */
 #define HZ_NEAR_CELLS_MAX 256       /* the first rounds' queue sets are sized for a reach of this many cells (or HZ_NEAR_CELLS, if larger) */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one

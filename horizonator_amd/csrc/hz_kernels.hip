@@ -96,12 +96,13 @@ struct hz_env_t
     int    march_debug;             /* HZ_MARCH_DEBUG: timing splits (wrong pictures), see hz_params_t::debug */
     int    no_fast_math;            /* HZ_NO_FAST_MATH=1: the unabridged transform everywhere */
     int    two_pass;                /* HZ_TWO_PASS=0/1 forces one / two rounds; -1: the draw decides */
-    int    near_cells;              /* HZ_NEAR_CELLS: the first round's reach in cells; -1: MR_NEAR_CELLS */
+    int    near_cells;              /* HZ_NEAR_CELLS: the first round's reach in cells; -1: from the view (plan_rounds) */
     double two_pass_min_mpix;       /* HZ_TWO_PASS_MIN_MPIX (default 24) */
     int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
     int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
+    double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static hz_env_t read_env(void)
@@ -119,6 +120,8 @@ static hz_env_t read_env(void)
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
+    e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
+    if(!(e.near_px >= 0.5)) e.near_px = 20.0;
     return e;
 }
 
@@ -911,7 +914,19 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
 static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
 {
     const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
-    const int near_cells = d->env.near_cells >= 0 ? d->env.near_cells : MR_NEAR_CELLS;
+    /* The first round's reach: the cells that are wider than ~20 pixels on screen - a cell r rows
+     * from the viewer is about ppr/r pixels wide (ppr = pixels per radian of azimuth), so r = ppr/20:
+     * 127 cells for a 16000-wide panorama (where 32..256 were timed: hz_k_march.h), 64 for 8000, 256
+     * (the most the first rounds' queues are sized for) from 32768 on and for zoomed views.
+     * profiles/r3_scenes.json holds the sweep over the scenes of tools/scenes.py. */
+    int near_cells = d->env.near_cells;
+    if(near_cells < 0)
+    {
+        const float ppr = p.halfW * p.u.az_ndc_per_rad;
+        near_cells = (int)(ppr / (float)d->env.near_px + 0.5f);
+        if(near_cells < 16) near_cells = 16;
+        if(near_cells > HZ_NEAR_CELLS_MAX) near_cells = HZ_NEAR_CELLS_MAX;
+    }
     p.near_x0 = (int)floorf((p.u.viewer_cell_i - (float)near_cells)/(float)MR_COLS);
     p.near_x1 = (int)floorf((p.u.viewer_cell_i + (float)near_cells)/(float)MR_COLS);
     if(p.near_x0 < 0) p.near_x0 = 0;
