@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # SURVEY.md section 8(d) / BASELINE.md section 3
 CONFIGS = {
@@ -44,8 +45,11 @@ def parse():
                     help="far clip range in m; 600 km keeps every triangle of the mosaic live")
     ap.add_argument("--raster", type=int, default=0, help="HZ_RASTER_* (0 auto, 1 scatter, 2 march)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary zfar=40 km measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (zfar = 40 km, the scenes)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-inclusive measurement (results into host memory)")
+    ap.add_argument("--no-scenes", action="store_true",
+                    help="skip the scenes the kernel was not tuned on (tools/scenes.py: rough DEM, summit, valley, 45 degree zoom, "
+                         "configs[1], configs[3], configs[4]; a few renders each)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="diagnostics: gloo moves the strips through host memory (lets two ranks share one GPU "
                          "to exercise the N>1 loop where only one GPU exists); the driver's runs use nccl = RCCL")
@@ -408,20 +412,25 @@ def main():
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    traffic_note = ("RECORDED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, "
+                    "profiles/pmc_latest.json") if traffic is not None else None
 
     # what actually bounds the dominant kernel: the SIMDs' vector issue slots.
     # Recorded counters of the same workload (profiles/), set against the duration measured now.
     valu = None
-    mix = os.path.join(ROOT, "profiles", "pmc_r2_instruction_mix_cfg3.json")
+    mix = os.path.join(ROOT, "profiles", "pmc_r3_instruction_mix_cfg3.json")
+    if not os.path.exists(mix):
+        mix = os.path.join(ROOT, "profiles", "pmc_r2_instruction_mix_cfg3.json")
     if args.config == "cfg3" and args.zfar == 600000.0 and world == 1 and args.raster in (0, 2) and os.path.exists(mix):
         try:
             rec = json.load(open(mix))
             far = max((v for k, v in rec.items() if k.startswith("k_march grid")), key=lambda v: v["SQ_INSTS_VALU"])
             busy_ms = far["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3     # quad-cycles -> cycles, 1024 SIMDs at 2.4 GHz
-            valu = {"wave_instructions": far["SQ_INSTS_VALU"], "active_quad_cycles": far["SQ_ACTIVE_INST_VALU"],
+            valu = {"recorded": True, "wave_instructions": far["SQ_INSTS_VALU"], "active_quad_cycles": far["SQ_ACTIVE_INST_VALU"],
                     "cycles_per_instruction": 4.0 * far["SQ_ACTIVE_INST_VALU"] / far["SQ_INSTS_VALU"],
                     "issue_busy_ms": busy_ms, "frac_of_kernel_ms": busy_ms / raster_ms,
-                    "source": "profiles/pmc_r2_instruction_mix_cfg3.json (recorded), profiles/valu_issue.json (issue rates per instruction kind)"}
+                    "source": "counters RECORDED in profiles/" + os.path.basename(mix) + " (a rocprofv3 --pmc run of this workload), set against the "
+                              "kernel duration measured live in this run; issue rates per instruction kind: profiles/valu_issue.json"}
         except Exception:
             valu = None
 
@@ -474,11 +483,15 @@ def main():
         mosaic = od.mosaic()
         v = od.view(LAT, LON, W, H, -180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
         cores = os.cpu_count() or 1
-        t0 = time.perf_counter()
-        oracle.render(mosaic, v, W, H, want=("bgr", "ranges"))
-        cdt = time.perf_counter() - t0
+        samples = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.render(mosaic, v, W, H, want=("bgr", "ranges"))
+            samples.append(time.perf_counter() - t0)
+        cdt = float(np.median(samples))
         cpu = {"value": W * H / cdt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
-               "sample": f"1 full {W}x{H} render of the same workload by oracle/ (C + OpenMP, {cores} threads), {cdt:.1f} s"}
+               "sample": f"3 full {W}x{H} renders of the same workload by oracle/ (C + OpenMP, {cores} threads): "
+                         + ", ".join(f"{x:.2f}" for x in samples) + " s; value = the median"}
 
     # the reference's own shaders on Mesa llvmpipe cannot run on the GPU box (neither /root/reference nor Mesa's
     # software driver is there): what tools/llvmpipe_timing.py measured in the build container, with its machine
@@ -493,6 +506,25 @@ def main():
                                "recorded in the build container by tools/llvmpipe_timing.py (profiles/llvmpipe_timing.json), not measured in this run"}
     except Exception:
         ref_rec = None
+
+    # scenes the kernel was not tuned on: a few renders each, ms per render and picoseconds per
+    # triangle of the mosaic; profiles/r3_scenes.json holds the same scenes with the waves' counters
+    scene_recs = None
+    if rank == 0 and world == 1 and not args.no_scenes and not args.no_extra:
+        import scenes
+        scene_recs = {}
+        cache = {"key": (R, W, H, False, False), "h": h} if args.config == "cfg3" else {}
+        for name in [n for n in scenes.DEFAULT if n != args.config]:
+            try:
+                scene_recs[name] = scenes.run_scene(name, steps=8, counters=False, cache=cache)
+            except Exception as e:      # never lose the line over an extra
+                scene_recs[name] = {"error": repr(e)}
+        if cache.get("h") is not None and cache["h"] is not h:
+            cache["h"].close()
+        head = value and (1e12 / (value * 1e6) * W * H / (2 * (N - 1) ** 2))      # ps per triangle of the headline run
+        for rec in scene_recs.values():
+            if "ps_per_triangle" in rec and head:
+                rec["ps_per_triangle_vs_headline"] = rec["ps_per_triangle"] / head
 
     if rank == 0:
         line = {
@@ -515,7 +547,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "k_scatter" if args.raster == 1 else "k_march", "kernel_ms": raster_ms,
                 "kernel_launch": ("second round of a two-round draw: every strip but those next to the viewer (the first round's "
                                   "k_march is in other_kernels_ms.round1_near_viewer with its queue kernels)") if near_ms > 0.05 else "the draw's only k_march launch",
@@ -531,6 +563,8 @@ def main():
         }
         if host_incl is not None:
             line["host_inclusive"] = host_incl
+        if scene_recs is not None:
+            line["scenes"] = scene_recs
         if verified is not None:
             line["gathered_panorama_equals_single_gpu_render"] = verified
         line.update(extra)

@@ -26,6 +26,7 @@ struct hz_params_t
     int   near_x0, near_x1;            /* strip columns [x0,x1] and                                             */
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
+    int   pretest;                     /* k_big: read a framebuffer word before the atomic and skip fragments that cannot win */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
     float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
     int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */

@@ -353,7 +353,13 @@ void k_big(unsigned long long* __restrict__ fb,
             {
                 uint32_t zi, r8;
                 if(hz_tri_fragment(&tri, px, py, &zi, &r8))
-                    hz_fb_min(fb, p, px, py, hz_pack(zi, prim, r8));
+                {
+                    const unsigned long long key = hz_pack(zi, prim, r8);
+                    /* p.pretest (views with heavy overdraw, see plan_rounds): look first, and leave the atomic
+                     * out where the fragment cannot win - a stale larger value only costs the atomic */
+                    if(!p.pretest || key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        hz_fb_min(fb, p, px, py, key);
+                }
             }
         }
     }

@@ -97,11 +97,12 @@ struct hz_env_t
     int    no_fast_math;            /* HZ_NO_FAST_MATH=1: the unabridged transform everywhere */
     int    two_pass;                /* HZ_TWO_PASS=0/1 forces one / two rounds; -1: the draw decides */
     int    near_cells;              /* HZ_NEAR_CELLS: the first round's reach in cells; -1: from the view (plan_rounds) */
-    double two_pass_min_mpix;       /* HZ_TWO_PASS_MIN_MPIX (default 24) */
+    double two_pass_min_mpix;       /* HZ_TWO_PASS_MIN_MPIX (default 6) */
     int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
     int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
+    int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -115,11 +116,12 @@ static hz_env_t read_env(void)
     e.no_fast_math     = env_int("HZ_NO_FAST_MATH", 0) != 0;
     e.two_pass         = getenv("HZ_TWO_PASS") ? (env_int("HZ_TWO_PASS", 0) != 0) : -1;
     e.near_cells       = getenv("HZ_NEAR_CELLS") ? env_int("HZ_NEAR_CELLS", 0) : -1;
-    e.two_pass_min_mpix= getenv("HZ_TWO_PASS_MIN_MPIX") ? atof(getenv("HZ_TWO_PASS_MIN_MPIX")) : 24.0;
+    e.two_pass_min_mpix= getenv("HZ_TWO_PASS_MIN_MPIX") ? atof(getenv("HZ_TWO_PASS_MIN_MPIX")) : 6.0;
     e.always_wait_near = getenv("HZ_ALWAYS_WAIT_NEAR") != NULL;
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
+    e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
     if(!(e.near_px >= 0.5)) e.near_px = 20.0;
     return e;
@@ -324,14 +326,18 @@ static int create_impl(hz_dev_t* d)
     }
     d->fbi = HZ_NFB-1; d->d_fb = d->d_fbs[HZ_NFB-1];
     /* queues of triangles too large for the marching wave (k_scatter: for the in-block
-     * pass).  cfg3 (16000x4000) produces ~0.3 M records and ~0.4 M work items; the sizes
-     * follow the image, 2^21 records for 64 Mpix and more (a full queue is correct,
-     * only slow: the producer then rasterises on the spot).  A first round only sees
-     * the triangles of the strips next to the viewer - at most 2*(2r+2)*(2r+126)
-     * for a reach of r cells - and never queues medium boxes. */
+     * pass).  The benchmark panorama (16000x4000) produces ~0.3 M records and ~0.4 M work
+     * items, a 45 degree view of the same size 1.5 M records (every triangle covers 64
+     * times the pixels).  A full queue is correct but slow - the producer then rasterises
+     * on the spot, one lane per triangle: the zoomed view took 48 ms instead of 4 with
+     * queues of a million records - so the sizes follow the image generously, one record
+     * per 16 pixels (HBM is not what this path is short of): 4 M records = 0.4 GB per set
+     * for 64 Mpix, 32 K for the smallest contexts.  A first round only sees the triangles
+     * of the strips next to the viewer - at most 2*(2r+2)*(2r+126) for a reach of r
+     * cells - and never queues medium boxes. */
     {
-        const size_t mpix64 = (size_t)d->W*d->H/64;
-        unsigned int rec = mpix64 > (1u<<21) ? (1u<<21) : mpix64 < (1u<<15) ? (1u<<15) : (unsigned int)mpix64;
+        const size_t per16 = (size_t)d->W*d->H/16;
+        unsigned int rec = per16 > (1u<<24) ? (1u<<24) : per16 < (1u<<15) ? (1u<<15) : (unsigned int)per16;
         d->bigrec_capacity  = rec;
         d->bigitem_capacity = 2*rec;
         d->midrec_capacity  = rec;
@@ -638,6 +644,7 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.z_guard = 1.0f/500.0f + (float)(d->W > d->H ? d->W : d->H) * (1.0f/4194304.0f);
     p.z_hide_k = 1.03f * p.z_guard * 16777215.f;
     p.quad_max_dx = d->W >= 64 && d->W <= (1<<20) ? 256*(d->W/16 - 1) : 0;
+    p.pretest = d->env.pretest > 0 ? 1 : 0;
     p.debug   = d->env.march_debug;
     p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
     return p;
@@ -812,8 +819,8 @@ static int upload_list(hz_dev_t* d, int which, hipStream_t st, const std::vector
  * their framebuffer (hz_counters_consume; no launch for that in front of k_march).
  *
  * HZ_TWO_PASS=0/1 forces one / two rounds; otherwise contexts of at least
- * HZ_TWO_PASS_MIN_MPIX (default 24) megapixels whose far clip lies well
- * beyond the first round's strips draw in two rounds. */
+ * HZ_TWO_PASS_MIN_MPIX (default 6) megapixels whose far clip lies well
+ * beyond the first round's strips draw in two rounds (plan_rounds). */
 static int draw_impl(hz_dev_t* d, const hz_view_t* view);
 
 extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
@@ -933,18 +940,18 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
     if(p.near_x1 > nsx-1) p.near_x1 = nsx-1;
     p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
     p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
-    /* two rounds pay where there is a lot of terrain behind the first round's
-     * strips: a large image (many pixel tests to save) and a far clip well
-     * beyond them - with the API's default 40 km far clip most of a large
-     * mosaic is never transformed at all and one round is faster (measured:
-     * 16000x4000 over 7x7 tiles, 0.85 vs 0.91 ms).  An azimuth sector of such an image
-     * (one GPU of several) draws in two rounds as well: its renders overlap just the
-     * same, and the rank that also converts everybody's strips gains most (own sector
-     * + conversion of all strips, 2 / 4 / 8 sectors: 1.37 -> 1.18, 0.99 -> 0.81,
-     * 0.80 -> 0.66 ms per panorama; tools/sector_timing.py) */
+    /* Two rounds pay where there is terrain behind the first round's strips to be hidden by them
+     * and enough pixels for the second round's early depth test to save work; a small image is
+     * faster in one round (three kernel launches less).  Measured over the scenes of tools/scenes.py
+     * (profiles/r3_scenes.json, ms per render one round / two rounds): 2000x500 0.143 / 0.167,
+     * 4000x1000 0.224 / 0.225, 8000x2000 0.353 / 0.316 (a batch of viewpoints of that size 0.512 /
+     * 0.465), 16000x4000 1.33 / 1.12, with the API's 40 km far clip 0.752 / 0.725, 32768x8192 12.5 /
+     * 11.1 - so: from 6 Mpix on, and a far clip at least three reaches of the first round away.
+     * (Round 2 drew this line at 24 Mpix and 12 reaches, from the benchmark scene alone.)  Azimuth
+     * sectors decide by the size of the whole image: their renders overlap just the same. */
     const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
     const bool want_two = d->env.two_pass >= 0 ? d->env.two_pass != 0
-                             : ((double)p.W*(double)p.H >= d->env.two_pass_min_mpix*1e6 && cells_to_zfar >= 1536.0f && cells_to_zfar >= 12.0f*(float)near_cells);
+                             : ((double)p.W*(double)p.H >= d->env.two_pass_min_mpix*1e6 && cells_to_zfar >= 3.0f*(float)near_cells);
     return want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
 }
 

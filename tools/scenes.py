@@ -9,7 +9,7 @@ bench.py runs the same scenes (small step counts) and puts them into its line un
 tools/gpu_scenes.sh sweeps the library's heuristics (first round's reach, one / two rounds) over
 them for profiles/r3_scenes.json.
 
-Per scene: ms per render, ns per triangle of the mosaic (2 (N-1)^2 of them: what the reference
+Per scene: ms per render, picoseconds per triangle of the mosaic (2 (N-1)^2 of them: what the reference
 would push through its draw call, reference horizonator-lib.c:203,897), Gpix/s, and with
 --counters the marching waves' own counts (one extra draw by the counting instance of the
 kernel): triangles that reached the set-up stage, how many of those the early depth test
@@ -37,6 +37,8 @@ SCENES = {
     "cfg3_zoom45":   dict(R=4200, W=16000, H=4000, az=(-22.5, 22.5), what="a 45 degree view at 16000x4000 (only the strips behind it are launched)"),
     "cfg3_zfar40km": dict(R=4200, W=16000, H=4000, zfar=40000.0, what="the API's default far clip (reference horizonator.h:10)"),
     "cfg2":          dict(R=1800, W=8000, H=2000, what="BASELINE configs[1]: 3x3 SRTM3 tiles, 8000x2000"),
+    "cfg1":          dict(R=600, W=2000, H=500, steps=40, what="BASELINE configs[0]: one SRTM3 tile's worth, 2000x500"),
+    "mid_4000":      dict(R=1800, W=4000, H=1000, steps=20, what="3x3 SRTM3 tiles, 4000x1000"),
     "cfg4_32":       dict(R=3000, W=8000, H=2000, batch=32, what="BASELINE configs[3]: viewpoints of the 16x16 lattice over 5x5 tiles, 8000x2000 BGR each, one batch"),
     "cfg5":          dict(R=19800, W=32768, H=8192, srtm1=True, steps=3, what="BASELINE configs[4]: 11x11 SRTM1 tiles (3.1 G triangles), 32768x8192"),
 }
@@ -141,7 +143,7 @@ def run_scene(name, steps=8, counters=False, cache=None):
         rec["terrain_fraction"] = float((d_rng[::8, ::8] >= 0).float().mean().item())
         rec["steps"] = steps
     rec["ms_per_render"] = per * 1e3
-    rec["ns_per_triangle"] = per * 1e9 / rec["triangles"]
+    rec["ps_per_triangle"] = per * 1e12 / rec["triangles"]
     rec["Gpix_per_s"] = W * H / per / 1e9
     if counters and not n:
         rec["counters"] = wave_counters(h)
