@@ -122,17 +122,134 @@ __device__ static inline float mr_from_east(float v)
 __device__ static inline int32_t hz_imin(int32_t a, int32_t b) { return a < b ? a : b; }
 __device__ static inline int32_t hz_imax(int32_t a, int32_t b) { return a > b ? a : b; }
 
-/* what k_march keeps of a vertex row for the cells between it and the next */
+/* what k_march keeps of a vertex row for the cells between it and the next (mr_rowstate_of) */
 struct mr_rowstate_t
 {
     float    xn;                        /* NDC x (discard rule)                              */
     int32_t  xs, ys;                    /* snapped position                                  */
     uint32_t cmask;                     /* clip mask (0 in rows that are wholly inside)      */
-    int32_t  c_x, f_x, c_y, f_y;        /* first / last pixel column and row at or beyond / up to the vertex, clipped to the scissor */
-    int32_t  h_c_x, h_f_x, h_c_y, h_f_y;        /* the same, over the vertex and its eastern neighbour */
+    uint32_t c, f1;                     /* first pixel column | row << 16 at or beyond the vertex; 1 + the last up to it; clipped to the scissor */
+    uint32_t e_c, e_f1;                 /* those of the eastern neighbour */
+    uint32_t h_c, h_f1;                 /* ... and over the vertex and its eastern neighbour */
     int32_t  h_dx, h_dy;                /* eastern neighbour's snapped position minus this vertex's */
 };
 
+/* window position of a transformed vertex as hz_to_window() computes it, and two
+ * facts about it that decide how the cells of its row are culled: inside the view
+ * volume (clip mask 0: with xn + 1 < 0 <=> xn < -1 for every float, "inside" is
+ * |x|,|y|,|z| <= 1; fmaxf skips a NaN, as the six comparisons of hz_clip_mask() do:
+ * all false) and inside the guard band (a NaN is outside) */
+__device__ static inline hz_wvert_t mr_window(const hz_vertex_t& vtx, const hz_params_t& p, bool* in_volume, bool* in_guard)
+{
+    hz_wvert_t cur;
+    cur.xn  = vtx.x;
+    cur.wx  = vtx.x*p.halfW + p.halfW;
+    cur.wy  = vtx.y*p.halfH + p.halfH;
+    cur.zw  = vtx.z*0.5f + 0.5f;
+    cur.red = vtx.red;
+    const float fxw = cur.wx - 0.5f, fyw = cur.wy - 0.5f;
+    *in_guard  = hz_abs(fxw) <= HZ_GUARD_PX && hz_abs(fyw) <= HZ_GUARD_PX;
+    *in_volume = __builtin_fmaxf(__builtin_fmaxf(hz_abs(vtx.x), hz_abs(vtx.y)), hz_abs(vtx.z)) <= 1.0f;
+    cur.xs = (int32_t)hz_roundeven(fxw*256.f);
+    cur.ys = (int32_t)hz_roundeven(fyw*256.f);
+    cur.cmask = 0;
+    return cur;
+}
+/* ... what a row that is not "simple" (some vertex outside the volume or the band) adds */
+__device__ static inline void mr_window_flags(hz_wvert_t& cur, const hz_vertex_t& vtx, bool in_guard)
+{
+    cur.cmask = hz_clip_mask(vtx.x, vtx.y, vtx.z);
+    if(!in_guard) { cur.xs = HZ_OUTSIDE_GUARD; cur.ys = 0; }
+}
+
+/* What a row keeps of its vertices for the cull of the cells above and below it.
+ * Pixel columns/rows of a vertex: a triangle's pixel box is the min of its
+ * vertices' first and the max of their last (hz_tri_box: the shifts are monotone),
+ * clipped to the scissor here already (max and min distribute over it).  Columns
+ * and rows travel as pairs of unsigned 16-bit halves, x low and y high, so that
+ * every min / max below is one packed instruction for both axes: `c` = first pixel
+ * at or beyond the vertex, `f1` = 1 + the last pixel up to it (the +1 keeps a
+ * vertex left of / below the scissor, whose last pixel is -1, representable).
+ * Both lie in [0, max(W,H)] - images of up to 65535 pixels a side: make_params - in
+ * rows whose vertices are all inside the view volume (window position in [0,W] x
+ * [0,H]), the only rows that use them. */
+__device__ static inline uint32_t mr_pk_min(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ static inline uint32_t mr_pk_max(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+/* both halves of a below those of b?  (two 16-bit compares, the upper one through SDWA) */
+__device__ static inline bool mr_pk_lt(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return x.x < y.x && x.y < y.y;
+}
+__device__ static inline uint32_t mr_from_east_u(uint32_t v) { return (uint32_t)mr_from_east((int32_t)v); }
+
+__device__ static inline mr_rowstate_t mr_rowstate_of(const hz_wvert_t& cur, const hz_params_t& p)
+{
+    mr_rowstate_t now;
+    now.xn = cur.xn; now.xs = cur.xs; now.ys = cur.ys; now.cmask = cur.cmask;
+    /* (rows with a vertex outside the view volume do not use these: there a half may overflow into the other) */
+    const uint32_t c_x  = (uint32_t)((cur.xs + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS), c_y  = (uint32_t)((cur.ys + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS);
+    const uint32_t f1_x = (uint32_t)((cur.xs + HZ_SUBPIXEL_ONE) >> HZ_SUBPIXEL_BITS),     f1_y = (uint32_t)((cur.ys + HZ_SUBPIXEL_ONE) >> HZ_SUBPIXEL_BITS);
+    now.c  = mr_pk_max(c_x  | (c_y  << 16), (uint32_t)p.col0);                        /* (row 0 is the scissor's first) */
+    now.f1 = mr_pk_min(f1_x | (f1_y << 16), (uint32_t)p.col1 | ((uint32_t)p.H << 16));
+    /* the same over this vertex and its eastern neighbour (the neighbour's value
+     * comes through a DPP wave shift), and the step to that neighbour */
+    now.e_c  = mr_from_east_u(now.c);
+    now.e_f1 = mr_from_east_u(now.f1);
+    now.h_c  = mr_pk_min(now.e_c,  now.c);
+    now.h_f1 = mr_pk_max(now.e_f1, now.f1);
+    now.h_dx = (int32_t)((uint32_t)mr_from_east(cur.xs) - (uint32_t)cur.xs);     /* (wraps for guard-band markers; unused then) */
+    now.h_dy = (int32_t)((uint32_t)mr_from_east(cur.ys) - (uint32_t)cur.ys);
+    return now;
+}
+
+/* The cull of the two triangles of cell (i, j-1) - v00 = prev, v01 = now, v10 / v11 =
+ * those of the lane to the east; t0 = (v00,v11,v01), t1 = (v00,v10,v11), reference
+ * horizonator-lib.c:500-506 - for rows whose vertices all lie inside the view volume
+ * and the guard band.  Returns false if the row has to go the long way
+ * (hz_tri_cull), which is decided for the whole wave; else keep0 / keep1.
+ *
+ * Reference geometry.glsl:21-27 (a triangle spanning more than 0.5 in NDC x = a
+ * quarter of the image is dropped) cannot apply to a cell whose vertices are all
+ * within quad_max_dx of v00 in snapped x: any two of them are then less than a
+ * quarter of the image minus two pixels apart, and window x follows NDC x to
+ * within a hundredth of a pixel.  A wider cell is rare (the +-180 degree seam,
+ * cells next to the viewer) and sends the row the long way.  With all four
+ * vertices inside the volume and the band and no discard, what is left of
+ * hz_tri_cull() is the back-face test on the snapped area and the pixel box.
+ * (tests/test_gpu_exactness.py checks this function against hz_tri_cull() on
+ * seeded rows around every one of those borders.) */
+__device__ static inline bool mr_simple_cull(const mr_rowstate_t& prev, const mr_rowstate_t& now, bool has_cell,
+                                             const hz_params_t& p, bool* keep0, bool* keep1)
+{
+    /* steps from v00 to the cell's other vertices, in 1/256 pixel */
+    const int32_t d01x = (int32_t)((uint32_t)now.xs - (uint32_t)prev.xs);               /* v01 - v00 */
+    const int32_t d01y = (int32_t)((uint32_t)now.ys - (uint32_t)prev.ys);
+    const int32_t d11x = (int32_t)((uint32_t)d01x + (uint32_t)now.h_dx);                /* v11 - v00 = (v01 - v00) + (v11 - v01) */
+    const int32_t d11y = (int32_t)((uint32_t)d01y + (uint32_t)now.h_dy);
+    const int32_t d10x = prev.h_dx, d10y = prev.h_dy;                                   /* v10 - v00 */
+    const int32_t lo = hz_imin(hz_imin(d01x, d11x), d10x), hi = hz_imax(hz_imax(d01x, d11x), d10x);
+    if(__any(has_cell && !(lo > -p.quad_max_dx && hi < p.quad_max_dx))) return false;
+    const int64_t area0 = (int64_t)d11x*(int64_t)d01y - (int64_t)d01x*(int64_t)d11y;
+    const int64_t area1 = (int64_t)d10x*(int64_t)d11y - (int64_t)d11x*(int64_t)d10y;
+    /* t0 = the row's own edge v01-v11 plus v00; t1 = the lower edge v00-v10 plus v11.
+     * A box holds a pixel centre iff first < 1 + last on both axes */
+    const uint32_t c0 = mr_pk_min(now.h_c, prev.c),                 f0 = mr_pk_max(now.h_f1, prev.f1);
+    const uint32_t c1 = mr_pk_min(now.e_c, prev.h_c), f1 = mr_pk_max(now.e_f1, prev.h_f1);
+    const bool box0 = mr_pk_lt(c0, f0), box1 = mr_pk_lt(c1, f1);
+    *keep0 = has_cell && area0 > 0 && box0;
+    *keep1 = has_cell && area1 > 0 && box1;
+    return true;
+}
 
 /* lane k holds triangle record r with npix pixel centres in its box (0 = none):
  * spread all those pixel centres over the 64 lanes (wave prefix sum + search),
@@ -518,30 +635,10 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         const bool fast = fast_strip && (rel >= 64 ? hzf_in_range(n) : (int)((fast_rows >> rel) & 1ull));
         const hz_vertex_t vtx = fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z);
 
-        /* window position as hz_to_window() computes it.  Two facts about the
-         * whole row are established on the way, which decide how its cells are
-         * culled: every vertex inside the view volume (clip mask 0: with
-         * xn + 1 < 0 <=> xn < -1 for every float, "inside" is |x|,|y|,|z| <= 1)
-         * and every vertex inside the guard band. */
-        hz_wvert_t cur;
-        cur.xn  = vtx.x;
-        cur.wx  = vtx.x*p.halfW + p.halfW;
-        cur.wy  = vtx.y*p.halfH + p.halfH;
-        cur.zw  = vtx.z*0.5f + 0.5f;
-        cur.red = vtx.red;
-        const float fxw = cur.wx - 0.5f, fyw = cur.wy - 0.5f;
-        const bool  in_guard  = hz_abs(fxw) <= HZ_GUARD_PX && hz_abs(fyw) <= HZ_GUARD_PX;     /* a NaN is outside */
-        /* fmaxf skips a NaN, as the six comparisons of hz_clip_mask() do (all false) */
-        const bool  in_volume = __builtin_fmaxf(__builtin_fmaxf(hz_abs(vtx.x), hz_abs(vtx.y)), hz_abs(vtx.z)) <= 1.0f;
-        const bool  cur_simple = __all(in_guard && in_volume);
-        cur.xs = (int32_t)hz_roundeven(fxw*256.f);
-        cur.ys = (int32_t)hz_roundeven(fyw*256.f);
-        cur.cmask = 0;
-        if(!cur_simple)
-        {
-            cur.cmask = hz_clip_mask(vtx.x, vtx.y, vtx.z);
-            if(!in_guard) { cur.xs = HZ_OUTSIDE_GUARD; cur.ys = 0; }
-        }
+        bool in_volume, in_guard;
+        hz_wvert_t cur = mr_window(vtx, p, &in_volume, &in_guard);
+        const bool cur_simple = __all(in_guard && in_volume);
+        if(!cur_simple) mr_window_flags(cur, vtx, in_guard);
 
         /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
          * still need it are set up now (happens where survivors are sparse) */
@@ -555,25 +652,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         }
         mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
 
-        mr_rowstate_t now;
-        now.xn = cur.xn; now.xs = cur.xs; now.ys = cur.ys; now.cmask = cur.cmask;
-        /* pixel columns/rows of the vertex: a triangle's pixel box is the min of
-         * its vertices' first and the max of their last (hz_tri_box: the shifts
-         * are monotone), clipped to the scissor here already (max and min
-         * distribute over it) */
-        now.c_x = hz_imax((cur.xs + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, p.col0);
-        now.f_x = hz_imin(cur.xs >> HZ_SUBPIXEL_BITS, p.col1-1);
-        now.c_y = hz_imax((cur.ys + (HZ_SUBPIXEL_ONE-1)) >> HZ_SUBPIXEL_BITS, 0);
-        now.f_y = hz_imin(cur.ys >> HZ_SUBPIXEL_BITS, p.H-1);
-        /* the same over this vertex and its eastern neighbour (one DPP-fused
-         * instruction each: the neighbour's value never lands in a register of
-         * its own), and the step to that neighbour */
-        now.h_c_x  = hz_imin(mr_from_east(now.c_x), now.c_x);
-        now.h_f_x  = hz_imax(mr_from_east(now.f_x), now.f_x);
-        now.h_c_y  = hz_imin(mr_from_east(now.c_y), now.c_y);
-        now.h_f_y  = hz_imax(mr_from_east(now.f_y), now.f_y);
-        now.h_dx   = (int32_t)((uint32_t)mr_from_east(cur.xs) - (uint32_t)cur.xs);     /* (wraps for guard-band markers; unused then) */
-        now.h_dy   = (int32_t)((uint32_t)mr_from_east(cur.ys) - (uint32_t)cur.ys);
+        const mr_rowstate_t now = mr_rowstate_of(cur, p);
 
         if(j > jbeg && !skip_cells)
         {
@@ -581,39 +660,8 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
              * the east; triangles t0 = (v00,v11,v01), t1 = (v00,v10,v11), reference
              * horizonator-lib.c:500-506 */
             bool keep0 = false, keep1 = false;
-            bool simple = cur_simple && prev_simple;
-            /* steps from v00 to the cell's other vertices, in 1/256 pixel */
-            const int32_t d01x = (int32_t)((uint32_t)cur.xs - (uint32_t)prev.xs);               /* v01 - v00 */
-            const int32_t d01y = (int32_t)((uint32_t)cur.ys - (uint32_t)prev.ys);
-            const int32_t d11x = (int32_t)((uint32_t)d01x + (uint32_t)now.h_dx);                /* v11 - v00 = (v01 - v00) + (v11 - v01) */
-            const int32_t d11y = (int32_t)((uint32_t)d01y + (uint32_t)now.h_dy);
-            const int32_t d10x = prev.h_dx, d10y = prev.h_dy;                                   /* v10 - v00 */
-            if(simple)
+            if(cur_simple && prev_simple && mr_simple_cull(prev, now, has_cell, p, &keep0, &keep1))
             {
-                /* reference geometry.glsl:21-27 (a triangle spanning more than 0.5 in
-                 * NDC x = a quarter of the image is dropped) cannot apply to a cell
-                 * whose vertices are all within quad_max_dx of v00 in snapped x: any
-                 * two of them are then less than a quarter of the image minus two
-                 * pixels apart, and window x follows NDC x to within a hundredth
-                 * of a pixel.  A wider cell is rare (the +-180 degree seam, cells
-                 * next to the viewer) and sends the row the long way. */
-                const int32_t lo = hz_imin(hz_imin(d01x, d11x), d10x), hi = hz_imax(hz_imax(d01x, d11x), d10x);
-                if(__any(has_cell && !(lo > -p.quad_max_dx && hi < p.quad_max_dx))) simple = false;
-            }
-            if(simple)
-            {
-                /* all four vertices inside the view volume and the guard band, no
-                 * discard: what is left of hz_tri_cull() is the back-face test on
-                 * the snapped area and the pixel box */
-                const int64_t area0 = (int64_t)d11x*(int64_t)d01y - (int64_t)d01x*(int64_t)d11y;
-                const int64_t area1 = (int64_t)d10x*(int64_t)d11y - (int64_t)d11x*(int64_t)d10y;
-                /* t0 = the row's own edge v01-v11 plus v00; t1 = the lower edge v00-v10 plus v11 */
-                const int32_t px0_0 = hz_imin(now.h_c_x, prev.c_x), px1_0 = hz_imax(now.h_f_x, prev.f_x);
-                const int32_t py0_0 = hz_imin(now.h_c_y, prev.c_y), py1_0 = hz_imax(now.h_f_y, prev.f_y);
-                const int32_t px0_1 = hz_imin(mr_from_east(now.c_x), prev.h_c_x), px1_1 = hz_imax(mr_from_east(now.f_x), prev.h_f_x);
-                const int32_t py0_1 = hz_imin(mr_from_east(now.c_y), prev.h_c_y), py1_1 = hz_imax(mr_from_east(now.f_y), prev.h_f_y);
-                keep0 = has_cell && area0 > 0 && px0_0 <= px1_0 && py0_0 <= py1_0;
-                keep1 = has_cell && area1 > 0 && px0_1 <= px1_1 && py0_1 <= py1_1;
             }
             else
             {

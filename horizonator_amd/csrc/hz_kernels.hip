@@ -643,7 +643,8 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.big_min    = HZ_INLINE_MAX_PIX;
     p.z_guard = 1.0f/500.0f + (float)(d->W > d->H ? d->W : d->H) * (1.0f/4194304.0f);
     p.z_hide_k = 1.03f * p.z_guard * 16777215.f;
-    p.quad_max_dx = d->W >= 64 && d->W <= (1<<20) ? 256*(d->W/16 - 1) : 0;
+    /* (0 = no cell is ever culled the short way: tiny images, and sides that do not fit the packed 16-bit pixel boxes) */
+    p.quad_max_dx = d->W >= 64 && d->W <= 65535 && d->H <= 65535 ? 256*(d->W/16 - 1) : 0;
     p.pretest = d->env.pretest > 0 ? 1 : 0;
     p.debug   = d->env.march_debug;
     p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
@@ -1788,6 +1789,206 @@ extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long se
     if(first_bad) HZ_CHECK(hipMemcpy(first_bad, d_first, 4*sizeof(float), hipMemcpyDeviceToHost));
     *mismatches = h[0];
     (void)hipFree(d_bad); (void)hipFree(d_first);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* self-checks of the two shortcuts the marching kernel takes on the strength of  */
+/* an argument rather than of the reference's arithmetic (hz_tri_hidden, the      */
+/* cull of whole cells): on seeded inputs around every border of the argument     */
+
+/* k_check_hidden: one triangle per thread.  Vertices as the rasteriser has them
+ * (window position, depth, snapped position); families: 0 far-field (a pixel or two
+ * across), 1 slivers (third vertex a hair off the line through the other two:
+ * |area| down to 2^-12 px^2, the depth plane extrapolated over the snapping
+ * distance is what hz_tri_hidden's slack is for), 2 grazing (depth gradients up to
+ * 10^5 LSB per pixel), 3 anything up to 16 pixels across.  For each triangle that
+ * survives the cull the LARGEST stored depth zs for which hz_tri_hidden() still
+ * answers "hidden" is found by bisection (the answer is monotone in zs) and every
+ * pixel centre the triangle covers (hz_tri_covers) is drawn (hz_tri_planes,
+ * hz_tri_fragment): no fragment may pass GL_LESS against zs, i.e. have a depth
+ * <= zs.  out[0] triangles tested, [1] of them hidden for some zs, [2] fragments
+ * drawn, [3] violations, [4] the smallest (fragment depth - zs) seen, + 2^32. */
+__global__ __launch_bounds__(256)
+void k_check_hidden(unsigned long long seed, unsigned long long n, int W, int H, unsigned long long* out)
+{
+    const float z_guard = 1.0f/500.0f + (float)(W > H ? W : H) * (1.0f/4194304.0f);
+    const float kk = 1.03f * z_guard * 16777215.f;
+    unsigned long long tested = 0, hidden = 0, frags = 0, bad = 0, margin = ~0ull;
+    for(unsigned long long t = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x*blockDim.x)
+    {
+        const unsigned long long r0 = hz_mix64(seed + 4*t), r1 = hz_mix64(seed + 4*t + 1), r2 = hz_mix64(seed + 4*t + 2), r3 = hz_mix64(seed + 4*t + 3);
+        auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };   /* [0,1) */
+        const int family = (int)(r0 & 3);
+        /* where: anywhere in the image, often next to its right / top border (large coordinates: coarse float spacing) */
+        float bx = unit(r0, 8) * (float)W, by = unit(r0, 32) * (float)H;
+        if(((r0 >> 2) & 7) == 0) bx = (float)W - 4.0f*unit(r1, 0);
+        if(((r0 >> 5) & 7) == 0) by = (float)H - 4.0f*unit(r1, 24);
+        float x[3], y[3], z[3];
+        const float ext = family == 3 ? 16.0f*unit(r3, 40) : family == 0 ? 2.5f : 4.0f;
+        x[0] = bx; y[0] = by;
+        x[1] = bx + (unit(r1, 8) - 0.5f)*ext;  y[1] = by + (unit(r1, 36) - 0.5f)*ext;
+        x[2] = bx + (unit(r2, 0) - 0.5f)*ext;  y[2] = by + (unit(r2, 24) - 0.5f)*ext;
+        if(family == 1)
+        {
+            /* the third vertex on the line through the first two, then off it by 2^-1 .. 2^-14 pixels */
+            const float tt = unit(r2, 0)*1.5f - 0.25f, off = __builtin_ldexpf(1.0f, -1 - (int)((r2 >> 40) % 14)) * ((r2 >> 63) ? 1.0f : -1.0f);
+            const float dx = x[1] - x[0], dy = y[1] - y[0], len = hz_sqrt(dx*dx + dy*dy) + 1e-6f;
+            x[2] = x[0] + tt*dx - off*dy/len; y[2] = y[0] + tt*dy + off*dx/len;
+        }
+        /* depth: a base anywhere in (0,1), differences from 10^-8 (a few LSB) to 10^-2 (10^5 LSB) */
+        const float zb = 0.02f + 0.96f*unit(r3, 0);
+        const float dz = (family == 2 ? 6e-3f : 1e-3f) * __builtin_ldexpf(1.0f, -(int)((r3 >> 24) % 18));
+        z[0] = zb; z[1] = zb + (unit(r3, 30) - 0.5f)*dz; z[2] = zb + (unit(r2, 40) - 0.5f)*dz;
+        hz_wvert_t v[3];
+        bool inside = true;
+        for(int k=0; k<3; k++)
+        {
+            /* as mr_window(): the survivors of the cull are inside the view volume */
+            v[k].xn = 0.f; v[k].wx = x[k]; v[k].wy = y[k]; v[k].zw = z[k]; v[k].red = 0.25f*(float)k; v[k].cmask = 0;
+            inside = inside && x[k] >= 0.f && x[k] <= (float)W && y[k] >= 0.f && y[k] <= (float)H && z[k] >= 0.f && z[k] <= 1.f;
+            v[k].xs = (int32_t)hz_roundeven((x[k] - 0.5f)*256.f);
+            v[k].ys = (int32_t)hz_roundeven((y[k] - 0.5f)*256.f);
+        }
+        if(!inside) continue;
+        hz_box_t box;
+        /* either winding: the back face of one is the front face of the other */
+        if(!hz_tri_cull_window(&box, &v[0], &v[1], &v[2], 0, W-1, 0, H-1))
+        {
+            const hz_wvert_t tmp = v[1]; v[1] = v[2]; v[2] = tmp;
+            if(!hz_tri_cull_window(&box, &v[0], &v[1], &v[2], 0, W-1, 0, H-1)) continue;
+        }
+        tested++;
+        if(!hz_tri_hidden(&v[0], &v[1], &v[2], kk, 0u)) continue;              /* not even behind depth 0 */
+        uint32_t lo = 0, hi = HZ_Z24_MAX;                                       /* hidden at lo, not (or untested) at hi */
+        if(hz_tri_hidden(&v[0], &v[1], &v[2], kk, hi)) lo = hi;
+        while(hi - lo > 1u)
+        {
+            const uint32_t mid = lo + (hi - lo)/2u;
+            if(hz_tri_hidden(&v[0], &v[1], &v[2], kk, mid)) lo = mid; else hi = mid;
+        }
+        hidden++;
+        hz_tri_t tri;
+        hz_tri_planes(&tri, &v[0], &v[1], &v[2]);
+        for(int py = box.py0; py <= box.py1; py++)
+            for(int px = box.px0; px <= box.px1; px++)
+            {
+                if(!hz_tri_covers(&tri, px, py)) continue;
+                uint32_t zi, r8;
+                if(!hz_tri_fragment(&tri, px, py, &zi, &r8)) continue;          /* at or beyond the cleared depth: never drawn */
+                frags++;
+                if(zi <= lo) bad++;
+                const unsigned long long m = (unsigned long long)((long long)zi - (long long)lo + (1ll << 32));
+                if(m < margin) margin = m;
+            }
+    }
+    atomicAdd(&out[0], tested); atomicAdd(&out[1], hidden); atomicAdd(&out[2], frags); atomicAdd(&out[3], bad);
+    atomicMin(&out[4], margin);
+}
+
+/* k_check_cull: one wave per case = two vertex rows of 64 as k_march sees them, NDC
+ * positions seeded around the borders of mr_simple_cull()'s argument: cells about
+ * a sixteenth of the image wide (quad_max_dx), rows that touch the edges of the view
+ * volume (|x|,|y|,|z| = 1 and a float beyond), positions that snap onto pixel
+ * centres, the +-180 degree seam (x jumping from one image border to the other),
+ * back faces and empty boxes of every kind.  Wherever the wave would take the
+ * short way, its verdict must be hz_tri_cull()'s.  out[0] cases, [1] cases that
+ * took the short way, [2] cells compared, [3] disagreements, [4] triangles kept. */
+__global__ __launch_bounds__(64)
+void k_check_cull(unsigned long long seed, unsigned long long ncases, int W, int H, int col0, int col1, unsigned long long* out)
+{
+    hz_params_t p;
+    memset(&p, 0, sizeof(p));
+    p.halfW = (float)W*0.5f; p.halfH = (float)H*0.5f; p.W = W; p.H = H; p.col0 = col0; p.col1 = col1; p.SW = col1 - col0;
+    p.quad_max_dx = W >= 64 && W <= 65535 && H <= 65535 ? 256*(W/16 - 1) : 0;
+    const int lane = threadIdx.x;
+    const bool has_cell = lane < MR_COLS;
+    unsigned long long cases = 0, shortway = 0, cells = 0, bad = 0, kept = 0;
+    for(unsigned long long t = blockIdx.x; t < ncases; t += gridDim.x)
+    {
+        const unsigned long long rc = hz_mix64(seed + 977*t);                   /* per case (wave-uniform) */
+        auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };
+        const int kind = (int)(rc & 7);
+        /* the step between neighbouring vertices, in NDC x: around the threshold (2/16 of the width), tiny, or ordinary */
+        float step = 2.0f/16.0f * (0.97f + 0.06f*unit(rc, 8));
+        if(kind >= 3) step = 2.0f/(float)W * (0.1f + 8.0f*unit(rc, 8));
+        if(kind == 5) step = -step;                                             /* back faces */
+        const float x_first = kind == 1 ? -1.0f : kind == 2 ? 1.0f - 63.0f*step : -1.0f + 2.0f*unit(rc, 32) - 32.0f*step;
+        const float y_base  = ((rc >> 56) & 3) == 0 ? 1.0f - 4.0f/(float)H*unit(rc, 40) : -1.0f + 2.0f*unit(rc, 40);
+        hz_vertex_t vt[2];
+        for(int row=0; row<2; row++)
+        {
+            const unsigned long long r = hz_mix64(seed + 977*t + 131*(unsigned long long)(row + 1) + 7*(unsigned long long)lane);
+            float xn = x_first + (float)lane*step + (unit(r, 0) - 0.5f)*hz_abs(step)*0.6f;
+            float yn = y_base + (row ? 1 : 0)*(2.0f/(float)H)*(0.2f + 4.0f*unit(rc, 16)) + (unit(r, 24) - 0.5f)*(2.0f/(float)H);
+            float zn = -1.0f + 2.0f*unit(r, 40);
+            if(kind == 4 && ((r >> 60) & 3) == 0)                               /* onto a pixel centre / a pixel border, exactly */
+                xn = ((float)(int)(unit(r, 8)*(float)W) + (((r >> 59) & 1) ? 0.5f : 0.0f))/p.halfW - 1.0f;
+            if(kind == 6 && lane >= 32) xn -= 2.0f - 40.0f*hz_abs(step);        /* the seam: the row jumps to the other border */
+            if(kind == 7 && ((r >> 58) & 15) == 0)                              /* a vertex on / just beyond a face of the view volume */
+            {
+                const float edge[4] = { 1.0f, -1.0f, 1.00000012f, -1.00000012f };
+                if((r >> 62) & 1) xn = edge[(r >> 56) & 3]; else if((r >> 63) & 1) yn = edge[(r >> 56) & 3]; else zn = edge[(r >> 56) & 3];
+            }
+            vt[row].x = xn; vt[row].y = yn; vt[row].z = zn; vt[row].red = 0.5f;
+        }
+        mr_rowstate_t st[2];
+        hz_wvert_t wv[2];
+        bool simple[2];
+        for(int row=0; row<2; row++)
+        {
+            bool in_volume, in_guard;
+            wv[row] = mr_window(vt[row], p, &in_volume, &in_guard);
+            simple[row] = __all(in_guard && in_volume);
+            if(!simple[row]) mr_window_flags(wv[row], vt[row], in_guard);
+            st[row] = mr_rowstate_of(wv[row], p);
+        }
+        cases++;
+        bool keep0 = false, keep1 = false;
+        if(!(simple[0] && simple[1] && mr_simple_cull(st[0], st[1], has_cell, p, &keep0, &keep1))) continue;
+        shortway++;
+        /* the long way, as k_march takes it */
+        hz_wvert_t v00 = {}, v01 = {}, v10 = {}, v11 = {};
+        v00.xn = st[0].xn; v00.xs = st[0].xs; v00.ys = st[0].ys; v00.cmask = st[0].cmask;
+        v01.xn = st[1].xn; v01.xs = st[1].xs; v01.ys = st[1].ys; v01.cmask = st[1].cmask;
+        v10.xn = mr_from_east(st[0].xn); v10.xs = mr_from_east(st[0].xs); v10.ys = mr_from_east(st[0].ys); v10.cmask = (uint32_t)mr_from_east((int32_t)st[0].cmask);
+        v11.xn = mr_from_east(st[1].xn); v11.xs = mr_from_east(st[1].xs); v11.ys = mr_from_east(st[1].ys); v11.cmask = (uint32_t)mr_from_east((int32_t)st[1].cmask);
+        if(has_cell)
+        {
+            hz_box_t box;
+            const bool want0 = hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_DRAW;
+            const bool want1 = hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_DRAW;
+            cells++;
+            if(want0 != keep0) bad++;
+            if(want1 != keep1) bad++;
+            kept += (keep0 ? 1 : 0) + (keep1 ? 1 : 0);
+        }
+    }
+    atomicAdd(&out[0], lane == 0 ? cases : 0ull); atomicAdd(&out[1], lane == 0 ? shortway : 0ull);
+    atomicAdd(&out[2], cells); atomicAdd(&out[3], bad); atomicAdd(&out[4], kept);
+}
+
+/* what: 0 = hz_tri_hidden (n triangles), 1 = the cull of whole cells (n cases of two rows of 64 vertices);
+ * image W x H (and, for 1, the drawn columns [col0,col1)); out: 5 words, see the kernels */
+extern "C" int hz_hip_check_exactness(int device, int what, unsigned long long seed, unsigned long long n,
+                                      int W, int H, int col0, int col1, unsigned long long* out)
+{
+    hz_device_guard device_guard_(device);
+    if(!device_guard_.ok) return -1;
+    if(what < 0 || what > 1 || W < 1 || H < 1 || col0 < 0 || col1 > W || col0 >= col1)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_exactness: bad arguments");
+        return -1;
+    }
+    unsigned long long* d_out = NULL;
+    HZ_CHECK(hipMalloc(&d_out, 5*sizeof(unsigned long long)));
+    const unsigned long long init[5] = { 0, 0, 0, 0, what == 0 ? ~0ull : 0ull };
+    HZ_CHECK(hipMemcpy(d_out, init, sizeof(init), hipMemcpyHostToDevice));
+    if(what == 0) hipLaunchKernelGGL(k_check_hidden, dim3(256*32), dim3(256), 0, 0, seed, n, W, H, d_out);
+    else          hipLaunchKernelGGL(k_check_cull, dim3(256*64), dim3(64), 0, 0, seed, n, W, H, col0, col1, d_out);
+    HZ_CHECK(hipGetLastError());
+    HZ_CHECK(hipMemcpy(out, d_out, 5*sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_out);
     return 0;
 }
 

@@ -234,6 +234,25 @@ int   hz_hip_wait_for(hz_dev_t* d, void* stream);
 int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsigned long long n,
                            unsigned long long* mismatches, float* first_bad);
 
+/* Self-checks of the marching kernel's two shortcuts that rest on an argument instead of
+ * on the reference's arithmetic, on seeded inputs around every border of the argument:
+ *   what 0  hz_tri_hidden() (the early depth test without its division): n triangles -
+ *           far-field ones, slivers with |area| down to 2^-12 px^2, depth gradients up to
+ *           10^5 LSB per pixel, coordinates up to W x H; for each the largest stored depth
+ *           that still reads "hidden" is found and every covered pixel centre drawn with
+ *           hz_tri_planes()/hz_tri_fragment(): no fragment may pass GL_LESS (reference
+ *           horizonator-lib.c:183).  out: triangles tested, hidden for some depth, fragments
+ *           drawn, VIOLATIONS, smallest (fragment depth - stored depth) + 2^32
+ *   what 1  the cull of whole cells (mr_simple_cull) against hz_tri_cull() (reference
+ *           geometry.glsl:21-27 + GL's cull and scissor): n cases of two rows of 64
+ *           vertices - cells about a sixteenth of the image wide, rows touching the view
+ *           volume's faces, positions on pixel centres, the +-180 degree seam, back faces;
+ *           drawn columns [col0,col1).  out: cases, cases culled the short way, cells
+ *           compared, DISAGREEMENTS, triangles kept
+ * 0 violations / disagreements is the only acceptable answer. */
+int  hz_hip_check_exactness(int device, int what, unsigned long long seed, unsigned long long n,
+                            int W, int H, int col0, int col1, unsigned long long* out);
+
 /* diagnostics (tools/bigqueue_stats.py): the queue of large triangles the last
  * draw left behind - set 0: its only or second round, 1: the first round of a
  * two-round draw.  counters: 6 words (mr_queue_t); recs: 10 int32 per record
