@@ -1909,22 +1909,24 @@ void k_check_cull(unsigned long long seed, unsigned long long ncases, int W, int
         const unsigned long long rc = hz_mix64(seed + 977*t);                   /* per case (wave-uniform) */
         auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };
         const int kind = (int)(rc & 7);
-        /* the step between neighbouring vertices, in NDC x: around the threshold (2/16 of the width), tiny, or ordinary */
-        float step = 2.0f/16.0f * (0.97f + 0.06f*unit(rc, 8));
-        if(kind >= 3) step = 2.0f/(float)W * (0.1f + 8.0f*unit(rc, 8));
+        /* the step between neighbouring vertices, in NDC x: a fraction of a pixel to 8 pixels; kinds 0-2: ONE cell of the
+         * row about a sixteenth of the image wide (the threshold quad_max_dx, +-3 %), at a seeded lane */
+        float step = 2.0f/(float)W * (0.1f + 8.0f*unit(rc, 8));
         if(kind == 5) step = -step;                                             /* back faces */
-        const float x_first = kind == 1 ? -1.0f : kind == 2 ? 1.0f - 63.0f*step : -1.0f + 2.0f*unit(rc, 32) - 32.0f*step;
+        const float jump = kind <= 2 ? 2.0f/16.0f * (0.97f + 0.06f*unit(rc, 44)) : 0.0f;
+        const int   jump_lane = (int)((rc >> 3) & 63);
+        const float x_first = kind == 1 ? -1.0f : kind == 2 ? 1.0f - 63.0f*step - jump : -1.0f + (2.0f - 64.0f*hz_abs(step) - jump)*unit(rc, 32);
         const float y_base  = ((rc >> 56) & 3) == 0 ? 1.0f - 4.0f/(float)H*unit(rc, 40) : -1.0f + 2.0f*unit(rc, 40);
         hz_vertex_t vt[2];
         for(int row=0; row<2; row++)
         {
             const unsigned long long r = hz_mix64(seed + 977*t + 131*(unsigned long long)(row + 1) + 7*(unsigned long long)lane);
-            float xn = x_first + (float)lane*step + (unit(r, 0) - 0.5f)*hz_abs(step)*0.6f;
+            float xn = x_first + (float)lane*step + (lane > jump_lane ? jump : 0.0f) + (unit(r, 0) - 0.5f)*hz_abs(step)*0.6f;
             float yn = y_base + (row ? 1 : 0)*(2.0f/(float)H)*(0.2f + 4.0f*unit(rc, 16)) + (unit(r, 24) - 0.5f)*(2.0f/(float)H);
             float zn = -1.0f + 2.0f*unit(r, 40);
             if(kind == 4 && ((r >> 60) & 3) == 0)                               /* onto a pixel centre / a pixel border, exactly */
                 xn = ((float)(int)(unit(r, 8)*(float)W) + (((r >> 59) & 1) ? 0.5f : 0.0f))/p.halfW - 1.0f;
-            if(kind == 6 && lane >= 32) xn -= 2.0f - 40.0f*hz_abs(step);        /* the seam: the row jumps to the other border */
+            if(kind == 6 && lane >= 32) xn -= 1.9f*unit(rc, 20);                /* the seam: the row jumps back towards the other border */
             if(kind == 7 && ((r >> 58) & 15) == 0)                              /* a vertex on / just beyond a face of the view volume */
             {
                 const float edge[4] = { 1.0f, -1.0f, 1.00000012f, -1.00000012f };
