@@ -64,14 +64,55 @@ def test_the_built_module_imports_and_is_the_reference_type(built):
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
 
 
-def test_standalone_calls_only_what_is_exported_or_documented_as_missing():
-    """standalone.c cannot be compiled here (FreeImage.h, epoxy/gl.h, GL/freeglut.h are not in the image and
-    are not stubbed): check its horizonator_* / annotate call sites textually against the export list -
-    everything but annotate() (cairo drawing) must be there"""
-    import re
-    text = open(os.path.join(REF, "standalone.c")).read()
-    called = set(re.findall(r"\b(horizonator_[a-z_]+)\s*\(", text)) | set(re.findall(r"\b(annotate)\s*\(", text))
+STUBS = os.path.join(ROOT, "tests", "caller_stubs")
+
+
+@pytest.fixture(scope="module")
+def standalone(tmp_path_factory):
+    """the reference's CLI: standalone.c + annotator.c compiled where they lie (BASELINE north_star: "so
+    standalone.c links unchanged"; reference Makefile:21 puts annotator.c beside the library) against include/,
+    with stand-ins for the CLI's OWN dependencies only (tests/caller_stubs: FreeImage, epoxy, freeglut, cairo,
+    swscale - none in this image); every horizonator_* call resolves to libhorizonator.so"""
+    out = tmp_path_factory.mktemp("standalone")
+    exe = str(out / "standalone")
+    cmd = ["gcc", "-std=gnu99", "-O1", "-w", "-I" + STUBS, "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "horizonator_amd", "csrc"),
+           os.path.join(REF, "standalone.c"), os.path.join(REF, "annotator.c"), os.path.join(STUBS, "stubs.c"),
+           "-o", exe, "-L" + LIBDIR, "-lhorizonator", "-Wl,-rpath," + LIBDIR, "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, "the reference's standalone.c / annotator.c no longer build and link against include/ + libhorizonator.so:\n" + r.stderr
+    return exe
+
+
+def test_standalone_and_annotator_link_unchanged(standalone):
+    undefined = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--undefined-only", standalone], text=True).splitlines()}
+    ours = {u for u in undefined if u.startswith("horizonator")}
     exported = {l.split()[-1] for l in subprocess.check_output(
         ["nm", "-D", "--defined-only", os.path.join(LIBDIR, "libhorizonator.so")], text=True).splitlines()}
-    missing = {c for c in called if c not in exported}
-    assert missing <= {"annotate"}, missing
+    # reference standalone.c:433-460 (init, set_zextents, pan_zoom, render_offscreen), :59-108 (redraw, resized: its window
+    # mode), annotator.c:228-348 (unproject, project, x_from_az)
+    assert ours == {"horizonator_init", "horizonator_set_zextents", "horizonator_pan_zoom", "horizonator_render_offscreen",
+                    "horizonator_redraw", "horizonator_resized", "horizonator_project", "horizonator_unproject",
+                    "horizonator_x_from_az"}, ours
+    assert ours <= exported
+    # annotate() is the reference's own annotator.c, compiled into the CLI: the library does not have to export it
+    defined = subprocess.check_output(["nm", "--defined-only", standalone], text=True)
+    assert " T annotate" in defined
+    # nothing of the stand-ins leaks into the render path: they define no horizonator_* symbol
+    stubs_text = open(os.path.join(STUBS, "stubs.c")).read()
+    assert "horizonator" not in stubs_text
+
+
+def test_the_reference_cli_runs_up_to_the_device(standalone, tmp_path):
+    """--help works; a render goes through horizonator_init() of THIS library, which without a HIP device (this
+    container) fails with a message instead of falling back to anything"""
+    r = subprocess.run([standalone, "--help"], capture_output=True, text=True)
+    assert "--dirdems DIRECTORY" in r.stdout
+    import hzutil
+    if hzutil.hip_available():
+        pytest.skip("a GPU is here: tests/test_gpu_standalone.py runs the CLI for real")
+    dems = hzutil.dem_dir_for(hzutil.VIEW_LAT, hzutil.VIEW_LON, 200)
+    r = subprocess.run([standalone, "--width", "400", "--height", "100", "--image", str(tmp_path / "out.png"), "--dirdems", dems,
+                        "--zfar", "15000", str(hzutil.VIEW_LAT), str(hzutil.VIEW_LON), "0", "90"], capture_output=True, text=True)
+    assert not (tmp_path / "out.png").exists()
+    assert "horizonator_init() failed" in r.stderr and ("HIP" in r.stderr or "device" in r.stderr), r.stderr[-800:]
