@@ -112,8 +112,10 @@ __device__ static inline void hz_counters_consume(unsigned int* a, unsigned int*
 #ifndef HZ_NFB
 #define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
 #endif
-#define HZ_STAGE_SLOTS 4                /* pinned staging chunks in flight between device and caller memory */
-#define HZ_STAGE_BYTES ((size_t)32 << 20)
+#define HZ_STAGE_SLOTS 8                /* pinned staging chunks in flight between device and caller memory */
+#define HZ_STAGE_BYTES ((size_t)16 << 20)
+#define HZ_COPY_STREAMS 2               /* device -> host copies alternate between that many streams (copy engines) */
+#define HZ_HOST_BANDS  4                /* the conversion runs in that many bands of rows when its results go to the host */
 #define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */

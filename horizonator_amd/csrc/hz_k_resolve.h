@@ -73,14 +73,17 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
                 unsigned char* __restrict__ bgr, float* __restrict__ ranges,
                 int32_t* __restrict__ index, uint32_t* __restrict__ z24,
                 int SW, int H, float znear, float zfar,
-                unsigned char* __restrict__ touched, int seg_stride, unsigned int* qa, unsigned int* qb)
+                unsigned char* __restrict__ touched, int seg_stride, unsigned int* qa, unsigned int* qb,
+                int yo0, int yo1)
 {
-    if(CLEAR && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
+    /* (output rows [yo0,yo1): the conversion may run in bands, so that the first results can leave for the host
+     * while the rest is converted; qa: only the band that comes first empties the queue sets) */
+    if(CLEAR && qa && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
     /* a wave = 64 lanes x 4 pixels = one HZ_SEG-pixel segment of a row */
     static_assert(HZ_SEG == 256, "k_resolve4: one wave converts one segment");
     const int x = (int)(blockIdx.x*blockDim.x + threadIdx.x)*4;
     if(x >= SW) return;
-    for(int yo = blockIdx.y; yo < H; yo += gridDim.y)
+    for(int yo = yo0 + (int)blockIdx.y; yo < yo1; yo += gridDim.y)
     {
         const int row = H-1 - yo;               /* GL row, reference horizonator-lib.c:949-958 */
         ulonglong2* src = (ulonglong2*)(fb + (size_t)row*SW + x);

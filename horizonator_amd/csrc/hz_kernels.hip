@@ -26,8 +26,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -204,10 +206,10 @@ struct hz_dev
     /* results into caller-owned host memory (hz_hip_resolve_to_host): a ring of
      * pinned staging chunks between the copy engine and the threads that move
      * the bytes on into the caller's (pageable) buffers */
-    hipStream_t    cstream;
+    hipStream_t    cstream[HZ_COPY_STREAMS];
     unsigned char* h_stage[HZ_STAGE_SLOTS];
     hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
-    hipEvent_t     ev_resolved;
+    hipEvent_t     ev_band[HZ_HOST_BANDS];
 
     /* internal output buffers for *_to_host */
     unsigned char* d_bgr;
@@ -274,14 +276,14 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
-    if(d->cstream) (void)hipStreamSynchronize(d->cstream);
+    for(int k=0; k<HZ_COPY_STREAMS; k++) if(d->cstream[k]) (void)hipStreamSynchronize(d->cstream[k]);
     for(int k=0; k<HZ_STAGE_SLOTS; k++)
     {
         if(d->h_stage[k])  (void)hipHostFree(d->h_stage[k]);
         if(d->ev_stage[k]) (void)hipEventDestroy(d->ev_stage[k]);
     }
-    if(d->ev_resolved) (void)hipEventDestroy(d->ev_resolved);
-    if(d->cstream) (void)hipStreamDestroy(d->cstream);
+    for(int k=0; k<HZ_HOST_BANDS; k++)   if(d->ev_band[k]) (void)hipEventDestroy(d->ev_band[k]);
+    for(int k=0; k<HZ_COPY_STREAMS; k++) if(d->cstream[k]) (void)hipStreamDestroy(d->cstream[k]);
     (void)hipFree(d->d_bgr);
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
@@ -1105,10 +1107,12 @@ static int rstream_after_draw(hz_dev_t* d)
     return 0;
 }
 
-extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
-                              unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
+/* the conversion of the last draw into DEVICE buffers; nbands > 1 (wide path only): in that many bands of
+ * rows, top first, ev_band[k] recorded on rstream behind band k - copy_out lets the first band's bytes leave
+ * for the host while the others are still being converted */
+static int resolve_impl(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                        unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24, int nbands, hipEvent_t* ev_band, int* band_rows)
 {
-    HZ_ON_DEVICE(d);
     const int SW = d->col1 - d->col0;
     const bool prof = d->profiling != 0;
     if(ranges)
@@ -1130,25 +1134,40 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
     const bool clears = d->env.resolve_clears && !(d->tex_on && bgr);
     unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];    /* emptied with the framebuffer */
     const bool wide = (SW % 4) == 0 && (((uintptr_t)bgr | (uintptr_t)ranges | (uintptr_t)index | (uintptr_t)z24 | (uintptr_t)d->d_fb) & 15u) == 0;
+    if(!wide || (d->tex_on && bgr) || nbands < 1) nbands = 1;
+    if(nbands > d->H) nbands = d->H;
+    if(band_rows) *band_rows = (d->H + nbands-1)/nbands;
     if(wide)
     {
-        const dim3 grid((unsigned)((SW/4 + 255)/256), (unsigned)(d->H < 2048 ? d->H : 2048));
-        if(clears)
-            hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
-                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride, qa, qb);
-        else
-            hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
-                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride, qa, qb);
+        const int rows = (d->H + nbands-1)/nbands;
+        for(int k=0; k<nbands; k++)
+        {
+            const int yo0 = k*rows, yo1 = (k+1)*rows < d->H ? (k+1)*rows : d->H;
+            const dim3 grid((unsigned)((SW/4 + 255)/256), (unsigned)(yo1 - yo0 < 2048 ? yo1 - yo0 : 2048));
+            if(clears)
+                hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
+                                   bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride,
+                                   k == 0 ? qa : (unsigned int*)NULL, qb, yo0, yo1);
+            else
+                hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
+                                   bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride,
+                                   (unsigned int*)NULL, (unsigned int*)NULL, yo0, yo1);
+            HZ_CHECK(hipGetLastError());
+            if(ev_band) HZ_CHECK(hipEventRecord(ev_band[k], d->rstream));
+        }
     }
-    else if(clears)
-        hipLaunchKernelGGL(k_resolve<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
-                           d->d_fb, (const float*)d->d_tanel,
-                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, qa, qb);
     else
-        hipLaunchKernelGGL(k_resolve<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
-                           d->d_fb, (const float*)d->d_tanel,
-                           bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, qa, qb);
-    HZ_CHECK(hipGetLastError());
+    {
+        if(clears)
+            hipLaunchKernelGGL(k_resolve<true>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
+                               d->d_fb, (const float*)d->d_tanel,
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, qa, qb);
+        else
+            hipLaunchKernelGGL(k_resolve<false>, dim3((unsigned)nblocks), dim3(256), 0, d->rstream,
+                               d->d_fb, (const float*)d->d_tanel,
+                               bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, qa, qb);
+        HZ_CHECK(hipGetLastError());
+    }
     if(clears && fb_mark_consumed(d) != 0) return -1;
     if(d->tex_on && bgr)
     {
@@ -1161,12 +1180,21 @@ extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* t
                            (const uint32_t*)d->d_texels, d->tex, bgr, p);
         HZ_CHECK(hipGetLastError());
     }
+    if(!wide && ev_band) HZ_CHECK(hipEventRecord(ev_band[0], d->rstream));
+    else if(wide && nbands == 1 && ev_band && d->tex_on && bgr) HZ_CHECK(hipEventRecord(ev_band[0], d->rstream));   /* (behind the shading kernel) */
     if(prof)
     {
         HZ_CHECK(hipEventRecord(d->ev[5], d->rstream));
         d->have_times = 2;
     }
-    return 0;
+    return nbands;
+}
+
+extern "C" int hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                              unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
+{
+    HZ_ON_DEVICE(d);
+    return resolve_impl(d, view, tanel, bgr, ranges, index, z24, 1, NULL, NULL) < 0 ? -1 : 0;
 }
 
 /* the draw's result as one word per pixel, z24<<8 | red8, top row first:
@@ -1320,21 +1348,31 @@ static int ensure_out_buffers(hz_dev_t* d, bool bgr, bool ranges, bool index, bo
  * horizonator-lib.c:936-1048: glReadPixels into the caller's buffers), and so
  * does horizonator_render_offscreen().  A 16000x4000 panorama is 448 MB of
  * results.  hipMemcpy into pageable memory moves that at ~11 GB/s (40 ms,
- * twenty times the render); here the copy engine writes 32 MB chunks into a
- * ring of pinned staging buffers at the link's rate while a few host threads
- * move each finished chunk on into the caller's buffer (non-temporal memcpy,
- * the pages faulted in by several threads at once), chunk k+1.. being in
- * flight meanwhile. */
+ * twenty times the render); here
+ *   - the conversion runs in HZ_HOST_BANDS bands of rows, and the bytes of a band
+ *     leave as soon as that band is converted;
+ *   - the copy engines (two streams in turn) write 16 MB chunks into a ring of
+ *     pinned staging buffers at the link's rate;
+ *   - a pool of host threads moves each finished chunk on into the caller's
+ *     (pageable) buffer while the next chunks are in flight - and, before the
+ *     first chunk has arrived, has the kernel map the caller's pages
+ *     (MADV_POPULATE_WRITE): arrays fresh from the allocator - what the
+ *     reference's Python wrapper hands over on every call,
+ *     horizonator-pywrap.c:234-250 - otherwise fault in page by page under the
+ *     copies (14.6 instead of 10.0 ms per 16000x4000 render in round 2). */
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 struct hz_copy_pool
 {
-    std::mutex m, busy;                 /* busy: one copy() at a time (contexts on several threads share the pool) */
+    struct batch_t { int pending; };
+    struct task_t  { unsigned char* dst; const unsigned char* src; size_t n; batch_t* batch; };     /* src == NULL: map the pages of dst */
+    std::mutex m, busy;                 /* busy: one copy_out at a time (contexts on several threads share the pool) */
     std::condition_variable cv_work, cv_done;
     std::vector<std::thread> threads;
-    unsigned char* dst = nullptr; const unsigned char* src = nullptr;
-    size_t bytes = 0;
-    int nparts = 0, next = 0, pending = 0;
-    unsigned long long generation = 0;
+    std::deque<task_t> q;
     bool stop = false;
+    bool populate_works = true;         /* cleared by the first madvise that does not know MADV_POPULATE_WRITE */
 
     explicit hz_copy_pool(int n)
     {
@@ -1346,33 +1384,53 @@ struct hz_copy_pool
         cv_work.notify_all();
         for(auto& t : threads) t.join();
     }
+    void map_pages(unsigned char* p, size_t n)
+    {
+        const uintptr_t page = 4096, lo = ((uintptr_t)p + page-1) & ~(page-1), hi = ((uintptr_t)p + n) & ~(page-1);
+        if(hi <= lo) return;
+        if(populate_works && madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+        populate_works = false;
+        /* an older kernel: a write that changes nothing, one per page (atomic: a copy into the same page may be running) */
+        for(uintptr_t a = lo; a < hi; a += page) (void)__atomic_fetch_add((unsigned char*)a, 0, __ATOMIC_RELAXED);
+    }
     void run()
     {
         std::unique_lock<std::mutex> lk(m);
         for(;;)
         {
-            cv_work.wait(lk, [this] { return stop || next < nparts; });
+            cv_work.wait(lk, [this] { return stop || !q.empty(); });
             if(stop) return;
-            const int part = next++;
-            const size_t lo = bytes*(size_t)part/(size_t)nparts, hi = bytes*(size_t)(part+1)/(size_t)nparts;
-            unsigned char* d = dst; const unsigned char* s = src;
+            const task_t t = q.front(); q.pop_front();
             lk.unlock();
-            memcpy(d + lo, s + lo, hi - lo);
+            if(t.src) memcpy(t.dst, t.src, t.n); else map_pages(t.dst, t.n);
             lk.lock();
-            if(--pending == 0) cv_done.notify_all();
+            if(--t.batch->pending == 0) cv_done.notify_all();
         }
     }
-    /* dst[0..bytes) = src[0..bytes), split over the pool; returns when done */
+    /* the tasks of one job: [dst, dst+n) in parts of at least `grain` bytes, at most one per thread */
+    void push(batch_t* b, unsigned char* d, const unsigned char* s, size_t n, size_t grain)
+    {
+        size_t nparts = threads.size(); if(nparts > n/grain + 1) nparts = n/grain + 1;
+        std::lock_guard<std::mutex> lk(m);
+        for(size_t k=0; k<nparts; k++)
+        {
+            const size_t lo = n*k/nparts, hi = n*(k+1)/nparts;
+            q.push_back({ d + lo, s ? s + lo : NULL, hi - lo, b });
+            b->pending++;
+        }
+        cv_work.notify_all();
+    }
+    void wait(batch_t* b)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [b] { return b->pending == 0; });
+    }
+    /* dst[0..n) = src[0..n), split over the pool; returns when done */
     void copy(unsigned char* d, const unsigned char* s, size_t n)
     {
-        std::lock_guard<std::mutex> one(busy);
-        std::unique_lock<std::mutex> lk(m);
-        dst = d; src = s; bytes = n;
-        nparts = (int)threads.size(); if((size_t)nparts > n/65536 + 1) nparts = (int)(n/65536 + 1);
-        next = 0; pending = nparts;
-        cv_work.notify_all();
-        cv_done.wait(lk, [this] { return pending == 0; });
-        nparts = 0;
+        batch_t b = { 0 };
+        push(&b, d, s, n, 65536);
+        wait(&b);
     }
 };
 
@@ -1397,9 +1455,9 @@ static hz_copy_pool* copy_pool()
 
 static int ensure_staging(hz_dev_t* d)
 {
-    if(d->cstream) return 0;
-    HZ_CHECK(hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking));
-    HZ_CHECK(hipEventCreateWithFlags(&d->ev_resolved, hipEventDisableTiming));
+    if(d->cstream[0]) return 0;
+    for(int k=0; k<HZ_COPY_STREAMS; k++) HZ_CHECK(hipStreamCreateWithFlags(&d->cstream[k], hipStreamNonBlocking));
+    for(int k=0; k<HZ_HOST_BANDS; k++)   HZ_CHECK(hipEventCreateWithFlags(&d->ev_band[k], hipEventDisableTiming));
     for(int k=0; k<HZ_STAGE_SLOTS; k++)
     {
         HZ_CHECK(hipHostMalloc((void**)&d->h_stage[k], HZ_STAGE_BYTES, hipHostMallocDefault));
@@ -1408,35 +1466,54 @@ static int ensure_staging(hz_dev_t* d)
     return 0;
 }
 
-/* the device buffers of the last conversion -> the caller's host buffers */
-static int copy_out(hz_dev_t* d, int nbuf, unsigned char* const* dst, const unsigned char* const* src, const size_t* bytes)
+/* The device buffers of the conversion just queued -> the caller's host buffers.  The conversion ran in
+ * `nbands` bands of `band_rows` rows (ev_band[k] behind band k); buffer b has row_bytes[b] bytes per row:
+ * the chunks go band by band, every buffer's rows of a band before the next band's. */
+static int copy_out(hz_dev_t* d, int nbuf, unsigned char* const* dst, const unsigned char* const* src, const size_t* row_bytes,
+                    int rows_total, int nbands, int band_rows, hz_copy_pool* pool)
 {
-    if(ensure_staging(d) != 0) return -1;
-    hz_copy_pool* pool = copy_pool();
-    HZ_CHECK(hipEventRecord(d->ev_resolved, d->rstream));
-    HZ_CHECK(hipStreamWaitEvent(d->cstream, d->ev_resolved, 0));
-    /* the chunks of all buffers, in order */
-    struct chunk_t { unsigned char* dst; const unsigned char* src; size_t n; };
+    std::lock_guard<std::mutex> one(pool->busy);
+    struct chunk_t { unsigned char* dst; const unsigned char* src; size_t n; int band; };
     std::vector<chunk_t> chunks;
-    for(int b=0; b<nbuf; b++)
-        for(size_t off=0; off<bytes[b]; off+=HZ_STAGE_BYTES)
-            chunks.push_back({ dst[b] + off, src[b] + off, bytes[b] - off < HZ_STAGE_BYTES ? bytes[b] - off : HZ_STAGE_BYTES });
+    for(int k=0; k<nbands; k++)
+    {
+        const int y0 = k*band_rows, y1 = (k+1)*band_rows < rows_total ? (k+1)*band_rows : rows_total;
+        for(int b=0; b<nbuf; b++)
+        {
+            const size_t lo = (size_t)y0*row_bytes[b], hi = (size_t)y1*row_bytes[b];
+            for(size_t off=lo; off<hi; off+=HZ_STAGE_BYTES)
+                chunks.push_back({ dst[b] + off, src[b] + off, hi - off < HZ_STAGE_BYTES ? hi - off : HZ_STAGE_BYTES, k });
+        }
+    }
     const size_t nc = chunks.size();
     size_t issued = 0;
+    int band_seen[HZ_COPY_STREAMS];
+    for(int k=0; k<HZ_COPY_STREAMS; k++) band_seen[k] = -1;
+    /* the host threads' copies are queued as the chunks arrive and waited for together at the end; a staging
+     * slot is reused only after the copy out of it (two chunks back, at least) has been waited for */
+    std::vector<hz_copy_pool::batch_t> done(nc);
+    for(size_t k=0; k<nc; k++) done[k].pending = 0;
     for(size_t k=0; k<nc; k++)
     {
-        /* keep the copy engine HZ_STAGE_SLOTS chunks ahead of the host threads; slot
-         * k % SLOTS is free again once chunk k - SLOTS has been moved out (done below, in order) */
-        for(; issued < nc && issued < k + HZ_STAGE_SLOTS; issued++)
+        /* keep the copy engines up to HZ_STAGE_SLOTS - 2 chunks ahead of the chunk the host threads work on */
+        for(; issued < nc && issued < k + HZ_STAGE_SLOTS - 2; issued++)
         {
             const int slot = (int)(issued % HZ_STAGE_SLOTS);
-            HZ_CHECK(hipMemcpyAsync(d->h_stage[slot], chunks[issued].src, chunks[issued].n, hipMemcpyDeviceToHost, d->cstream));
-            HZ_CHECK(hipEventRecord(d->ev_stage[slot], d->cstream));
+            if(issued >= HZ_STAGE_SLOTS) pool->wait(&done[issued - HZ_STAGE_SLOTS]);    /* the slot's previous chunk has left it */
+            hipStream_t cs = d->cstream[issued % HZ_COPY_STREAMS];
+            if(band_seen[issued % HZ_COPY_STREAMS] < chunks[issued].band)
+            {
+                HZ_CHECK(hipStreamWaitEvent(cs, d->ev_band[chunks[issued].band], 0));
+                band_seen[issued % HZ_COPY_STREAMS] = chunks[issued].band;
+            }
+            HZ_CHECK(hipMemcpyAsync(d->h_stage[slot], chunks[issued].src, chunks[issued].n, hipMemcpyDeviceToHost, cs));
+            HZ_CHECK(hipEventRecord(d->ev_stage[slot], cs));
         }
         const int slot = (int)(k % HZ_STAGE_SLOTS);
         HZ_CHECK(hipEventSynchronize(d->ev_stage[slot]));
-        pool->copy(chunks[k].dst, d->h_stage[slot], chunks[k].n);
+        pool->push(&done[k], chunks[k].dst, d->h_stage[slot], chunks[k].n, 65536);
     }
+    for(size_t k=0; k<nc; k++) pool->wait(&done[k]);
     return 0;
 }
 
@@ -1445,23 +1522,35 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
 {
     HZ_ON_DEVICE(d);
     if(ensure_out_buffers(d, bgr != NULL, ranges != NULL, index != NULL, z24 != NULL) != 0) return -1;
-    if(hz_hip_resolve(d, view, tanel,
-                      bgr ? d->d_bgr : NULL, ranges ? d->d_ranges : NULL,
-                      index ? d->d_index : NULL, z24 ? d->d_z24 : NULL) != 0) return -1;
-    const size_t npix = (size_t)(d->col1 - d->col0)*d->H;
-    unsigned char* dst[4]; const unsigned char* src[4]; size_t bytes[4];
+    if(ensure_staging(d) != 0) return -1;
+    const int SW = d->col1 - d->col0;
+    const size_t npix = (size_t)SW*d->H;
+    unsigned char* dst[4]; const unsigned char* src[4]; size_t row_bytes[4];
     int nbuf = 0;
-    if(bgr)    { dst[nbuf] = bgr;                    src[nbuf] = d->d_bgr;                            bytes[nbuf++] = npix*3; }
-    if(ranges) { dst[nbuf] = (unsigned char*)ranges; src[nbuf] = (const unsigned char*)d->d_ranges;   bytes[nbuf++] = npix*sizeof(float); }
-    if(index)  { dst[nbuf] = (unsigned char*)index;  src[nbuf] = (const unsigned char*)d->d_index;    bytes[nbuf++] = npix*sizeof(int32_t); }
-    if(z24)    { dst[nbuf] = (unsigned char*)z24;    src[nbuf] = (const unsigned char*)d->d_z24;      bytes[nbuf++] = npix*sizeof(uint32_t); }
-    if(d->env.plain_copy)                               /* diagnostics: hipMemcpy into the caller's memory as it is */
+    if(bgr)    { dst[nbuf] = bgr;                    src[nbuf] = d->d_bgr;                            row_bytes[nbuf++] = (size_t)SW*3; }
+    if(ranges) { dst[nbuf] = (unsigned char*)ranges; src[nbuf] = (const unsigned char*)d->d_ranges;   row_bytes[nbuf++] = (size_t)SW*sizeof(float); }
+    if(index)  { dst[nbuf] = (unsigned char*)index;  src[nbuf] = (const unsigned char*)d->d_index;    row_bytes[nbuf++] = (size_t)SW*sizeof(int32_t); }
+    if(z24)    { dst[nbuf] = (unsigned char*)z24;    src[nbuf] = (const unsigned char*)d->d_z24;      row_bytes[nbuf++] = (size_t)SW*sizeof(uint32_t); }
+    /* the draw is in flight (asynchronous): while it runs, the pool maps the caller's pages */
+    hz_copy_pool* pool = d->env.plain_copy ? NULL : copy_pool();
+    hz_copy_pool::batch_t mapped = { 0 };
+    if(pool) for(int b=0; b<nbuf; b++) pool->push(&mapped, dst[b], NULL, row_bytes[b]*d->H, (size_t)4 << 20);
+    int band_rows = d->H;
+    /* (small images: one band - an event and a launch per band are not free) */
+    const int want_bands = pool && npix*7 >= ((size_t)64 << 20) ? HZ_HOST_BANDS : 1;
+    const int nbands = resolve_impl(d, view, tanel, bgr ? d->d_bgr : NULL, ranges ? d->d_ranges : NULL,
+                                    index ? d->d_index : NULL, z24 ? d->d_z24 : NULL, want_bands, d->ev_band, &band_rows);
+    int rc = nbands < 0 ? -1 : 0;
+    if(rc == 0 && !pool)                                /* diagnostics: hipMemcpy into the caller's memory as it is */
     {
-        for(int b=0; b<nbuf; b++) HZ_CHECK(hipMemcpyAsync(dst[b], src[b], bytes[b], hipMemcpyDeviceToHost, d->rstream));
-        HZ_CHECK(hipStreamSynchronize(d->rstream));
-        return 0;
+        for(int b=0; b<nbuf && rc == 0; b++)
+            if(hipMemcpyAsync(dst[b], src[b], row_bytes[b]*d->H, hipMemcpyDeviceToHost, d->rstream) != hipSuccess) rc = -1;
+        if(hipStreamSynchronize(d->rstream) != hipSuccess) rc = -1;
+        return rc;
     }
-    return copy_out(d, nbuf, dst, src, bytes);
+    if(rc == 0) rc = copy_out(d, nbuf, dst, src, row_bytes, d->H, nbands, band_rows, pool);
+    pool->wait(&mapped);                                /* (its tasks name the caller's buffers: none may outlive this call) */
+    return rc;
 }
 
 extern "C" int hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24)
