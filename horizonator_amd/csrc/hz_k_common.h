@@ -27,6 +27,8 @@ struct hz_params_t
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
     int   pretest;                     /* k_big: read a framebuffer word before the atomic and skip fragments that cannot win */
+    int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
+    int   nsx;                         /* strip columns of the mosaic; a launch grid may be wider (HZ_EXP_XCD_PAD) */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
     float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
     int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */
@@ -44,10 +46,21 @@ struct hz_params_t
 #define HZ_SEG_LOG2 8
 #define HZ_SEG      (1 << HZ_SEG_LOG2)
 
-/* the one place fragments enter the framebuffer */
+/* the one place fragments enter the framebuffer.  p.exp_fb (HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG, experiments
+ * with WRONG pictures - profiles/r3_experiments.json): 1 = the fragment is dropped here, 2 = a plain store
+ * instead of the atomic minimum: what the atomics cost, i.e. what a rasteriser that owned its pixels could gain */
+#define HZ_WHO_MARCH 0
+#define HZ_WHO_BIG   1
+#define HZ_WHO_OTHER 2                  /* (k_clip's own fragments: never part of an experiment) */
+template<int WHO = HZ_WHO_OTHER>
 __device__ static inline void hz_fb_min(unsigned long long* fb, const hz_params_t& p, int px, int py, unsigned long long key)
 {
     const int x = px - p.col0;
+    if(WHO != HZ_WHO_OTHER && p.exp_fb[WHO == HZ_WHO_OTHER ? 0 : WHO])
+    {
+        if(p.exp_fb[WHO] == 2) { p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1; fb[(size_t)py*p.SW + x] = key; }
+        return;
+    }
     p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1;
     atomicMin(&fb[(size_t)py*p.SW + x], key);
 }
@@ -166,10 +179,10 @@ __device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_param
     if(PRETEST)
     {
         if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            hz_fb_min(fb, p, px, py, key);
+            hz_fb_min<HZ_WHO_MARCH>(fb, p, px, py, key);
     }
     else
-        hz_fb_min(fb, p, px, py, key);
+        hz_fb_min<HZ_WHO_MARCH>(fb, p, px, py, key);
 }
 
 /* PRETEST: read the word first and skip the atomic when the fragment cannot

@@ -504,8 +504,15 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
  * counters into p.wave_cycles).  The production instance carries none of it -
  * no scratch memory for the counters, none of their branches, fewer scalar
  * registers held. */
+/* MR_WAVES_PER_EU (a build-time experiment, profiles/r3_experiments.json): ask the compiler for that many
+ * marching waves per SIMD instead of the four that 105 registers allow */
+#ifdef MR_WAVES_PER_EU
+#define MR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MR_WAVES_PER_EU, MR_WAVES_PER_EU)))
+#else
+#define MR_OCCUPANCY
+#endif
 template<bool COUNTERS>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) MR_OCCUPANCY
 void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
              mr_queue_t q, mr_zones_t zn, hz_params_t p)
 {
@@ -526,6 +533,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         sx = (int)(item & ((1u << MR_ITEM_SX_BITS) - 1u)); seg = (int)(item >> MR_ITEM_SX_BITS);
     }
     else { sx = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0); seg = (int)blockIdx.y; }
+    if(sx >= p.nsx) return;                             /* (a launch grid padded beyond the mosaic: HZ_EXP_XCD_PAD) */
     const int i0   = sx*MR_COLS;
     const int i    = i0 + lane;
     int jbeg, jend;                                     /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */

@@ -358,7 +358,7 @@ void k_big(unsigned long long* __restrict__ fb,
                     /* p.pretest (views with heavy overdraw, see plan_rounds): look first, and leave the atomic
                      * out where the fragment cannot win - a stale larger value only costs the atomic */
                     if(!p.pretest || key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        hz_fb_min(fb, p, px, py, key);
+                        hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
                 }
             }
         }

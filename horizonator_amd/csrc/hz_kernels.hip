@@ -105,6 +105,8 @@ struct hz_env_t
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
+    int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
+    int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -123,6 +125,9 @@ static hz_env_t read_env(void)
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
+    e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
+    e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
+    e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
     if(!(e.near_px >= 0.5)) e.near_px = 20.0;
@@ -648,6 +653,8 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     /* (0 = no cell is ever culled the short way: tiny images, and sides that do not fit the packed 16-bit pixel boxes) */
     p.quad_max_dx = d->W >= 64 && d->W <= 65535 && d->H <= 65535 ? 256*(d->W/16 - 1) : 0;
     p.pretest = d->env.pretest > 0 ? 1 : 0;
+    p.exp_fb[HZ_WHO_MARCH] = d->env.exp_fb_march; p.exp_fb[HZ_WHO_BIG] = d->env.exp_fb_big;
+    p.nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
     p.debug   = d->env.march_debug;
     p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
     return p;
@@ -898,7 +905,7 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
                         const uint32_t* d_list, unsigned int nlist)
 {
     const int nsx = (pm.N-1 + MR_COLS-1)/MR_COLS;
-    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : nsx, zn.total);
+    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : (d->env.exp_xcd_pad ? (nsx + 7) & ~7 : nsx), zn.total);
     pm.worklist = NULL;
     if(d_list)
     {

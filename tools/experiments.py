@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""The measurements behind DESIGN.md section 4's design decisions, each reproducible with the switch named
+beside it: run on the GPU box, writes one JSON document.
+
+    python tools/experiments.py > gpurun_out/r3_experiments.json
+
+For every row: the benchmark workload (cfg3: 7x7 SRTM3 tiles, 16000x4000, 360 degrees, zfar 600 km; rows
+marked zfar 40 km: the API's default far clip), 40 renders back to back, three times -> the median ms per
+render; and once with every kernel alone on the chip (HZ_SERIAL=1) -> the stage times of HIP events.
+Rows whose switch makes the picture WRONG say so: they bound what a different design could gain, they are
+not candidates.  Build-time variants (another register budget, two framebuffers) are built into a copy of
+the tree under /tmp."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = ["bench.py", "--steps", "40", "--warmup", "6", "--no-cpu-baseline", "--no-host", "--no-extra"]
+
+
+def run(env, root=ROOT, zfar=None, repeat=3):
+    e = dict(os.environ, **env)
+    args = BENCH + (["--zfar", str(zfar)] if zfar else [])
+    out = {"ms_per_render": [], "serial": None}
+    for k in range(repeat):
+        r = subprocess.run([sys.executable] + args, cwd=root, env=e, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            out["error"] = r.stderr[-400:]
+            return out
+        out["ms_per_render"].append(json.loads(line[0])["ms_per_step"])
+    r = subprocess.run([sys.executable] + args, cwd=root, env=dict(e, HZ_SERIAL="1"), capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if line:
+        d = json.loads(line[0])
+        out["serial"] = {"ms_per_render": d["ms_per_step"], "k_march_second_round_ms": d["roofline"]["kernel_ms"],
+                         **{k: v for k, v in d["roofline"]["other_kernels_ms"].items()}}
+    out["median_ms_per_render"] = sorted(out["ms_per_render"])[len(out["ms_per_render"]) // 2]
+    return out
+
+
+def variant(name, flags):
+    """a copy of the tree built with extra hipcc flags"""
+    dst = os.path.join("/tmp", "hz_variant_" + name)
+    shutil.rmtree(dst, ignore_errors=True)
+    shutil.copytree(ROOT, dst, ignore=shutil.ignore_patterns("gpurun_out", ".git", "build", "*.so", "__pycache__", "profiles"))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(dst, "horizonator_amd", "csrc"), "HIPFLAGS_EXTRA=" + flags], capture_output=True, text=True)
+    if r.returncode != 0:
+        return None, r.stderr[-400:]
+    subprocess.run(["make", "-s", "-C", os.path.join(dst, "oracle")], capture_output=True, text=True)
+    return dst, None
+
+
+ROWS = [
+    ("as shipped", {}, None, "the reference point of every other row"),
+    ("one round forced", {"HZ_TWO_PASS": "0"}, None, "no first round, no early depth test"),
+    ("k_big: fragments dropped instead of written (WRONG picture)", {"HZ_EXP_FB_BIG": "1"}, None,
+     "upper bound of what k_big's atomics cost: nothing of the near field reaches the framebuffer (the early depth test then finds no occluders, the conversion skips most segments)"),
+    ("k_big: plain stores instead of atomic minima (WRONG picture)", {"HZ_EXP_FB_BIG": "2"}, None,
+     "what a first round that OWNED its pixels (tile-binned, depth in LDS, one store per pixel: north_star's design) could gain at the very most"),
+    ("k_march: its own fragments dropped (WRONG picture)", {"HZ_EXP_FB_MARCH": "1"}, None,
+     "upper bound of what the marching waves' atomics cost"),
+    ("k_march: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2"}, None, "the same with the store kept"),
+    ("both: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2", "HZ_EXP_FB_BIG": "2"}, None, "no atomic anywhere"),
+    ("k_big looks before its atomics", {"HZ_PRETEST": "1"}, None, "reads the word first, skips fragments that cannot win"),
+    ("launch grid padded to a multiple of 8 strip columns", {"HZ_EXP_XCD_PAD": "1"}, None,
+     "all segments of a strip column on one XCD (workgroups are dealt to the XCDs round-robin): L2 locality against balance"),
+    ("first round reaches cells wider than 10 px", {"HZ_NEAR_PX": "10"}, None, "default 20"),
+    ("first round reaches cells wider than 40 px", {"HZ_NEAR_PX": "40"}, None, "default 20"),
+    ("second round always waits for the first", {"HZ_ALWAYS_WAIT_NEAR": "1"}, None, ""),
+    ("as shipped, zfar 40 km", {}, 40000.0, "the API's default far clip"),
+    ("k_big: plain stores, zfar 40 km (WRONG picture)", {"HZ_EXP_FB_BIG": "2"}, 40000.0, "with the 40 km far clip k_big is the longest kernel"),
+    ("two rounds forced, zfar 40 km", {"HZ_TWO_PASS": "1"}, 40000.0, ""),
+]
+VARIANTS = [
+    ("five marching waves per SIMD", "waves5", "-DMR_WAVES_PER_EU=5", "96 registers per wave instead of 105"),
+    ("three marching waves per SIMD", "waves3", "-DMR_WAVES_PER_EU=3", ""),
+    ("two framebuffers and queue sets instead of three", "nfb2", "-DHZ_NFB=2", "the first round of panorama k+1 then waits for the conversion of k-1"),
+    ("four framebuffers", "nfb4", "-DHZ_NFB=4", ""),
+]
+
+
+def main():
+    doc = {"workload": "bench.py cfg3 (7x7 SRTM3 tiles, 16000x4000, 360 degrees, zfar 600 km unless a row says otherwise), 40 renders back to back",
+           "how": "python tools/experiments.py on one MI355X; every row: the environment switch (or build flag) that reproduces it",
+           "rows": []}
+    for what, env, zfar, note in ROWS:
+        rec = {"what": what, "switch": " ".join(f"{k}={v}" for k, v in env.items()) or "-", "zfar_m": zfar or 600000.0, "note": note}
+        rec.update(run(env, zfar=zfar))
+        doc["rows"].append(rec)
+        print(what, rec.get("median_ms_per_render"), rec.get("serial"), file=sys.stderr, flush=True)
+    for what, name, flags, note in VARIANTS:
+        rec = {"what": what, "switch": "make -C horizonator_amd/csrc HIPFLAGS_EXTRA=" + flags, "zfar_m": 600000.0, "note": note}
+        root, err = variant(name, flags)
+        if root is None:
+            rec["error"] = err
+        else:
+            rec.update(run({}, root=root))
+            # the registers the variant's marching kernel got
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import test_kernel_resources as tk
+                save = tk.ROOT
+                tk.ROOT = root
+                k = tk._kernels()
+                tk.ROOT = save
+                rec["k_march_resources"] = tk._one(k, "k_marchILb0E")
+            except Exception as e:
+                rec["k_march_resources"] = repr(e)
+        doc["rows"].append(rec)
+        print(what, rec.get("median_ms_per_render"), rec.get("serial"), rec.get("k_march_resources"), file=sys.stderr, flush=True)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
