@@ -106,6 +106,7 @@ struct hz_env_t
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
+    int    pretest_march;           /* HZ_PRETEST_MARCH=0: the marching waves do not look before their atomics (default: they do) */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
@@ -128,6 +129,7 @@ static hz_env_t read_env(void)
     e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
     e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
+    e.pretest_march    = env_int("HZ_PRETEST_MARCH", 1) != 0;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
     if(!(e.near_px >= 0.5)) e.near_px = 20.0;
@@ -655,6 +657,7 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.pretest = d->env.pretest > 0 ? 1 : 0;
     p.exp_fb[HZ_WHO_MARCH] = d->env.exp_fb_march; p.exp_fb[HZ_WHO_BIG] = d->env.exp_fb_big;
     p.nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
+    p.pretest_march = d->env.pretest_march;
     p.debug   = d->env.march_debug;
     p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
     return p;

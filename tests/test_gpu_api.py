@@ -239,7 +239,7 @@ def test_context_from_a_broadcast_mosaic(scene):
 
 
 def test_pipelined_renders_equal_waited_for_renders():
-    """The library overlaps consecutive renders (two framebuffers and queue sets, three streams).
+    """The library overlaps consecutive renders (three framebuffers and queue sets in turn, four streams).
     A seeded random sequence of moves, azimuth / depth-extent / sector changes, texture switches,
     picks and renders into separate device buffers, queued WITHOUT waiting in between, must leave
     exactly what the same sequence leaves when every render is waited for."""
