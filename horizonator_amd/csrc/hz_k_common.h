@@ -27,7 +27,7 @@ struct hz_params_t
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
     int   pretest;                     /* k_big: read a framebuffer word before the atomic and skip fragments that cannot win */
-    int   pretest_march;               /* the marching waves read a word before the atomic */
+    int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
     int   nsx;                         /* strip columns of the mosaic; a launch grid may be wider (HZ_EXP_XCD_PAD) */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
@@ -177,11 +177,8 @@ __device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_param
     uint32_t zi, r8;
     if(!hz_tri_fragment(&t, px, py, &zi, &r8)) return;
     const unsigned long long key = hz_pack(zi, r.prim, r8);
-    /* p.pretest_march (default on; HZ_PRETEST_MARCH=0): the marching waves read the word first and leave the atomic
-     * out where the fragment cannot win - a stale, larger value only costs the atomic.  The second round's survivors
-     * passed the early depth test as TRIANGLES (some pixel of their box may still be won); most of their fragments
-     * lose all the same, and a 64-bit device-scope atomic costs the memory system more than a load that hits L2:
-     * 1.062 -> 0.996 ms per 16000x4000 render (profiles/r3_experiments.json; k_big's own pre-test loses: 1.15) */
+    /* p.pretest_march (second rounds into framebuffers beyond the last-level cache: draw_impl): the marching waves
+     * read the word first and leave the atomic out where the fragment cannot win */
     if(PRETEST || p.pretest_march)
     {
         if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))

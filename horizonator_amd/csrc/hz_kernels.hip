@@ -106,7 +106,7 @@ struct hz_env_t
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
-    int    pretest_march;           /* HZ_PRETEST_MARCH=0: the marching waves do not look before their atomics (default: they do) */
+    int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
@@ -129,7 +129,7 @@ static hz_env_t read_env(void)
     e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
     e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
-    e.pretest_march    = env_int("HZ_PRETEST_MARCH", 1) != 0;
+    e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
     if(!(e.near_px >= 0.5)) e.near_px = 20.0;
@@ -657,7 +657,7 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.pretest = d->env.pretest > 0 ? 1 : 0;
     p.exp_fb[HZ_WHO_MARCH] = d->env.exp_fb_march; p.exp_fb[HZ_WHO_BIG] = d->env.exp_fb_big;
     p.nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
-    p.pretest_march = d->env.pretest_march;
+    p.pretest_march = 0;                /* (the second round of a two-round draw may switch it on: draw_impl) */
     p.debug   = d->env.march_debug;
     p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
     return p;
@@ -1043,6 +1043,17 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
             /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
             p.pass = 2; p.early_z = ((unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32)) ? 1 : 0;
+            /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment
+             * cannot win (a stale, larger value only costs the atomic) - where the framebuffer is larger than the
+             * 256 MB of the chip's last-level cache.  Behind the first round's occluders most fragments of the second
+             * lose; an atomic that has to go out to HBM then costs more than the read it saves is worth - 16000x4000
+             * (512 MB): 1.06 -> 1.00 ms per render, the rough DEM 1.26 -> 1.17, a 45 degree view 3.9 -> 2.9.  With
+             * the framebuffer resident in that cache the atomics are cheap and the read's latency is all that is
+             * left: 8000x2000 (128 MB) 0.32 -> 0.38, a quarter-sector of 16000x4000 0.28 -> 0.31; and in a first
+             * round or a one-round draw most fragments win (2000x500: 0.144 -> 0.205).  profiles/r3_experiments.json,
+             * profiles/r3_scenes.json; k_big's own look before its atomics loses everywhere (HZ_PRETEST=1). */
+            p.pretest_march = d->env.pretest_march >= 0 ? d->env.pretest_march
+                                                        : ((unsigned long long)p.SW*(unsigned long long)p.H*8ull > (256ull << 20) ? 1 : 0);
         }
         else if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
         HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));

@@ -65,7 +65,7 @@ ROWS = [
     ("k_march: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2"}, None, "the same with the store kept"),
     ("both: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2", "HZ_EXP_FB_BIG": "2"}, None, "no atomic anywhere"),
     ("k_big looks before its atomics", {"HZ_PRETEST": "1"}, None, "reads the word first, skips fragments that cannot win"),
-    ("the marching waves do not look before their atomics", {"HZ_PRETEST_MARCH": "0"}, None, "round 2's behaviour: every fragment of the marching waves is an atomic"),
+    ("the second round's waves do not look before their atomics", {"HZ_PRETEST_MARCH": "0"}, None, "round 2's behaviour: every fragment of the marching waves is an atomic (default for framebuffers of up to 256 MB)"),
     ("launch grid padded to a multiple of 8 strip columns", {"HZ_EXP_XCD_PAD": "1"}, None,
      "all segments of a strip column on one XCD (workgroups are dealt to the XCDs round-robin): L2 locality against balance"),
     ("first round reaches cells wider than 10 px", {"HZ_NEAR_PX": "10"}, None, "default 20"),
