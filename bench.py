@@ -303,6 +303,10 @@ def main():
         d_pk = S["d_pk"]
         if sparse:
             ex = exchange()
+            if on_gpu:
+                # the strip buffer of this slot was last read by the exchange of two panoramas ago, on torch's stream
+                # (finish() made that stream wait for it): the conversion that refills it is ordered behind that
+                h.waits_for_stream(my_stream())
             if S["SW"] > 0:
                 h.render_sparse(d_pk[slot].data_ptr(), S["MSTRIDE"])
             if on_gpu:
