@@ -192,7 +192,8 @@ struct hz_dev
      * round, which runs on a stream of its own (nstream) beside the second round
      * of the panorama before. */
     hipStream_t         qstream, nstream;
-    hipEvent_t          ev_marched, ev_qfree[HZ_NFB], ev_near, ev_nqfree[HZ_NFB];
+    hipEvent_t          ev_marched, ev_near;
+    int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
     hz_bigitem_t*       d_bigitem_s[2*HZ_NFB];
     hz_rec_t*           d_midrec_s[2*HZ_NFB];
@@ -265,11 +266,6 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
         (void)hipFree(d->d_midrec_s[i]);
         (void)hipFree(d->d_clip_s[i]);
         (void)hipFree(d->d_big_counters_s[i]);
-    }
-    for(int i=0; i<HZ_NFB; i++)
-    {
-        if(d->ev_qfree[i])  (void)hipEventDestroy(d->ev_qfree[i]);
-        if(d->ev_nqfree[i]) (void)hipEventDestroy(d->ev_nqfree[i]);
     }
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
@@ -377,13 +373,6 @@ static int create_impl(hz_dev_t* d)
         HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)q.clip_capacity*sizeof(uint32_t)));
         HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], HZ_NCOUNTERS*sizeof(unsigned int)));
         HZ_CHECK(hipMemset(d->d_big_counters_s[i], 0, HZ_NCOUNTERS*sizeof(unsigned int)));
-    }
-    for(int i=0; i<HZ_NFB; i++)
-    {
-        HZ_CHECK(hipEventCreateWithFlags(&d->ev_qfree[i],  hipEventDisableTiming));
-        HZ_CHECK(hipEventCreateWithFlags(&d->ev_nqfree[i], hipEventDisableTiming));
-        HZ_CHECK(hipEventRecord(d->ev_qfree[i],  d->qstream));
-        HZ_CHECK(hipEventRecord(d->ev_nqfree[i], d->nstream));
     }
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
@@ -842,7 +831,12 @@ extern "C" int hz_hip_draw(hz_dev_t* d, const hz_view_t* view)
     return draw_impl(d, view);
 }
 
-/* The framebuffer of the previous draw goes back to "cleared" (glClear,
+/* (Every command between two marching kernels on `stream` - an event to record, an event to wait for - is a packet the
+ * command processor works through before it launches the second: ~50 us lay between consecutive second rounds with three
+ * waits and three records in there, profiles/r3_pipelined_timeline.txt.  So: ev_free[i] stands for the queue sets of
+ * framebuffer i as well - it is recorded behind a conversion or a clear, both of which wait for ev_drawn, the end of
+ * every kernel of the draw -, and `stream` only tells rstream about readers of the framebuffer when there were any.)
+ * The framebuffer of the previous draw goes back to "cleared" (glClear,
  * reference horizonator-lib.c:896: depth = 1.0 -> all-ones words): its
  * conversion did that already (k_resolve<true>), or a memset does it now on
  * rstream, behind the conversions of that draw and behind whatever `stream`
@@ -851,8 +845,12 @@ static int next_framebuffer(hz_dev_t* d, hz_params_t& p)
 {
     const bool prof = d->profiling != 0;
     const int prev = d->fbi, next = (prev + 1) % HZ_NFB;
-    HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
-    HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
+    if(d->stream_reads_fb)
+    {
+        HZ_CHECK(hipEventRecord(d->ev_readers, d->stream));
+        HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_readers, 0));
+        d->stream_reads_fb = 0;
+    }
     HZ_CHECK(hipStreamWaitEvent(d->rstream, d->ev_drawn, 0));       /* the previous draw's last kernels (qstream) */
     if(prof) HZ_CHECK(hipEventRecord(d->ev[0], d->rstream));
     if(d->fb_used[prev])
@@ -978,11 +976,11 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
 
     const mr_queue_t q = queue_set(d, next);        /* one-round draw, or second round */
     bool near_beside_far = false;                   /* the second round did not wait for the first */
+    bool waited_near = false;                       /* ... or it did */
 
     if(d->raster == HZ_RASTER_SCATTER)
     {
-        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
-        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));  /* (the framebuffer is free: so are its queue sets) */
         if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); HZ_CHECK(hipEventRecord(d->ev[9], d->stream)); }
         dim3 grid((p.N-1 + SC_CX-1)/SC_CX, (p.N-1 + SC_CY-1)/SC_CY);
         hipLaunchKernelGGL(k_scatter, grid, dim3(SC_THREADS), 0, d->stream,
@@ -1017,7 +1015,6 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             /* round 1, on its own stream */
             const mr_queue_t qn = queue_set(d, HZ_NFB + next);
             HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_free[next], 0));
-            HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_nqfree[next], 0));
             hz_params_t p1 = p;
             p1.pass = 1; p1.early_z = 0;
             if(fresh_lists)
@@ -1029,7 +1026,6 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
             if(queue_kernels(d, qn, p1, d->nstream) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
-            HZ_CHECK(hipEventRecord(d->ev_nqfree[next], d->nstream));
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
              * finds the marching kernel of the draw before it finished (a single render, or
@@ -1037,7 +1033,10 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
              * early depth test then sees fewer occluders and skips less; what it skips is
              * hidden whenever it looks (depths only decrease), so the bytes are the same. */
             if(d->env.always_wait_near || hipEventQuery(d->ev_marched) != hipSuccess)
+            {
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
+                waited_near = true;             /* (the first round itself waited for the framebuffer: no second wait for that below) */
+            }
             else
                 near_beside_far = true;         /* "drawn" then has to wait for both rounds: see qstream below */
             (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
@@ -1056,8 +1055,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                                                         : ((unsigned long long)p.SW*(unsigned long long)p.H*8ull > (256ull << 20) ? 1 : 0);
         }
         else if(prof) { HZ_CHECK(hipEventRecord(d->ev[7], d->stream)); HZ_CHECK(hipEventRecord(d->ev[6], d->stream)); }
-        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
-        HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_qfree[next], 0));  /* the queue set is free again */
+        if(!waited_near) HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
         if(fresh_lists)
         {
             list_items(p, zn, a0, a1, *d->lists.scratch);
@@ -1078,7 +1076,6 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
     if(queue_kernels(d, q, p, d->qstream) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
-    HZ_CHECK(hipEventRecord(d->ev_qfree[next], d->qstream));
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
     return 0;
@@ -1579,6 +1576,7 @@ extern "C" int hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24)
     HZ_ON_DEVICE(d);
     if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
+    d->stream_reads_fb = 1;
     if(x < d->col0 || x >= d->col1 || y < 0 || y >= d->H)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_read_depth: (%d,%d) outside the drawn sector", x, y);
@@ -1720,6 +1718,7 @@ extern "C" int hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float
     HZ_ON_DEVICE(d);
     if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
+    d->stream_reads_fb = 1;
     if(d->col0 != 0 || d->col1 != d->W || cell_w <= 0 || cell_h <= 0 || nx <= 0 || ny <= 0)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells: needs a full-width context and positive sizes");
@@ -1754,6 +1753,7 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
     HZ_ON_DEVICE(d);
     if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
+    d->stream_reads_fb = 1;
     if(d->col0 != 0 || d->col1 != d->W || npois < 0)
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_poi_visibility: needs a full-width context");
