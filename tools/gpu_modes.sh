@@ -2,12 +2,15 @@
 # The GPU test suite once under every global mode switch (about one minute each on an MI355X):
 # one stream; one / two rounds forced on every scene (two rounds on small scenes make the first
 # round the longer one - that is how the conversion-waits-for-both-rounds bug of round 2 showed);
-# first rounds of 8 and 300 cells; the unabridged transform; no clearing conversion; plain copies.
+# first rounds of 8 and 300 cells; the unabridged transform; no clearing conversion; plain copies;
+# round 3: no work lists, reads before the atomics forced on, odd segment lengths and a padded launch grid.
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 rc=0
 for env in "HZ_SERIAL=1" "HZ_TWO_PASS=0" "HZ_TWO_PASS=1" "HZ_TWO_PASS=1 HZ_SERIAL=1" "HZ_TWO_PASS=1 HZ_NEAR_CELLS=8" \
            "HZ_TWO_PASS=1 HZ_NEAR_CELLS=300" "HZ_TWO_PASS=1 HZ_RESOLVE_CLEARS=0" "HZ_NO_FAST_MATH=1" "HZ_RESOLVE_CLEARS=0" \
-           "HZ_ALWAYS_WAIT_NEAR=1 HZ_TWO_PASS=1" "HZ_PLAIN_COPY=1" "HZ_COPY_THREADS=1"; do
+           "HZ_ALWAYS_WAIT_NEAR=1 HZ_TWO_PASS=1" "HZ_PLAIN_COPY=1" "HZ_COPY_THREADS=1" \
+           "HZ_NO_WORKLIST=1" "HZ_NO_WORKLIST=1 HZ_TWO_PASS=1" "HZ_TWO_PASS=1 HZ_PRETEST_MARCH=1" "HZ_TWO_PASS=1 HZ_PRETEST=1 HZ_NEAR_PX=3" \
+           "HZ_TWO_PASS=1 HZ_FAR_ROWS=5 HZ_EXP_XCD_PAD=1"; do
   echo "== $env"
   env $env timeout 900 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_bench_multi.py 2>&1 | grep -E "passed|failed|error" | tail -2
   [ ${PIPESTATUS[0]} -ne 0 ] && rc=1
