@@ -61,6 +61,7 @@ bool horizonator_amd_sync(const horizonator_context_t* ctx);
  *   horizonator_amd_waits_for_stream: conversions queued on the context from now on (e.g.
  *     horizonator_amd_resolve_sparse_strips of strips that `stream` is still receiving) run after
  *     everything queued on `stream` so far. */
+/* (`stream` must be a stream of the context's device) */
 bool horizonator_amd_stream_waits_for_outputs(const horizonator_context_t* ctx, void* stream);
 bool horizonator_amd_waits_for_stream(const horizonator_context_t* ctx, void* stream);
 

@@ -218,7 +218,9 @@ int  hz_hip_last_times(hz_dev_t* d, hz_times_t* t);
 void* hz_hip_stream(hz_dev_t* d);
 int   hz_hip_wait_outputs(hz_dev_t* d, void* stream);
 /* ... and the other way round: conversions queued from now on run after
- * everything queued on `stream` so far (strips a collective is still delivering) */
+ * everything queued on `stream` so far (strips a collective is still delivering).
+ * `stream` must belong to the context's device in both calls (an event of one
+ * device cannot be recorded on a stream of another: the call then fails). */
 int   hz_hip_wait_for(hz_dev_t* d, void* stream);
 
 /* Self-check of the marching kernel's abridged division / square-root

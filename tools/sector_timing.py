@@ -16,15 +16,19 @@ h.set_profiling(True)
 fit = []
 for G in (1, 2, 4, 8):
     worst = 0
+    worst_lat = 0
     for r in range(G):
         c0, c1 = sector_columns(W, G, r)
         h.set_sector(c0, c1)
         img = torch.empty((H, c1-c0, 3), dtype=torch.uint8, device="cuda")
         rng = torch.empty((H, c1-c0), dtype=torch.float32, device="cuda")
-        ts = []
+        ts, lat = [], []
         for k in range(6):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
             h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+            lat.append((time.perf_counter() - t0) * 1e3)
             ts.append(h.last_times()["total_ms"])
+        worst_lat = max(worst_lat, float(np.median(lat[1:])))
         if G == 8: print("   sector", r, {k: round(v, 3) for k, v in h.last_times().items()})
         worst = max(worst, float(np.median(ts[1:])))
         if r == 0 and G > 1:
@@ -82,7 +86,8 @@ for G in (1, 2, 4, 8):
     extra = (f"; rank 0 (own sector + conversion of all {G} strips): packed {rank0:.3f} ms, sparse {rank0s:.3f} ms wall; "
              f"a rank of --gather rotate (sector every panorama, conversion every {G}th, back to back): {rot:.3f} ms per panorama; "
              f"sector alone back to back: {alone:.3f} ms") if G > 1 else ""
-    print(f"G={G}: slowest sector {worst:.3f} ms device time (sum of stages, one render waited for){extra}")
+    print(f"G={G}: slowest sector {worst:.3f} ms device time (sum of stages, one render waited for; its stages overlap: "
+          f"host clock around that render {worst_lat:.3f} ms){extra}")
     fit.append((1.0 / G, worst, alone if G > 1 else None))
 xs = np.array([f[0] for f in fit]); ys = np.array([f[1] for f in fit])
 b, a = np.polyfit(xs, ys, 1)
