@@ -1,6 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-host --no-extra"
-for e in "X=1" "HZ_RESOLVE_CONST=0" "X=1" "HZ_RESOLVE_CONST=0" "X=1" "HZ_RESOLVE_CONST=0"; do
- echo "$e $(env $e $B 2>/dev/null | grep '^{' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4))")"
-done
+for e in "X=1" "HZ_PRETEST=2" "X=1" "HZ_PRETEST=2"; do echo "== $e"; env $e python tools/scenes.py --scenes cfg3,cfg3_rough,cfg3_summit,cfg3_zoom45,cfg5 --steps 20 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print({k: round(v.get('ms_per_render',-1),4) for k,v in d['scenes'].items()})"; done
