@@ -1,7 +1,12 @@
 /* oracle_annot.c - TEST INFRASTRUCTURE (see oracle.h).
- * CPU restatement of the two passes the reference's annotator makes over the
- * range image (reference annotator.c:228-264 and :280-348) and of the two
- * library functions they call (reference horizonator-lib.c:1053-1213).
+ * Restates, NEARLY VERBATIM - the mixed float/double evaluation order is what has
+ * to be reproduced -, the two passes the reference's annotator makes over the range
+ * image (reference annotator.c:228-264 and :280-348) and the two library functions
+ * they call (reference horizonator-lib.c:1053-1213).  PARITY UNPINNED by a run of
+ * the reference: annotator.c needs cairo and libswscale, which this image lacks
+ * (tests/caller_stubs holds stand-ins for LINKING the reference's CLI; a run
+ * against stand-ins would pin nothing).  The device kernels are compared with this
+ * file within 1e-6 degrees / 1e-3 pixels (tests/test_annot.py), not bit for bit.
  */
 #define _GNU_SOURCE
 #include <float.h>
