@@ -290,7 +290,12 @@ def main():
             state["converted"] += 1
         pending[slot] = None
 
+    host_us = {"finish": 0.0, "render": 0.0, "post": 0.0, "n": 0}    # diagnostics (BENCH_HOST_TIMES=1): host time per part of a step
+
     def step():
+        if os.environ.get("BENCH_HOST_TIMES") and multi and sparse:
+            t0 = time.perf_counter(); slot = state["k"] % NBUF; finish(slot); t1 = time.perf_counter()
+            host_us["finish"] += (t1 - t0) * 1e6
         slot = state["k"] % NBUF
         dst = state["k"] % world if rotate else 0      # the rank that gathers and converts this panorama
         state["k"] += 1
@@ -303,6 +308,7 @@ def main():
         d_pk = S["d_pk"]
         if sparse:
             ex = exchange()
+            t0 = time.perf_counter()
             if on_gpu:
                 # the strip buffer of this slot was last read by the exchange of two panoramas ago, on torch's stream
                 # (finish() made that stream wait for it): the conversion that refills it is ordered behind that
@@ -317,8 +323,10 @@ def main():
                 h.sync()
                 send = d_pk[slot].cpu()                 # gloo (diagnostics): through host memory
             S["sent"][slot] = send
+            t1 = time.perf_counter()
             ex.post(slot, send, dst=dst)
             pending[slot] = True
+            host_us["render"] += (t1 - t0) * 1e6; host_us["post"] += (time.perf_counter() - t1) * 1e6; host_us["n"] += 1
             return
         if S["SW"] > 0:
             h.render_packed(d_pk[slot].data_ptr())
@@ -372,6 +380,8 @@ def main():
         drain()
         kern = []
         fence()
+        for key in host_us:
+            host_us[key] = 0.0
         t0 = time.perf_counter()
         for k in range(steps):
             # HIP events around the kernels of the LAST of the K panoramas only: every event is a packet the command
@@ -574,6 +584,8 @@ def main():
             line["scenes"] = scene_recs
         if verified is not None:
             line["gathered_panorama_equals_single_gpu_render"] = verified
+        if os.environ.get("BENCH_HOST_TIMES") and host_us["n"]:
+            line["host_us_per_step"] = {k: v / host_us["n"] for k, v in host_us.items() if k != "n"}
         line.update(extra)
         print(json.dumps(line))
     h.close()

@@ -258,8 +258,8 @@ class StripExchange:
     the ranks agree ONCE on a capacity (`cap`: the longest strip seen so far plus a margin)
     and every panorama sends exactly that many words: the strip's own first word says how many of
     them mean anything.  Buffers - send side and the gathering rank's bins - are allocated once per
-    slot and reused.  Whether any strip did not fit travels beside the strips as one flag word,
-    all-reduced asynchronously; it is looked at when the exchange is completed, a panorama
+    slot and reused.  Whether any strip did not fit travels beside the strips as one word - the longest
+    strip's length -, all-reduced (MAX) asynchronously; it is looked at when the exchange is completed, a panorama
     later and off the critical path, and grow() then redoes that one exchange with more room.
 
     The gathering rank is chosen per exchange (post(..., dst=r)): with `any_dst` every rank keeps
@@ -321,8 +321,9 @@ class StripExchange:
         self._fit_slot(slot)
         cap = self.slot_cap[slot]
         self.slot_dst[slot] = dst
-        # does this rank's strip fit?  (device-side: no value leaves the device here)
-        self.flags[slot].copy_((strip[0:1] > (cap - self.hdr)).to(torch.int32))
+        # does every rank's strip fit?  The longest strip's length travels beside the strips (device-side: no value
+        # leaves the device here; the comparison with the capacity is the host's, when it looks at the word later)
+        self.flags[slot].copy_(strip[0:1])
         send = strip[:cap]
         if self.world == 1:
             self.bins[slot][0].copy_(send)
@@ -353,11 +354,12 @@ class StripExchange:
             w1.wait()                               # nccl: the current stream waits; gloo: the host does
         if self.cuda:
             self.flag_ready[slot].synchronize()
-            overflow = bool(int(self.flag_host[slot][0]))
+            longest = int(self.flag_host[slot][0])
         else:
             if w2 is not None:
                 w2.wait()
-            overflow = bool(int(self.flags[slot][0]))
+            longest = int(self.flags[slot][0])
+        overflow = longest > self.slot_cap[slot] - self.hdr
         return (self.bins[slot] if self.rank == self.slot_dst[slot] else None), overflow
 
     def grow(self, slot, strip):
