@@ -1,4 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for e in "X=1" "HZ_PRETEST=2" "X=1" "HZ_PRETEST=2"; do echo "== $e"; env $e python tools/scenes.py --scenes cfg3,cfg3_rough,cfg3_summit,cfg3_zoom45,cfg5 --steps 20 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print({k: round(v.get('ms_per_render',-1),4) for k,v in d['scenes'].items()})"; done
+bash tools/gpu_tests.sh
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+( time python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err ) 2>&1 | grep real
+python3 -c "
+import json; d=json.load(open('gpurun_out/bench_default.json')); print(d['steps'], d['ms_per_step'], d['value'], d['roofline']['frac'], d['host_inclusive']['ms'], d['host_inclusive']['ms_with_fresh_arrays_per_call'], {k:round(v.get('ms_per_render',-1),3) for k,v in d['scenes'].items()})"
