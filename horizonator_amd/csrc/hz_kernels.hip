@@ -28,6 +28,7 @@
 #include <string.h>
 #include <sys/mman.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -1390,7 +1391,7 @@ struct hz_copy_pool
     std::vector<std::thread> threads;
     std::deque<task_t> q;
     bool stop = false;
-    bool populate_works = true;         /* cleared by the first madvise that does not know MADV_POPULATE_WRITE */
+    std::atomic<bool> populate_works{true};     /* cleared by the first madvise that does not know MADV_POPULATE_WRITE */
 
     explicit hz_copy_pool(int n)
     {
@@ -1566,8 +1567,8 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
         if(hipStreamSynchronize(d->rstream) != hipSuccess) rc = -1;
         return rc;
     }
-    if(rc == 0) rc = copy_out(d, nbuf, dst, src, row_bytes, d->H, nbands, band_rows, pool);
-    pool->wait(&mapped);                                /* (its tasks name the caller's buffers: none may outlive this call) */
+    if(rc == 0 && pool) rc = copy_out(d, nbuf, dst, src, row_bytes, d->H, nbands, band_rows, pool);
+    if(pool) pool->wait(&mapped);                       /* (its tasks name the caller's buffers: none may outlive this call) */
     return rc;
 }
 
