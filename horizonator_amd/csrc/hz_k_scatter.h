@@ -267,6 +267,38 @@ __device__ static inline int32_t hz_floor_div(int64_t n, int32_t d, double r)
     return q;
 }
 
+/* The covered pixel centres of row `row` of a set-up triangle: a span [x0, x1] inside the columns [xlo, xhi] given -
+ * each edge function is linear in px, so each edge bounds the span from one side, at a column that an integer division
+ * gives exactly (the ownership of zeros included).  Returns the number of pixels (0: none). */
+__device__ static inline uint32_t hz_row_span(const hz_edges_t& e, int row, int32_t xlo, int32_t xhi, int32_t* first)
+{
+    int32_t x0 = xlo, x1 = xhi;
+    bool any = true;
+    #pragma unroll
+    for(int m=0; m<3; m++)
+    {
+        /* edge m covers px in this row iff g + dx*row - dy*px >= 0 (hz_edges_t), g and
+         * the deltas wave-uniform: a bound on px from one side, by an exact division */
+        const int32_t dx = e.dx[m], dy = -e.ndy[m];
+        const int64_t n8 = hz_edges_g(&e, m) + (int64_t)dx*(int64_t)row;
+        if(dy > 0)
+        {
+            /* dy*px <= n8  <=>  px <= floor(n8 / dy) */
+            const int32_t q = hz_floor_div(n8, dy, hz_rcp_f64((double)dy));
+            x1 = x1 < q ? x1 : q;
+        }
+        else if(dy < 0)
+        {
+            /* |dy|*px >= -n8  <=>  px >= ceil(-n8 / |dy|) = -floor(n8 / |dy|) */
+            const int32_t q = hz_floor_div(n8, -dy, hz_rcp_f64((double)(-dy)));
+            x0 = x0 > -q ? x0 : -q;
+        }
+        else if(n8 < 0) any = false;                /* a horizontal edge: the whole row is on one side */
+    }
+    *first = x0;
+    return (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
+}
+
 /* large triangles: one wave per work item = 64 pixel rows of a queued triangle.
  * Lane = row: the covered pixel centres of a row are a span [x0, x1] - each
  * edge function is linear in px, so each edge bounds the span from one side, at
@@ -279,8 +311,10 @@ __global__ __launch_bounds__(256)
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
            const unsigned int* __restrict__ big_counters,
-           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p)
+           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p, const unsigned int* tile_state)
 {
+    /* (tile_state: the round's triangles were binned and drawn by screen tile - hz_k_tile.h - unless there were too many) */
+    if(tile_state && tile_state[1]) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
     const unsigned int nitems = min(big_counters[1], ~big_counters[2]);
     (void)bigrec_capacity; (void)bigitem_capacity;
@@ -307,30 +341,9 @@ void k_big(unsigned long long* __restrict__ fb,
         const int rows_log2 = hz_big_rows_log2(bw);
         const int row_first = py0 + ((int)item.chunk << rows_log2);
         const int row = row_first + lane;
-        int32_t x0 = px0, x1 = px0 + bw - 1;
-        bool any = lane < (1 << rows_log2) && row < py0 + bh;
-        #pragma unroll
-        for(int m=0; m<3; m++)
-        {
-            /* edge m covers px in this row iff g + dx*row - dy*px >= 0 (hz_edges_t), g and
-             * the deltas wave-uniform: a bound on px from one side, by an exact division */
-            const int32_t dx = br.r.e.dx[m], dy = -br.r.e.ndy[m];
-            const int64_t n8 = hz_edges_g(&br.r.e, m) + (int64_t)dx*(int64_t)row;
-            if(dy > 0)
-            {
-                /* dy*px <= n8  <=>  px <= floor(n8 / dy) */
-                const int32_t q = hz_floor_div(n8, dy, hz_rcp_f64((double)dy));
-                x1 = x1 < q ? x1 : q;
-            }
-            else if(dy < 0)
-            {
-                /* |dy|*px >= -n8  <=>  px >= ceil(-n8 / |dy|) = -floor(n8 / |dy|) */
-                const int32_t q = hz_floor_div(n8, -dy, hz_rcp_f64((double)(-dy)));
-                x0 = x0 > -q ? x0 : -q;
-            }
-            else if(n8 < 0) any = false;                /* a horizontal edge: the whole row is on one side */
-        }
-        const uint32_t count = (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
+        int32_t x0 = px0;
+        const uint32_t span = hz_row_span(br.r.e, row, px0, px0 + bw - 1, &x0);
+        const uint32_t count = (lane < (1 << rows_log2) && row < py0 + bh) ? span : 0u;
 
         /* lane = pixel */
         const uint32_t incl  = mr_scan(count, lane);

@@ -83,6 +83,7 @@ struct hz_device_guard
 
 #include "hz_k_common.h"
 #include "hz_k_scatter.h"
+#include "hz_k_tile.h"
 #include "hz_k_march.h"
 #include "hz_k_resolve.h"
 #include "hz_k_tex.h"
@@ -108,6 +109,8 @@ struct hz_env_t
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
+    int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
+                                     * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
@@ -130,6 +133,7 @@ static hz_env_t read_env(void)
     e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
     e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
+    e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
@@ -202,6 +206,7 @@ struct hz_dev
     unsigned int*       d_big_counters_s[2*HZ_NFB];    /* HZ_NCOUNTERS each, see mr_queue_t */
     unsigned int        bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
     unsigned int        near_bigrec_capacity, near_bigitem_capacity, near_clip_capacity;    /* first rounds' sets: no medium queue */
+    tl_bins_t           tiles_s[2*HZ_NFB];             /* the tile bins of each queue set (hz_k_tile.h) */
     /* the last draw: a conversion that clears the framebuffer behind itself
      * (k_resolve<true>) consumes it; whoever wants to read it after that gets it
      * drawn again first (fb_refill) */
@@ -267,6 +272,8 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
         (void)hipFree(d->d_midrec_s[i]);
         (void)hipFree(d->d_clip_s[i]);
         (void)hipFree(d->d_big_counters_s[i]);
+        (void)hipFree(d->tiles_s[i].count); (void)hipFree(d->tiles_s[i].offset); (void)hipFree(d->tiles_s[i].cursor);
+        (void)hipFree(d->tiles_s[i].pairs); (void)hipFree(d->tiles_s[i].state);
     }
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
@@ -374,6 +381,19 @@ static int create_impl(hz_dev_t* d)
         HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)q.clip_capacity*sizeof(uint32_t)));
         HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], HZ_NCOUNTERS*sizeof(unsigned int)));
         HZ_CHECK(hipMemset(d->d_big_counters_s[i], 0, HZ_NCOUNTERS*sizeof(unsigned int)));
+        if(d->env.tiles > 0)                /* (the tile bins exist only where HZ_TILES=1 asks for them) */
+        {
+            tl_bins_t& tb = d->tiles_s[i];
+            const size_t ntiles = (size_t)((d->W + TL_W-1)/TL_W)*((d->H + TL_H-1)/TL_H);
+            tb.capacity = 2*q.bigrec_capacity;
+            HZ_CHECK(hipMalloc(&tb.count,  ntiles*sizeof(unsigned int)));
+            HZ_CHECK(hipMalloc(&tb.offset, (ntiles + 1)*sizeof(unsigned int)));
+            HZ_CHECK(hipMalloc(&tb.cursor, ntiles*sizeof(unsigned int)));
+            HZ_CHECK(hipMalloc(&tb.pairs,  (size_t)tb.capacity*sizeof(unsigned int)));
+            HZ_CHECK(hipMalloc(&tb.state,  2*sizeof(unsigned int)));
+            HZ_CHECK(hipMemset(tb.count, 0, ntiles*sizeof(unsigned int)));
+            HZ_CHECK(hipMemset(tb.state, 0, 2*sizeof(unsigned int)));
+        }
     }
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
@@ -883,7 +903,7 @@ static mr_queue_t queue_set(const hz_dev_t* d, int k)
 }
 
 /* what the marching waves queued: clipper, medium boxes, large boxes */
-static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st)
+static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st, int set, bool by_tile)
 {
     hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
     HZ_CHECK(hipGetLastError());
@@ -894,9 +914,25 @@ static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp
                            q.midrec_capacity, pp);
         HZ_CHECK(hipGetLastError());
     }
+    const unsigned int* tile_state = NULL;
+    if(by_tile)
+    {
+        /* the round's large triangles by screen tile, depth in LDS (hz_k_tile.h): count, scan, fill, draw.  k_big
+         * follows and stands down unless the scan found more (triangle, tile) pairs than there is room for. */
+        tl_bins_t tb = d->tiles_s[set];
+        tb.tiles_x = (pp.SW + TL_W-1)/TL_W; tb.tiles_y = (pp.H + TL_H-1)/TL_H;
+        hipLaunchKernelGGL(k_tile_bin<false>, dim3(1024), dim3(256), 0, st, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
+                           (const unsigned int*)q.counters, q.bigrec_capacity, tb, pp);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tb);
+        hipLaunchKernelGGL(k_tile_bin<true>, dim3(1024), dim3(256), 0, st, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
+                           (const unsigned int*)q.counters, q.bigrec_capacity, tb, pp);
+        hipLaunchKernelGGL(k_tile_raster, dim3((unsigned)(tb.tiles_x*tb.tiles_y)), dim3(256), 0, st, d->d_fb, (const hz_bigrec_t*)q.bigrec, tb, pp);
+        HZ_CHECK(hipGetLastError());
+        tile_state = tb.state;
+    }
     hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, st,
                        d->d_fb, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
-                       q.counters, q.bigrec_capacity, q.bigitem_capacity, pp);
+                       q.counters, q.bigrec_capacity, q.bigitem_capacity, pp, tile_state);
     HZ_CHECK(hipGetLastError());
     return 0;
 }
@@ -976,6 +1012,10 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     const int next = d->fbi;
 
     const mr_queue_t q = queue_set(d, next);        /* one-round draw, or second round */
+    /* large triangles by screen tile instead of by k_big's atomics (HZ_TILES; hz_k_tile.h).  A tile's workgroup must be
+     * the only writer of its pixels: the kernels before it on its stream are done, and the second round of a two-round
+     * draw then always waits for the first (a second round beside its first would write the same framebuffer). */
+    const bool by_tile = d->env.tiles > 0 && d->raster != HZ_RASTER_SCATTER;
     bool near_beside_far = false;                   /* the second round did not wait for the first */
     bool waited_near = false;                       /* ... or it did */
 
@@ -1025,7 +1065,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             }
             if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
-            if(queue_kernels(d, qn, p1, d->nstream) != 0) return -1;
+            if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
@@ -1033,7 +1073,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
              * the first of a series) starts its second round at once, beside its first.  The
              * early depth test then sees fewer occluders and skips less; what it skips is
              * hidden whenever it looks (depths only decrease), so the bytes are the same. */
-            if(d->env.always_wait_near || hipEventQuery(d->ev_marched) != hipSuccess)
+            if(d->env.always_wait_near || by_tile || hipEventQuery(d->ev_marched) != hipSuccess)
             {
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
                 waited_near = true;             /* (the first round itself waited for the framebuffer: no second wait for that below) */
@@ -1075,7 +1115,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * second round's queue kernels only as long as the second round itself waited for the first */
     if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
-    if(queue_kernels(d, q, p, d->qstream) != 0) return -1;
+    if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;

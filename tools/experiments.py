@@ -66,6 +66,9 @@ ROWS = [
     ("both: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2", "HZ_EXP_FB_BIG": "2"}, None, "no atomic anywhere"),
     ("k_big looks before its atomics", {"HZ_PRETEST": "1"}, None, "reads the word first, skips fragments that cannot win"),
     ("the second round's waves do not look before their atomics", {"HZ_PRETEST_MARCH": "0"}, None, "round 2's behaviour: every fragment of the marching waves is an atomic (default for framebuffers of up to 256 MB)"),
+    ("north_star's tile-binned rasteriser with depth in LDS for the large triangles (hz_k_tile.h)", {"HZ_TILES": "1"}, None,
+     "64x32-pixel tiles owned by one workgroup each: LDS atomic minima, one plain store per pixel; byte-identical"),
+    ("the same, zfar 40 km", {"HZ_TILES": "1"}, 40000.0, "where the near field is most of the work"),
     ("launch grid padded to a multiple of 8 strip columns", {"HZ_EXP_XCD_PAD": "1"}, None,
      "all segments of a strip column on one XCD (workgroups are dealt to the XCDs round-robin): L2 locality against balance"),
     ("first round reaches cells wider than 10 px", {"HZ_NEAR_PX": "10"}, None, "default 20"),

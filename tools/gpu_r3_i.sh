@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_tests.sh
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-( time python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err ) 2>&1 | grep real
-python3 -c "
-import json; d=json.load(open('gpurun_out/bench_default.json')); print(d['steps'], d['ms_per_step'], d['value'], d['roofline']['frac'], d['host_inclusive']['ms'], d['host_inclusive']['ms_with_fresh_arrays_per_call'], {k:round(v.get('ms_per_render',-1),3) for k,v in d['scenes'].items()})"
+HZ_TILES=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_api.py tests/test_fullsize_checksums.py tests/test_gpu_sequences.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+for e in "X=1" "HZ_TILES=1" "X=1" "HZ_TILES=1"; do echo "== $e"; env $e python tools/scenes.py --scenes cfg3,cfg3_zfar40km,cfg3_zoom45,cfg2,cfg1 --steps 20 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print({k: round(v.get('ms_per_render',-1),4) for k,v in d['scenes'].items()})"; done
+HZ_SERIAL=1 HZ_TILES=1 python tools/scene_times.py cfg3 cfg3_zoom45 2>&1 | grep -v amdgpu.ids
+HZ_SERIAL=1 python tools/scene_times.py cfg3 cfg3_zoom45 2>&1 | grep -v amdgpu.ids
