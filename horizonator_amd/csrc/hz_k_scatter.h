@@ -314,7 +314,7 @@ void k_big(unsigned long long* __restrict__ fb,
            unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p, const unsigned int* tile_state)
 {
     /* (tile_state: the round's triangles were binned and drawn by screen tile - hz_k_tile.h - unless there were too many) */
-    if(tile_state && tile_state[1]) return;
+    if(tile_state && tile_state[0] == 0) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
     const unsigned int nitems = min(big_counters[1], ~big_counters[2]);
     (void)bigrec_capacity; (void)bigitem_capacity;

@@ -111,6 +111,7 @@ struct hz_env_t
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
     int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
                                      * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
+    int    tile_list;               /* HZ_TILE_LIST=n: a tile's list holds n triangles instead of 256 (tests: the fall-back to k_big) */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
@@ -134,6 +135,7 @@ static hz_env_t read_env(void)
     e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.tiles            = env_int("HZ_TILES", 0) != 0;
+    e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
@@ -272,8 +274,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
         (void)hipFree(d->d_midrec_s[i]);
         (void)hipFree(d->d_clip_s[i]);
         (void)hipFree(d->d_big_counters_s[i]);
-        (void)hipFree(d->tiles_s[i].count); (void)hipFree(d->tiles_s[i].offset); (void)hipFree(d->tiles_s[i].cursor);
-        (void)hipFree(d->tiles_s[i].pairs); (void)hipFree(d->tiles_s[i].state);
+        (void)hipFree(d->tiles_s[i].cursor); (void)hipFree(d->tiles_s[i].pairs); (void)hipFree(d->tiles_s[i].state); (void)hipFree(d->tiles_s[i].busy);
     }
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
@@ -385,13 +386,11 @@ static int create_impl(hz_dev_t* d)
         {
             tl_bins_t& tb = d->tiles_s[i];
             const size_t ntiles = (size_t)((d->W + TL_W-1)/TL_W)*((d->H + TL_H-1)/TL_H);
-            tb.capacity = 2*q.bigrec_capacity;
-            HZ_CHECK(hipMalloc(&tb.count,  ntiles*sizeof(unsigned int)));
-            HZ_CHECK(hipMalloc(&tb.offset, (ntiles + 1)*sizeof(unsigned int)));
             HZ_CHECK(hipMalloc(&tb.cursor, ntiles*sizeof(unsigned int)));
-            HZ_CHECK(hipMalloc(&tb.pairs,  (size_t)tb.capacity*sizeof(unsigned int)));
+            HZ_CHECK(hipMalloc(&tb.pairs,  ntiles*TL_LIST*sizeof(unsigned int)));
             HZ_CHECK(hipMalloc(&tb.state,  2*sizeof(unsigned int)));
-            HZ_CHECK(hipMemset(tb.count, 0, ntiles*sizeof(unsigned int)));
+            HZ_CHECK(hipMalloc(&tb.busy,   ntiles*sizeof(unsigned int)));
+            HZ_CHECK(hipMemset(tb.cursor, 0, ntiles*sizeof(unsigned int)));
             HZ_CHECK(hipMemset(tb.state, 0, 2*sizeof(unsigned int)));
         }
     }
@@ -917,16 +916,15 @@ static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp
     const unsigned int* tile_state = NULL;
     if(by_tile)
     {
-        /* the round's large triangles by screen tile, depth in LDS (hz_k_tile.h): count, scan, fill, draw.  k_big
-         * follows and stands down unless the scan found more (triangle, tile) pairs than there is room for. */
+        /* the round's large triangles by screen tile, depth in LDS (hz_k_tile.h): list, draw.  k_big follows and
+         * stands down unless some tile's list overflowed. */
         tl_bins_t tb = d->tiles_s[set];
         tb.tiles_x = (pp.SW + TL_W-1)/TL_W; tb.tiles_y = (pp.H + TL_H-1)/TL_H;
-        hipLaunchKernelGGL(k_tile_bin<false>, dim3(1024), dim3(256), 0, st, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
+        tb.list_cap = d->env.tile_list > 0 && d->env.tile_list < TL_LIST ? (unsigned int)d->env.tile_list : TL_LIST;
+        HZ_CHECK(hipMemsetAsync(tb.state, 0, 2*sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_tile_bin, dim3(1024), dim3(256), 0, st, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
                            (const unsigned int*)q.counters, q.bigrec_capacity, tb, pp);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tb);
-        hipLaunchKernelGGL(k_tile_bin<true>, dim3(1024), dim3(256), 0, st, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
-                           (const unsigned int*)q.counters, q.bigrec_capacity, tb, pp);
-        hipLaunchKernelGGL(k_tile_raster, dim3((unsigned)(tb.tiles_x*tb.tiles_y)), dim3(256), 0, st, d->d_fb, (const hz_bigrec_t*)q.bigrec, tb, pp);
+        hipLaunchKernelGGL(k_tile_raster, dim3(2048), dim3(256), 0, st, d->d_fb, (const hz_bigrec_t*)q.bigrec, tb, pp);
         HZ_CHECK(hipGetLastError());
         tile_state = tb.state;
     }

@@ -328,15 +328,15 @@ def test_random_views_bit_exact_vs_oracle_and_vs_reference(seed):
         assert hashlib.sha256(full["z24"].tobytes()).hexdigest() == g["z24_sha256"]
 
 
-@pytest.mark.parametrize("capacity", [None, 40])
+@pytest.mark.parametrize("capacity", [None, 3])
 def test_tile_binned_rasteriser_draws_the_same_bytes(capacity, monkeypatch):
     """HZ_TILES=1 (hz_k_tile.h: BASELINE north_star's tile-binned rasteriser with per-bin depth in LDS, for the large
-    triangles of both rounds): a whole image, a sector and a zoomed view against the oracle on every output; with queues so
-    small that the (triangle, tile) pairs do not fit, the round must fall back to k_big - same bytes either way"""
+    triangles of both rounds): a whole image, a sector and a zoomed view against the oracle on every output; with tile lists
+    of three triangles some tile's list overflows and the round must fall back to k_big - same bytes either way"""
     monkeypatch.setenv("HZ_TILES", "1")
     monkeypatch.setenv("HZ_TWO_PASS", "1")
     if capacity is not None:
-        monkeypatch.setenv("HZ_QUEUE_CAPACITY", str(capacity))
+        monkeypatch.setenv("HZ_TILE_LIST", str(capacity))
     R, W, H = 500, 3001, 750                                    # (odd width: partial tiles at the right edge)
     d = hzutil.dem_dir_for(LAT, LON, R)
     od = oracle.Dem(LAT, LON, d, radius_cells=R)
@@ -344,4 +344,4 @@ def test_tile_binned_rasteriser_draws_the_same_bytes(capacity, monkeypatch):
     for az0, az1, c0, c1 in ((-180, 180, 0, W), (-180, 180, 700, 1500), (10, 55, 0, W)):
         v = od.view(LAT, LON, W, H, az0, az1, zfar=200000.0)
         hzutil.assert_same_render(hzutil.hip_render(m, v, W, H, c0, c1, raster=2), oracle.render(m, v, W, H, c0, c1),
-                                  f"tiles, az [{az0},{az1}], columns [{c0},{c1}), capacity {capacity}")
+                                  f"tiles, az [{az0},{az1}], columns [{c0},{c1}), list of {capacity}")
