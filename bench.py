@@ -29,6 +29,9 @@ CONFIGS = {
     "cfg1": dict(R=600, W=2000, H=500, tiles="1 SRTM3 tile window (2x2 tiles touched)"),
     "cfg2": dict(R=1800, W=8000, H=2000, tiles="3x3 SRTM3 tile mosaic"),
     "cfg3": dict(R=4200, W=16000, H=4000, tiles="7x7 SRTM3 tile mosaic"),
+    # BASELINE configs[4]: beyond what the reference can load; meant for --gpus 2..8 (a sparse strip holds up to 16384
+    # columns; one GPU renders it in tools/scenes.py)
+    "cfg5": dict(R=19800, W=32768, H=8192, srtm1=True, tiles="11x11 SRTM1 tile mosaic"),
 }
 LAT, LON = 34.4137, -117.5621
 ZNEAR = 100.0
@@ -87,6 +90,10 @@ def main():
             sys.exit(subprocess.call(cmd, env=env))
         args.gpus = world
 
+    if args.config == "cfg5":
+        # 3.1 G triangles: the CPU oracle needs half a minute per render, the results are 1.9 GB - the side measurements are cfg3's
+        args.no_cpu_baseline = args.no_host = args.no_scenes = True
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -125,9 +132,9 @@ def main():
     t0 = time.perf_counter()
     h = None
     if rank == 0:
-        dems = hzutil.dem_dir_for(LAT, LON, R)
+        dems = hzutil.dem_dir_for(LAT, LON, R, srtm1=cfg.get("srtm1", False))
         t0 = time.perf_counter()
-        h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R)
+        h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R, SRTM1=cfg.get("srtm1", False))
     if world > 1:
         window, mosaic = broadcast_dem(h.window() if rank == 0 else None, h.mosaic() if rank == 0 else None,
                                        device=dev if args.backend == "nccl" else None)

@@ -227,7 +227,7 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
  * (same-address atomics are serialised at ~10 ns each). */
 #define SP_WAVES  4                     /* rows per workgroup                            */
 #define SP_STEPS  8                     /* steps whose words stay in registers           */
-#define SP_MAXIT  64                    /* steps per row: sectors up to 16384 columns    */
+#define SP_MAXIT  256                   /* steps per row: sectors up to 65536 columns    */
 
 /* one step of one row: loads, terrain bits (nibble per lane), mask words */
 __device__ static inline uint32_t sp_step(const unsigned long long* row, int SW, int it, int lane, bool flagged,
@@ -311,11 +311,13 @@ void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ o
         uint32_t* mask = out + 1 + H + (size_t)(have ? yo : 0)*mask_stride;
         unsigned long long key[SP_STEPS][4];
         uint32_t nibs = 0;                                  /* the nibbles of the cached steps */
-        unsigned long long flagged = 0;                     /* bit it: segment `it` of the row has been drawn into */
+        unsigned long long flagged = 0;                     /* bit it: segment `it` of the row has been drawn into (the first 64
+                                                             * segments; the ones beyond - rows of more than 16384 pixels - are read) */
+        auto is_flagged = [&](int it) -> bool { return it >= 64 || ((flagged >> it) & 1ull); };
         uint32_t count = 0;
         if(have)
         {
-            for(int it=lane; it<nit; it+=64) if(flags[it]) flagged |= 1ull << it;
+            if(lane < nit && flags[lane]) flagged = 1ull << lane;
             #pragma unroll
             for(int m=32; m>=1; m>>=1) flagged |= __shfl_xor(flagged, m);
             if(cached)
@@ -324,7 +326,7 @@ void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ o
                 for(int it=0; it<SP_STEPS; it++)
                     if(it < nit)
                     {
-                        const uint32_t nib = sp_step(row, SW, it, lane, (flagged >> it) & 1ull, key[it], mask);
+                        const uint32_t nib = sp_step(row, SW, it, lane, is_flagged(it), key[it], mask);
                         nibs |= nib << (4*it);
                     }
                 count = (uint32_t)__popc(nibs);
@@ -333,7 +335,7 @@ void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ o
                 for(int it=0; it<nit; it++)
                 {
                     unsigned long long k4[4];
-                    count += (uint32_t)__popc(sp_step(row, SW, it, lane, (flagged >> it) & 1ull, k4, mask));
+                    count += (uint32_t)__popc(sp_step(row, SW, it, lane, is_flagged(it), k4, mask));
                 }
             #pragma unroll
             for(int m=32; m>=1; m>>=1) count += __shfl_xor(count, m);
@@ -358,12 +360,12 @@ void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ o
             {
                 #pragma unroll
                 for(int it=0; it<SP_STEPS; it++)
-                    if(it < nit && ((flagged >> it) & 1ull))
+                    if(it < nit && is_flagged(it))
                         at = sp_emit<CLEAR>(row, SW, it, lane, (nibs >> (4*it)) & 0xFu, key[it], data, at);
             }
             else
                 for(int it=0; it<nit; it++)
-                    if((flagged >> it) & 1ull)
+                    if(is_flagged(it))
                     {
                         /* (read again: the row has just been through this XCD's L2) */
                         unsigned long long k4[4];
@@ -377,7 +379,7 @@ void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ o
                         }
                         at = sp_emit<CLEAR>(row, SW, it, lane, nib, k4, data, at);
                     }
-            if(CLEAR) for(int it=lane; it<nit; it+=64) if((flagged >> it) & 1ull) flags[it] = 0;
+            if(CLEAR) for(int it=lane; it<nit; it+=64) if(is_flagged(it)) flags[it] = 0;
         }
         __syncthreads();                                    /* row_count / row_base are reused */
     }

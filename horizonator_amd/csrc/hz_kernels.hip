@@ -1322,7 +1322,7 @@ extern "C" int hz_hip_pack_sparse(hz_dev_t* d, uint32_t* d_out, int mask_stride)
     if(d->tex_on || mask_stride < (SW + 31)/32 || SW > SP_MAXIT*256)
     {
         snprintf(g_last_error, sizeof(g_last_error), d->tex_on ? "hz_hip_pack_sparse: strips carry the shade only, not a textured colour"
-                                                    : SW > SP_MAXIT*256 ? "hz_hip_pack_sparse: sectors of up to 16384 columns"
+                                                    : SW > SP_MAXIT*256 ? "hz_hip_pack_sparse: sectors of up to 65536 columns"
                                                                : "hz_hip_pack_sparse: mask stride too small");
         return -1;
     }
