@@ -111,6 +111,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    elif args.exchange_anyway and args.backend == "nccl":
+        # the one rank there is, as an RCCL process group of its own: the strips then travel through dist.gather /
+        # dist.all_reduce like those of N ranks do (the same calls, the same stream ordering), not through a copy
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -254,7 +263,8 @@ def main():
                 h.sync()
                 words += int(S["d_pk"][0][0].item())
             cap = agree_on_capacity(words, S["HDR"], S["FULL"], cdev)
-            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF, any_dst=rotate)
+            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF, any_dst=rotate,
+                                    collectives_even_alone=args.exchange_anyway and on_gpu)
             S["sent"] = [None] * NBUF
             state["wire_words"] = S["ex"].cap
         return S["ex"]
@@ -596,7 +606,7 @@ def main():
         line.update(extra)
         print(json.dumps(line))
     h.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

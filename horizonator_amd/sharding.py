@@ -277,8 +277,11 @@ class StripExchange:
     they were posted with; those slots take the new capacity over when they are posted next.
     """
 
-    def __init__(self, cap_words, full_words, header_words, device, nslots=2, group=None, dst=0, any_dst=False):
+    def __init__(self, cap_words, full_words, header_words, device, nslots=2, group=None, dst=0, any_dst=False,
+                 collectives_even_alone=False):
         self.world, self.rank = _world_and_rank(group)
+        # (a process group of one rank: go through the collectives all the same - bench.py --exchange-anyway)
+        self.collective = self.world > 1 or (collectives_even_alone and dist.is_available() and dist.is_initialized())
         self.group, self.dst, self.device = group, dst, device
         self.any_dst = bool(any_dst)
         self.full, self.hdr = int(full_words), int(header_words)
@@ -325,7 +328,7 @@ class StripExchange:
         # leaves the device here; the comparison with the capacity is the host's, when it looks at the word later)
         self.flags[slot].copy_(strip[0:1])
         send = strip[:cap]
-        if self.world == 1:
+        if not self.collective:
             self.bins[slot][0].copy_(send)
             w1 = w2 = None
         else:
@@ -369,7 +372,7 @@ class StripExchange:
         the new capacity at their next post()."""
         assert self.work[slot] is None, "grow() follows complete() of the same slot"
         n = torch.tensor([self.hdr + int(strip[0].item())], dtype=torch.int64, device=self.device)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
         self.cap = self._clamp(int(int(n.item()) * 1.1) + 1024)
         self.resends += 1
