@@ -74,8 +74,12 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
                 int32_t* __restrict__ index, uint32_t* __restrict__ z24,
                 int SW, int H, float znear, float zfar,
                 unsigned char* __restrict__ touched, int seg_stride, unsigned int* qa, unsigned int* qb,
-                int yo0, int yo1)
+                int yo0, int yo1, int nt)
 {
+    /* (nt: the results leave with non-temporal stores - written once, read by nobody on this chip before they are
+     * complete - so that 448 MB of them per panorama do not push the framebuffer lines of the marching kernel that runs
+     * beside this one out of L2: 0.984 -> 0.959, 0.994 -> 0.979 ms per pipelined render in two A/B pairs on one box;
+     * HZ_RESOLVE_NT=0 for plain stores.  Reading the framebuffer non-temporally as well, or the DEM in k_march: nothing.) */
     /* (output rows [yo0,yo1): the conversion may run in bands, so that the first results can leave for the host
      * while the rest is converted; qa: only the band that comes first empties the queue sets) */
     if(CLEAR && qa && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
@@ -117,7 +121,8 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
             w.x = pix[0] | (pix[1] << 24);
             w.y = (pix[1] >> 8) | (pix[2] << 16);
             w.z = (pix[2] >> 16) | (pix[3] << 8);
-            *(uint3*)(bgr + o*3) = w;
+            if(nt) { uint32_t* q = (uint32_t*)(bgr + o*3); __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q+1); __builtin_nontemporal_store(w.z, q+2); }
+            else *(uint3*)(bgr + o*3) = w;
         }
         if(index)
         {
@@ -126,9 +131,15 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
             w.y = zi[1] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[1] >> 8);
             w.z = zi[2] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[2] >> 8);
             w.w = zi[3] == HZ_Z24_MAX ? -1 : (int32_t)(uint32_t)(key[3] >> 8);
-            *(int4*)(index + o) = w;
+            if(nt) { int32_t* q = index + o; __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q+1); __builtin_nontemporal_store(w.z, q+2); __builtin_nontemporal_store(w.w, q+3); }
+            else *(int4*)(index + o) = w;
         }
-        if(z24) { uint4 w = { zi[0], zi[1], zi[2], zi[3] }; *(uint4*)(z24 + o) = w; }
+        if(z24)
+        {
+            uint4 w = { zi[0], zi[1], zi[2], zi[3] };
+            if(nt) { uint32_t* q = z24 + o; __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q+1); __builtin_nontemporal_store(w.z, q+2); __builtin_nontemporal_store(w.w, q+3); }
+            else *(uint4*)(z24 + o) = w;
+        }
         if(ranges)
         {
             const float tr = tanel[row];
@@ -137,7 +148,8 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
             w.y = zi[1] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[1], tr, znear, zfar);
             w.z = zi[2] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[2], tr, znear, zfar);
             w.w = zi[3] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[3], tr, znear, zfar);
-            *(float4*)(ranges + o) = w;
+            if(nt) { float* q = ranges + o; __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q+1); __builtin_nontemporal_store(w.z, q+2); __builtin_nontemporal_store(w.w, q+3); }
+            else *(float4*)(ranges + o) = w;
         }
     }
 }
@@ -463,9 +475,16 @@ void k_resolve_sparse(hz_strips_t st, int mask_stride,
                     w.x = pix[0] | (pix[1] << 24);
                     w.y = (pix[1] >> 8) | (pix[2] << 16);
                     w.z = (pix[2] >> 16) | (pix[3] << 8);
-                    *(uint3*)(bgr + o*3) = w;
+                    /* (non-temporal, as k_resolve4's: nobody on this chip reads the panorama while it is assembled) */
+                    uint32_t* q = (uint32_t*)(bgr + o*3);
+                    __builtin_nontemporal_store(w.x, q); __builtin_nontemporal_store(w.y, q+1); __builtin_nontemporal_store(w.z, q+2);
                 }
-                if(ranges) { const float4 w = { rng[0], rng[1], rng[2], rng[3] }; *(float4*)(ranges + o) = w; }
+                if(ranges)
+                {
+                    float* q = ranges + o;
+                    __builtin_nontemporal_store(rng[0], q); __builtin_nontemporal_store(rng[1], q+1);
+                    __builtin_nontemporal_store(rng[2], q+2); __builtin_nontemporal_store(rng[3], q+3);
+                }
             }
             else
             {

@@ -112,6 +112,7 @@ struct hz_env_t
     int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
                                      * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
     int    tile_list;               /* HZ_TILE_LIST=n: a tile's list holds n triangles instead of 256 (tests: the fall-back to k_big) */
+    int    resolve_nt;              /* HZ_RESOLVE_NT=0: the conversion's results leave with plain instead of non-temporal stores */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
 };
@@ -134,6 +135,7 @@ static hz_env_t read_env(void)
     e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
     e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
+    e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
@@ -1204,11 +1206,11 @@ static int resolve_impl(hz_dev_t* d, const hz_view_t* view, const float* tanel,
             if(clears)
                 hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
                                    bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride,
-                                   k == 0 ? qa : (unsigned int*)NULL, qb, yo0, yo1);
+                                   k == 0 ? qa : (unsigned int*)NULL, qb, yo0, yo1, d->env.resolve_nt);
             else
                 hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
                                    bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride,
-                                   (unsigned int*)NULL, (unsigned int*)NULL, yo0, yo1);
+                                   (unsigned int*)NULL, (unsigned int*)NULL, yo0, yo1, d->env.resolve_nt);
             HZ_CHECK(hipGetLastError());
             if(ev_band) HZ_CHECK(hipEventRecord(ev_band[k], d->rstream));
         }

@@ -69,6 +69,7 @@ ROWS = [
     ("north_star's tile-binned rasteriser with depth in LDS for the large triangles (hz_k_tile.h)", {"HZ_TILES": "1"}, None,
      "64x32-pixel tiles owned by one workgroup each: LDS atomic minima, one plain store per pixel; byte-identical"),
     ("the same, zfar 40 km", {"HZ_TILES": "1"}, 40000.0, "where the near field is most of the work"),
+    ("the conversion stores its results the plain way", {"HZ_RESOLVE_NT": "0"}, None, "default: non-temporal stores (448 MB per panorama that nobody on the chip reads)"),
     ("launch grid padded to a multiple of 8 strip columns", {"HZ_EXP_XCD_PAD": "1"}, None,
      "all segments of a strip column on one XCD (workgroups are dealt to the XCDs round-robin): L2 locality against balance"),
     ("first round reaches cells wider than 10 px", {"HZ_NEAR_PX": "10"}, None, "default 20"),
