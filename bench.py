@@ -604,7 +604,7 @@ def main():
         if os.environ.get("BENCH_HOST_TIMES") and host_us["n"]:
             line["host_us_per_step"] = {k: v / host_us["n"] for k, v in host_us.items() if k != "n"}
         line.update(extra)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     h.close()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -5,6 +5,10 @@
 /* ------------------------------------------------------------------------ */
 /* kernel parameters                                                         */
 
+/* coarse depth (hz_k_hiz.h): the largest upper half of a framebuffer word per 8 x 4 (l1) and 32 x 16 (l2) pixels,
+ * w1 / w2 tiles per row; l1 == NULL: the draw has none */
+struct hz_hiz_t { uint32_t* l1; uint32_t* l2; int w1, w2; };
+
 struct hz_params_t
 {
     hz_xform_t u;
@@ -30,6 +34,7 @@ struct hz_params_t
     int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
     int   nsx;                         /* strip columns of the mosaic; a launch grid may be wider (HZ_EXP_XCD_PAD) */
+    hz_hiz_t hiz;                      /* mr_flush: the early depth test of boxes larger than 4 x 2 pixels looks here (second rounds of zoomed views) */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
     float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
     int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */

@@ -37,7 +37,38 @@ struct mr_lds_t
 {
     uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
     uint32_t ids[MR_CAP];
+    uint32_t clip[64];              /* ids on their way to k_clip's queue (mr_clip_note) */
 };
+
+/* Triangles that cross a plane of the view volume: their ids go to k_clip (as hz_queue_clip), but collected here
+ * first, 64 to one atomic.  hz_queue_clip's one atomic per call was two returning atomics per row for every strip
+ * along the image's border, on the address every wave of the draw appends to - in a zoomed view, whose border runs
+ * through hundreds of strips, the waves spent most of their time queueing for it (tools/wave_timing.py: a strip
+ * with two flushes took 700 us). */
+__device__ static inline void mr_clip_flush(mr_lds_t& L, unsigned int& nclip, const mr_queue_t& q, int lane)
+{
+    if(!nclip) return;
+    uint32_t base = 0;
+    if(lane == 0) base = atomicAdd(&q.counters[4], nclip);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    __syncthreads();                /* (one wave: orders the lanes' LDS writes before the reads below) */
+    if((unsigned int)lane < nclip)
+    {
+        const uint32_t at = base + (uint32_t)lane;
+        if(at < q.clip_capacity) q.clip[at] = L.clip[lane];     /* ids that do not fit are counted, not stored: k_clip then rescans */
+    }
+    __syncthreads();
+    nclip = 0;
+}
+__device__ static inline void mr_clip_note(mr_lds_t& L, unsigned int& nclip, const mr_queue_t& q, bool want, uint32_t prim, int lane)
+{
+    const unsigned long long m = __ballot(want);
+    if(!m) return;
+    const unsigned int n = (unsigned int)__popcll(m);
+    if(nclip + n > 64u) mr_clip_flush(L, nclip, q, lane);
+    if(want) L.clip[nclip + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = prim;
+    nclip += n;
+}
 
 __device__ static inline void mr_store_row(mr_lds_t& L, int slot, int lane, const hz_wvert_t& v)
 {
@@ -398,6 +429,25 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
             if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }
+        else if(valid && p.hiz.l1)
+        {
+            /* larger boxes, where the draw keeps coarse depth (hz_k_hiz.h): a box of at most 9 x 5 pixels lies in
+             * 2 x 2 tiles of 8 x 4, one of at most 33 x 17 in 2 x 2 tiles of 32 x 16.  Each word is >= the depth
+             * of every pixel of its tile (taken earlier in this draw; depths only decrease). */
+            const int bw1 = box.px1 - box.px0, bh1 = box.py1 - box.py0;
+            const bool lv1 = bw1 <= (1 << HIZ1_W_LOG2) && bh1 <= (1 << HIZ1_H_LOG2);
+            if(lv1 || (bw1 <= (1 << HIZ2_W_LOG2) && bh1 <= (1 << HIZ2_H_LOG2)))
+            {
+                const uint32_t* t = lv1 ? p.hiz.l1 : p.hiz.l2;
+                const int sx = lv1 ? HIZ1_W_LOG2 : HIZ2_W_LOG2, sy = lv1 ? HIZ1_H_LOG2 : HIZ2_H_LOG2;
+                const uint32_t tw = (uint32_t)(lv1 ? p.hiz.w1 : p.hiz.w2);
+                const uint32_t tx0 = (uint32_t)(box.px0 - p.col0) >> sx, tx1 = (uint32_t)(box.px1 - p.col0) >> sx;
+                const uint32_t o0 = ((uint32_t)box.py0 >> sy)*tw, o1 = ((uint32_t)box.py1 >> sy)*tw;
+                const uint32_t z00 = t[o0 + tx0], z01 = t[o0 + tx1], z10 = t[o1 + tx0], z11 = t[o1 + tx1];
+                const uint32_t zs = max(max(z00, z01), max(z10, z11)) >> 8;
+                if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
+            }
+        }
         if(dbg) { dbg[5] += (unsigned int)__popcll(__ballot(valid && !live)); }
         if(p.debug == 2) return;
         if(!__any(live))
@@ -442,13 +492,14 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         uint32_t rbase = 0, ibase = 0, ok = 0;
         if(lane == 0)
         {
-            rbase = atomicAdd(&q.counters[0], nb);
-            if(rbase + nb <= q.bigrec_capacity)
-            {
-                ibase = atomicAdd(&q.counters[1], total);
-                if(ibase + total <= q.bigitem_capacity) ok = 1;
-                else atomicMax(&q.counters[2], ~ibase);         /* items from here on are not valid */
-            }
+            /* records and items in one step: the two counters are the halves of one 64-bit word.  Every wave of the
+             * draw comes through these two addresses, and atomics on one address are served one after the other:
+             * in a zoomed view (a flush with large triangles every few microseconds on every SIMD) the second
+             * atomic was the kernel's critical path. */
+            const unsigned long long both = atomicAdd((unsigned long long*)&q.counters[0], (unsigned long long)nb | ((unsigned long long)total << 32));
+            rbase = (uint32_t)both; ibase = (uint32_t)(both >> 32);
+            if((unsigned long long)rbase + nb <= q.bigrec_capacity && (unsigned long long)ibase + total <= q.bigitem_capacity) ok = 1;
+            else atomicMax(&q.counters[2], ~ibase);             /* items from here on are not valid */
         }
         rbase = __shfl(rbase, 0); ibase = __shfl(ibase, 0); ok = __shfl(ok, 0);
         if(is_big)
@@ -611,7 +662,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     const unsigned long long fast_rows = __ballot(hzf_in_range(n_tab));
 
     /* pending-triangle ring, wave-uniform state */
-    unsigned int head = 0, count = 0;
+    unsigned int head = 0, count = 0, nclip = 0;
     int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
     /* what a row keeps of itself for the cells above it (the attributes of its
      * vertices live in LDS, where mr_flush takes them from): per lane the
@@ -688,8 +739,8 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                 const int verdict1 = has_cell ? hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
                 /* crossing the image border or the near/far sphere: k_clip */
                 const uint32_t prim0 = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2);
-                hz_queue_clip(q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
-                hz_queue_clip(q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
+                mr_clip_note(L, nclip, q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
+                mr_clip_note(L, nclip, q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
                 keep0 = verdict0 == HZ_TRI_DRAW; keep1 = verdict1 == HZ_TRI_DRAW;
             }
             #pragma unroll
@@ -725,6 +776,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         __syncthreads();
         mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
     }
+    mr_clip_flush(L, nclip, q, lane);
     if(COUNTERS && p.wave_cycles && lane == 0)
     {
         unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];     /* (grid launches) */

@@ -82,6 +82,7 @@ struct hz_device_guard
 #define HZ_ON_DEVICE(d) hz_device_guard device_guard_((d)->device); if(!device_guard_.ok) return -1
 
 #include "hz_k_common.h"
+#include "hz_k_hiz.h"
 #include "hz_k_scatter.h"
 #include "hz_k_tile.h"
 #include "hz_k_march.h"
@@ -115,6 +116,8 @@ struct hz_env_t
     int    resolve_nt;              /* HZ_RESOLVE_NT=0: the conversion's results leave with plain instead of non-temporal stores */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
+    int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: the draw decides */
+    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 40): ... from this cell width at the first round's reach on */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static hz_env_t read_env(void)
@@ -138,6 +141,8 @@ static hz_env_t read_env(void)
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
+    e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
+    e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 40.0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
@@ -202,6 +207,9 @@ struct hz_dev
      * of the panorama before. */
     hipStream_t         qstream, nstream;
     hipEvent_t          ev_marched, ev_near;
+    /* coarse depth of each framebuffer (hz_k_hiz.h), allocated by the first draw that wants it */
+    uint32_t*           d_hiz[HZ_NFB];
+    int                 hiz_last;               /* the last draw kept coarse depth (diagnostics) */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
     hz_bigitem_t*       d_bigitem_s[2*HZ_NFB];
@@ -280,6 +288,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     }
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
+    for(int i=0; i<HZ_NFB; i++) (void)hipFree(d->d_hiz[i]);
     for(int k=0; k<2; k++)
     {
         (void)hipFree(d->lists.d_items[k]);
@@ -1003,6 +1012,27 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
     return want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
 }
 
+/* Coarse depth of framebuffer `next` (hz_k_hiz.h): the tables of a draw with the geometry of p, allocated on first use */
+static int hiz_tables(hz_dev_t* d, int next, const hz_params_t& p, hz_hiz_t* hz)
+{
+    if(!d->d_hiz[0])
+        for(int i=0; i<HZ_NFB; i++)
+            HZ_CHECK(hipMalloc(&d->d_hiz[i], hiz_words(d->W, d->H)*sizeof(uint32_t)));
+    hz->w1 = (int)hiz_w1(p.SW); hz->w2 = (int)hiz_w2(p.SW);
+    hz->l1 = d->d_hiz[next];
+    hz->l2 = hz->l1 + (size_t)hz->w1*hiz_h1(p.H);
+    return 0;
+}
+/* one sweep over the framebuffer on `st`: every tile of both levels is written (nothing to reset between draws) */
+static int hiz_sweep(hz_dev_t* d, hipStream_t st, int next, const hz_params_t& p, const hz_hiz_t& hz)
+{
+    const unsigned int nunits = (unsigned int)d->seg_stride*(unsigned int)((p.H + HIZ_UNIT_ROWS-1)/HIZ_UNIT_ROWS);
+    hipLaunchKernelGGL(k_hiz, dim3((nunits + 3)/4), dim3(256), 0, st,
+                       (const unsigned long long*)d->d_fbs[next], (const unsigned char*)d->d_touched[next], d->seg_stride, p.SW, p.H, hz, nunits);
+    HZ_CHECK(hipGetLastError());
+    return 0;
+}
+
 static int draw_impl(hz_dev_t* d, const hz_view_t* view)
 {
     hz_params_t p = make_params(d, view);
@@ -1018,6 +1048,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     const bool by_tile = d->env.tiles > 0 && d->raster != HZ_RASTER_SCATTER;
     bool near_beside_far = false;                   /* the second round did not wait for the first */
     bool waited_near = false;                       /* ... or it did */
+    bool use_hiz = false;                           /* the second round keeps coarse depth (hz_k_hiz.h) */
 
     if(d->raster == HZ_RASTER_SCATTER)
     {
@@ -1067,13 +1098,29 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
             if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
+            /* Zoomed views: where the first round ends a cell is still ppr/reach pixels wide (20 in a whole
+             * panorama, 80 in a 45 degree view of 16000 columns: the reach is capped), and most of the second
+             * round's boxes are beyond the 4 x 2 pixels its early depth test reads itself.  Those draws keep coarse
+             * depth for the larger boxes (hz_k_hiz.h): the tables take in the first round's picture, on its stream,
+             * and the second round waits for them.  tools/hiz_ab.py: the 45 degree view 2.93 -> 2.26 ms with this
+             * sweep alone (more sweeps beside the second round: no gain); whole panoramas lose 2-5 % (their
+             * boxes are small: 4 x 2 reaches 93 % of them) and do not have tables. */
+            const bool early_z = (unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32);
+            hz_hiz_t hz = {};
+            {
+                const float ppr = p.halfW * p.u.az_ndc_per_rad;
+                const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
+                use_hiz = early_z && !by_tile
+                          && (d->env.hiz >= 0 ? d->env.hiz != 0 : (reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px));
+                if(use_hiz && (hiz_tables(d, next, p, &hz) != 0 || hiz_sweep(d, d->nstream, next, p, hz) != 0)) return -1;
+            }
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
              * finds the marching kernel of the draw before it finished (a single render, or
              * the first of a series) starts its second round at once, beside its first.  The
              * early depth test then sees fewer occluders and skips less; what it skips is
              * hidden whenever it looks (depths only decrease), so the bytes are the same. */
-            if(d->env.always_wait_near || by_tile || hipEventQuery(d->ev_marched) != hipSuccess)
+            if(use_hiz || d->env.always_wait_near || by_tile || hipEventQuery(d->ev_marched) != hipSuccess)
             {
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
                 waited_near = true;             /* (the first round itself waited for the framebuffer: no second wait for that below) */
@@ -1082,7 +1129,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 near_beside_far = true;         /* "drawn" then has to wait for both rounds: see qstream below */
             (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
             /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
-            p.pass = 2; p.early_z = ((unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32)) ? 1 : 0;
+            p.pass = 2; p.early_z = early_z ? 1 : 0;
+            p.hiz = hz;
             /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment
              * cannot win (a stale, larger value only costs the atomic) - where the framebuffer is larger than the
              * 256 MB of the chip's last-level cache.  Behind the first round's occluders most fragments of the second
@@ -1115,8 +1163,11 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * second round's queue kernels only as long as the second round itself waited for the first */
     if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
+    /* ... and once more, now with what the second round's waves have drawn, for its large triangles (k_big's own test) */
+    if(use_hiz && hiz_sweep(d, d->qstream, next, p, p.hiz) != 0) return -1;
     if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
+    d->hiz_last = use_hiz ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
     return 0;

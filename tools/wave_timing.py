@@ -8,7 +8,8 @@ LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
 R, W, H = 4200, 16000, 4000
 h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
 ZFAR = float(os.environ.get("HZ_WT_ZFAR", "600000"))
-h.set_view(-180, 180, zfar=ZFAR)
+AZ = [float(x) for x in os.environ.get("HZ_WT_AZ", "-180,180").split(",")]
+h.set_view(AZ[0], AZ[1], zfar=ZFAR)
 import torch
 img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda"); rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
 for _ in range(2):
