@@ -479,6 +479,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     const bool is_big = live && npix > p.big_min;
     const unsigned long long bigmask = __ballot(is_big);
     if(dbg) { dbg[0] += 1; dbg[1] += n; dbg[2] += (unsigned int)__popcll(bigmask); }
+    const unsigned long long t_app0 = (dbg && p.debug == 4) ? __builtin_amdgcn_s_memtime() : 0ull;
     if(bigmask)
     {
         uint32_t chunks = 0;
@@ -547,6 +548,15 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         else if(lane == 0) atomicMax(&q.counters[5], ~mbase);
     }
 
+    if(dbg && p.debug == 4)
+    {
+        /* HZ_MARCH_DEBUG=4 (tools/wave_timing.py): "mid" and "items" count cycles / 16 of the queue appends and of the pixel turns */
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        dbg[3] += (unsigned int)((t1 - t_app0) >> 4);
+        mr_distribute(r, npix, lane, fb, p);
+        dbg[4] += (unsigned int)((__builtin_amdgcn_s_memtime() - t1) >> 4);
+        return;
+    }
     if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }
     mr_distribute(r, npix, lane, fb, p);
 }

@@ -117,7 +117,7 @@ struct hz_env_t
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
     int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: the draw decides */
-    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 40): ... from this cell width at the first round's reach on */
+    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 30): ... from this cell width at the first round's reach on */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static hz_env_t read_env(void)
@@ -142,7 +142,7 @@ static hz_env_t read_env(void)
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
-    e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 40.0;
+    e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 30.0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;

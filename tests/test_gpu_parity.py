@@ -345,3 +345,24 @@ def test_tile_binned_rasteriser_draws_the_same_bytes(capacity, monkeypatch):
         v = od.view(LAT, LON, W, H, az0, az1, zfar=200000.0)
         hzutil.assert_same_render(hzutil.hip_render(m, v, W, H, c0, c1, raster=2), oracle.render(m, v, W, H, c0, c1),
                                   f"tiles, az [{az0},{az1}], columns [{c0},{c1}), list of {capacity}")
+
+
+@pytest.mark.parametrize("near_cells", [None, 24])
+def test_coarse_depth_draws_the_same_bytes(near_cells, monkeypatch):
+    """HZ_HIZ=1 (hz_k_hiz.h: the largest depth per 8x4 / 32x16 pixels, swept from the framebuffer after the first round
+    and again before k_big; zoomed views have it on their own): whole images, sectors (tiles are counted from the
+    sector's first column) and zoomed views of odd sizes (partial tiles at the right and bottom edges) against the
+    oracle on every output.  With a first round of 24 cells the second round starts where cells are still tens of
+    pixels wide: its boxes are the ones the tables are for."""
+    monkeypatch.setenv("HZ_HIZ", "1")
+    monkeypatch.setenv("HZ_TWO_PASS", "1")
+    if near_cells is not None:
+        monkeypatch.setenv("HZ_NEAR_CELLS", str(near_cells))
+    R, W, H = 500, 3001, 749
+    d = hzutil.dem_dir_for(LAT, LON, R, rough=near_cells is not None)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    for az0, az1, c0, c1 in ((-180, 180, 0, W), (-180, 180, 701, 1500), (10, 55, 0, W), (-8, 8, 0, W), (-8, 8, 1203, 2950)):
+        v = od.view(LAT, LON, W, H, az0, az1, zfar=200000.0)
+        hzutil.assert_same_render(hzutil.hip_render(m, v, W, H, c0, c1, raster=2), oracle.render(m, v, W, H, c0, c1),
+                                  f"coarse depth, az [{az0},{az1}], columns [{c0},{c1}), first round of {near_cells} cells")

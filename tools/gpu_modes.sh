@@ -10,7 +10,7 @@ for env in "HZ_SERIAL=1" "HZ_TWO_PASS=0" "HZ_TWO_PASS=1" "HZ_TWO_PASS=1 HZ_SERIA
            "HZ_TWO_PASS=1 HZ_NEAR_CELLS=300" "HZ_TWO_PASS=1 HZ_RESOLVE_CLEARS=0" "HZ_NO_FAST_MATH=1" "HZ_RESOLVE_CLEARS=0" \
            "HZ_ALWAYS_WAIT_NEAR=1 HZ_TWO_PASS=1" "HZ_PLAIN_COPY=1" "HZ_COPY_THREADS=1" \
            "HZ_NO_WORKLIST=1" "HZ_NO_WORKLIST=1 HZ_TWO_PASS=1" "HZ_TWO_PASS=1 HZ_PRETEST_MARCH=1" "HZ_TWO_PASS=1 HZ_PRETEST=1 HZ_NEAR_PX=3" \
-           "HZ_TWO_PASS=1 HZ_FAR_ROWS=5 HZ_EXP_XCD_PAD=1" "HZ_TILES=1" "HZ_TILES=1 HZ_TWO_PASS=1 HZ_TILE_LIST=5"; do
+           "HZ_TWO_PASS=1 HZ_FAR_ROWS=5 HZ_EXP_XCD_PAD=1" "HZ_TILES=1" "HZ_TILES=1 HZ_TWO_PASS=1 HZ_TILE_LIST=5" "HZ_HIZ=1 HZ_TWO_PASS=1" "HZ_HIZ=1 HZ_TWO_PASS=1 HZ_NEAR_CELLS=16 HZ_SERIAL=1" "HZ_HIZ=0"; do
   echo "== $env"
   env $env timeout 900 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_bench_multi.py 2>&1 | grep -E "passed|failed|error" | tail -2
   [ ${PIPESTATUS[0]} -ne 0 ] && rc=1

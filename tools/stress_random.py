@@ -18,6 +18,8 @@ for seed in range(lo, hi):
         os.environ["HZ_TWO_PASS"] = "1"
     else:
         os.environ.pop("HZ_TWO_PASS", None)
+    if os.environ.get("STRESS_HIZ"):   # every draw in two rounds with coarse depth (hz_k_hiz.h), short first rounds: large boxes in the second
+        os.environ["HZ_TWO_PASS"] = "1"; os.environ["HZ_HIZ"] = "1"; os.environ["HZ_NEAR_CELLS"] = str((8, 16, 40)[seed % 3])
     d = hzutil.dem_dir_for(LAT, LON, R, rough=c["rough"])
     od = oracle.Dem(LAT, LON, d, radius_cells=R)
     m = od.mosaic()
