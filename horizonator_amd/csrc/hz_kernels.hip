@@ -1015,9 +1015,15 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
 /* Coarse depth of framebuffer `next` (hz_k_hiz.h): the tables of a draw with the geometry of p, allocated on first use */
 static int hiz_tables(hz_dev_t* d, int next, const hz_params_t& p, hz_hiz_t* hz)
 {
-    if(!d->d_hiz[0])
+    if(!d->d_hiz[HZ_NFB-1])
         for(int i=0; i<HZ_NFB; i++)
-            HZ_CHECK(hipMalloc(&d->d_hiz[i], hiz_words(d->W, d->H)*sizeof(uint32_t)));
+            if(!d->d_hiz[i] && hipMalloc(&d->d_hiz[i], hiz_words(d->W, d->H)*sizeof(uint32_t)) != hipSuccess)
+            {
+                /* no memory for them: the draw does without (same bytes, more fragments) */
+                (void)hipGetLastError();
+                d->d_hiz[i] = NULL;
+                return 1;
+            }
     hz->w1 = (int)hiz_w1(p.SW); hz->w2 = (int)hiz_w2(p.SW);
     hz->l1 = d->d_hiz[next];
     hz->l2 = hz->l1 + (size_t)hz->w1*hiz_h1(p.H);
@@ -1112,7 +1118,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
                 use_hiz = early_z && !by_tile
                           && (d->env.hiz >= 0 ? d->env.hiz != 0 : (reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px));
-                if(use_hiz && (hiz_tables(d, next, p, &hz) != 0 || hiz_sweep(d, d->nstream, next, p, hz) != 0)) return -1;
+                if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
+                if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
             }
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
