@@ -34,7 +34,8 @@ struct hz_params_t
     int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
     int   nsx;                         /* strip columns of the mosaic; a launch grid may be wider (HZ_EXP_XCD_PAD) */
-    hz_hiz_t hiz;                      /* mr_flush: the early depth test of boxes larger than 4 x 2 pixels looks here (second rounds of zoomed views) */
+    const uint32_t* hiz;               /* mr_flush, k_big: coarse depth (hz_k_hiz.h: level 1, level 2 behind it; second rounds of zoomed views), or NULL.
+                                        * (One pointer, the rest follows from SW and H: every scalar register k_march holds costs it lane spills in its loop.) */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
     float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
     int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */

@@ -27,12 +27,15 @@
 #define HIZ2_H_LOG2 4
 #define HIZ_UNIT_ROWS 16                /* one wave sweeps 256 columns (a segment of hz_params_t::touched) x 16 rows */
 
-static inline size_t hiz_w1(int SW) { return (size_t)((SW + (1 << HIZ1_W_LOG2) - 1) >> HIZ1_W_LOG2); }
-static inline size_t hiz_w2(int SW) { return (size_t)((SW + (1 << HIZ2_W_LOG2) - 1) >> HIZ2_W_LOG2); }
-static inline size_t hiz_h1(int H)  { return (size_t)((H  + (1 << HIZ1_H_LOG2) - 1) >> HIZ1_H_LOG2); }
-static inline size_t hiz_h2(int H)  { return (size_t)((H  + (1 << HIZ2_H_LOG2) - 1) >> HIZ2_H_LOG2); }
+/* tiles per row / rows of tiles of the two levels of a framebuffer of SW x H */
+__host__ __device__ static inline size_t hiz_w1(int SW) { return (size_t)((SW + (1 << HIZ1_W_LOG2) - 1) >> HIZ1_W_LOG2); }
+__host__ __device__ static inline size_t hiz_w2(int SW) { return (size_t)((SW + (1 << HIZ2_W_LOG2) - 1) >> HIZ2_W_LOG2); }
+__host__ __device__ static inline size_t hiz_h1(int H)  { return (size_t)((H  + (1 << HIZ1_H_LOG2) - 1) >> HIZ1_H_LOG2); }
+__host__ __device__ static inline size_t hiz_h2(int H)  { return (size_t)((H  + (1 << HIZ2_H_LOG2) - 1) >> HIZ2_H_LOG2); }
 /* words of both levels for an image of W x H (level 2 behind level 1) */
-static inline size_t hiz_words(int W, int H) { return hiz_w1(W)*hiz_h1(H) + hiz_w2(W)*hiz_h2(H); }
+__host__ __device__ static inline size_t hiz_words(int W, int H) { return hiz_w1(W)*hiz_h1(H) + hiz_w2(W)*hiz_h2(H); }
+/* level 2 of the tables a draw's parameters point to */
+__device__ static inline const uint32_t* hiz_level2(const hz_params_t& p) { return p.hiz + hiz_w1(p.SW)*hiz_h1(p.H); }
 
 /* largest of a value over the 2 / 8 lanes of an aligned group (all lanes get it) */
 __device__ static inline uint32_t hiz_max_xor(uint32_t v, int mask)
@@ -98,22 +101,45 @@ void k_hiz(const unsigned long long* __restrict__ fb, const unsigned char* __res
     }
 }
 
+/* The smallest 24-bit depth hz_tri_fragment() gives any pixel centre of columns [x0, x1] x rows [y0, y1]: the depth is
+ * round(dzdy*py + round(dzdx*px + z_org)), clamped to [0, 1], scaled and rounded - every step monotone in px and in
+ * py (roundings are), the direction in px the same on every row - so it is the smallest of the four corners',
+ * exactly.  false: a corner's depth is not a number (hz_tri_fragment drops such fragments; nothing is concluded).
+ * tests/test_gpu_exactness.py compares it with the minimum over all the pixels of seeded rectangles and planes. */
+__device__ static inline bool hiz_rect_min_depth(const hz_tri_t& tri, int x0, int x1, int y0, int y1, uint32_t* qmin)
+{
+    bool numbers = true;
+    uint32_t m = 0xFFFFFFFFu;
+    #pragma unroll
+    for(int c=0; c<4; c++)
+    {
+        const float fpx = (float)((c & 1) ? x1 : x0), fpy = (float)((c & 2) ? y1 : y0);
+        float z = __builtin_fmaf(tri.dzdy, fpy, __builtin_fmaf(tri.dzdx, fpx, tri.z_org));      /* as hz_tri_fragment */
+        if(!(z == z)) numbers = false;
+        z = hz_min(hz_max(z, 0.f), 1.f);
+        const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
+        m = m < q ? m : q;
+    }
+    *qmin = m;
+    return numbers;
+}
+
 /* k_big's own look (one wave = up to 64 pixel rows of one set-up triangle, hz_k_scatter.h): can any fragment of the
- * columns [px0, px0+bw) x rows [y0, y0+nrows) of `tri` still win?  The depth hz_tri_fragment() computes is
- * round(dzdy*py + round(dzdx*px + z_org)), then clamped, scaled and rounded to 24 bits - every step monotone in px and
- * in py (roundings are), with the direction in px the same on every row: the smallest depth any fragment of the
- * rectangle can get is the smallest of the four corners', exactly, no slack.  If that is above every depth the level-2
- * tiles under the rectangle hold (each >= the pixels' own), every fragment loses GL_LESS.  Lanes read the tiles. */
+ * columns [px0, px0+bw) x rows [y0, y0+nrows) of `tri` still win?  Not if the smallest depth any of them can get
+ * (hiz_rect_min_depth: exact, no slack) is above every depth the level-2 tiles under the rectangle hold (each >= the
+ * pixels' own): every fragment then loses GL_LESS.  Lanes read the tiles. */
 __device__ static inline bool hiz_chunk_hidden(const hz_tri_t& tri, const hz_params_t& p, int px0, int bw, int y0, int nrows, int lane)
 {
     const int x0 = px0 - p.col0, x1 = x0 + bw - 1, y1 = y0 + nrows - 1;
     const int tx0 = x0 >> HIZ2_W_LOG2, ntx = (x1 >> HIZ2_W_LOG2) - tx0 + 1;
     const int ty0 = y0 >> HIZ2_H_LOG2, ty1 = y1 >> HIZ2_H_LOG2;
     uint32_t zs = 0u;
+    const uint32_t* l2 = hiz_level2(p);
+    const size_t w2 = hiz_w2(p.SW);
     for(int ty = ty0; ty <= ty1; ty++)
         for(int t = lane; t < ntx; t += 64)
         {
-            const uint32_t v = p.hiz.l2[(size_t)ty*p.hiz.w2 + (tx0 + t)];
+            const uint32_t v = l2[(size_t)ty*w2 + (tx0 + t)];
             zs = zs > v ? zs : v;
         }
     #pragma unroll
@@ -123,16 +149,6 @@ __device__ static inline bool hiz_chunk_hidden(const hz_tri_t& tri, const hz_par
         zs = zs > o ? zs : o;
     }
     zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)zs) >> 8;
-    bool hidden = true;
-    #pragma unroll
-    for(int c=0; c<4; c++)
-    {
-        const float fpx = (float)((c & 1) ? px0 + bw - 1 : px0), fpy = (float)((c & 2) ? y1 : y0);
-        float z = __builtin_fmaf(tri.dzdy, fpy, __builtin_fmaf(tri.dzdx, fpx, tri.z_org));      /* as hz_tri_fragment */
-        if(!(z == z)) hidden = false;
-        z = hz_min(hz_max(z, 0.f), 1.f);
-        const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
-        if(!(q > zs)) hidden = false;
-    }
-    return hidden;
+    uint32_t qmin;
+    return hiz_rect_min_depth(tri, px0, px0 + bw - 1, y0, y1, &qmin) && qmin > zs;
 }

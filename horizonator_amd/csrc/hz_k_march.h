@@ -38,6 +38,7 @@ struct mr_lds_t
     uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
     uint32_t ids[MR_CAP];
     uint32_t clip[64];              /* ids on their way to k_clip's queue (mr_clip_note) */
+    uint32_t nclip;                 /* ... how many: kept here, not in a register (one scalar less to carry through the marching loop) */
 };
 
 /* Triangles that cross a plane of the view volume: their ids go to k_clip (as hz_queue_clip), but collected here
@@ -45,29 +46,33 @@ struct mr_lds_t
  * along the image's border, on the address every wave of the draw appends to - in a zoomed view, whose border runs
  * through hundreds of strips, the waves spent most of their time queueing for it (tools/wave_timing.py: a strip
  * with two flushes took 700 us). */
-__device__ static inline void mr_clip_flush(mr_lds_t& L, unsigned int& nclip, const mr_queue_t& q, int lane)
+__device__ static inline void mr_clip_flush(mr_lds_t& L, const mr_queue_t& q, int lane)
 {
+    const unsigned int nclip = (unsigned int)__builtin_amdgcn_readfirstlane((int)L.nclip);
     if(!nclip) return;
     uint32_t base = 0;
     if(lane == 0) base = atomicAdd(&q.counters[4], nclip);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    __syncthreads();                /* (one wave: orders the lanes' LDS writes before the reads below) */
     if((unsigned int)lane < nclip)
     {
         const uint32_t at = base + (uint32_t)lane;
         if(at < q.clip_capacity) q.clip[at] = L.clip[lane];     /* ids that do not fit are counted, not stored: k_clip then rescans */
     }
+    __syncthreads();                /* (one wave: the reads above before the writes that follow) */
+    if(lane == 0) L.nclip = 0;
     __syncthreads();
-    nclip = 0;
 }
-__device__ static inline void mr_clip_note(mr_lds_t& L, unsigned int& nclip, const mr_queue_t& q, bool want, uint32_t prim, int lane)
+__device__ static inline void mr_clip_note(mr_lds_t& L, const mr_queue_t& q, bool want, uint32_t prim, int lane)
 {
     const unsigned long long m = __ballot(want);
     if(!m) return;
     const unsigned int n = (unsigned int)__popcll(m);
-    if(nclip + n > 64u) mr_clip_flush(L, nclip, q, lane);
+    unsigned int nclip = (unsigned int)__builtin_amdgcn_readfirstlane((int)L.nclip);
+    if(nclip + n > 64u) { mr_clip_flush(L, q, lane); nclip = 0; }
     if(want) L.clip[nclip + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = prim;
-    nclip += n;
+    __syncthreads();
+    if(lane == 0) L.nclip = nclip + n;
+    __syncthreads();
 }
 
 __device__ static inline void mr_store_row(mr_lds_t& L, int slot, int lane, const hz_wvert_t& v)
@@ -371,6 +376,7 @@ void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ mid
 }
 
 /* set up and rasterise the `n` (<= 64) oldest pending triangles */
+template<bool HIZ>
 __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned int n, int lane,
                                 int jbeg, int i0,
                                 unsigned long long* fb, const mr_queue_t& q, const hz_params_t& p,
@@ -429,7 +435,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
             if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }
-        else if(valid && p.hiz.l1)
+        else if(HIZ && valid && p.hiz)
         {
             /* larger boxes, where the draw keeps coarse depth (hz_k_hiz.h): a box of at most 9 x 5 pixels lies in
              * 2 x 2 tiles of 8 x 4, one of at most 33 x 17 in 2 x 2 tiles of 32 x 16.  Each word is >= the depth
@@ -438,9 +444,9 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             const bool lv1 = bw1 <= (1 << HIZ1_W_LOG2) && bh1 <= (1 << HIZ1_H_LOG2);
             if(lv1 || (bw1 <= (1 << HIZ2_W_LOG2) && bh1 <= (1 << HIZ2_H_LOG2)))
             {
-                const uint32_t* t = lv1 ? p.hiz.l1 : p.hiz.l2;
+                const uint32_t* t = lv1 ? p.hiz : hiz_level2(p);
                 const int sx = lv1 ? HIZ1_W_LOG2 : HIZ2_W_LOG2, sy = lv1 ? HIZ1_H_LOG2 : HIZ2_H_LOG2;
-                const uint32_t tw = (uint32_t)(lv1 ? p.hiz.w1 : p.hiz.w2);
+                const uint32_t tw = (uint32_t)(lv1 ? hiz_w1(p.SW) : hiz_w2(p.SW));
                 const uint32_t tx0 = (uint32_t)(box.px0 - p.col0) >> sx, tx1 = (uint32_t)(box.px1 - p.col0) >> sx;
                 const uint32_t o0 = ((uint32_t)box.py0 >> sy)*tw, o1 = ((uint32_t)box.py1 >> sy)*tw;
                 const uint32_t z00 = t[o0 + tx0], z01 = t[o0 + tx1], z10 = t[o1 + tx0], z11 = t[o1 + tx1];
@@ -572,7 +578,10 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
 #else
 #define MR_OCCUPANCY
 #endif
-template<bool COUNTERS>
+/* HIZ: the instance for draws that keep coarse depth (hz_k_hiz.h; zoomed views).  The test of the larger boxes is
+ * ~100 instructions in each of the four places the flush is inlined and a dozen scalars held across the marching
+ * loop: compiled into the one kernel it cost whole panoramas, which never use it, 2 % more instructions per render. */
+template<bool COUNTERS, bool HIZ>
 __global__ __launch_bounds__(64) MR_OCCUPANCY
 void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
              mr_queue_t q, mr_zones_t zn, hz_params_t p)
@@ -672,7 +681,9 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     const unsigned long long fast_rows = __ballot(hzf_in_range(n_tab));
 
     /* pending-triangle ring, wave-uniform state */
-    unsigned int head = 0, count = 0, nclip = 0;
+    unsigned int head = 0, count = 0;
+    if(lane == 0) L.nclip = 0;
+    __syncthreads();
     int first_row = 0;                                  /* cell row (relative) of the oldest pending triangle */
     /* what a row keeps of itself for the cells above it (the attributes of its
      * vertices live in LDS, where mr_flush takes them from): per lane the
@@ -714,7 +725,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         if(count && first_row <= rel - MR_RSLOTS)
         {
             __syncthreads();
-            mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+            mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
             __syncthreads();
             head = (head + count) & (MR_CAP-1);
             count = 0;
@@ -749,8 +760,8 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                 const int verdict1 = has_cell ? hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) : HZ_TRI_DROP;
                 /* crossing the image border or the near/far sphere: k_clip */
                 const uint32_t prim0 = (uint32_t)(((size_t)(j-1)*(p.N-1) + i)*2);
-                mr_clip_note(L, nclip, q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
-                mr_clip_note(L, nclip, q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
+                mr_clip_note(L, q, verdict0 == HZ_TRI_CLIP, prim0,   lane);
+                mr_clip_note(L, q, verdict1 == HZ_TRI_CLIP, prim0+1, lane);
                 keep0 = verdict0 == HZ_TRI_DRAW; keep1 = verdict1 == HZ_TRI_DRAW;
             }
             #pragma unroll
@@ -770,7 +781,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                     if(count >= 64)
                     {
                         __syncthreads();        /* one wave: orders the LDS writes before the reads */
-                        mr_flush(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
+                        mr_flush<HIZ>(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
                         head = (head + 64) & (MR_CAP-1);
                         count -= 64;
                         if(count) first_row = (int)(L.ids[head] >> 7);
@@ -784,9 +795,9 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     if(count)
     {
         __syncthreads();
-        mr_flush(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+        mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
     }
-    mr_clip_flush(L, nclip, q, lane);
+    mr_clip_flush(L, q, lane);
     if(COUNTERS && p.wave_cycles && lane == 0)
     {
         unsigned long long* o = &p.wave_cycles[((size_t)blockIdx.y*gridDim.x + blockIdx.x)*4];     /* (grid launches) */

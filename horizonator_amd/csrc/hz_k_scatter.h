@@ -341,7 +341,7 @@ void k_big(unsigned long long* __restrict__ fb,
         const int rows_log2 = hz_big_rows_log2(bw);
         const int row_first = py0 + ((int)item.chunk << rows_log2);
         /* draws that keep coarse depth (second rounds of zoomed views, hz_k_hiz.h): nothing of these rows can win? */
-        if(p.hiz.l2 && hiz_chunk_hidden(tri, p, px0, bw, row_first, min(1 << rows_log2, py0 + bh - row_first), lane)) continue;
+        if(p.hiz && hiz_chunk_hidden(tri, p, px0, bw, row_first, min(1 << rows_log2, py0 + bh - row_first), lane)) continue;
         const int row = row_first + lane;
         int32_t x0 = px0;
         const uint32_t span = hz_row_span(br.r.e, row, px0, px0 + bw - 1, &x0);

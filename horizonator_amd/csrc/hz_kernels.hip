@@ -16,9 +16,11 @@
  *           word = z24<<40 | primitive<<8 | red8, cleared to all ones
  *
  * One translation unit: the device code lives in hz_k_common.h (parameters,
- * records, helpers, k_clip), hz_k_scatter.h (k_scatter, k_big), hz_k_march.h
- * (k_march, k_mid), hz_k_resolve.h (conversions, strips), hz_k_tex.h (textured
- * resolve); this file holds the context (hz_dev), the streams and the C-ABI.
+ * records, helpers, k_clip), hz_k_hiz.h (coarse depth for zoomed views),
+ * hz_k_scatter.h (k_scatter, k_big), hz_k_tile.h (the tile-binned option),
+ * hz_k_march.h (k_march, k_mid), hz_k_resolve.h (conversions, strips),
+ * hz_k_tex.h (textured resolve); this file holds the context (hz_dev), the
+ * streams and the C-ABI.
  */
 #include <hip/hip_runtime.h>
 
@@ -966,10 +968,12 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
         if((size_t)grid.x*grid.y*4 > d->wave_timing.capacity) { snprintf(g_last_error, sizeof(g_last_error), "wave timing buffer too small"); return -1; }
         pm.wave_cycles = d->wave_timing.d_cycles;
         d->wave_timing.grid_x = grid.x; d->wave_timing.grid_y = grid.y;
-        hipLaunchKernelGGL(k_march<true>, grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+        hipLaunchKernelGGL((k_march<true, true>), grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     }
+    else if(pm.hiz)
+        hipLaunchKernelGGL((k_march<false, true>), grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     else
-        hipLaunchKernelGGL(k_march<false>, grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+        hipLaunchKernelGGL((k_march<false, false>), grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     HZ_CHECK(hipGetLastError());
     return 0;
 }
@@ -1137,7 +1141,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
             /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
             p.pass = 2; p.early_z = early_z ? 1 : 0;
-            p.hiz = hz;
+            p.hiz = hz.l1;
             /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment
              * cannot win (a stale, larger value only costs the atomic) - where the framebuffer is larger than the
              * 256 MB of the chip's last-level cache.  Behind the first round's occluders most fragments of the second
@@ -1171,7 +1175,11 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
     /* ... and once more, now with what the second round's waves have drawn, for its large triangles (k_big's own test) */
-    if(use_hiz && hiz_sweep(d, d->qstream, next, p, p.hiz) != 0) return -1;
+    if(use_hiz)
+    {
+        hz_hiz_t hz;
+        if(hiz_tables(d, next, p, &hz) != 0 || hiz_sweep(d, d->qstream, next, p, hz) != 0) return -1;
+    }
     if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     d->hiz_last = use_hiz ? 1 : 0;
@@ -2179,14 +2187,72 @@ void k_check_cull(unsigned long long seed, unsigned long long ncases, int W, int
     atomicAdd(&out[2], cells); atomicAdd(&out[3], bad); atomicAdd(&out[4], kept);
 }
 
-/* what: 0 = hz_tri_hidden (n triangles), 1 = the cull of whole cells (n cases of two rows of 64 vertices);
- * image W x H (and, for 1, the drawn columns [col0,col1)); out: 5 words, see the kernels */
+/* k_check_rect: hiz_rect_min_depth() (hz_k_hiz.h: the smallest depth a rectangle of pixel centres can get is the
+ * smallest of its corners') against the minimum over every pixel centre of the rectangle, one thread per case: depth
+ * planes from flat to 10^6 per pixel, signs of every kind, origins inside and outside [0, 1] (clamped depths), values
+ * that overflow, infinities and NaNs; rectangles of up to 48 x 48 anywhere in a W x H image.  out[0] cases, [1] cases
+ * whose corners are all numbers, [2] pixel centres evaluated, [3] disagreements (a different minimum, or a pixel
+ * without a depth inside a rectangle whose corners have one), [4] cases with a depth that is not a number. */
+__global__ __launch_bounds__(256)
+void k_check_rect(unsigned long long seed, unsigned long long ncases, int W, int H, unsigned long long* out)
+{
+    unsigned long long cases = 0, numbers = 0, pixels = 0, bad = 0, nans = 0;
+    for(unsigned long long t = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; t < ncases; t += (unsigned long long)gridDim.x*blockDim.x)
+    {
+        const unsigned long long r0 = hz_mix64(seed + 3*t), r1 = hz_mix64(seed + 3*t + 1), r2 = hz_mix64(seed + 3*t + 2);
+        auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };
+        auto slope = [&](unsigned long long r) -> float
+        {
+            const int kind = (int)(r & 15);
+            if(kind == 0) return 0.0f;
+            if(kind == 1) return (r >> 4) & 1 ? __builtin_inff() : -__builtin_inff();
+            if(kind == 2) return __builtin_nanf("");
+            if(kind == 3) return ((r >> 4) & 1 ? 1.0f : -1.0f) * 3.0e38f * unit(r, 8);             /* overflows once multiplied */
+            const float mag = exp2f(-40.0f + 60.0f*unit(r, 8));                                   /* 1e-12 .. 1e6 per pixel */
+            return ((r >> 4) & 1) ? mag : -mag;
+        };
+        hz_tri_t tri;
+        memset(&tri, 0, sizeof(tri));
+        tri.dzdx = slope(r0); tri.dzdy = slope(r1);
+        tri.z_org = ((r2 & 7) == 0) ? -3.0f + 7.0f*unit(r2, 8) : unit(r2, 8);
+        if((r2 & 63) == 1) tri.z_org = __builtin_inff();
+        /* (steep planes: an origin that puts the rectangle's depths near [0, 1] rather than far outside) */
+        const int bw = 1 + (int)((r2 >> 32) % 48u), bh = 1 + (int)((r2 >> 40) % 48u);
+        const int x0 = (int)((r0 >> 32) % (unsigned long long)(W - bw + 1)), y0 = (int)((r1 >> 32) % (unsigned long long)(H - bh + 1));
+        if((r2 >> 48) & 1) tri.z_org = 0.5f - tri.dzdx*(float)(x0 + bw/2) - tri.dzdy*(float)(y0 + bh/2);
+        uint32_t qmin = 0;
+        const bool ok = hiz_rect_min_depth(tri, x0, x0 + bw - 1, y0, y0 + bh - 1, &qmin);
+        uint32_t m = 0xFFFFFFFFu;
+        bool nan_inside = false;
+        for(int py = y0; py < y0 + bh; py++)
+            for(int px = x0; px < x0 + bw; px++)
+            {
+                /* hz_tri_fragment()'s depth, without its two early returns */
+                float z = __builtin_fmaf(tri.dzdy, (float)py, __builtin_fmaf(tri.dzdx, (float)px, tri.z_org));
+                if(!(z == z)) { nan_inside = true; continue; }
+                z = hz_min(hz_max(z, 0.f), 1.f);
+                const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
+                uint32_t zi, r8;
+                const int drawn = hz_tri_fragment(&tri, px, py, &zi, &r8);
+                if(drawn && zi != q) bad++;                                    /* (this loop is what hz_tri_fragment computes) */
+                m = m < q ? m : q;
+            }
+        cases++; pixels += (unsigned long long)bw*bh;
+        if(nan_inside) nans++;
+        if(ok) { numbers++; if(nan_inside || m != qmin) bad++; }
+    }
+    atomicAdd(&out[0], cases); atomicAdd(&out[1], numbers); atomicAdd(&out[2], pixels); atomicAdd(&out[3], bad); atomicAdd(&out[4], nans);
+}
+
+/* what: 0 = hz_tri_hidden (n triangles), 1 = the cull of whole cells (n cases of two rows of 64 vertices), 2 = the
+ * smallest depth of a rectangle (n rectangles); image W x H (and, for 1, the drawn columns [col0,col1)); out: 5 words,
+ * see the kernels */
 extern "C" int hz_hip_check_exactness(int device, int what, unsigned long long seed, unsigned long long n,
                                       int W, int H, int col0, int col1, unsigned long long* out)
 {
     hz_device_guard device_guard_(device);
     if(!device_guard_.ok) return -1;
-    if(what < 0 || what > 1 || W < 1 || H < 1 || col0 < 0 || col1 > W || col0 >= col1)
+    if(what < 0 || what > 2 || W < 1 || H < 1 || col0 < 0 || col1 > W || col0 >= col1 || (what == 2 && (W < 48 || H < 48)))
     {
         snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_exactness: bad arguments");
         return -1;
@@ -2195,8 +2261,9 @@ extern "C" int hz_hip_check_exactness(int device, int what, unsigned long long s
     HZ_CHECK(hipMalloc(&d_out, 5*sizeof(unsigned long long)));
     const unsigned long long init[5] = { 0, 0, 0, 0, what == 0 ? ~0ull : 0ull };
     HZ_CHECK(hipMemcpy(d_out, init, sizeof(init), hipMemcpyHostToDevice));
-    if(what == 0) hipLaunchKernelGGL(k_check_hidden, dim3(256*32), dim3(256), 0, 0, seed, n, W, H, d_out);
-    else          hipLaunchKernelGGL(k_check_cull, dim3(256*64), dim3(64), 0, 0, seed, n, W, H, col0, col1, d_out);
+    if(what == 0)      hipLaunchKernelGGL(k_check_hidden, dim3(256*32), dim3(256), 0, 0, seed, n, W, H, d_out);
+    else if(what == 1) hipLaunchKernelGGL(k_check_cull, dim3(256*64), dim3(64), 0, 0, seed, n, W, H, col0, col1, d_out);
+    else               hipLaunchKernelGGL(k_check_rect, dim3(256*16), dim3(256), 0, 0, seed, n, W, H, d_out);
     HZ_CHECK(hipGetLastError());
     HZ_CHECK(hipMemcpy(out, d_out, 5*sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(d_out);

@@ -251,6 +251,13 @@ int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsign
  *           volume's faces, positions on pixel centres, the +-180 degree seam, back faces;
  *           drawn columns [col0,col1).  out: cases, cases culled the short way, cells
  *           compared, DISAGREEMENTS, triangles kept
+ *   what 2  the smallest depth any pixel centre of a rectangle gets from a set-up triangle's
+ *           depth plane (hz_k_hiz.h: the smallest of the four corners', which lets k_big drop
+ *           chunks of rows in zoomed views) against the minimum over all of the rectangle's
+ *           pixel centres as hz_tri_fragment() computes them: n rectangles of up to 48 x 48,
+ *           planes flat to 10^6 per pixel, clamped, overflowing, infinite, NaN.  out: cases,
+ *           cases with numbers at all corners, pixel centres evaluated, DISAGREEMENTS, cases
+ *           with a depth that is not a number
  * 0 violations / disagreements is the only acceptable answer. */
 int  hz_hip_check_exactness(int device, int what, unsigned long long seed, unsigned long long n,
                             int W, int H, int col0, int col1, unsigned long long* out);

@@ -13,6 +13,10 @@ where a scene does not go looking").
   are culled with a back-face test and a pixel box alone.  Rules being protected: reference
   geometry.glsl:21-27 (triangles wider than a quarter of the image are dropped), GL's cull and
   scissor - its verdict must be hz_tri_cull()'s on every cell of every row it accepts.
+* hiz_rect_min_depth() (hz_k_hiz.h): in zoomed views k_big drops a chunk of a large triangle's rows when the smallest
+  depth any fragment of the chunk's rectangle can get lies behind everything already drawn there; that smallest depth
+  is taken from the rectangle's four corners (every step of hz_tri_fragment's depth is monotone in px and py).
+  Same GL rule; checked against the minimum over every pixel centre of seeded rectangles and depth planes.
 """
 import ctypes as C
 
@@ -51,3 +55,13 @@ def test_the_cull_of_whole_cells_is_the_cull_of_each_triangle(W, H, col0, col1):
     assert cases == 1 << 22 and shortway > cases // 8 and cells == 63 * shortway, (cases, shortway, cells)
     assert 0 < kept < 2 * cells                     # both verdicts occur
     print(f"{W}x{H} columns [{col0},{col1}): {shortway} of {cases} row pairs culled the short way, {2 * cells} verdicts, {kept} kept")
+
+
+@pytest.mark.parametrize("W,H", [(16000, 4000), (32768, 8192), (48, 48)])
+def test_the_smallest_depth_of_a_rectangle_is_at_a_corner(W, H):
+    n = 1 << 22
+    cases, numbers, pixels, bad, nans = _run(2, 0xD0C70000 + W, n, W, H)
+    assert bad == 0, f"{bad} rectangles whose smallest depth is not their corners' (or pixels hz_tri_fragment computes differently)"
+    # the check must have looked where it claims to: most planes are numbers, some are not, and the rectangles have an inside
+    assert cases == n and numbers > n // 2 and nans > n // 64 and pixels > 200 * n, (cases, numbers, pixels, nans)
+    print(f"{W}x{H}: {cases} rectangles, {pixels} pixel centres, {nans} with a depth that is not a number")

@@ -42,8 +42,10 @@ def _one(kernels, fragment):
 
 def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     k = _kernels()
-    march = _one(k, "k_marchILb0E")                 # the production instance (no per-wave counters)
-    assert march["private_segment_fixed_size"] == 0, "k_march<false> must not use scratch memory"
+    march = _one(k, "k_marchILb0ELb0E")             # the production instance (no per-wave counters, no coarse depth)
+    assert march["private_segment_fixed_size"] == 0, "k_march<false, false> must not use scratch memory"
+    zoomed = _one(k, "k_marchILb0ELb1E")            # ... of zoomed views (coarse depth, hz_k_hiz.h)
+    assert zoomed["private_segment_fixed_size"] == 0 and zoomed["vgpr_count"] <= 112 and zoomed["group_segment_fixed_size"] <= 7168, zoomed
     assert march["vgpr_count"] <= 112, "four marching waves + one wave of k_big / the conversion per SIMD: 4*112 + 48 <= 512"
     assert march["group_segment_fixed_size"] <= 7168
     left_vgprs = 512 - 4*((march["vgpr_count"] + 7)//8*8)
