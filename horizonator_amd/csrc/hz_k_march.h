@@ -27,7 +27,13 @@
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
 /* round 1 of a draw takes the strips within ppr/20 cells of the viewer (draw_impl: plan_rounds); timed at 16000x4000,
  * round 2: 32 cells 1.085 ms per render, 64: 1.063, 96: 1.056, 128: 1.052, 192: 1.064, 256: 1.12 */
-#define HZ_NEAR_CELLS_MAX 256       /* the first rounds' queue sets are sized for a reach of this many cells (or HZ_NEAR_CELLS, if larger) */
+/* The cap of the first round's reach (zoomed views and panoramas wider than 49000 columns hit it), and what the first
+ * rounds' queue sets are sized for (or HZ_NEAR_CELLS, if larger).  256 until zoomed views got coarse depth (hz_k_hiz.h):
+ * a narrow view's frustum is narrow in elevation too, little of the nearest terrain is inside it, and the ridge
+ * that hides most of the view tends to lie further out - seven 10 and 45 degree views (three viewpoints, four
+ * directions, the rough DEM; tools/hiz_ab.py, profiles/r3_coarse_depth.txt) take 14.5 ms in sum with a reach of 256
+ * cells, 11.0 with 384, 11.1 with 512 (five gain up to 2x, two lose 8 %). */
+#define HZ_NEAR_CELLS_MAX 384
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the

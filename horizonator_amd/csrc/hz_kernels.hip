@@ -119,7 +119,7 @@ struct hz_env_t
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
     int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: the draw decides */
-    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 30): ... from this cell width at the first round's reach on */
+    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): ... from this cell width at the first round's reach on */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static hz_env_t read_env(void)
@@ -144,7 +144,7 @@ static hz_env_t read_env(void)
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
-    e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 30.0;
+    e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 25.0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
     e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
@@ -984,8 +984,8 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
     const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
     /* The first round's reach: the cells that are wider than ~20 pixels on screen - a cell r rows
      * from the viewer is about ppr/r pixels wide (ppr = pixels per radian of azimuth), so r = ppr/20:
-     * 127 cells for a 16000-wide panorama (where 32..256 were timed: hz_k_march.h), 64 for 8000, 256
-     * (the most the first rounds' queues are sized for) from 32768 on and for zoomed views.
+     * 127 cells for a 16000-wide panorama (where 32..256 were timed: hz_k_march.h), 64 for 8000, 260
+     * for 32768, at most HZ_NEAR_CELLS_MAX (zoomed views: see there).
      * profiles/r3_scenes.json holds the sweep over the scenes of tools/scenes.py. */
     int near_cells = d->env.near_cells;
     if(near_cells < 0)
@@ -1109,12 +1109,13 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
             /* Zoomed views: where the first round ends a cell is still ppr/reach pixels wide (20 in a whole
-             * panorama, 80 in a 45 degree view of 16000 columns: the reach is capped), and most of the second
+             * panorama, 53 in a 45 degree view of 16000 columns: the reach is capped), and most of the second
              * round's boxes are beyond the 4 x 2 pixels its early depth test reads itself.  Those draws keep coarse
              * depth for the larger boxes (hz_k_hiz.h): the tables take in the first round's picture, on its stream,
-             * and the second round waits for them.  tools/hiz_ab.py: the 45 degree view 2.93 -> 2.26 ms with this
-             * sweep alone (more sweeps beside the second round: no gain); whole panoramas lose 2-5 % (their
-             * boxes are small: 4 x 2 reaches 93 % of them) and do not have tables. */
+             * and the second round waits for them.  One sweep: more of them beside the second round, one in front of
+             * k_big (which tests its chunks of rows against the same tables), one between a nearer and a farther
+             * band of the second round - each was measured, none paid.  Whole panoramas gain
+             * nothing (their boxes are small: 4 x 2 reaches 93 % of them) and do not have tables. */
             const bool early_z = (unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32);
             hz_hiz_t hz = {};
             {
@@ -1174,12 +1175,6 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * second round's queue kernels only as long as the second round itself waited for the first */
     if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
-    /* ... and once more, now with what the second round's waves have drawn, for its large triangles (k_big's own test) */
-    if(use_hiz)
-    {
-        hz_hiz_t hz;
-        if(hiz_tables(d, next, p, &hz) != 0 || hiz_sweep(d, d->qstream, next, p, hz) != 0) return -1;
-    }
     if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     d->hiz_last = use_hiz ? 1 : 0;

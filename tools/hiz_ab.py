@@ -17,16 +17,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+_set_here = []
+
+
 def run(name, settings, steps):
     import torch
     import hzutil
     import horizonator_amd
     import scenes
-    for k in [k for k in os.environ if k.startswith("HZ_HIZ")]:
-        del os.environ[k]
+    for k in _set_here:                 # (the switches of the setting before this one)
+        os.environ.pop(k, None)
+    _set_here.clear()
     for kv in settings.split():
         k, v = kv.split("=")
         os.environ[k] = v
+        _set_here.append(k)
     sc = scenes.SCENES[name]
     R, W, H = sc["R"], sc["W"], sc["H"]
     dems = hzutil.dem_dir_for(scenes.LAT, scenes.LON, R, srtm1=sc.get("srtm1", False), rough=sc.get("rough", False))

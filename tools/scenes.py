@@ -38,6 +38,11 @@ SCENES = {
     "cfg3_zoom90":   dict(R=4200, W=16000, H=4000, az=(-45.0, 45.0), what="a 90 degree view at 16000x4000"),
     "cfg3_zoom180":  dict(R=4200, W=16000, H=4000, az=(-90.0, 90.0), what="a 180 degree view at 16000x4000"),
     "cfg3_zoom10":   dict(R=4200, W=16000, H=4000, az=(-5.0, 5.0), what="a 10 degree view at 16000x4000"),
+    "cfg3_zoom45_summit": dict(R=4200, W=16000, H=4000, az=(-22.5, 22.5), viewpoint="summit", what="the 45 degree view from the summit viewpoint"),
+    "cfg3_zoom45_valley": dict(R=4200, W=16000, H=4000, az=(-22.5, 22.5), viewpoint="valley", what="the 45 degree view from the valley viewpoint"),
+    "cfg3_zoom45_rough":  dict(R=4200, W=16000, H=4000, az=(-22.5, 22.5), rough=True, what="the 45 degree view over the rough DEM"),
+    "cfg3_zoom45_east":   dict(R=4200, W=16000, H=4000, az=(67.5, 112.5), what="a 45 degree view to the east"),
+    "cfg3_zoom45_south":  dict(R=4200, W=16000, H=4000, az=(157.5, 202.5), what="a 45 degree view to the south"),
     "cfg3_zfar40km": dict(R=4200, W=16000, H=4000, zfar=40000.0, what="the API's default far clip (reference horizonator.h:10)"),
     "cfg2":          dict(R=1800, W=8000, H=2000, what="BASELINE configs[1]: 3x3 SRTM3 tiles, 8000x2000"),
     "cfg1":          dict(R=600, W=2000, H=500, steps=40, what="BASELINE configs[0]: one SRTM3 tile's worth, 2000x500"),
