@@ -11,10 +11,9 @@
  *
  * Depths in the framebuffer only ever decrease during a draw (atomicMin), so a maximum taken over a tile at ANY
  * earlier moment of the draw is still >= every depth of the tile: the summary may be as stale as it likes, it needs
- * no synchronisation with the kernels that draw, and a sweep can run beside them.  k_hiz is that sweep: launched a
- * few times in a row on a stream of its own while the second round marches (near strips are dispatched first; by the
- * time the far ones test their triangles the sweeps have seen the ridges in between).  A tile nobody has swept yet
- * holds all ones = the cleared depth = "nothing is hidden here".
+ * no synchronisation with the kernels that draw.  k_hiz is the sweep that takes it: once per draw, behind the first
+ * round (whose reach decides what the tables are worth: HZ_NEAR_CELLS_MAX); the second round waits for it.  Every tile of
+ * the drawn columns is written by every sweep, nothing is left over from the draw before.
  *
  * Exactness: the same hz_tri_hidden() with a zs that is merely larger (a superset of pixels, read earlier) than
  * the one the 4 x 2 test would use; tests/test_gpu_parity.py draws with and without (HZ_HIZ=1 / 0), the golden

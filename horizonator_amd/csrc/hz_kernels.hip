@@ -118,8 +118,8 @@ struct hz_env_t
     int    resolve_nt;              /* HZ_RESOLVE_NT=0: the conversion's results leave with plain instead of non-temporal stores */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
-    int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: the draw decides */
-    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): ... from this cell width at the first round's reach on */
+    int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: zoomed views, and every draw of a series */
+    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): "zoomed" = a cell at the first round's reach is at least this wide */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static hz_env_t read_env(void)
@@ -1108,38 +1108,42 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
             if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
-            /* Zoomed views: where the first round ends a cell is still ppr/reach pixels wide (20 in a whole
-             * panorama, 53 in a 45 degree view of 16000 columns: the reach is capped), and most of the second
-             * round's boxes are beyond the 4 x 2 pixels its early depth test reads itself.  Those draws keep coarse
-             * depth for the larger boxes (hz_k_hiz.h): the tables take in the first round's picture, on its stream,
-             * and the second round waits for them.  One sweep: more of them beside the second round, one in front of
-             * k_big (which tests its chunks of rows against the same tables), one between a nearer and a farther
-             * band of the second round - each was measured, none paid.  Whole panoramas gain
-             * nothing (their boxes are small: 4 x 2 reaches 93 % of them) and do not have tables. */
-            const bool early_z = (unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32);
-            hz_hiz_t hz = {};
-            {
-                const float ppr = p.halfW * p.u.az_ndc_per_rad;
-                const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
-                use_hiz = early_z && !by_tile
-                          && (d->env.hiz >= 0 ? d->env.hiz != 0 : (reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px));
-                if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
-                if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
-            }
-            HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
              * finds the marching kernel of the draw before it finished (a single render, or
              * the first of a series) starts its second round at once, beside its first.  The
              * early depth test then sees fewer occluders and skips less; what it skips is
              * hidden whenever it looks (depths only decrease), so the bytes are the same. */
-            if(use_hiz || d->env.always_wait_near || by_tile || hipEventQuery(d->ev_marched) != hipSuccess)
+            const bool busy = hipEventQuery(d->ev_marched) != hipSuccess;
+            (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
+            /* Coarse depth (hz_k_hiz.h) for the second round's boxes beyond the 4 x 2 pixels its early depth test
+             * reads itself: the tables take in the first round's picture, on its stream, and the second round waits
+             * for them.  Zoomed views always (where the first round ends a cell is still ppr/reach pixels wide: 20
+             * in a whole panorama, 53 in a 45 degree view of 16000 columns - the reach is capped - and few boxes are
+             * small: 2.3 -> 1.0 ms); the others when the second round has to wait for the first anyway, i.e. in a
+             * series of renders: the headline 0.98 -> 0.965 ms per render at K = 40, the rough DEM 1.095 -> 1.045,
+             * 8000 x 2000 0.283 -> 0.273, the summit +3 % - while a single render keeps its second round beside its
+             * first (with tables it would have to wait: 1.26 -> 1.40 ms).  One sweep: more of them beside the second
+             * round, one in front of k_big (which tests its chunks of rows against the same tables), one between a
+             * nearer and a farther band of the second round - each was measured, none paid. */
+            const bool early_z = (unsigned long long)p.SW*(unsigned long long)p.H*8ull < (1ull << 32);
+            hz_hiz_t hz = {};
+            {
+                const float ppr = p.halfW * p.u.az_ndc_per_rad;
+                const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
+                const bool zoomed = reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px;
+                /* (azimuth sectors: a half gains 8 %, a quarter loses 4, an eighth 7 - the sweep and the wait do not shrink with the work) */
+                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || (busy && 2*p.SW >= p.W)));
+                if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
+                if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
+            }
+            HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
+            if(use_hiz || d->env.always_wait_near || by_tile || busy)
             {
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
                 waited_near = true;             /* (the first round itself waited for the framebuffer: no second wait for that below) */
             }
             else
                 near_beside_far = true;         /* "drawn" then has to wait for both rounds: see qstream below */
-            (void)hipGetLastError();            /* (hipErrorNotReady from the query is not an error) */
             /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
             p.pass = 2; p.early_z = early_z ? 1 : 0;
             p.hiz = hz.l1;

@@ -33,7 +33,11 @@ copy("pmc_r3_final.json", "pmc_latest.json")
 copy("pmc_r3_mix.json", "pmc_r3_instruction_mix_cfg3.json")
 copy("host_inclusive.txt", "r3_host_inclusive.txt")
 copy("r3_experiments.json", "r3_experiments.json")
-copy("coarse_depth.txt", "r3_coarse_depth.txt")
+with open(os.path.join(P, "r3_coarse_depth.txt"), "w") as f:
+    f.write(open(os.path.join(O, "coarse_depth.txt")).read())
+    if os.path.exists(os.path.join(O, "coarse_depth_reach.txt")):          # (seven zoomed views x the first round's reach)
+        f.write(open(os.path.join(O, "coarse_depth_reach.txt")).read())
+print("r3_coarse_depth.txt")
 with open(os.path.join(P, "r3_sector_timing.txt"), "w") as f:
     f.write(open(os.path.join(O, "sector_timing.txt")).read())
     f.write("\ntools/sector_b2b.py: one sector rendered back to back as sparse strips, ms per strip\n")
