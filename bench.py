@@ -458,7 +458,9 @@ def main():
     if args.config == "cfg3" and args.zfar == 600000.0 and world == 1 and args.raster in (0, 2) and os.path.exists(mix):
         try:
             rec = json.load(open(mix))
-            far = max((v for k, v in rec.items() if k.startswith("k_march grid")), key=lambda v: v["SQ_INSTS_VALU"])
+            # (the second round's marching kernel; in a series of renders that is the instance with coarse depth, where the file has it)
+            far = max((v for k, v in rec.items() if k.startswith("k_march_coarse_depth grid")), key=lambda v: v["SQ_INSTS_VALU"], default=None) \
+                  or max((v for k, v in rec.items() if k.startswith("k_march grid")), key=lambda v: v["SQ_INSTS_VALU"])
             busy_ms = far["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3     # quad-cycles -> cycles, 1024 SIMDs at 2.4 GHz
             valu = {"recorded": True, "wave_instructions": far["SQ_INSTS_VALU"], "active_quad_cycles": far["SQ_ACTIVE_INST_VALU"],
                     "cycles_per_instruction": 4.0 * far["SQ_ACTIVE_INST_VALU"] / far["SQ_INSTS_VALU"],

@@ -21,8 +21,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(indir + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if name.startswith("k_march<"):          # k_march<false>: the production instance (no per-wave counters)
-            name = "k_march"
+        if name.startswith("k_march<"):          # k_march<COUNTERS, HIZ>: false, false = the plain production instance;
+            args = [a.strip() for a in name[name.index("<")+1:name.rindex(">")].split(",")]
+            name = "k_march_coarse_depth" if len(args) > 1 and args[1] == "true" else "k_march"    # (second rounds of a series / of zoomed views)
         if name == "k_march":
             # a two-round draw launches k_march twice: the strips next to the viewer (small grid), then the rest
             name += "_near_round" if int(r.get("Grid_Size", 0)) < 1000000 else ""
@@ -47,7 +48,7 @@ for k, cs in mean.items():
                          "launches_per_render": count[k] / renders,
                          "hbm_bytes_per_render": (2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024.0 * count[k] / renders,
                          **{c: v for c, v in cs.items() if c not in ("FETCH_SIZE", "WRITE_SIZE")}}
-dom = "k_march" if "k_march" in out["kernels"] else "k_scatter"
+dom = max((k for k in ("k_march_coarse_depth", "k_march", "k_scatter") if k in out["kernels"]), key=lambda k: count[k])
 out["kernel"] = dom
 out["hbm_bytes_per_launch"] = out["kernels"][dom]["hbm_bytes_per_launch"]
 out["hbm_bytes_per_render_all_kernels"] = sum(v["hbm_bytes_per_render"] for k, v in out["kernels"].items() if k.startswith("k_"))
