@@ -184,6 +184,7 @@ def load():
     sig("hz_hip_check_exactness", i, i, i, C.c_uint64, C.c_uint64, i, i, i, i, P(C.c_uint64))
     sig("hz_hip_debug_bigqueue", i, vp, i, vp, i, vp)
     sig("hz_hip_debug_wave_timing", i, vp, P(View), vp, C.c_size_t, vp)
+    sig("hz_hip_debug_last_plan", i, vp, vp)
     sig("hz_hip_debug_worklist", C.c_long, i, i, i, P(View), i, i, i, vp, C.c_size_t)
     sig("hz_hip_last_error", C.c_char_p)
     _lib = lib
@@ -215,7 +216,7 @@ DECLARED_SYMBOLS = [
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
     "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
-    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_check_fastmath", "hz_hip_check_exactness", "hz_hip_debug_bigqueue", "hz_hip_debug_wave_timing", "hz_hip_debug_worklist", "hz_hip_last_error",
+    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_check_fastmath", "hz_hip_check_exactness", "hz_hip_debug_bigqueue", "hz_hip_debug_wave_timing", "hz_hip_debug_last_plan", "hz_hip_debug_worklist", "hz_hip_last_error",
 ]
 
 

@@ -211,7 +211,7 @@ struct hz_dev
     hipEvent_t          ev_marched, ev_near;
     /* coarse depth of each framebuffer (hz_k_hiz.h), allocated by the first draw that wants it */
     uint32_t*           d_hiz[HZ_NFB];
-    int                 hiz_last;               /* the last draw kept coarse depth (diagnostics) */
+    int                 last_plan[4];           /* the last draw (hz_hip_debug_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
     hz_bigitem_t*       d_bigitem_s[2*HZ_NFB];
@@ -1181,7 +1181,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
     if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
-    d->hiz_last = use_hiz ? 1 : 0;
+    d->last_plan[0] = p.pass == 2 ? 2 : 1; d->last_plan[1] = use_hiz ? 1 : 0;
+    d->last_plan[2] = p.pass == 2 ? (p.near_j1 - p.near_j0)/2 : 0; d->last_plan[3] = p.cull_strips ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
     return 0;
@@ -2294,6 +2295,16 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
         for(int m=0; m<3; m++) { o[4+m] = h[r].r.e.dx[m]; o[7+m] = -h[r].r.e.ndy[m]; }
     }
     free(h);
+    return 0;
+}
+
+/* diagnostics / tests: what the last draw was - out[0] rounds (1 / 2), [1] its second round kept coarse depth
+ * (hz_k_hiz.h), [2] the first round's reach in cells (0: one round), [3] only the strips behind the drawn columns
+ * were launched (sectors, views of less than the full circle) */
+extern "C" int hz_hip_debug_last_plan(hz_dev_t* d, int* out)
+{
+    if(!d || !out) return -1;
+    for(int k=0; k<4; k++) out[k] = d->last_plan[k];
     return 0;
 }
 

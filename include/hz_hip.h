@@ -278,6 +278,11 @@ int  hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counters, int max
 long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view, int col0, int col1, int round,
                            int32_t* out, size_t capacity_items);
 
+/* diagnostics / tests: what the last draw of the context was - out[0] rounds (1 / 2), out[1] its
+ * second round kept coarse depth (zoomed views, draws of a series), out[2] the first round's
+ * reach in cells, out[3] only the strips behind the drawn columns were launched */
+int  hz_hip_debug_last_plan(hz_dev_t* d, int* out);
+
 /* diagnostics (tools/wave_timing.py): `view` drawn once more by the instance of the
  * marching kernel that counts; per wave of its second (or only) round 4 words: duration
  * in shader clock cycles, flushes<<32 | triangles set up, to k_big<<32 | to k_mid,

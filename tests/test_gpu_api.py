@@ -358,3 +358,46 @@ def test_single_renders_through_the_api_with_the_round_count_forced(two_pass, mo
                 fresh.close()
     finally:
         used.close()
+
+
+def test_which_draws_keep_coarse_depth(monkeypatch):
+    """hz_hip_debug_last_plan: a zoomed view keeps coarse depth (hz_k_hiz.h) and its first round reaches as far as the
+    cap allows; a whole panorama that is waited for does not (its second round runs beside its first); in a series of
+    renders the later ones do (they find the marching kernel of the render before them still running) - and the
+    pictures of the series are those of the renders that were waited for."""
+    import torch
+    import horizonator_amd
+    monkeypatch.setenv("HZ_TWO_PASS", "1")          # (two rounds at a size the test can afford)
+    R, W, H = 1000, 8000, 2000
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+    lib = h._lib
+    dev = lib.horizonator_amd_device(C.byref(h._ctx))
+
+    def plan():
+        out = (C.c_int * 4)()
+        assert lib.hz_hip_debug_last_plan(dev, out) == 0
+        return [int(x) for x in out]
+
+    try:
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
+        rng = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
+        h.set_view(-180, 180, zfar=200000.0)
+        h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+        h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+        rounds, coarse, reach, listed = plan()
+        assert (rounds, coarse, listed) == (2, 0, 0) and reach == 64, plan()      # 8000 columns: cells wider than 20 px = 64 cells
+        waited = (img.cpu().numpy().copy(), rng.cpu().numpy().copy())
+        seen = 0
+        for _ in range(12):                         # a series: nobody waits in between
+            h.render_device(img.data_ptr(), rng.data_ptr())
+            seen += plan()[1]
+        h.sync()
+        assert seen >= 6, f"only {seen} of 12 renders of a series kept coarse depth"
+        assert np.array_equal(img.cpu().numpy(), waited[0]) and np.array_equal(rng.cpu().numpy(), waited[1])
+        h.set_view(-10, 10, zfar=200000.0)          # a 20 degree view: ppr = 22900, the reach hits its cap
+        h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+        rounds, coarse, reach, listed = plan()
+        assert (rounds, coarse, listed) == (2, 1, 1) and reach == 384, plan()
+    finally:
+        h.close()

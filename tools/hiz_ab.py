@@ -2,7 +2,7 @@
 """coarse depth for zoomed views (hz_k_hiz.h) on / off: same bytes? how long? - scenes of tools/scenes.py, one process
 (the library reads its switches when a context is created)
 
-    python tools/hiz_ab.py [scene ...]  [--set "HZ_HIZ=1 HZ_HIZ_SWEEPS=4" ...]
+    python tools/hiz_ab.py [scene ...]  [--set "HZ_HIZ=1 HZ_NEAR_CELLS=512" ...]
 """
 import argparse
 import hashlib
