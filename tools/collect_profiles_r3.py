@@ -35,8 +35,10 @@ copy("host_inclusive.txt", "r3_host_inclusive.txt")
 copy("r3_experiments.json", "r3_experiments.json")
 with open(os.path.join(P, "r3_coarse_depth.txt"), "w") as f:
     f.write(open(os.path.join(O, "coarse_depth.txt")).read())
-    if os.path.exists(os.path.join(O, "coarse_depth_reach.txt")):          # (seven zoomed views x the first round's reach)
-        f.write(open(os.path.join(O, "coarse_depth_reach.txt")).read())
+    for part in ("coarse_depth_reach.txt",          # seven zoomed views x the first round's reach
+                 "coarse_depth_series.txt"):        # whole panoramas in a series of 30 renders, without / with, twice
+        if os.path.exists(os.path.join(O, part)):
+            f.write(open(os.path.join(O, part)).read())
 print("r3_coarse_depth.txt")
 with open(os.path.join(P, "r3_sector_timing.txt"), "w") as f:
     f.write(open(os.path.join(O, "sector_timing.txt")).read())

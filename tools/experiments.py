@@ -75,9 +75,14 @@ ROWS = [
     ("first round reaches cells wider than 10 px", {"HZ_NEAR_PX": "10"}, None, "default 20"),
     ("first round reaches cells wider than 40 px", {"HZ_NEAR_PX": "40"}, None, "default 20"),
     ("second round always waits for the first", {"HZ_ALWAYS_WAIT_NEAR": "1"}, None, ""),
+    ("no coarse depth in a series of renders", {"HZ_HIZ": "0"}, None,
+     "the second rounds without the tables of hz_k_hiz.h (default: zoomed views always, whole panoramas when they are part of a series): the build before them"),
+    ("coarse depth forced", {"HZ_HIZ": "1"}, None, "in a series the same as shipped; it differs for the first renders only"),
     ("as shipped, zfar 40 km", {}, 40000.0, "the API's default far clip"),
     ("k_big: plain stores, zfar 40 km (WRONG picture)", {"HZ_EXP_FB_BIG": "2"}, 40000.0, "with the 40 km far clip k_big is the longest kernel"),
     ("two rounds forced, zfar 40 km", {"HZ_TWO_PASS": "1"}, 40000.0, ""),
+    ("no coarse depth, zfar 40 km", {"HZ_HIZ": "0"}, 40000.0, ""),
+    ("as shipped, once more", {}, None, "the first row again at the end of the list: what the box drifts by during the run"),
 ]
 VARIANTS = [
     ("five marching waves per SIMD", "waves5", "-DMR_WAVES_PER_EU=5", "96 registers per wave instead of 105"),

@@ -22,6 +22,7 @@ bash tools/gpu_scenes.sh > $O/scenes_summary.txt 2>&1
 cp -r gpurun_out/scenes $O/
 timeout 900 python tools/hiz_ab.py cfg3_zoom10 cfg3_zoom45 cfg3_zoom90 cfg3_zoom180 cfg3 cfg3_zfar40km cfg5 --steps 8 --set "HZ_HIZ=0" --set "HZ_HIZ=1" --set "" > $O/coarse_depth.txt 2> $O/coarse_depth.err
 timeout 900 python tools/hiz_ab.py cfg3_zoom45_summit cfg3_zoom45_valley cfg3_zoom45_rough cfg3_zoom45_east cfg3_zoom45_south cfg3_zoom45 cfg3_zoom10 --steps 10 --set "HZ_NEAR_CELLS=256" --set "HZ_NEAR_CELLS=384" --set "HZ_NEAR_CELLS=512" --set "HZ_HIZ=0" > $O/coarse_depth_reach.txt 2> $O/coarse_depth_reach.err
+timeout 900 python tools/hiz_ab.py cfg3 cfg3_rough cfg3_summit cfg3_valley cfg2 --steps 30 --set "HZ_HIZ=0" --set "" --set "HZ_HIZ=0" --set "" > $O/coarse_depth_series.txt 2> $O/coarse_depth_series.err
 timeout 2400 python tools/experiments.py > $O/r3_experiments.json 2> $O/r3_experiments.err
 for g in rotate root0; do timeout 600 python bench.py --gpus 4 --backend gloo --same-gpu --steps 8 --warmup 2 --no-cpu-baseline --no-host --no-extra --gather $g 2>>$O/multi.err | grep "^{" > $O/multi_4ranks_one_gpu_$g.json; done
 timeout 300 python bench.py --gpus 1 --exchange-anyway --steps 20 --warmup 4 --no-cpu-baseline --no-host --no-extra 2>>$O/multi.err | grep "^{" > $O/exchange_anyway.json
