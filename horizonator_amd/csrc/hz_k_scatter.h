@@ -299,6 +299,9 @@ __device__ static inline uint32_t hz_row_span(const hz_edges_t& e, int row, int3
     return (any && x1 >= x0) ? (uint32_t)(x1 - x0 + 1) : 0u;
 }
 
+#ifndef KB_ROW_MIN
+#define KB_ROW_MIN 48                   /* k_big: average pixels per non-empty row from which a chunk is drawn row by row */
+#endif
 /* large triangles: one wave per work item = 64 pixel rows of a queued triangle.
  * Lane = row: the covered pixel centres of a row are a span [x0, x1] - each
  * edge function is linear in px, so each edge bounds the span from one side, at
@@ -351,6 +354,38 @@ void k_big(unsigned long long* __restrict__ fb,
         const uint32_t incl  = mr_scan(count, lane);
         const uint32_t excl  = incl - count;
         const uint32_t total = __shfl(incl, 63);
+        /* Long spans (the triangles next to the viewer: hundreds of pixels a row): row by row, the lanes side by side
+         * along the span - row and first column are scalars, no search for the row that owns a pixel (six dependent
+         * ds_bpermute per pass below: 40 % of this kernel's instructions).  Worth it from an average of 48 pixels per
+         * non-empty row on (a pass then has at most a quarter of its lanes idle at the spans' ends). */
+        unsigned long long rows_left = __ballot(count > 0u);
+        if(total >= (uint32_t)KB_ROW_MIN*(uint32_t)__popcll(rows_left))
+        {
+            while(rows_left)
+            {
+                const int r = (int)__builtin_ctzll(rows_left);
+                rows_left &= rows_left - 1ull;
+                const int rx0 = __builtin_amdgcn_readlane(x0, r);
+                const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)count, r);
+                const int py = row_first + r;
+                for(uint32_t o = 0; o < rc; o += 64u)
+                {
+                    const uint32_t k = o + (uint32_t)lane;
+                    if(k < rc)
+                    {
+                        const int px = rx0 + (int)k;
+                        uint32_t zi, r8;
+                        if(hz_tri_fragment(&tri, px, py, &zi, &r8))
+                        {
+                            const unsigned long long key = hz_pack(zi, prim, r8);
+                            if(!p.pretest || key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for(uint32_t base = 0; base < total; base += 64)
         {
             const uint32_t k = base + lane;
