@@ -20,7 +20,9 @@ def copy(src, dst):
 
 def largest(pattern):
     """(rocprofv3 writes one stats file per process of the command: the bench's own is the longest)"""
-    return max(glob.glob(os.path.join(O, pattern)), key=os.path.getsize)
+    files = glob.glob(os.path.join(O, pattern))
+    big = max(os.path.getsize(f) for f in files)
+    return max((f for f in files if os.path.getsize(f) >= 0.9*big), key=os.path.getmtime)     # (the newest: a short rerun leaves older ones behind)
 
 
 copy("bench.json", "r3_final_cfg3_bench.json")
