@@ -367,6 +367,8 @@ def test_which_draws_keep_coarse_depth(monkeypatch):
     pictures of the series are those of the renders that were waited for."""
     import torch
     import horizonator_amd
+    for k in [k for k in os.environ if k.startswith("HZ_") and k != "HZ_TEST_DEM_DIR"]:
+        monkeypatch.delenv(k)                       # (tools/gpu_modes.sh runs the suite under switches that change the plan: this test is about the defaults)
     monkeypatch.setenv("HZ_TWO_PASS", "1")          # (two rounds at a size the test can afford)
     R, W, H = 1000, 8000, 2000
     d = hzutil.dem_dir_for(LAT, LON, R)
