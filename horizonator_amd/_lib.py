@@ -12,6 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # address/undefined-behaviour-sanitized host code through it)
 LIB_PATH = os.environ.get("HORIZONATOR_AMD_LIB") or os.path.join(_HERE, "libhorizonator.so")
 DEMGEN_PATH = os.path.join(_HERE, "libhzdemgen.so")
+# the library's own sources built with -DHZ_SELFTEST (include/hz_selftest.h): device-side self-checks and
+# diagnostics entry points on top of everything libhorizonator.so exports; tests and tools only
+SELFTEST_PATH = os.path.join(_HERE, "libhorizonator_selftest.so")
 
 MAX_NDEMS_IJ = 4
 
@@ -86,19 +89,33 @@ class TexParams(C.Structure):
 RASTER_AUTO, RASTER_SCATTER, RASTER_MARCH = 0, 1, 2
 
 _lib = None
+_selftest = None
 
 
 def load():
     """dlopen libhorizonator.so and declare every prototype.  Raises if absent."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _open(LIB_PATH, selftest=os.path.basename(LIB_PATH) == os.path.basename(SELFTEST_PATH))
+    return _lib
+
+
+def load_selftest():
+    """dlopen libhorizonator_selftest.so: the same library with the self-checks and diagnostics of
+    include/hz_selftest.h.  A context made through it is its own (the two libraries share no state)."""
+    global _selftest
+    if _selftest is None:
+        _selftest = _open(SELFTEST_PATH, selftest=True)
+    return _selftest
+
+
+def _open(path, selftest):
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `make -C horizonator_amd/csrc` "
+            f"{path} is missing: build it with `make -C horizonator_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "horizonator_amd has no fallback implementation.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL if not selftest else C.RTLD_LOCAL)
     P = C.POINTER
     ctxp = P(Context)
     f, i, b, d = C.c_float, C.c_int, C.c_bool, C.c_double
@@ -180,14 +197,14 @@ def load():
     sig("hz_hip_wait_for", i, vp, vp)
     sig("horizonator_amd_stream_waits_for_outputs", b, ctxp, vp)
     sig("horizonator_amd_waits_for_stream", b, ctxp, vp)
-    sig("hz_hip_check_fastmath", i, i, i, C.c_uint64, C.c_uint64, P(C.c_uint64), vp)
-    sig("hz_hip_check_exactness", i, i, i, C.c_uint64, C.c_uint64, i, i, i, i, P(C.c_uint64))
-    sig("hz_hip_debug_bigqueue", i, vp, i, vp, i, vp)
-    sig("hz_hip_debug_wave_timing", i, vp, P(View), vp, C.c_size_t, vp)
-    sig("hz_hip_debug_last_plan", i, vp, vp)
-    sig("hz_hip_debug_worklist", C.c_long, i, i, i, P(View), i, i, i, vp, C.c_size_t)
+    sig("hz_hip_last_plan", i, vp, vp)
     sig("hz_hip_last_error", C.c_char_p)
-    _lib = lib
+    if selftest:
+        sig("hz_hip_check_fastmath", i, i, i, C.c_uint64, C.c_uint64, P(C.c_uint64), vp)
+        sig("hz_hip_check_exactness", i, i, i, C.c_uint64, C.c_uint64, i, i, i, i, P(C.c_uint64))
+        sig("hz_hip_debug_bigqueue", i, vp, i, vp, i, vp)
+        sig("hz_hip_debug_wave_timing", i, vp, P(View), vp, C.c_size_t, vp)
+        sig("hz_hip_debug_worklist", C.c_long, i, i, i, P(View), i, i, i, vp, C.c_size_t)
     return lib
 
 
@@ -216,8 +233,11 @@ DECLARED_SYMBOLS = [
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
     "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
-    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_check_fastmath", "hz_hip_check_exactness", "hz_hip_debug_bigqueue", "hz_hip_debug_wave_timing", "hz_hip_debug_last_plan", "hz_hip_debug_worklist", "hz_hip_last_error",
+    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_last_plan", "hz_hip_last_error",
 ]
+# include/hz_selftest.h: what libhorizonator_selftest.so exports on top of those (and libhorizonator.so must not)
+SELFTEST_SYMBOLS = ["hz_hip_check_fastmath", "hz_hip_check_exactness", "hz_hip_debug_bigqueue", "hz_hip_debug_wave_timing",
+                    "hz_hip_debug_worklist"]
 
 
 def load_demgen():

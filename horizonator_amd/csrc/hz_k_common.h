@@ -32,7 +32,9 @@ struct hz_params_t
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
     int   pretest;                     /* k_big: read a framebuffer word before the atomic and skip fragments that cannot win */
     int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
+#ifdef HZ_EXPERIMENTS
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
+#endif
     int   nsx;                         /* strip columns of the mosaic; a launch grid may be wider (HZ_EXP_XCD_PAD) */
     const uint32_t* hiz;               /* mr_flush, k_big: coarse depth (hz_k_hiz.h: level 1, level 2 behind it; second rounds of zoomed views), or NULL.
                                         * (One pointer, the rest follows from SW and H: every scalar register k_march holds costs it lane spills in its loop.) */
@@ -40,8 +42,10 @@ struct hz_params_t
     float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
     int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */
     int   quad_max_dx;                 /* k_march: 256*(W/16 - 1): see the cull of whole cells                  */
+#ifdef HZ_EXPERIMENTS
     int   debug;                       /* HZ_MARCH_DEBUG (timing splits, wrong pictures): 1 survivors are dropped,
                                         * 2 survivors are dropped after the early depth test */
+#endif
     /* one byte per HZ_SEG consecutive pixels of a framebuffer row (row stride
      * seg_stride): nonzero once anything was drawn there.  Every write to the
      * framebuffer sets it (hz_fb_min); the conversion skips reading - and
@@ -53,21 +57,30 @@ struct hz_params_t
 #define HZ_SEG_LOG2 8
 #define HZ_SEG      (1 << HZ_SEG_LOG2)
 
-/* the one place fragments enter the framebuffer.  p.exp_fb (HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG, experiments
- * with WRONG pictures - profiles/r3_experiments.json): 1 = the fragment is dropped here, 2 = a plain store
- * instead of the atomic minimum: what the atomics cost, i.e. what a rasteriser that owned its pixels could gain */
+/* the one place fragments enter the framebuffer.
+ * Builds with -DHZ_EXPERIMENTS only (tools/experiments.py; never the library that ships): p.exp_fb
+ * (HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG, experiments with WRONG pictures - profiles/r3_experiments.json):
+ * 1 = the fragment is dropped here, 2 = a plain store instead of the atomic minimum: what the atomics
+ * cost, i.e. what a rasteriser that owned its pixels could gain; p.debug (HZ_MARCH_DEBUG): timing splits */
 #define HZ_WHO_MARCH 0
 #define HZ_WHO_BIG   1
 #define HZ_WHO_OTHER 2                  /* (k_clip's own fragments: never part of an experiment) */
+#ifdef HZ_EXPERIMENTS
+#define HZ_DEBUG(p) ((p).debug)
+#else
+#define HZ_DEBUG(p) 0
+#endif
 template<int WHO = HZ_WHO_OTHER>
 __device__ static inline void hz_fb_min(unsigned long long* fb, const hz_params_t& p, int px, int py, unsigned long long key)
 {
     const int x = px - p.col0;
+#ifdef HZ_EXPERIMENTS
     if(WHO != HZ_WHO_OTHER && p.exp_fb[WHO == HZ_WHO_OTHER ? 0 : WHO])
     {
         if(p.exp_fb[WHO] == 2) { p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1; fb[(size_t)py*p.SW + x] = key; }
         return;
     }
+#endif
     p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1;
     atomicMin(&fb[(size_t)py*p.SW + x], key);
 }

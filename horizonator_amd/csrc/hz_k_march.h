@@ -461,7 +461,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             }
         }
         if(dbg) { dbg[5] += (unsigned int)__popcll(__ballot(valid && !live)); }
-        if(p.debug == 2) return;
+        if(HZ_DEBUG(p) == 2) return;
         if(!__any(live))
         {
             if(dbg) { dbg[0] += 1; dbg[1] += n; }
@@ -491,7 +491,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     const bool is_big = live && npix > p.big_min;
     const unsigned long long bigmask = __ballot(is_big);
     if(dbg) { dbg[0] += 1; dbg[1] += n; dbg[2] += (unsigned int)__popcll(bigmask); }
-    const unsigned long long t_app0 = (dbg && p.debug == 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_app0 = (dbg && HZ_DEBUG(p) == 4) ? __builtin_amdgcn_s_memtime() : 0ull;
     if(bigmask)
     {
         uint32_t chunks = 0;
@@ -560,7 +560,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         else if(lane == 0) atomicMax(&q.counters[5], ~mbase);
     }
 
-    if(dbg && p.debug == 4)
+    if(dbg && HZ_DEBUG(p) == 4)
     {
         /* HZ_MARCH_DEBUG=4 (tools/wave_timing.py): "mid" and "items" count cycles / 16 of the queue appends and of the pixel turns */
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -773,7 +773,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
             #pragma unroll
             for(int t=0; t<2; t++)
             {
-                const bool keep = (t == 0 ? keep0 : keep1) && p.debug != 1;
+                const bool keep = (t == 0 ? keep0 : keep1) && HZ_DEBUG(p) != 1;
                 const unsigned long long m = __ballot(keep);
                 if(m)
                 {

@@ -100,7 +100,10 @@ struct hz_env_t
     int    serial;                  /* HZ_SERIAL=1: the four streams are one (per-kernel times of a trace are then those of each kernel alone) */
     int    queue_capacity;          /* HZ_QUEUE_CAPACITY: tests shrink the queues to exercise the overflow paths; 0 = default sizes */
     int    resolve_clears;          /* HZ_RESOLVE_CLEARS=0 switches the fused clear of the conversion off */
+#ifdef HZ_EXPERIMENTS
     int    march_debug;             /* HZ_MARCH_DEBUG: timing splits (wrong pictures), see hz_params_t::debug */
+    int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
+#endif
     int    no_fast_math;            /* HZ_NO_FAST_MATH=1: the unabridged transform everywhere */
     int    two_pass;                /* HZ_TWO_PASS=0/1 forces one / two rounds; -1: the draw decides */
     int    near_cells;              /* HZ_NEAR_CELLS: the first round's reach in cells; -1: from the view (plan_rounds) */
@@ -110,7 +113,6 @@ struct hz_env_t
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
-    int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
     int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
                                      * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
@@ -128,7 +130,11 @@ static hz_env_t read_env(void)
     e.serial           = env_int("HZ_SERIAL", 0) != 0;
     e.queue_capacity   = env_int("HZ_QUEUE_CAPACITY", 0);
     e.resolve_clears   = env_int("HZ_RESOLVE_CLEARS", 1) != 0;
+#ifdef HZ_EXPERIMENTS                   /* (switches that draw wrong pictures exist in builds with -DHZ_EXPERIMENTS only: tools/experiments.py) */
     e.march_debug      = env_int("HZ_MARCH_DEBUG", 0);
+    e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
+    e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
+#endif
     e.no_fast_math     = env_int("HZ_NO_FAST_MATH", 0) != 0;
     e.two_pass         = getenv("HZ_TWO_PASS") ? (env_int("HZ_TWO_PASS", 0) != 0) : -1;
     e.near_cells       = getenv("HZ_NEAR_CELLS") ? env_int("HZ_NEAR_CELLS", 0) : -1;
@@ -137,8 +143,6 @@ static hz_env_t read_env(void)
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
-    e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
-    e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
     e.tiles            = env_int("HZ_TILES", 0) != 0;
@@ -161,10 +165,11 @@ struct hz_listkey_t
 struct hz_worklists_t
 {
     uint32_t*    d_items[2];
-    uint32_t*    h_items[2];            /* pinned */
+    uint32_t*    h_items[2][2];         /* pinned; two per list, taken in turn: the host only waits for the copy two lists back */
     size_t       cap[2];
     unsigned int n[2];
-    hipEvent_t   ev_copied[2];
+    hipEvent_t   ev_copied[2][2];
+    int          turn[2];
     int          valid;                 /* the resident lists are those of `key` */
     hz_listkey_t key;
     std::vector<uint32_t>* scratch;
@@ -211,7 +216,8 @@ struct hz_dev
     hipEvent_t          ev_marched, ev_near;
     /* coarse depth of each framebuffer (hz_k_hiz.h), allocated by the first draw that wants it */
     uint32_t*           d_hiz[HZ_NFB];
-    int                 last_plan[4];           /* the last draw (hz_hip_debug_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
+    int                 hiz_unavailable;        /* their allocation failed once: not tried again with every draw */
+    int                 last_plan[4];           /* the last draw (hz_hip_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
     hz_bigitem_t*       d_bigitem_s[2*HZ_NFB];
@@ -294,8 +300,11 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     for(int k=0; k<2; k++)
     {
         (void)hipFree(d->lists.d_items[k]);
-        if(d->lists.h_items[k])   (void)hipHostFree(d->lists.h_items[k]);
-        if(d->lists.ev_copied[k]) (void)hipEventDestroy(d->lists.ev_copied[k]);
+        for(int t=0; t<2; t++)
+        {
+            if(d->lists.h_items[k][t])   (void)hipHostFree(d->lists.h_items[k][t]);
+            if(d->lists.ev_copied[k][t]) (void)hipEventDestroy(d->lists.ev_copied[k][t]);
+        }
     }
     delete d->lists.scratch;
     (void)hipFree(d->d_texels);
@@ -677,10 +686,12 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     /* (0 = no cell is ever culled the short way: tiny images, and sides that do not fit the packed 16-bit pixel boxes) */
     p.quad_max_dx = d->W >= 64 && d->W <= 65535 && d->H <= 65535 ? 256*(d->W/16 - 1) : 0;
     p.pretest = d->env.pretest > 0 ? 1 : 0;
+#ifdef HZ_EXPERIMENTS
     p.exp_fb[HZ_WHO_MARCH] = d->env.exp_fb_march; p.exp_fb[HZ_WHO_BIG] = d->env.exp_fb_big;
+    p.debug   = d->env.march_debug;
+#endif
     p.nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
     p.pretest_march = 0;                /* (the second round of a two-round draw may switch it on: draw_impl) */
-    p.debug   = d->env.march_debug;
     p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
     return p;
 }
@@ -808,21 +819,32 @@ static int upload_list(hz_dev_t* d, int which, hipStream_t st, const std::vector
     {
         /* (rare: the first sector draw of a context, a much wider sector) kernels in flight may still read the old one */
         HZ_CHECK(sync_all(d));
-        (void)hipFree(wl.d_items[which]); (void)hipHostFree(wl.h_items[which]);
-        wl.d_items[which] = NULL; wl.h_items[which] = NULL; wl.cap[which] = 0;
+        (void)hipFree(wl.d_items[which]); wl.d_items[which] = NULL;
+        for(int t=0; t<2; t++) { if(wl.h_items[which][t]) (void)hipHostFree(wl.h_items[which][t]); wl.h_items[which][t] = NULL; }
+        wl.cap[which] = 0;
         const size_t cap = n + n/4 + 1024;
-        HZ_CHECK(hipMalloc(&wl.d_items[which], cap*sizeof(uint32_t)));
-        HZ_CHECK(hipHostMalloc((void**)&wl.h_items[which], cap*sizeof(uint32_t), hipHostMallocDefault));
+        hipError_t e = hipMalloc(&wl.d_items[which], cap*sizeof(uint32_t));
+        for(int t=0; t<2 && e == hipSuccess; t++) e = hipHostMalloc((void**)&wl.h_items[which][t], cap*sizeof(uint32_t), hipHostMallocDefault);
+        if(e != hipSuccess)
+        {
+            (void)hipFree(wl.d_items[which]); wl.d_items[which] = NULL;
+            for(int t=0; t<2; t++) { if(wl.h_items[which][t]) (void)hipHostFree(wl.h_items[which][t]); wl.h_items[which][t] = NULL; }
+            HZ_CHECK(e);
+        }
         wl.cap[which] = cap;
     }
-    if(!wl.ev_copied[which]) HZ_CHECK(hipEventCreateWithFlags(&wl.ev_copied[which], hipEventDisableTiming));
-    else HZ_CHECK(hipEventSynchronize(wl.ev_copied[which]));      /* the copy engine is done with the pinned buffer */
+    /* A view that moves from draw to draw (a sequence of viewpoints or azimuths over one sector) brings a new list with
+     * every draw.  The copy of a list sits on `st` behind that draw's wait for its framebuffer: with one pinned buffer
+     * the host would stall here about one draw behind the device; with two in turn it waits for the copy two lists back. */
+    const int t = wl.turn[which]; wl.turn[which] ^= 1;
+    if(!wl.ev_copied[which][t]) HZ_CHECK(hipEventCreateWithFlags(&wl.ev_copied[which][t], hipEventDisableTiming));
+    else HZ_CHECK(hipEventSynchronize(wl.ev_copied[which][t]));   /* the copy engine is done with this pinned buffer */
     if(n)
     {
-        memcpy(wl.h_items[which], items.data(), n*sizeof(uint32_t));
-        HZ_CHECK(hipMemcpyAsync(wl.d_items[which], wl.h_items[which], n*sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        memcpy(wl.h_items[which][t], items.data(), n*sizeof(uint32_t));
+        HZ_CHECK(hipMemcpyAsync(wl.d_items[which], wl.h_items[which][t], n*sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
-    HZ_CHECK(hipEventRecord(wl.ev_copied[which], st));
+    HZ_CHECK(hipEventRecord(wl.ev_copied[which][t], st));
     wl.n[which] = (unsigned int)n;
     return 0;
 }
@@ -962,7 +984,8 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
         pm.worklist = d_list;
         grid = dim3(nlist, 1);
     }
-    /* diagnostics (hz_hip_debug_wave_timing): the instance with per-wave counters */
+#ifdef HZ_SELFTEST
+    /* diagnostics (hz_hip_debug_wave_timing, libhorizonator_selftest.so only): the instance with per-wave counters */
     if(d->wave_timing.d_cycles && pm.pass != 1)
     {
         if((size_t)grid.x*grid.y*4 > d->wave_timing.capacity) { snprintf(g_last_error, sizeof(g_last_error), "wave timing buffer too small"); return -1; }
@@ -970,7 +993,9 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
         d->wave_timing.grid_x = grid.x; d->wave_timing.grid_y = grid.y;
         hipLaunchKernelGGL((k_march<true, true>), grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     }
-    else if(pm.hiz)
+    else
+#endif
+    if(pm.hiz)
         hipLaunchKernelGGL((k_march<false, true>), grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     else
         hipLaunchKernelGGL((k_march<false, false>), grid, dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
@@ -1019,13 +1044,15 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
 /* Coarse depth of framebuffer `next` (hz_k_hiz.h): the tables of a draw with the geometry of p, allocated on first use */
 static int hiz_tables(hz_dev_t* d, int next, const hz_params_t& p, hz_hiz_t* hz)
 {
+    if(d->hiz_unavailable) return 1;
     if(!d->d_hiz[HZ_NFB-1])
         for(int i=0; i<HZ_NFB; i++)
             if(!d->d_hiz[i] && hipMalloc(&d->d_hiz[i], hiz_words(d->W, d->H)*sizeof(uint32_t)) != hipSuccess)
             {
-                /* no memory for them: the draw does without (same bytes, more fragments) */
+                /* no memory for them: this and every later draw of the context does without (same bytes, more fragments) */
                 (void)hipGetLastError();
                 d->d_hiz[i] = NULL;
+                d->hiz_unavailable = 1;
                 return 1;
             }
     hz->w1 = (int)hiz_w1(p.SW); hz->w2 = (int)hiz_w2(p.SW);
@@ -1497,10 +1524,18 @@ struct hz_copy_pool
     std::vector<std::thread> threads;
     std::deque<task_t> q;
     bool stop = false;
-    std::atomic<bool> populate_works{true};     /* cleared by the first madvise that does not know MADV_POPULATE_WRITE */
+    std::atomic<bool> populate_works{true};     /* does this kernel know MADV_POPULATE_WRITE?  Probed once, on a page of our own (hz_copy_pool()) */
 
     explicit hz_copy_pool(int n)
     {
+        /* (EINVAL on a private anonymous page = the flag is unknown to this kernel; any later failure is about
+         * the caller's buffer - a pinned or device mapping, an unmapped range - and only skips that buffer) */
+        void* probe = mmap(NULL, 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if(probe != MAP_FAILED)
+        {
+            if(madvise(probe, 4096, MADV_POPULATE_WRITE) != 0) populate_works = false;
+            munmap(probe, 4096);
+        }
         for(int k=0; k<n; k++) threads.emplace_back([this] { run(); });
     }
     ~hz_copy_pool()
@@ -1513,8 +1548,7 @@ struct hz_copy_pool
     {
         const uintptr_t page = 4096, lo = ((uintptr_t)p + page-1) & ~(page-1), hi = ((uintptr_t)p + n) & ~(page-1);
         if(hi <= lo) return;
-        if(populate_works && madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
-        populate_works = false;
+        if(populate_works) { (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE); return; }     /* (a failure: the copies fault the pages in themselves) */
         /* an older kernel: a write that changes nothing, one per page (atomic: a copy into the same page may be running) */
         for(uintptr_t a = lo; a < hi; a += page) (void)__atomic_fetch_add((unsigned char*)a, 0, __ATOMIC_RELAXED);
     }
@@ -1618,27 +1652,40 @@ static int copy_out(hz_dev_t* d, int nbuf, unsigned char* const* dst, const unsi
      * slot is reused only after the copy out of it (two chunks back, at least) has been waited for */
     std::vector<hz_copy_pool::batch_t> done(nc);
     for(size_t k=0; k<nc; k++) done[k].pending = 0;
-    for(size_t k=0; k<nc; k++)
+    /* (a failing HIP call ends the issuing, not the function: the pool's tasks name `done` and the caller's
+     * buffers, so every batch already pushed is waited for before either goes away) */
+    hipError_t err = hipSuccess;
+    const char* what = "";
+    #define HZ_TRY(call) do { if(err == hipSuccess) { err = (call); if(err != hipSuccess) what = #call; } } while(0)
+    for(size_t k=0; k<nc && err == hipSuccess; k++)
     {
         /* keep the copy engines up to HZ_STAGE_SLOTS - 2 chunks ahead of the chunk the host threads work on */
-        for(; issued < nc && issued < k + HZ_STAGE_SLOTS - 2; issued++)
+        for(; issued < nc && issued < k + HZ_STAGE_SLOTS - 2 && err == hipSuccess; issued++)
         {
             const int slot = (int)(issued % HZ_STAGE_SLOTS);
             if(issued >= HZ_STAGE_SLOTS) pool->wait(&done[issued - HZ_STAGE_SLOTS]);    /* the slot's previous chunk has left it */
             hipStream_t cs = d->cstream[issued % HZ_COPY_STREAMS];
             if(band_seen[issued % HZ_COPY_STREAMS] < chunks[issued].band)
             {
-                HZ_CHECK(hipStreamWaitEvent(cs, d->ev_band[chunks[issued].band], 0));
+                HZ_TRY(hipStreamWaitEvent(cs, d->ev_band[chunks[issued].band], 0));
                 band_seen[issued % HZ_COPY_STREAMS] = chunks[issued].band;
             }
-            HZ_CHECK(hipMemcpyAsync(d->h_stage[slot], chunks[issued].src, chunks[issued].n, hipMemcpyDeviceToHost, cs));
-            HZ_CHECK(hipEventRecord(d->ev_stage[slot], cs));
+            HZ_TRY(hipMemcpyAsync(d->h_stage[slot], chunks[issued].src, chunks[issued].n, hipMemcpyDeviceToHost, cs));
+            HZ_TRY(hipEventRecord(d->ev_stage[slot], cs));
         }
         const int slot = (int)(k % HZ_STAGE_SLOTS);
-        HZ_CHECK(hipEventSynchronize(d->ev_stage[slot]));
-        pool->push(&done[k], chunks[k].dst, d->h_stage[slot], chunks[k].n, 65536);
+        HZ_TRY(hipEventSynchronize(d->ev_stage[slot]));
+        if(err == hipSuccess) pool->push(&done[k], chunks[k].dst, d->h_stage[slot], chunks[k].n, 65536);
     }
+    #undef HZ_TRY
     for(size_t k=0; k<nc; k++) pool->wait(&done[k]);
+    if(err != hipSuccess)
+    {
+        for(int k=0; k<HZ_COPY_STREAMS; k++) (void)hipStreamSynchronize(d->cstream[k]);     /* copies in flight write the staging ring */
+        snprintf(g_last_error, sizeof(g_last_error), "copy_out: %s -> %s", what, hipGetErrorString(err));
+        fprintf(stderr, "hz_hip: %s\n", g_last_error);
+        return -1;
+    }
     return 0;
 }
 
@@ -1894,475 +1941,20 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
     return rc;
 }
 
-/* ------------------------------------------------------------------------ */
-/* self-check of hz_fast.h: the abridged sequences against `/` and sqrtf       */
-
-__device__ static inline unsigned long long hz_mix64(unsigned long long x)
-{
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-/* a float with seeded mantissa and sign and an exponent in [elo, ehi] (biased) */
-__device__ static inline float hz_seeded_float(unsigned long long r, int elo, int ehi)
-{
-    const uint32_t mant = (uint32_t)r & 0x7FFFFFu, sign = (uint32_t)(r >> 23) & 1u;
-    const uint32_t ex = (uint32_t)elo + (uint32_t)((r >> 24) % (unsigned long long)(ehi - elo + 1));
-    return __uint_as_float((sign << 31) | (ex << 23) | mant);
-}
-
-__global__ __launch_bounds__(256)
-void k_check_fastmath(int what, unsigned long long seed, unsigned long long n, unsigned long long* mismatches, float* first_bad)
-{
-    unsigned long long bad = 0;
-    for(unsigned long long k = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; k < n; k += (unsigned long long)gridDim.x*blockDim.x)
-    {
-        float a = 0.f, b = 0.f, want = 0.f, got = 0.f;
-        bool in_range = true;
-        if(what == 0)                       /* reciprocal: every bit pattern (k = the pattern), those in range checked */
-        {
-            b = __uint_as_float((uint32_t)k);
-            in_range = hzf_in_range(b);
-            if(in_range) { want = 1.0f / b; got = hzf_rcp(b); }
-        }
-        else if(what == 1)                  /* square root: every bit pattern from 2^-96 up to the largest finite float */
-        {
-            b = __uint_as_float((uint32_t)k);
-            in_range = b >= 1.26217745e-29f && b <= 3.40282347e38f;
-            if(in_range) { want = __builtin_sqrtf(b); got = hzf_sqrt(b); }
-        }
-        else if(what == 2)                  /* division: seeded pairs, numerator 0 or 2^-60..2^60, denominator 2^-31..2^31 */
-        {
-            const unsigned long long r1 = hz_mix64(seed + 2*k), r2 = hz_mix64(seed + 2*k + 1);
-            a = hz_seeded_float(r1, 127-60, 127+60);
-            b = hz_seeded_float(r2, 127-31, 127+31);
-            /* the shapes the transform divides: any pair, min/max of a pair and 1, a shared mantissa, zero */
-            if((r2 >> 61) == 1) { const float t = hz_abs(a); a = hz_min(t, 1.0f); b = hz_max(t, 1.0f); }
-            if((r2 >> 61) == 2) a = __uint_as_float((__float_as_uint(a) & 0xFF800000u) | (__float_as_uint(b) & 0x7FFFFFu));
-            if((r1 >> 60) == 0) a = 0.0f;            /* +0 */
-            want = a / b; got = hzf_div(a, b);
-        }
-        else if(what == 4)                  /* hz_rcp_f64: every divisor 1 <= d < 2^31 (k = d - 1): within 2^-50 of 1/d? */
-        {
-            const double dd = (double)(k + 1);
-            const double r = hz_rcp_f64(dd);
-            /* d*r - 1 is the relative error of r; the fma gives it without cancellation */
-            const double rel = __builtin_fabs(__builtin_fma(dd, r, -1.0));
-            a = (float)dd; b = (float)rel; want = 0.f; got = rel < 8.8817841970012523e-16 ? 0.f : 1.f;      /* 2^-50 */
-        }
-        else if(what == 5)                  /* hz_floor_div against 64-bit integer division: seeded n (|n| < 2^55), d (1 <= d < 2^31) */
-        {
-            const unsigned long long r1 = hz_mix64(seed + 2*k), r2 = hz_mix64(seed + 2*k + 1);
-            /* divisors of every magnitude; numerators of every magnitude and both signs, and the
-             * hard ones: multiples of d and their neighbours */
-            const int32_t d = (int32_t)(((r2 >> 8) & 0x7FFFFFFFull) >> (r2 & 31)) | 1;
-            int64_t n = (int64_t)(r1 >> 9) >> ((r1 >> 3) & 63);
-            if(r1 & 1) n = -n;
-            if((r1 & 6) == 2) n = (n / d)*(int64_t)d + (int64_t)((r2 >> 40) % 3) - 1;
-            int64_t q = n / d;                                  /* truncates */
-            if((n % d) != 0 && n < 0) q--;                      /* floor */
-            const int32_t f = hz_floor_div(n, d, hz_rcp_f64((double)d));
-            a = (float)n; b = (float)d;
-            /* beyond +-2^30 any value beyond is right (see hz_floor_div) */
-            const bool ok = (q > 1073741824ll) ? f >= 1073741824 : (q < -1073741824ll) ? f <= -1073741824 : (int64_t)f == q;
-            want = 0.f; got = ok ? 0.f : 1.f;
-        }
-        else                                /* division by a per-draw constant through hzf_div_by: k = numerator pattern */
-        {
-            b = __uint_as_float((uint32_t)seed);
-            a = __uint_as_float((uint32_t)k);
-            const float aa = hz_abs(a);
-            /* (+0 only: a negative zero would come out positive - see hz_fast.h on why none gets here) */
-            in_range = __float_as_uint(a) == 0u || (aa >= 8.67361738e-19f && aa <= 1.15292150e18f);
-            if(in_range) { want = a / b; got = hzf_div_by(a, b, hzf_refined_rcp(b)); }
-        }
-        if(in_range && __float_as_uint(want) != __float_as_uint(got))
-        {
-            if(bad == 0 && atomicAdd(mismatches + 1, 1ull) == 0) { first_bad[0] = a; first_bad[1] = b; first_bad[2] = want; first_bad[3] = got; }
-            bad++;
-        }
-    }
-    if(bad) atomicAdd(mismatches, bad);
-}
-
-extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsigned long long n,
-                                     unsigned long long* mismatches, float* first_bad)
-{
-    hz_device_guard device_guard_(device);
-    if(!device_guard_.ok) return -1;
-    if(what < 0 || what > 5) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
-    if(what == 0 || what == 1 || what == 3) n = 1ull << 32;
-    if(what == 4) n = (1ull << 31) - 1;
-    unsigned long long* d_bad = NULL; float* d_first = NULL;
-    HZ_CHECK(hipMalloc(&d_bad, 2*sizeof(unsigned long long)));
-    HZ_CHECK(hipMalloc(&d_first, 4*sizeof(float)));
-    HZ_CHECK(hipMemset(d_bad, 0, 2*sizeof(unsigned long long)));
-    HZ_CHECK(hipMemset(d_first, 0, 4*sizeof(float)));
-    hipLaunchKernelGGL(k_check_fastmath, dim3(256*32), dim3(256), 0, 0, what, seed, n, d_bad, d_first);
-    HZ_CHECK(hipGetLastError());
-    unsigned long long h[2] = {0, 0};
-    HZ_CHECK(hipMemcpy(h, d_bad, sizeof(h), hipMemcpyDeviceToHost));
-    if(first_bad) HZ_CHECK(hipMemcpy(first_bad, d_first, 4*sizeof(float), hipMemcpyDeviceToHost));
-    *mismatches = h[0];
-    (void)hipFree(d_bad); (void)hipFree(d_first);
-    return 0;
-}
-
-/* ------------------------------------------------------------------------ */
-/* self-checks of the two shortcuts the marching kernel takes on the strength of  */
-/* an argument rather than of the reference's arithmetic (hz_tri_hidden, the      */
-/* cull of whole cells): on seeded inputs around every border of the argument     */
-
-/* k_check_hidden: one triangle per thread.  Vertices as the rasteriser has them
- * (window position, depth, snapped position); families: 0 far-field (a pixel or two
- * across), 1 slivers (third vertex a hair off the line through the other two:
- * |area| down to 2^-12 px^2, the depth plane extrapolated over the snapping
- * distance is what hz_tri_hidden's slack is for), 2 grazing (depth gradients up to
- * 10^5 LSB per pixel), 3 anything up to 16 pixels across.  For each triangle that
- * survives the cull the LARGEST stored depth zs for which hz_tri_hidden() still
- * answers "hidden" is found by bisection (the answer is monotone in zs) and every
- * pixel centre the triangle covers (hz_tri_covers) is drawn (hz_tri_planes,
- * hz_tri_fragment): no fragment may pass GL_LESS against zs, i.e. have a depth
- * <= zs.  out[0] triangles tested, [1] of them hidden for some zs, [2] fragments
- * drawn, [3] violations, [4] the smallest (fragment depth - zs) seen, + 2^32. */
-__global__ __launch_bounds__(256)
-void k_check_hidden(unsigned long long seed, unsigned long long n, int W, int H, unsigned long long* out)
-{
-    const float z_guard = 1.0f/500.0f + (float)(W > H ? W : H) * (1.0f/4194304.0f);
-    const float kk = 1.03f * z_guard * 16777215.f;
-    unsigned long long tested = 0, hidden = 0, frags = 0, bad = 0, margin = ~0ull;
-    for(unsigned long long t = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x*blockDim.x)
-    {
-        const unsigned long long r0 = hz_mix64(seed + 4*t), r1 = hz_mix64(seed + 4*t + 1), r2 = hz_mix64(seed + 4*t + 2), r3 = hz_mix64(seed + 4*t + 3);
-        auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };   /* [0,1) */
-        const int family = (int)(r0 & 3);
-        /* where: anywhere in the image, often next to its right / top border (large coordinates: coarse float spacing) */
-        float bx = unit(r0, 8) * (float)W, by = unit(r0, 32) * (float)H;
-        if(((r0 >> 2) & 7) == 0) bx = (float)W - 4.0f*unit(r1, 0);
-        if(((r0 >> 5) & 7) == 0) by = (float)H - 4.0f*unit(r1, 24);
-        float x[3], y[3], z[3];
-        const float ext = family == 3 ? 16.0f*unit(r3, 40) : family == 0 ? 2.5f : 4.0f;
-        x[0] = bx; y[0] = by;
-        x[1] = bx + (unit(r1, 8) - 0.5f)*ext;  y[1] = by + (unit(r1, 36) - 0.5f)*ext;
-        x[2] = bx + (unit(r2, 0) - 0.5f)*ext;  y[2] = by + (unit(r2, 24) - 0.5f)*ext;
-        if(family == 1)
-        {
-            /* the third vertex on the line through the first two, then off it by 2^-1 .. 2^-14 pixels */
-            const float tt = unit(r2, 0)*1.5f - 0.25f, off = __builtin_ldexpf(1.0f, -1 - (int)((r2 >> 40) % 14)) * ((r2 >> 63) ? 1.0f : -1.0f);
-            const float dx = x[1] - x[0], dy = y[1] - y[0], len = hz_sqrt(dx*dx + dy*dy) + 1e-6f;
-            x[2] = x[0] + tt*dx - off*dy/len; y[2] = y[0] + tt*dy + off*dx/len;
-        }
-        /* depth: a base anywhere in (0,1), differences from 10^-8 (a few LSB) to 10^-2 (10^5 LSB) */
-        const float zb = 0.02f + 0.96f*unit(r3, 0);
-        const float dz = (family == 2 ? 6e-3f : 1e-3f) * __builtin_ldexpf(1.0f, -(int)((r3 >> 24) % 18));
-        z[0] = zb; z[1] = zb + (unit(r3, 30) - 0.5f)*dz; z[2] = zb + (unit(r2, 40) - 0.5f)*dz;
-        hz_wvert_t v[3];
-        bool inside = true;
-        for(int k=0; k<3; k++)
-        {
-            /* as mr_window(): the survivors of the cull are inside the view volume */
-            v[k].xn = 0.f; v[k].wx = x[k]; v[k].wy = y[k]; v[k].zw = z[k]; v[k].red = 0.25f*(float)k; v[k].cmask = 0;
-            inside = inside && x[k] >= 0.f && x[k] <= (float)W && y[k] >= 0.f && y[k] <= (float)H && z[k] >= 0.f && z[k] <= 1.f;
-            v[k].xs = (int32_t)hz_roundeven((x[k] - 0.5f)*256.f);
-            v[k].ys = (int32_t)hz_roundeven((y[k] - 0.5f)*256.f);
-        }
-        if(!inside) continue;
-        hz_box_t box;
-        /* either winding: the back face of one is the front face of the other */
-        if(!hz_tri_cull_window(&box, &v[0], &v[1], &v[2], 0, W-1, 0, H-1))
-        {
-            const hz_wvert_t tmp = v[1]; v[1] = v[2]; v[2] = tmp;
-            if(!hz_tri_cull_window(&box, &v[0], &v[1], &v[2], 0, W-1, 0, H-1)) continue;
-        }
-        tested++;
-        if(!hz_tri_hidden(&v[0], &v[1], &v[2], kk, 0u)) continue;              /* not even behind depth 0 */
-        uint32_t lo = 0, hi = HZ_Z24_MAX;                                       /* hidden at lo, not (or untested) at hi */
-        if(hz_tri_hidden(&v[0], &v[1], &v[2], kk, hi)) lo = hi;
-        while(hi - lo > 1u)
-        {
-            const uint32_t mid = lo + (hi - lo)/2u;
-            if(hz_tri_hidden(&v[0], &v[1], &v[2], kk, mid)) lo = mid; else hi = mid;
-        }
-        hidden++;
-        hz_tri_t tri;
-        hz_tri_planes(&tri, &v[0], &v[1], &v[2]);
-        for(int py = box.py0; py <= box.py1; py++)
-            for(int px = box.px0; px <= box.px1; px++)
-            {
-                if(!hz_tri_covers(&tri, px, py)) continue;
-                uint32_t zi, r8;
-                if(!hz_tri_fragment(&tri, px, py, &zi, &r8)) continue;          /* at or beyond the cleared depth: never drawn */
-                frags++;
-                if(zi <= lo) bad++;
-                const unsigned long long m = (unsigned long long)((long long)zi - (long long)lo + (1ll << 32));
-                if(m < margin) margin = m;
-            }
-    }
-    atomicAdd(&out[0], tested); atomicAdd(&out[1], hidden); atomicAdd(&out[2], frags); atomicAdd(&out[3], bad);
-    atomicMin(&out[4], margin);
-}
-
-/* k_check_cull: one wave per case = two vertex rows of 64 as k_march sees them, NDC
- * positions seeded around the borders of mr_simple_cull()'s argument: cells about
- * a sixteenth of the image wide (quad_max_dx), rows that touch the edges of the view
- * volume (|x|,|y|,|z| = 1 and a float beyond), positions that snap onto pixel
- * centres, the +-180 degree seam (x jumping from one image border to the other),
- * back faces and empty boxes of every kind.  Wherever the wave would take the
- * short way, its verdict must be hz_tri_cull()'s.  out[0] cases, [1] cases that
- * took the short way, [2] cells compared, [3] disagreements, [4] triangles kept. */
-__global__ __launch_bounds__(64)
-void k_check_cull(unsigned long long seed, unsigned long long ncases, int W, int H, int col0, int col1, unsigned long long* out)
-{
-    hz_params_t p;
-    memset(&p, 0, sizeof(p));
-    p.halfW = (float)W*0.5f; p.halfH = (float)H*0.5f; p.W = W; p.H = H; p.col0 = col0; p.col1 = col1; p.SW = col1 - col0;
-    p.quad_max_dx = W >= 64 && W <= 65535 && H <= 65535 ? 256*(W/16 - 1) : 0;
-    const int lane = threadIdx.x;
-    const bool has_cell = lane < MR_COLS;
-    unsigned long long cases = 0, shortway = 0, cells = 0, bad = 0, kept = 0;
-    for(unsigned long long t = blockIdx.x; t < ncases; t += gridDim.x)
-    {
-        const unsigned long long rc = hz_mix64(seed + 977*t);                   /* per case (wave-uniform) */
-        auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };
-        const int kind = (int)(rc & 7);
-        /* the step between neighbouring vertices, in NDC x: a fraction of a pixel to 8 pixels; kinds 0-2: ONE cell of the
-         * row about a sixteenth of the image wide (the threshold quad_max_dx, +-3 %), at a seeded lane */
-        float step = 2.0f/(float)W * (0.1f + 8.0f*unit(rc, 8));
-        if(kind == 5) step = -step;                                             /* back faces */
-        const float jump = kind <= 2 ? 2.0f/16.0f * (0.97f + 0.06f*unit(rc, 44)) : 0.0f;
-        const int   jump_lane = (int)((rc >> 3) & 63);
-        const float x_first = kind == 1 ? -1.0f : kind == 2 ? 1.0f - 63.0f*step - jump : -1.0f + (2.0f - 64.0f*hz_abs(step) - jump)*unit(rc, 32);
-        const float y_base  = ((rc >> 56) & 3) == 0 ? 1.0f - 4.0f/(float)H*unit(rc, 40) : -1.0f + 2.0f*unit(rc, 40);
-        hz_vertex_t vt[2];
-        for(int row=0; row<2; row++)
-        {
-            const unsigned long long r = hz_mix64(seed + 977*t + 131*(unsigned long long)(row + 1) + 7*(unsigned long long)lane);
-            float xn = x_first + (float)lane*step + (lane > jump_lane ? jump : 0.0f) + (unit(r, 0) - 0.5f)*hz_abs(step)*0.6f;
-            float yn = y_base + (row ? 1 : 0)*(2.0f/(float)H)*(0.2f + 4.0f*unit(rc, 16)) + (unit(r, 24) - 0.5f)*(2.0f/(float)H);
-            float zn = -1.0f + 2.0f*unit(r, 40);
-            if(kind == 4 && ((r >> 60) & 3) == 0)                               /* onto a pixel centre / a pixel border, exactly */
-                xn = ((float)(int)(unit(r, 8)*(float)W) + (((r >> 59) & 1) ? 0.5f : 0.0f))/p.halfW - 1.0f;
-            if(kind == 6 && lane >= 32) xn -= 1.9f*unit(rc, 20);                /* the seam: the row jumps back towards the other border */
-            if(kind == 7 && ((r >> 58) & 15) == 0)                              /* a vertex on / just beyond a face of the view volume */
-            {
-                const float edge[4] = { 1.0f, -1.0f, 1.00000012f, -1.00000012f };
-                if((r >> 62) & 1) xn = edge[(r >> 56) & 3]; else if((r >> 63) & 1) yn = edge[(r >> 56) & 3]; else zn = edge[(r >> 56) & 3];
-            }
-            vt[row].x = xn; vt[row].y = yn; vt[row].z = zn; vt[row].red = 0.5f;
-        }
-        mr_rowstate_t st[2];
-        hz_wvert_t wv[2];
-        bool simple[2];
-        for(int row=0; row<2; row++)
-        {
-            bool in_volume, in_guard;
-            wv[row] = mr_window(vt[row], p, &in_volume, &in_guard);
-            simple[row] = __all(in_guard && in_volume);
-            if(!simple[row]) mr_window_flags(wv[row], vt[row], in_guard);
-            st[row] = mr_rowstate_of(wv[row], p);
-        }
-        cases++;
-        bool keep0 = false, keep1 = false;
-        if(!(simple[0] && simple[1] && mr_simple_cull(st[0], st[1], has_cell, p, &keep0, &keep1))) continue;
-        shortway++;
-        /* the long way, as k_march takes it */
-        hz_wvert_t v00 = {}, v01 = {}, v10 = {}, v11 = {};
-        v00.xn = st[0].xn; v00.xs = st[0].xs; v00.ys = st[0].ys; v00.cmask = st[0].cmask;
-        v01.xn = st[1].xn; v01.xs = st[1].xs; v01.ys = st[1].ys; v01.cmask = st[1].cmask;
-        v10.xn = mr_from_east(st[0].xn); v10.xs = mr_from_east(st[0].xs); v10.ys = mr_from_east(st[0].ys); v10.cmask = (uint32_t)mr_from_east((int32_t)st[0].cmask);
-        v11.xn = mr_from_east(st[1].xn); v11.xs = mr_from_east(st[1].xs); v11.ys = mr_from_east(st[1].ys); v11.cmask = (uint32_t)mr_from_east((int32_t)st[1].cmask);
-        if(has_cell)
-        {
-            hz_box_t box;
-            const bool want0 = hz_tri_cull(&box, &v00, &v11, &v01, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_DRAW;
-            const bool want1 = hz_tri_cull(&box, &v00, &v10, &v11, p.col0, p.col1-1, 0, p.H-1) == HZ_TRI_DRAW;
-            cells++;
-            if(want0 != keep0) bad++;
-            if(want1 != keep1) bad++;
-            kept += (keep0 ? 1 : 0) + (keep1 ? 1 : 0);
-        }
-    }
-    atomicAdd(&out[0], lane == 0 ? cases : 0ull); atomicAdd(&out[1], lane == 0 ? shortway : 0ull);
-    atomicAdd(&out[2], cells); atomicAdd(&out[3], bad); atomicAdd(&out[4], kept);
-}
-
-/* k_check_rect: hiz_rect_min_depth() (hz_k_hiz.h: the smallest depth a rectangle of pixel centres can get is the
- * smallest of its corners') against the minimum over every pixel centre of the rectangle, one thread per case: depth
- * planes from flat to 10^6 per pixel, signs of every kind, origins inside and outside [0, 1] (clamped depths), values
- * that overflow, infinities and NaNs; rectangles of up to 48 x 48 anywhere in a W x H image.  out[0] cases, [1] cases
- * whose corners are all numbers, [2] pixel centres evaluated, [3] disagreements (a different minimum, or a pixel
- * without a depth inside a rectangle whose corners have one), [4] cases with a depth that is not a number. */
-__global__ __launch_bounds__(256)
-void k_check_rect(unsigned long long seed, unsigned long long ncases, int W, int H, unsigned long long* out)
-{
-    unsigned long long cases = 0, numbers = 0, pixels = 0, bad = 0, nans = 0;
-    for(unsigned long long t = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x; t < ncases; t += (unsigned long long)gridDim.x*blockDim.x)
-    {
-        const unsigned long long r0 = hz_mix64(seed + 3*t), r1 = hz_mix64(seed + 3*t + 1), r2 = hz_mix64(seed + 3*t + 2);
-        auto unit = [](unsigned long long r, int shift) { return (float)((r >> shift) & 0xFFFFFFull) * (1.0f/16777216.0f); };
-        auto slope = [&](unsigned long long r) -> float
-        {
-            const int kind = (int)(r & 15);
-            if(kind == 0) return 0.0f;
-            if(kind == 1) return (r >> 4) & 1 ? __builtin_inff() : -__builtin_inff();
-            if(kind == 2) return __builtin_nanf("");
-            if(kind == 3) return ((r >> 4) & 1 ? 1.0f : -1.0f) * 3.0e38f * unit(r, 8);             /* overflows once multiplied */
-            const float mag = exp2f(-40.0f + 60.0f*unit(r, 8));                                   /* 1e-12 .. 1e6 per pixel */
-            return ((r >> 4) & 1) ? mag : -mag;
-        };
-        hz_tri_t tri;
-        memset(&tri, 0, sizeof(tri));
-        tri.dzdx = slope(r0); tri.dzdy = slope(r1);
-        tri.z_org = ((r2 & 7) == 0) ? -3.0f + 7.0f*unit(r2, 8) : unit(r2, 8);
-        if((r2 & 63) == 1) tri.z_org = __builtin_inff();
-        /* (steep planes: an origin that puts the rectangle's depths near [0, 1] rather than far outside) */
-        const int bw = 1 + (int)((r2 >> 32) % 48u), bh = 1 + (int)((r2 >> 40) % 48u);
-        const int x0 = (int)((r0 >> 32) % (unsigned long long)(W - bw + 1)), y0 = (int)((r1 >> 32) % (unsigned long long)(H - bh + 1));
-        if((r2 >> 48) & 1) tri.z_org = 0.5f - tri.dzdx*(float)(x0 + bw/2) - tri.dzdy*(float)(y0 + bh/2);
-        uint32_t qmin = 0;
-        const bool ok = hiz_rect_min_depth(tri, x0, x0 + bw - 1, y0, y0 + bh - 1, &qmin);
-        uint32_t m = 0xFFFFFFFFu;
-        bool nan_inside = false;
-        for(int py = y0; py < y0 + bh; py++)
-            for(int px = x0; px < x0 + bw; px++)
-            {
-                /* hz_tri_fragment()'s depth, without its two early returns */
-                float z = __builtin_fmaf(tri.dzdy, (float)py, __builtin_fmaf(tri.dzdx, (float)px, tri.z_org));
-                if(!(z == z)) { nan_inside = true; continue; }
-                z = hz_min(hz_max(z, 0.f), 1.f);
-                const uint32_t q = (uint32_t)hz_roundeven(z * 16777215.f);
-                uint32_t zi, r8;
-                const int drawn = hz_tri_fragment(&tri, px, py, &zi, &r8);
-                if(drawn && zi != q) bad++;                                    /* (this loop is what hz_tri_fragment computes) */
-                m = m < q ? m : q;
-            }
-        cases++; pixels += (unsigned long long)bw*bh;
-        if(nan_inside) nans++;
-        if(ok) { numbers++; if(nan_inside || m != qmin) bad++; }
-    }
-    atomicAdd(&out[0], cases); atomicAdd(&out[1], numbers); atomicAdd(&out[2], pixels); atomicAdd(&out[3], bad); atomicAdd(&out[4], nans);
-}
-
-/* what: 0 = hz_tri_hidden (n triangles), 1 = the cull of whole cells (n cases of two rows of 64 vertices), 2 = the
- * smallest depth of a rectangle (n rectangles); image W x H (and, for 1, the drawn columns [col0,col1)); out: 5 words,
- * see the kernels */
-extern "C" int hz_hip_check_exactness(int device, int what, unsigned long long seed, unsigned long long n,
-                                      int W, int H, int col0, int col1, unsigned long long* out)
-{
-    hz_device_guard device_guard_(device);
-    if(!device_guard_.ok) return -1;
-    if(what < 0 || what > 2 || W < 1 || H < 1 || col0 < 0 || col1 > W || col0 >= col1 || (what == 2 && (W < 48 || H < 48)))
-    {
-        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_exactness: bad arguments");
-        return -1;
-    }
-    unsigned long long* d_out = NULL;
-    HZ_CHECK(hipMalloc(&d_out, 5*sizeof(unsigned long long)));
-    const unsigned long long init[5] = { 0, 0, 0, 0, what == 0 ? ~0ull : 0ull };
-    HZ_CHECK(hipMemcpy(d_out, init, sizeof(init), hipMemcpyHostToDevice));
-    if(what == 0)      hipLaunchKernelGGL(k_check_hidden, dim3(256*32), dim3(256), 0, 0, seed, n, W, H, d_out);
-    else if(what == 1) hipLaunchKernelGGL(k_check_cull, dim3(256*64), dim3(64), 0, 0, seed, n, W, H, col0, col1, d_out);
-    else               hipLaunchKernelGGL(k_check_rect, dim3(256*16), dim3(256), 0, 0, seed, n, W, H, d_out);
-    HZ_CHECK(hipGetLastError());
-    HZ_CHECK(hipMemcpy(out, d_out, 5*sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    (void)hipFree(d_out);
-    return 0;
-}
-
-/* diagnostics: the large-triangle queue of the last draw (set 0: its only or
- * second round, set 1: the first round of a two-round draw): counters[6] and,
- * for the first min(max_rec, counters[0]) records, px0 py0 bw bh + the three
- * edge vectors dx, dy in 1/256 pixel (10 int32 each) */
-extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counters, int max_rec, int32_t* recs)
-{
-    HZ_ON_DEVICE(d);
-    if(hz_hip_sync(d) != 0) return -1;
-    const int k = (set ? HZ_NFB : 0) + d->fbi;
-    /* (a conversion that cleared the framebuffer emptied the queues too and left a copy of the counters) */
-    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k] + (d->fb_consumed ? HZ_CNT_LAST : 0), 6*sizeof(unsigned int), hipMemcpyDeviceToHost));
-    counters[2] = ~counters[2]; counters[5] = ~counters[5];     /* as documented: the first invalid index */
-    unsigned int n = counters[0] < d->bigrec_capacity ? counters[0] : d->bigrec_capacity;
-    if((int)n > max_rec) n = (unsigned int)max_rec;
-    if(n == 0 || recs == NULL) return 0;
-    hz_bigrec_t* h = (hz_bigrec_t*)malloc((size_t)n*sizeof(hz_bigrec_t));
-    if(!h) return -1;
-    HZ_CHECK(hipMemcpy(h, d->d_bigrec_s[k], (size_t)n*sizeof(hz_bigrec_t), hipMemcpyDeviceToHost));
-    for(unsigned int r=0; r<n; r++)
-    {
-        int32_t* o = recs + (size_t)r*10;
-        o[0] = h[r].r.px0; o[1] = h[r].r.py0; o[2] = h[r].r.bw; o[3] = h[r].bh;
-        for(int m=0; m<3; m++) { o[4+m] = h[r].r.e.dx[m]; o[7+m] = -h[r].r.e.ndy[m]; }
-    }
-    free(h);
-    return 0;
-}
-
-/* diagnostics / tests: what the last draw was - out[0] rounds (1 / 2), [1] its second round kept coarse depth
- * (hz_k_hiz.h), [2] the first round's reach in cells (0: one round), [3] only the strips behind the drawn columns
- * were launched (sectors, views of less than the full circle) */
-extern "C" int hz_hip_debug_last_plan(hz_dev_t* d, int* out)
+/* what the last draw was (bench.py records it beside every timing, tests assert on it) - out[0] rounds (1 / 2),
+ * [1] its second round kept coarse depth (hz_k_hiz.h), [2] the first round's reach in cells (0: one round), [3] only
+ * the strips behind the drawn columns were launched (sectors, views of less than the full circle) */
+extern "C" int hz_hip_last_plan(hz_dev_t* d, int* out)
 {
     if(!d || !out) return -1;
     for(int k=0; k<4; k++) out[k] = d->last_plan[k];
     return 0;
 }
 
-/* diagnostics / tests, no device needed: the work list draw_impl would build for a context of
- * N samples per axis and a W x H image drawing columns [col0,col1) of `view`.  round: 0 the
- * only round of a one-round draw, 1 / 2 the rounds of a two-round draw.  out: 3 int32 per
- * item (strip column, first cell row, cell row behind the last); returns the number of items
- * (also when capacity_items is smaller: then only that many were written), -1 if such a
- * draw would launch the whole grid instead (full circle). */
-extern "C" long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view, int col0, int col1, int round,
-                                      int32_t* out, size_t capacity_items)
-{
-    hz_dev_t* d = (hz_dev_t*)calloc(1, sizeof(*d));
-    if(!d) return -1;
-    d->env = read_env();
-    d->N = N; d->W = W; d->H = H; d->col0 = col0; d->col1 = col1;
-    d->seg_stride = (W + HZ_SEG-1)/HZ_SEG;
-    hz_params_t p = make_params(d, view);
-    (void)plan_rounds(d, view, p);
-    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0, d->env.far_rows);
-    free(d);
-    p.pass = round & 3;
-    double a0 = 0, a1 = 0;
-    const bool every_strip = (round & 256) != 0;
-    if(!every_strip && !azimuths_of_columns(p, &a0, &a1)) return -1;
-    std::vector<uint32_t> items;
-    list_items(p, zn, a0, a1, items, every_strip);
-    for(size_t k=0; k<items.size() && k<capacity_items; k++)
-    {
-        int jbeg, jend;
-        mr_segment_rows(zn, (int)(items[k] >> MR_ITEM_SX_BITS), &jbeg, &jend);
-        out[3*k] = (int32_t)(items[k] & ((1u << MR_ITEM_SX_BITS) - 1u)); out[3*k+1] = jbeg; out[3*k+2] = jend;
-    }
-    return (long)items.size();
-}
-
-/* diagnostics (tools/wave_timing.py): draws `view` once more with the instance of k_march
- * that counts, and returns, per wave of its second (or only) round's launch, 4 words:
- * duration in shader clock cycles, flushes<<32 | triangles set up, to k_big<<32 | to k_mid,
- * hidden by the early depth test<<32 | pixel centres tested in the wave.  out: room for
- * capacity_words; grid[2] = the launch grid (a work-list launch is grid[0] x 1). */
-extern "C" int hz_hip_debug_wave_timing(hz_dev_t* d, const hz_view_t* view, unsigned long long* out, size_t capacity_words, unsigned int* grid)
-{
-    HZ_ON_DEVICE(d);
-    HZ_CHECK(sync_all(d));
-    unsigned long long* d_cycles = NULL;
-    HZ_CHECK(hipMalloc(&d_cycles, capacity_words*sizeof(unsigned long long)));
-    HZ_CHECK(hipMemset(d_cycles, 0, capacity_words*sizeof(unsigned long long)));
-    d->wave_timing.d_cycles = d_cycles; d->wave_timing.capacity = capacity_words;
-    d->wave_timing.grid_x = d->wave_timing.grid_y = 0;
-    int rc = draw_impl(d, view);
-    d->wave_timing.d_cycles = NULL; d->wave_timing.capacity = 0;
-    if(rc == 0 && sync_all(d) != hipSuccess) rc = -1;
-    grid[0] = d->wave_timing.grid_x; grid[1] = d->wave_timing.grid_y;
-    if(rc == 0 && hipMemcpy(out, d_cycles, (size_t)grid[0]*grid[1]*4*sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
-    (void)hipFree(d_cycles);
-    return rc;
-}
+#ifdef HZ_SELFTEST
+#include "hz_selftest.h"         /* include/: the declarations */
+#include "hz_selftest_impl.h"
+#endif
 
 extern "C" int hz_hip_sync(hz_dev_t* d)
 {

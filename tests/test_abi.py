@@ -26,6 +26,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
 
 
+def test_self_checks_and_diagnostics_live_in_a_library_of_their_own():
+    """include/hz_selftest.h -> libhorizonator_selftest.so (the library's sources + the device-side self-checks and
+    the diagnostics of tools/): it exports everything the product does plus those; the product exports none of them"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hz_selftest.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(hz_hip_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(_lib.SELFTEST_SYMBOLS), declared ^ set(_lib.SELFTEST_SYMBOLS)
+    product, selftest = _lib.load(), _lib.load_selftest()
+    for name in sorted(declared):
+        assert hasattr(selftest, name), name
+        assert not hasattr(product, name), f"{name}: a self-check / diagnostics entry point in the library that ships"
+    for name in _lib.DECLARED_SYMBOLS:
+        assert hasattr(selftest, name), name
+
+
 def test_rccl_library_exports_what_its_header_declares():
     """include/horizonator_rccl.h -> libhorizonator_rccl.so (the exchange steps for a C caller; a
     library of its own so that libhorizonator.so does not depend on RCCL)"""

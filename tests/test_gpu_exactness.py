@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(what, seed, n, W, H, col0=0, col1=None):
-    lib = hzlib.load()
+    lib = hzlib.load_selftest()          # (libhorizonator_selftest.so: the library's sources + the check kernels, include/hz_selftest.h)
     out = (C.c_uint64 * 5)()
     rc = lib.hz_hip_check_exactness(0, what, seed, n, W, H, col0, W if col1 is None else col1, out)
     assert rc == 0, lib.hz_hip_last_error()

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _check(what, seed=0, n=0):
-    lib = hzlib.load()
+    lib = hzlib.load_selftest()          # (libhorizonator_selftest.so: the library's sources + the check kernels, include/hz_selftest.h)
     bad = C.c_uint64(12345)
     first = (C.c_float * 4)()
     assert lib.hz_hip_check_fastmath(0, what, seed, n, C.byref(bad), first) == 0, lib.hz_hip_last_error()

@@ -26,9 +26,15 @@ def _read_raw(path):
         return np.frombuffer(f.read(), np.uint8).reshape(h, w, bpp)
 
 
-@pytest.mark.skipif(not os.path.exists(EXE), reason="the reference's CLI was not built (no /root/reference where build() ran)")
 def test_the_reference_cli_renders_through_this_library(tmp_path):
     import horizonator_amd
+    if not os.path.exists(EXE):
+        # the binary is built where /root/reference is (the build container) and travels with the tree, untracked: on a
+        # box that got neither, this test cannot run - and says so where a -q run shows it (pytest.ini: -rs)
+        why = (f"NOT RUN: {os.path.relpath(EXE, ROOT)} is missing - the reference's standalone.c is linked against this library only "
+               "where /root/reference exists (python -c 'import __graft_entry__ as g; g.build()' in the build container)")
+        print("\n" + why, flush=True)
+        pytest.skip(why)
     lat, lon, W, H, zfar, azc, azr = hzutil.VIEW_LAT, hzutil.VIEW_LON, 1200, 300, 20000.0, 35.0, 70.0
     # radius given in metres (reference standalone.c:438: radius_cells = -1, radius_m = zfar)
     R = int(round(zfar / (6371000.0 * np.pi / 180.0 * np.cos(np.radians(np.float32(lat))) / 1200)))

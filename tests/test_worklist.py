@@ -49,7 +49,7 @@ def _pixel_x(v, N, W):
 
 
 def _listed(N, W, H, v, c0, c1, rnd):
-    lib = hzlib.load()
+    lib = hzlib.load_selftest()          # (hz_hip_debug_worklist is a diagnostics entry point: include/hz_selftest.h)
     cap = 1 << 20
     out = np.zeros((cap, 3), np.int32)
     n = lib.hz_hip_debug_worklist(N, W, H, C.byref(v), c0, c1, rnd, out.ctypes.data, cap)

@@ -20,7 +20,7 @@ with hzutil.HipDev(m, W, H, raster=2) as dev:
         cnt = (C.c_uint * 6)()
         MAXR = 1 << 21
         recs = np.zeros((MAXR, 10), np.int32)
-        assert lib.hz_hip_debug_bigqueue(dev.dev, which, cnt, MAXR, recs.ctypes.data) == 0
+        assert hzutil.hzlib.load_selftest().hz_hip_debug_bigqueue(dev.dev, which, cnt, MAXR, recs.ctypes.data) == 0
         n = min(cnt[0], MAXR)
         r = recs[:n].astype(np.int64)
         bw, bh = r[:, 2], r[:, 3]

@@ -8,8 +8,9 @@ For every row: the benchmark workload (cfg3: 7x7 SRTM3 tiles, 16000x4000, 360 de
 marked zfar 40 km: the API's default far clip), 40 renders back to back, three times -> the median ms per
 render; and once with every kernel alone on the chip (HZ_SERIAL=1) -> the stage times of HIP events.
 Rows whose switch makes the picture WRONG say so: they bound what a different design could gain, they are
-not candidates.  Build-time variants (another register budget, two framebuffers) are built into a copy of
-the tree under /tmp."""
+not candidates - and the library that ships does not know their switches: those rows run in a copy of the
+tree built with -DHZ_EXPERIMENTS.  Build-time variants (another register budget, two framebuffers) are
+built into copies of the tree under /tmp likewise."""
 import json
 import os
 import shutil
@@ -92,13 +93,22 @@ VARIANTS = [
 ]
 
 
+def wrong_picture(env):
+    return any(k.startswith("HZ_EXP_FB") or k == "HZ_MARCH_DEBUG" for k in env)
+
+
 def main():
+    exp_root, exp_err = variant("experiments", "-DHZ_EXPERIMENTS")
     doc = {"workload": "bench.py cfg3 (7x7 SRTM3 tiles, 16000x4000, 360 degrees, zfar 600 km unless a row says otherwise), 40 renders back to back",
            "how": "python tools/experiments.py on one MI355X; every row: the environment switch (or build flag) that reproduces it",
            "rows": []}
     for what, env, zfar, note in ROWS:
         rec = {"what": what, "switch": " ".join(f"{k}={v}" for k, v in env.items()) or "-", "zfar_m": zfar or 600000.0, "note": note}
-        rec.update(run(env, zfar=zfar))
+        if wrong_picture(env):
+            rec["build"] = "make -C horizonator_amd/csrc HIPFLAGS_EXTRA=-DHZ_EXPERIMENTS"
+            rec.update(run(env, root=exp_root, zfar=zfar) if exp_root else {"error": exp_err})
+        else:
+            rec.update(run(env, zfar=zfar))
         doc["rows"].append(rec)
         print(what, rec.get("median_ms_per_render"), rec.get("serial"), file=sys.stderr, flush=True)
     for what, name, flags, note in VARIANTS:
@@ -116,7 +126,7 @@ def main():
                 tk.ROOT = root
                 k = tk._kernels()
                 tk.ROOT = save
-                rec["k_march_resources"] = tk._one(k, "k_marchILb0E")
+                rec["k_march_resources"] = {"k_march<false,false>": tk._one(k, "k_marchILb0ELb0E"), "k_march<false,true> (coarse depth)": tk._one(k, "k_marchILb0ELb1E")}
             except Exception as e:
                 rec["k_march_resources"] = repr(e)
         doc["rows"].append(rec)

@@ -74,13 +74,14 @@ def wave_counters(h):
     import numpy as np
     import horizonator_amd
     lib = horizonator_amd._lib.load()
+    st = horizonator_amd._lib.load_selftest()   # the diagnostics entry points (include/hz_selftest.h); the context itself is the product's
     v = horizonator_amd.View()
     for k, x in h.view().items():
         setattr(v, k, x)
     cap = 8 << 20
     buf = np.zeros(cap, np.uint64)
     grid = (C.c_uint * 2)()
-    if lib.hz_hip_debug_wave_timing(lib.horizonator_amd_device(C.byref(h._ctx)), C.byref(v), buf.ctypes.data, cap, grid) != 0:
+    if st.hz_hip_debug_wave_timing(lib.horizonator_amd_device(C.byref(h._ctx)), C.byref(v), buf.ctypes.data, cap, grid) != 0:
         return None
     a = buf[:int(grid[0]) * int(grid[1]) * 4].reshape(-1, 4)
     setup = int((a[:, 1] & 0xFFFFFFFF).sum())

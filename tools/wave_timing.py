@@ -16,13 +16,14 @@ for _ in range(2):
     h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
 import ctypes as C
 lib = horizonator_amd._lib.load()
+st = horizonator_amd._lib.load_selftest()     # the diagnostics entry points (include/hz_selftest.h); the context itself is the product's
 v = horizonator_amd.View()
 for k, x in h.view().items():
     setattr(v, k, x)
 cap = 4 * 4 * 1024 * 1024
 buf = np.zeros(cap, np.uint64)
 grid = (C.c_uint * 2)()
-assert lib.hz_hip_debug_wave_timing(lib.horizonator_amd_device(C.byref(h._ctx)), C.byref(v), buf.ctypes.data, cap, grid) == 0
+assert st.hz_hip_debug_wave_timing(lib.horizonator_amd_device(C.byref(h._ctx)), C.byref(v), buf.ctypes.data, cap, grid) == 0
 gx, gy = int(grid[0]), int(grid[1])
 a = buf[:gx * gy * 4].reshape(gy, gx, 4)
 t = a[:, :, 0].astype(np.float64) / 2400.0          # shader clock ~2.4 GHz -> us
