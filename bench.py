@@ -422,6 +422,40 @@ def main():
         rebalance()
     dt, kern = timed(args.zfar, args.steps, args.warmup)
     verified = verify()
+
+    # "parity gates recorded with every timing".  The panorama that was just timed - the LAST of
+    # the K queued back to back, i.e. drawn by the kernels of a series: second round with coarse depth (k_march<false,
+    # true>, k_hiz, k_big's chunk drop), reads before the atomics - is kept and compared below: with the oracle's render
+    # of the same workload (the cpu_baseline leg computes it anyway) and with the SHA-256 of what the reference's own
+    # shaders drew for this scene on Mesa llvmpipe (tests/golden/render_checksums.json; the reference's draw:
+    # horizonator-lib.c:887-899).  A false entry makes the exit code non-zero.
+    import hashlib
+
+    def golden(zfar):
+        """the committed reference render of this workload, if there is one and the DEM is the one it was made on"""
+        name = {("cfg3", 600000.0): "cfg3_7x7_16000x4000", ("cfg3", 40000.0): "cfg3_7x7_16000x4000_zfar40km",
+                ("cfg2", 600000.0): "cfg2_3x3_8000x2000"}.get((args.config, float(zfar)))
+        try:
+            c = json.load(open(os.path.join(ROOT, "tests", "golden", "render_checksums.json")))[name]
+        except Exception:
+            return None
+        if S.get("mosaic_sha") is None:
+            S["mosaic_sha"] = hashlib.sha256(np.ascontiguousarray(h.mosaic()).tobytes()).hexdigest()
+        if S["mosaic_sha"] != c["mosaic_sha256"] or (c["W"], c["H"], c["R"], c["znear"]) != (W, H, R, ZNEAR):
+            return None
+        return c
+
+    def keep_last(zfar):
+        """the last timed panorama (N = 1: what d_img / d_rng hold now) and the plan of its draw"""
+        if world != 1 or args.exchange_anyway or args.raster == 1:
+            return None
+        plan = h.last_plan()
+        img = d_img.cpu().numpy()
+        g = golden(zfar)
+        return {"img": img, "rng": d_rng.cpu().numpy(), "plan": plan,
+                "bgr_sha_is_llvmpipe": (hashlib.sha256(img.tobytes()).hexdigest() == g["bgr_sha256"]) if g else None}
+
+    last = keep_last(args.zfar)
     ms_per_step = dt / args.steps * 1e3
     value = W * H * args.steps / dt / 1e6
 
@@ -474,9 +508,15 @@ def main():
     if not args.no_extra and abs(args.zfar - 40000.0) > 1:
         dt40, k40 = timed(40000.0, max(3, args.steps // 2), 1)
         n40 = max(3, args.steps // 2)
+        last40 = keep_last(40000.0)
         extra["zfar_40km"] = {"value": W * H * n40 / dt40 / 1e6, "unit": "Mpix/s",
                               "ms_per_step": dt40 / n40 * 1e3,
                               "note": "API default far clip (reference horizonator.h:10); >95% of the mosaic is beyond it"}
+        if last40 is not None:
+            extra["zfar_40km"]["parity"] = {"bgr_sha_is_llvmpipe": last40["bgr_sha_is_llvmpipe"], "rounds": last40["plan"]["rounds"],
+                                            "coarse_depth_in_series": last40["plan"]["coarse_depth"],
+                                            "what": "the last of the timed panoramas: SHA-256 of its BGR bytes against the reference's shaders on llvmpipe"}
+        del last40
 
     # the reference hands its results over in HOST memory.  The same panorama through
     # horizonator_render_offscreen() into caller-owned (pageable) buffers that the caller keeps, as
@@ -520,10 +560,14 @@ def main():
         v = od.view(LAT, LON, W, H, -180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
         cores = os.cpu_count() or 1
         samples = []
-        for _ in range(3):
+        for k in range(3):
             t0 = time.perf_counter()
-            oracle.render(mosaic, v, W, H, want=("bgr", "ranges"))
+            ref = oracle.render(mosaic, v, W, H, want=("bgr", "ranges"))
             samples.append(time.perf_counter() - t0)
+            if k == 0 and last is not None:         # the checker's picture against the panorama that was timed (outside the clock)
+                last["bgr_is_oracle"] = bool(np.array_equal(ref["bgr"], last["img"]))
+                last["ranges_is_oracle"] = bool(np.array_equal(ref["ranges"], last["rng"]))
+            del ref
         cdt = float(np.median(samples))
         cpu = {"value": W * H / cdt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
                "sample": f"3 full {W}x{H} renders of the same workload by oracle/ (C + OpenMP, {cores} threads): "
@@ -603,13 +647,28 @@ def main():
             line["scenes"] = scene_recs
         if verified is not None:
             line["gathered_panorama_equals_single_gpu_render"] = verified
+        if last is not None:
+            line["parity"] = {"bgr": last.get("bgr_is_oracle"), "ranges": last.get("ranges_is_oracle"),
+                              "bgr_sha_is_llvmpipe": last["bgr_sha_is_llvmpipe"],
+                              "coarse_depth_in_series": last["plan"]["coarse_depth"], "rounds": last["plan"]["rounds"],
+                              "what": "the LAST of the K timed panoramas (a draw of a series: the kernel instances the clock saw), every BGR byte and "
+                                      "every float32 range against oracle/'s render of the same workload (null: --no-cpu-baseline), and the SHA-256 of "
+                                      "its BGR bytes against what the reference's vertex/geometry/fragment.glsl drew on Mesa llvmpipe "
+                                      "(tests/golden/render_checksums.json; null: no reference render of this workload is committed)"}
         if os.environ.get("BENCH_HOST_TIMES") and host_us["n"]:
             line["host_us_per_step"] = {k: v / host_us["n"] for k, v in host_us.items() if k != "n"}
         line.update(extra)
         print(json.dumps(line), flush=True)
+        gates = [line.get("parity", {}).get(k) for k in ("bgr", "ranges", "bgr_sha_is_llvmpipe")]
+        gates.append(extra.get("zfar_40km", {}).get("parity", {}).get("bgr_sha_is_llvmpipe"))
+        gates.append(line.get("gathered_panorama_equals_single_gpu_render"))
+        gates.append(host_incl["equals_device_render"] if host_incl is not None else None)
+        failed = any(g is False for g in gates)
     h.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0 and failed:
+        sys.exit("bench.py: a parity gate of the line above is false - the timing is void")
 
 
 if __name__ == "__main__":

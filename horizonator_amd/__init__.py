@@ -379,6 +379,15 @@ class horizonator:
             return None
         return {n: getattr(t, n) for n, _ in Times._fields_}
 
+    def last_plan(self):
+        """what the last draw was: {"rounds": 1 | 2, "coarse_depth": its second round kept coarse depth (zoomed views, the
+        draws of a series), "reach_cells": the first round's reach, "work_list": only the strips behind the drawn columns
+        were launched} (include/hz_hip.h: hz_hip_last_plan)"""
+        out = (C.c_int * 4)()
+        if self._lib.hz_hip_last_plan(self._lib.horizonator_amd_device(C.byref(self._ctx)), out) != 0:
+            raise RuntimeError("hz_hip_last_plan() failed")
+        return {"rounds": int(out[0]), "coarse_depth": bool(out[1]), "reach_cells": int(out[2]), "work_list": bool(out[3])}
+
     def view(self):
         v = View()
         if not self._lib.horizonator_amd_get_view(C.byref(self._ctx), C.byref(v)):

@@ -155,6 +155,182 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
 }
 
 /* ------------------------------------------------------------------------ */
+/* results for the caller's HOST memory, without the sky                     */
+/*
+ * horizonator_render_offscreen() hands its results over in host memory (reference horizonator-lib.c:936-1048),
+ * and what lies between this kernel and the caller's buffers is PCIe: 448 MB per 16000 x 4000 panorama at ~55 GB/s
+ * was 8 of the 10.9 ms a call took.  62 % of those bytes say "sky".  This conversion writes the terrain pixels only,
+ * as a stream of blobs (hz_scatter.h / hz_scatter.c: a blob = the terrain pixels of 4 rows x <= 2048 columns, with a
+ * mask; tiles without terrain send nothing), 5 bytes per terrain pixel for BGR + range - the shade and the float32
+ * range, computed here exactly as k_resolve4 computes it - and the host threads put them in their places between
+ * the sky constants they filled in while the draw was running.
+ * One workgroup per blob, one wave per row, the tile's words kept in registers between the count and the write-out
+ * (as k_pack_sparse); a blob takes its place in the stream with one compare-and-swap that also keeps blobs from
+ * straddling the chunks the stream travels in. */
+struct hz_hostpack_t
+{
+    uint32_t*     out;              /* the stream                                                              */
+    unsigned int* cursor;           /* [0] words of the stream in use, [1] blobs, [2] nonzero: a blob did not fit */
+    unsigned int  capacity;         /* words                                                                   */
+    unsigned int  chunk_words;      /* no blob straddles a multiple of this                                    */
+    uint32_t      flags;            /* HZ_BLOB_*: the arrays a blob carries                                    */
+};
+#define HP_NONE 0xFFFFFFFFu
+
+template<bool CLEAR>
+__global__ __launch_bounds__(64*HZ_BLOB_ROWS)
+void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const float* __restrict__ tanel,
+                 int SW, int H, float znear, float zfar,
+                 unsigned char* __restrict__ touched, int seg_stride, unsigned int* qa, unsigned int* qb)
+{
+    static_assert(HZ_SEG == 256 && HZ_BLOB_COLS == 8*HZ_SEG && HZ_BLOB_ROWS == 4, "k_pack_host: a wave = a row of eight segments");
+    __shared__ uint32_t s_count[HZ_BLOB_ROWS], s_start;
+    if(CLEAR && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hz_counters_consume(qa, qb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = (int)blockIdx.x*HZ_BLOB_COLS, n = min(HZ_BLOB_COLS, SW - x0), mw = (n + 31) >> 5, nit = (n + 255) >> 8;
+    const int yo0 = (int)blockIdx.y*HZ_BLOB_ROWS, yo = yo0 + wave;
+    const bool have = yo < H;
+    const int glrow = H-1 - (have ? yo : 0);         /* GL row, reference horizonator-lib.c:949-958 */
+    unsigned long long* row = fb + (size_t)glrow*SW + x0;
+    unsigned char* segflag = touched + (size_t)glrow*seg_stride + (x0 >> HZ_SEG_LOG2);
+    const bool wide = (SW & 3) == 0;
+
+    unsigned long long key[8][4];
+    uint32_t nibs = 0, flagged = 0;
+    #pragma unroll
+    for(int it=0; it<8; it++)
+    {
+        key[it][0] = key[it][1] = key[it][2] = key[it][3] = HZ_FB_CLEAR;
+        if(it < nit && have && segflag[it])                 /* (the same byte for the whole wave) */
+        {
+            flagged |= 1u << it;
+            const int c = (it << 8) + 4*lane;
+            if(c + 3 < n && wide)
+            {
+                const ulonglong2 a = *(const ulonglong2*)(row + c), b = *(const ulonglong2*)(row + c + 2);
+                key[it][0] = a.x; key[it][1] = a.y; key[it][2] = b.x; key[it][3] = b.y;
+            }
+            else
+            {
+                #pragma unroll
+                for(int k=0; k<4; k++) if(c + k < n) key[it][k] = row[c + k];
+            }
+            #pragma unroll
+            for(int k=0; k<4; k++) nibs |= ((uint32_t)(key[it][k] >> 40) != HZ_Z24_MAX ? 1u : 0u) << (4*it + k);
+        }
+    }
+    uint32_t count = (uint32_t)__popc(nibs);
+    #pragma unroll
+    for(int m=32; m>=1; m>>=1) count += __shfl_xor(count, m);
+    if(lane == 0) s_count[wave] = count;
+    __syncthreads();
+    const uint32_t words_per_pixel = ((o.flags & HZ_BLOB_RANGES) ? 1u : 0u) + ((o.flags & HZ_BLOB_INDEX) ? 1u : 0u) + ((o.flags & HZ_BLOB_Z24) ? 1u : 0u);
+    const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+    if(threadIdx.x == 0)
+    {
+        uint32_t start = HP_NONE;
+        if(total)
+        {
+            uint32_t size = HZ_BLOB_HDR + (uint32_t)(HZ_BLOB_ROWS*mw) + total*words_per_pixel + ((o.flags & HZ_BLOB_RED) ? (total + 3u) >> 2 : 0u);
+            size = (size + 3u) & ~3u;
+            uint32_t old = __hip_atomic_load(&o.cursor[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for(;;)
+            {
+                const uint32_t room = o.chunk_words - old % o.chunk_words;
+                const bool skip = size > room;                                      /* the rest of this chunk stays empty */
+                const uint32_t at = skip ? old + room : old;
+                if((unsigned long long)at + size > o.capacity) { atomicExch(&o.cursor[2], 1u); break; }
+                const uint32_t seen = atomicCAS(&o.cursor[0], old, at + size);
+                if(seen == old)
+                {
+                    if(skip) o.out[old] = 0xFFFFFFFFu;                              /* "no further blob in this chunk" */
+                    atomicAdd(&o.cursor[1], 1u);
+                    start = at;
+                    break;
+                }
+                old = seen;
+            }
+            if(start != HP_NONE)
+            {
+                uint32_t* b = o.out + start;
+                b[0] = (uint32_t)yo0 | (o.flags << 16); b[1] = (uint32_t)x0;
+                b[2] = s_count[0]; b[3] = s_count[1]; b[4] = s_count[2]; b[5] = s_count[3];
+                b[6] = size; b[7] = (uint32_t)n;
+            }
+        }
+        s_start = start;
+    }
+    __syncthreads();
+    const uint32_t start = s_start;
+    if(start != HP_NONE)
+    {
+        uint32_t* blob = o.out + start;
+        uint32_t* mask = blob + HZ_BLOB_HDR + wave*mw;
+        uint32_t* p = blob + HZ_BLOB_HDR + HZ_BLOB_ROWS*mw;
+        float*    d_rng = NULL; int32_t* d_idx = NULL; uint32_t* d_z = NULL; unsigned char* d_red = NULL;
+        if(o.flags & HZ_BLOB_RANGES) { d_rng = (float*)p;   p += total; }
+        if(o.flags & HZ_BLOB_INDEX)  { d_idx = (int32_t*)p; p += total; }
+        if(o.flags & HZ_BLOB_Z24)    { d_z   = p;           p += total; }
+        if(o.flags & HZ_BLOB_RED)    { d_red = (unsigned char*)p; }
+        uint32_t at = 0;
+        #pragma unroll
+        for(int w=0; w<HZ_BLOB_ROWS; w++) if(w < wave) at += s_count[w];
+        const float tan_row = tanel ? tanel[glrow] : 0.f;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        #pragma unroll
+        for(int it=0; it<8; it++)
+            if(it < nit)
+            {
+                const uint32_t nib = (nibs >> (4*it)) & 0xFu;
+                /* mask word w of the segment = the nibbles of lanes 8w..8w+7 (all zero where nothing was drawn, and in rows beyond the image) */
+                uint32_t v = nib << (4*(lane & 7));
+                v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
+                if((lane & 7) == 0 && (it << 8) + 4*lane < n) mask[(it << 3) + (lane >> 3)] = v;
+                if(!((flagged >> it) & 1u)) continue;
+                unsigned long long b[4];
+                #pragma unroll
+                for(int k=0; k<4; k++) b[k] = __ballot((nib >> k) & 1u);
+                uint32_t q = at + (uint32_t)(__popcll(b[0] & lt) + __popcll(b[1] & lt) + __popcll(b[2] & lt) + __popcll(b[3] & lt));
+                #pragma unroll
+                for(int k=0; k<4; k++)
+                    if((nib >> k) & 1u)
+                    {
+                        const unsigned long long kk = key[it][k];
+                        const uint32_t zi = (uint32_t)(kk >> 40);
+                        if(d_rng) d_rng[q] = hz_range_from_z24(zi, tan_row, znear, zfar);
+                        if(d_idx) d_idx[q] = (int32_t)(uint32_t)(kk >> 8);
+                        if(d_z)   d_z[q]   = zi;
+                        if(d_red) d_red[q] = (unsigned char)(kk & 0xFFu);       /* reference fragment.glsl:15-16: colour = (red,0,0) */
+                        q++;
+                    }
+                at += (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+            }
+    }
+    if(CLEAR && have)
+    {
+        /* glClear behind the last reader (reference horizonator-lib.c:896), as k_resolve4<true> */
+        #pragma unroll
+        for(int it=0; it<8; it++)
+            if((flagged >> it) & 1u)
+            {
+                const int c = (it << 8) + 4*lane;
+                if(c + 3 < n && wide)
+                {
+                    const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
+                    if((key[it][0] & key[it][1]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c)     = ones;
+                    if((key[it][2] & key[it][3]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c + 2) = ones;
+                }
+                else
+                {
+                    #pragma unroll
+                    for(int k=0; k<4; k++) if(c + k < n && key[it][k] != HZ_FB_CLEAR) row[c + k] = HZ_FB_CLEAR;
+                }
+                if(lane == 0) segflag[it] = 0;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* packed strips for the multi-GPU gather                                    */
 /*
  * A finished strip as BGR8 + float32 range is 7 bytes per pixel, and with N

@@ -41,6 +41,7 @@
 #include "hz_raster.h"
 #include "hz_fast.h"
 #include "hz_tex.h"
+#include "hz_scatter.h"
 
 /* ------------------------------------------------------------------------ */
 /* errors                                                                    */
@@ -111,6 +112,7 @@ struct hz_env_t
     int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
     int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
+    int    host_dense;              /* HZ_HOST_DENSE=1: results for host memory travel whole (every pixel, as before round 4) instead of without the sky */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
@@ -142,6 +144,7 @@ static hz_env_t read_env(void)
     e.always_wait_near = getenv("HZ_ALWAYS_WAIT_NEAR") != NULL;
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
+    e.host_dense       = env_int("HZ_HOST_DENSE", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
@@ -245,6 +248,13 @@ struct hz_dev
     hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
     hipEvent_t     ev_band[HZ_HOST_BANDS];
 
+    /* ... without the sky (k_pack_host, hz_scatter.c): the stream of blobs, its cursor words on the device and in pinned memory */
+    uint32_t*      d_hs;
+    size_t         hs_capacity;         /* words */
+    unsigned int*  d_hs_cursor;
+    unsigned int*  h_hs_cursor;
+    hipEvent_t     ev_hs;
+
     /* internal output buffers for *_to_host */
     unsigned char* d_bgr;
     float*         d_ranges;
@@ -318,6 +328,9 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     }
     for(int k=0; k<HZ_HOST_BANDS; k++)   if(d->ev_band[k]) (void)hipEventDestroy(d->ev_band[k]);
     for(int k=0; k<HZ_COPY_STREAMS; k++) if(d->cstream[k]) (void)hipStreamDestroy(d->cstream[k]);
+    (void)hipFree(d->d_hs); (void)hipFree(d->d_hs_cursor);
+    if(d->h_hs_cursor) (void)hipHostFree(d->h_hs_cursor);
+    if(d->ev_hs) (void)hipEventDestroy(d->ev_hs);
     (void)hipFree(d->d_bgr);
     (void)hipFree(d->d_ranges);
     (void)hipFree(d->d_index);
@@ -1518,7 +1531,24 @@ static int ensure_out_buffers(hz_dev_t* d, bool bgr, bool ranges, bool index, bo
 struct hz_copy_pool
 {
     struct batch_t { int pending; };
-    struct task_t  { unsigned char* dst; const unsigned char* src; size_t n; batch_t* batch; };     /* src == NULL: map the pages of dst */
+    /* what the blobs of a panorama are scattered into (hz_scatter.c), and the bands of rows the sky was filled in by:
+     * a blob waits until the fill of its rows is done (band_left: fill tasks of band b still queued or running) */
+    struct scatter_t
+    {
+        int SW, H, band_rows, nbands;
+        unsigned char* bgr; float* ranges; int32_t* index; uint32_t* z24;
+        std::atomic<int>* band_left;
+        std::atomic<int> bad;
+    };
+    enum { COPY = 0, MAP, FILL, SCATTER };
+    struct task_t
+    {
+        int kind;
+        unsigned char* dst; const unsigned char* src; size_t n;     /* COPY: dst[0..n) = src[0..n); MAP: the pages of dst[0..n); FILL: bytes [lo, lo+n) of dst */
+        size_t lo; int sky; std::atomic<int>* left;                /* FILL: which constants (HZ_SKY_*), and the band counter it reports to */
+        scatter_t* sc; const uint32_t* chunk; const size_t* offs; size_t nblobs;     /* SCATTER: blobs chunk + offs[0..nblobs) */
+        batch_t* batch;
+    };
     std::mutex m, busy;                 /* busy: one copy_out at a time (contexts on several threads share the pool) */
     std::condition_variable cv_work, cv_done;
     std::vector<std::thread> threads;
@@ -1561,7 +1591,25 @@ struct hz_copy_pool
             if(stop) return;
             const task_t t = q.front(); q.pop_front();
             lk.unlock();
-            if(t.src) memcpy(t.dst, t.src, t.n); else map_pages(t.dst, t.n);
+            switch(t.kind)
+            {
+            case COPY: memcpy(t.dst, t.src, t.n); break;
+            case MAP:  map_pages(t.dst, t.n); break;
+            case FILL: hz_sky_fill(t.dst, t.lo, t.lo + t.n, t.sky); if(t.left) t.left->fetch_sub(1, std::memory_order_release); break;
+            case SCATTER:
+                for(size_t k=0; k<t.nblobs; k++)
+                {
+                    const uint32_t* blob = t.chunk + t.offs[k];
+                    /* the sky of these rows first.  (Fill tasks were all queued before the first scatter task: whatever is
+                     * left of a band is running on another thread right now - a short wait, never a deadlock.) */
+                    const int yo = (int)(blob[0] & 0xFFFFu);
+                    const int b0 = yo / t.sc->band_rows, b1 = (yo + HZ_BLOB_ROWS - 1) / t.sc->band_rows;
+                    for(int b=b0; b<=b1 && b<t.sc->nbands; b++)
+                        while(t.sc->band_left[b].load(std::memory_order_acquire) > 0) std::this_thread::yield();
+                    if(hz_blob_scatter(blob, t.sc->SW, t.sc->H, t.sc->bgr, t.sc->ranges, t.sc->index, t.sc->z24) != 0) t.sc->bad.store(1);
+                }
+                break;
+            }
             lk.lock();
             if(--t.batch->pending == 0) cv_done.notify_all();
         }
@@ -1574,10 +1622,20 @@ struct hz_copy_pool
         for(size_t k=0; k<nparts; k++)
         {
             const size_t lo = n*k/nparts, hi = n*(k+1)/nparts;
-            q.push_back({ d + lo, s ? s + lo : NULL, hi - lo, b });
+            task_t t = {};
+            t.kind = s ? COPY : MAP; t.dst = d + lo; t.src = s ? s + lo : NULL; t.n = hi - lo; t.batch = b;
+            q.push_back(t);
             b->pending++;
         }
         cv_work.notify_all();
+    }
+    void push_task(batch_t* b, const task_t& t0)
+    {
+        task_t t = t0; t.batch = b;
+        std::lock_guard<std::mutex> lk(m);
+        q.push_back(t);
+        b->pending++;
+        cv_work.notify_one();
     }
     void wait(batch_t* b)
     {
@@ -1689,10 +1747,190 @@ static int copy_out(hz_dev_t* d, int nbuf, unsigned char* const* dst, const unsi
     return 0;
 }
 
+/* ---- ... without the sky ---------------------------------------------------------
+ * Most of a panorama is sky - 62 % of the benchmark image -, every sky pixel is the same
+ * constant (reference horizonator-lib.c:185 and :1016), and the link is what a call waits
+ * for.  So only the terrain pixels travel (k_pack_host: blobs of 5 bytes per terrain pixel
+ * for BGR + range, hz_scatter.h), and the pool that used to copy 448 MB out of the staging
+ * ring instead
+ *   - fills the caller's buffers with the sky's constants, band of rows by band of rows,
+ *     while the draw is still running (streaming stores; fresh pages are mapped by these
+ *     writes' MADV_POPULATE_WRITE in front of them), and
+ *   - puts each chunk's blobs in their places as the chunk arrives.
+ * Same bytes in the caller's buffers (the GPU suite runs through this path: hzutil.hip_render
+ * takes its four outputs this way; HZ_HOST_DENSE=1 is the path above). */
+static size_t hs_words_needed(int SW, int H, uint32_t flags)
+{
+    const size_t npix = (size_t)SW*H;
+    const size_t wpp = ((flags & HZ_BLOB_RANGES) ? 1 : 0) + ((flags & HZ_BLOB_INDEX) ? 1 : 0) + ((flags & HZ_BLOB_Z24) ? 1 : 0);
+    const size_t tiles = (size_t)((SW + HZ_BLOB_COLS-1)/HZ_BLOB_COLS)*(size_t)((H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS);
+    /* every pixel terrain: its words, a byte of shade, per blob header + masks + padding; and per chunk one blob's worth of skipped room */
+    size_t words = npix*wpp + ((flags & HZ_BLOB_RED) ? npix/4 + tiles : 0) + tiles*(HZ_BLOB_HDR + HZ_BLOB_ROWS*(HZ_BLOB_COLS/32) + 4);
+    const size_t blob_max = HZ_BLOB_HDR + HZ_BLOB_ROWS*(HZ_BLOB_COLS/32) + (size_t)HZ_BLOB_ROWS*HZ_BLOB_COLS*(wpp + 1) + 4;
+    words += (words/(HZ_STAGE_BYTES/4) + 2)*blob_max;
+    return words;
+}
+
+static int resolve_to_host_sparse(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                                  unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
+{
+    const int SW = d->col1 - d->col0, H = d->H;
+    const bool prof = d->profiling != 0;
+    const uint32_t flags = (bgr ? HZ_BLOB_RED : 0u) | (ranges ? HZ_BLOB_RANGES : 0u) | (index ? HZ_BLOB_INDEX : 0u) | (z24 ? HZ_BLOB_Z24 : 0u);
+    if(ranges)
+    {
+        if(!tanel) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: ranges requested without a tanel table"); return -1; }
+        if(upload_tanel(d, tanel) != 0) return -1;
+    }
+    const size_t need = hs_words_needed(SW, H, flags);
+    if(need >= ((size_t)1 << 32)) return 1;                    /* (the stream is addressed in 32 bits: the dense path) */
+    if(need > d->hs_capacity)
+    {
+        HZ_CHECK(sync_all(d));
+        (void)hipFree(d->d_hs); d->d_hs = NULL; d->hs_capacity = 0;
+        if(hipMalloc(&d->d_hs, need*sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        d->hs_capacity = need;
+    }
+    if(!d->d_hs_cursor)
+    {
+        HZ_CHECK(hipMalloc(&d->d_hs_cursor, 4*sizeof(unsigned int)));
+        HZ_CHECK(hipHostMalloc((void**)&d->h_hs_cursor, 4*sizeof(unsigned int), hipHostMallocDefault));
+        HZ_CHECK(hipEventCreateWithFlags(&d->ev_hs, hipEventDisableTiming));
+    }
+    hz_copy_pool* pool = copy_pool();
+
+    /* the sky, while the draw runs: bands of rows, every requested buffer */
+    hz_copy_pool::scatter_t sc;
+    sc.SW = SW; sc.H = H; sc.bgr = bgr; sc.ranges = ranges; sc.index = index; sc.z24 = z24; sc.bad.store(0);
+    sc.nbands = H < 64 ? 1 : 64;
+    if((size_t)SW*H*7 < ((size_t)8 << 20)) sc.nbands = 1;
+    sc.band_rows = (H + sc.nbands-1)/sc.nbands;
+    sc.nbands = (H + sc.band_rows-1)/sc.band_rows;
+    std::vector<std::atomic<int>> band_left(sc.nbands);
+    sc.band_left = band_left.data();
+    struct { unsigned char* p; size_t px_bytes; int sky; } bufs[4];
+    int nbuf = 0;
+    if(bgr)    bufs[nbuf++] = { bgr, 3, HZ_SKY_BGR };
+    if(ranges) bufs[nbuf++] = { (unsigned char*)ranges, 4, HZ_SKY_RANGES };
+    if(index)  bufs[nbuf++] = { (unsigned char*)index, 4, HZ_SKY_INDEX };
+    if(z24)    bufs[nbuf++] = { (unsigned char*)z24, 4, HZ_SKY_Z24 };
+    hz_copy_pool::batch_t filled = { 0 };
+    for(int b=0; b<sc.nbands; b++) band_left[b].store(nbuf);
+    for(int b=0; b<sc.nbands; b++)
+    {
+        const int y0 = b*sc.band_rows, y1 = (b+1)*sc.band_rows < H ? (b+1)*sc.band_rows : H;
+        for(int k=0; k<nbuf; k++)
+        {
+            hz_copy_pool::task_t t = {};
+            t.kind = hz_copy_pool::FILL; t.dst = bufs[k].p; t.lo = (size_t)y0*SW*bufs[k].px_bytes; t.n = (size_t)(y1 - y0)*SW*bufs[k].px_bytes;
+            t.sky = bufs[k].sky; t.left = &band_left[b];
+            pool->push_task(&filled, t);
+        }
+    }
+    /* from here on the pool's tasks name this frame's variables and the caller's buffers: no return before they are done */
+    int rc = 0;
+    hipError_t err = hipSuccess;
+    const char* what = "";
+    #define HZ_TRY(call) do { if(err == hipSuccess) { err = (call); if(err != hipSuccess) what = #call; } } while(0)
+
+    if(fb_refill(d) != 0) rc = -1;
+    if(rc == 0 && rstream_after_draw(d) != 0) rc = -1;
+    unsigned int total_words = 0;
+    if(rc == 0)
+    {
+        if(prof) HZ_TRY(hipEventRecord(d->ev[4], d->rstream));
+        HZ_TRY(hipMemsetAsync(d->d_hs_cursor, 0, 4*sizeof(unsigned int), d->rstream));
+        hz_hostpack_t hp = { d->d_hs, d->d_hs_cursor, (unsigned int)d->hs_capacity, (unsigned int)(HZ_STAGE_BYTES/4), flags };
+        const dim3 grid((unsigned)((SW + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), (unsigned)((H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS));
+        unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];
+        if(err == hipSuccess)
+        {
+            if(d->env.resolve_clears)
+                hipLaunchKernelGGL(k_pack_host<true>, grid, dim3(64*HZ_BLOB_ROWS), 0, d->rstream, d->d_fb, hp, (const float*)(ranges ? d->d_tanel : NULL),
+                                   SW, H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride, qa, qb);
+            else
+                hipLaunchKernelGGL(k_pack_host<false>, grid, dim3(64*HZ_BLOB_ROWS), 0, d->rstream, d->d_fb, hp, (const float*)(ranges ? d->d_tanel : NULL),
+                                   SW, H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride, (unsigned int*)NULL, (unsigned int*)NULL);
+            HZ_TRY(hipGetLastError());
+        }
+        if(err == hipSuccess && d->env.resolve_clears && fb_mark_consumed(d) != 0) rc = -1;
+        if(prof) { HZ_TRY(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
+        HZ_TRY(hipMemcpyAsync(d->h_hs_cursor, d->d_hs_cursor, 4*sizeof(unsigned int), hipMemcpyDeviceToHost, d->rstream));
+        HZ_TRY(hipEventRecord(d->ev_hs, d->rstream));
+        HZ_TRY(hipEventSynchronize(d->ev_hs));
+        if(err == hipSuccess && rc == 0)
+        {
+            total_words = d->h_hs_cursor[0];
+            if(d->h_hs_cursor[2]) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: the stream of blobs overflowed (%zu words)", d->hs_capacity); rc = -1; }
+        }
+    }
+    /* the stream, chunk by chunk through the staging ring; a chunk's blobs are scattered while the next chunks travel */
+    const size_t chunk_words = HZ_STAGE_BYTES/4;
+    const size_t nc = (err == hipSuccess && rc == 0) ? ((size_t)total_words + chunk_words-1)/chunk_words : 0;
+    std::vector<hz_copy_pool::batch_t> done(nc);
+    std::vector<std::vector<size_t>> offs(nc);
+    for(size_t k=0; k<nc; k++) done[k].pending = 0;
+    size_t issued = 0;
+    for(size_t k=0; k<nc && err == hipSuccess && rc == 0; k++)
+    {
+        for(; issued < nc && issued < k + HZ_STAGE_SLOTS - 2 && err == hipSuccess; issued++)
+        {
+            const int slot = (int)(issued % HZ_STAGE_SLOTS);
+            if(issued >= HZ_STAGE_SLOTS) pool->wait(&done[issued - HZ_STAGE_SLOTS]);
+            hipStream_t cs = d->cstream[issued % HZ_COPY_STREAMS];
+            const size_t w0 = issued*chunk_words, w1 = w0 + chunk_words < total_words ? w0 + chunk_words : total_words;
+            HZ_TRY(hipMemcpyAsync(d->h_stage[slot], d->d_hs + w0, (w1 - w0)*sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+            HZ_TRY(hipEventRecord(d->ev_stage[slot], cs));
+        }
+        const int slot = (int)(k % HZ_STAGE_SLOTS);
+        HZ_TRY(hipEventSynchronize(d->ev_stage[slot]));
+        if(err != hipSuccess) break;
+        const size_t w0 = k*chunk_words, nw = (w0 + chunk_words < total_words ? chunk_words : total_words - w0);
+        const uint32_t* chunk = (const uint32_t*)d->h_stage[slot];
+        const size_t cap = nw/HZ_BLOB_HDR + 1;
+        offs[k].resize(cap);
+        const size_t nb = hz_blob_walk(chunk, nw, offs[k].data(), cap);
+        if(nb == (size_t)-1) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: chunk %zu of the stream is not a sequence of blobs", k); rc = -1; break; }
+        /* tasks of ~256 KB of blobs */
+        for(size_t b0=0; b0<nb; )
+        {
+            size_t b1 = b0 + 1;
+            while(b1 < nb && offs[k][b1] - offs[k][b0] < 65536) b1++;
+            hz_copy_pool::task_t t = {};
+            t.kind = hz_copy_pool::SCATTER; t.sc = &sc; t.chunk = chunk; t.offs = offs[k].data() + b0; t.nblobs = b1 - b0;
+            pool->push_task(&done[k], t);
+            b0 = b1;
+        }
+    }
+    #undef HZ_TRY
+    for(size_t k=0; k<nc; k++) pool->wait(&done[k]);
+    pool->wait(&filled);
+    if(err != hipSuccess)
+    {
+        for(int k=0; k<HZ_COPY_STREAMS; k++) (void)hipStreamSynchronize(d->cstream[k]);
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: %s -> %s", what, hipGetErrorString(err));
+        fprintf(stderr, "hz_hip: %s\n", g_last_error);
+        return -1;
+    }
+    if(rc == 0 && sc.bad.load()) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: a blob does not describe pixels of this image"); rc = -1; }
+    return rc;
+}
+
 extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                                       unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
     HZ_ON_DEVICE(d);
+    /* without the sky, unless: a textured colour (three bytes per terrain pixel that are not the shade), an image too
+     * large for a blob's 16-bit row field, nothing asked for, or a switch says so */
+    if(!d->env.host_dense && !d->env.plain_copy && !(d->tex_on && bgr) && (bgr || ranges || index || z24) &&
+       d->H <= 65535 && (d->col1 - d->col0) >= 1)
+    {
+        if(ensure_staging(d) != 0) return -1;
+        std::lock_guard<std::mutex> one(copy_pool()->busy);
+        const int rc = resolve_to_host_sparse(d, view, tanel, bgr, ranges, index, z24);
+        if(rc <= 0) return rc;
+        /* (1: no room for the stream - the dense path) */
+    }
     if(ensure_out_buffers(d, bgr != NULL, ranges != NULL, index != NULL, z24 != NULL) != 0) return -1;
     if(ensure_staging(d) != 0) return -1;
     const int SW = d->col1 - d->col0;
