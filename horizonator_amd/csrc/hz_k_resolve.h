@@ -165,8 +165,8 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
  * range, computed here exactly as k_resolve4 computes it - and the host threads put them in their places between
  * the sky constants they filled in while the draw was running.
  * One workgroup per blob, one wave per row, the tile's words kept in registers between the count and the write-out
- * (as k_pack_sparse); a blob takes its place in the stream with one compare-and-swap that also keeps blobs from
- * straddling the chunks the stream travels in. */
+ * (as k_pack_sparse); a blob takes its place in the stream with one atomic add (and another if the place straddles
+ * two of the chunks the stream travels in). */
 struct hz_hostpack_t
 {
     uint32_t*     out;              /* the stream                                                              */
@@ -233,23 +233,18 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const flo
         {
             uint32_t size = HZ_BLOB_HDR + (uint32_t)(HZ_BLOB_ROWS*mw) + total*words_per_pixel + ((o.flags & HZ_BLOB_RED) ? (total + 3u) >> 2 : 0u);
             size = (size + 3u) & ~3u;
-            uint32_t old = __hip_atomic_load(&o.cursor[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            /* Its place in the stream: one atomic add.  (A compare-and-swap that also stepped over chunk boundaries was
+             * tried first: with two thousand workgroups after the one word, one CAS succeeds per round trip to the atomic
+             * unit and the rest start over - 9 ms for 4143 blobs.)  A place that straddles a chunk boundary is given up -
+             * marked as a void the reader steps over, hz_scatter.c - and another is taken. */
             for(;;)
             {
-                const uint32_t room = o.chunk_words - old % o.chunk_words;
-                const bool skip = size > room;                                      /* the rest of this chunk stays empty */
-                const uint32_t at = skip ? old + room : old;
+                const uint32_t at = atomicAdd(&o.cursor[0], size);
                 if((unsigned long long)at + size > o.capacity) { atomicExch(&o.cursor[2], 1u); break; }
-                const uint32_t seen = atomicCAS(&o.cursor[0], old, at + size);
-                if(seen == old)
-                {
-                    if(skip) o.out[old] = 0xFFFFFFFFu;                              /* "no further blob in this chunk" */
-                    atomicAdd(&o.cursor[1], 1u);
-                    start = at;
-                    break;
-                }
-                old = seen;
+                if(at / o.chunk_words == (at + size - 1u) / o.chunk_words) { start = at; break; }
+                o.out[at] = HZ_BLOB_VOID; o.out[at + 1] = size;
             }
+            if(start != HP_NONE) atomicAdd(&o.cursor[1], 1u);
             if(start != HP_NONE)
             {
                 uint32_t* b = o.out + start;

@@ -31,6 +31,7 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -112,6 +113,7 @@ struct hz_env_t
     int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
     int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
     int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
+    int    host_times;              /* HZ_HOST_TIMES=1 (diagnostics): hz_hip_resolve_to_host says on stderr where a call's time went */
     int    host_dense;              /* HZ_HOST_DENSE=1: results for host memory travel whole (every pixel, as before round 4) instead of without the sky */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
@@ -145,6 +147,7 @@ static hz_env_t read_env(void)
     e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
     e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
     e.host_dense       = env_int("HZ_HOST_DENSE", 0) != 0;
+    e.host_times       = env_int("HZ_HOST_TIMES", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
@@ -1531,11 +1534,11 @@ static int ensure_out_buffers(hz_dev_t* d, bool bgr, bool ranges, bool index, bo
 struct hz_copy_pool
 {
     struct batch_t { int pending; };
-    /* what the blobs of a panorama are scattered into (hz_scatter.c), and the bands of rows the sky was filled in by:
-     * a blob waits until the fill of its rows is done (band_left: fill tasks of band b still queued or running) */
+    /* what the blobs of a panorama are scattered into (hz_scatter.c), and how far the sky is: the buffers are
+     * filled in bands of band_rows rows, band_left[b] = fill tasks of band b not yet finished */
     struct scatter_t
     {
-        int SW, H, band_rows, nbands;
+        int SW, H, band_rows;
         unsigned char* bgr; float* ranges; int32_t* index; uint32_t* z24;
         std::atomic<int>* band_left;
         std::atomic<int> bad;
@@ -1545,7 +1548,7 @@ struct hz_copy_pool
     {
         int kind;
         unsigned char* dst; const unsigned char* src; size_t n;     /* COPY: dst[0..n) = src[0..n); MAP: the pages of dst[0..n); FILL: bytes [lo, lo+n) of dst */
-        size_t lo; int sky; std::atomic<int>* left;                /* FILL: which constants (HZ_SKY_*), and the band counter it reports to */
+        size_t lo; int sky; std::atomic<int>* left;                /* FILL: which constants (HZ_SKY_*), the band's counter */
         scatter_t* sc; const uint32_t* chunk; const size_t* offs; size_t nblobs;     /* SCATTER: blobs chunk + offs[0..nblobs) */
         batch_t* batch;
     };
@@ -1600,11 +1603,13 @@ struct hz_copy_pool
                 for(size_t k=0; k<t.nblobs; k++)
                 {
                     const uint32_t* blob = t.chunk + t.offs[k];
-                    /* the sky of these rows first.  (Fill tasks were all queued before the first scatter task: whatever is
-                     * left of a band is running on another thread right now - a short wait, never a deadlock.) */
+                    /* The terrain goes on top of the sky, which has to be there first.  With buffers the caller keeps it
+                     * is, long before the first chunk arrives; pages fresh from the allocator are mapped by the fill's
+                     * own writes, which takes this box's kernel 4 ms for 448 MB however many threads ask - so a blob
+                     * waits for the band(s) of its rows only.  (The queue is first in first out: when a scatter task
+                     * runs, every fill task has been taken by some thread - the wait is for threads that are working.) */
                     const int yo = (int)(blob[0] & 0xFFFFu);
-                    const int b0 = yo / t.sc->band_rows, b1 = (yo + HZ_BLOB_ROWS - 1) / t.sc->band_rows;
-                    for(int b=b0; b<=b1 && b<t.sc->nbands; b++)
+                    for(int b = yo/t.sc->band_rows; b <= (yo + HZ_BLOB_ROWS-1)/t.sc->band_rows && (size_t)b*t.sc->band_rows < (size_t)t.sc->H; b++)
                         while(t.sc->band_left[b].load(std::memory_order_acquire) > 0) std::this_thread::yield();
                     if(hz_blob_scatter(blob, t.sc->SW, t.sc->H, t.sc->bgr, t.sc->ranges, t.sc->index, t.sc->z24) != 0) t.sc->bad.store(1);
                 }
@@ -1629,13 +1634,17 @@ struct hz_copy_pool
         }
         cv_work.notify_all();
     }
-    void push_task(batch_t* b, const task_t& t0)
+    /* several tasks of one batch at once (one trip through the lock) */
+    void push_tasks(batch_t* b, std::vector<task_t>& ts)
     {
-        task_t t = t0; t.batch = b;
-        std::lock_guard<std::mutex> lk(m);
-        q.push_back(t);
-        b->pending++;
-        cv_work.notify_one();
+        if(ts.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for(task_t& t : ts) { t.batch = b; q.push_back(t); }
+            b->pending += (int)ts.size();
+        }
+        cv_work.notify_all();
+        ts.clear();
     }
     void wait(batch_t* b)
     {
@@ -1660,10 +1669,13 @@ static hz_copy_pool* copy_pool()
     std::lock_guard<std::mutex> g(m);
     if(!pool)
     {
-        int n = 12;
+        /* 24: a 16000x4000 panorama into kept buffers takes 5.6 / 4.9 / 4.2 ms with 8 / 12 / 24 threads on the 2 x 64-core
+         * host of an 8-GPU node (profiles/r4_host_inclusive.txt); at most an eighth of the machine's hardware threads, so
+         * that eight processes, one per GPU, do not get in each other's way */
+        const unsigned hw = std::thread::hardware_concurrency();
+        int n = hw >= 32 ? (int)(hw/8 < 24 ? hw/8 : 24) : 4;
         const char* e = getenv("HZ_COPY_THREADS");
         if(e && atoi(e) > 0) n = atoi(e);
-        const unsigned hw = std::thread::hardware_concurrency();
         if(hw && (unsigned)n > hw) n = (int)hw;
         pool = new hz_copy_pool(n);
     }
@@ -1798,16 +1810,14 @@ static int resolve_to_host_sparse(hz_dev_t* d, const hz_view_t* view, const floa
         HZ_CHECK(hipEventCreateWithFlags(&d->ev_hs, hipEventDisableTiming));
     }
     hz_copy_pool* pool = copy_pool();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_known = 0, t_first = 0, t_arrived = 0, t_sky = 0;
 
-    /* the sky, while the draw runs: bands of rows, every requested buffer */
+    /* the sky, while the draw runs: every requested buffer, in pieces of ~4 MB.  (This box's cores fill 448 MB in
+     * 1.2-1.5 ms with 12 threads' streaming stores - tools/hostfill_bench.c -, about what the draw takes.) */
     hz_copy_pool::scatter_t sc;
     sc.SW = SW; sc.H = H; sc.bgr = bgr; sc.ranges = ranges; sc.index = index; sc.z24 = z24; sc.bad.store(0);
-    sc.nbands = H < 64 ? 1 : 64;
-    if((size_t)SW*H*7 < ((size_t)8 << 20)) sc.nbands = 1;
-    sc.band_rows = (H + sc.nbands-1)/sc.nbands;
-    sc.nbands = (H + sc.band_rows-1)/sc.band_rows;
-    std::vector<std::atomic<int>> band_left(sc.nbands);
-    sc.band_left = band_left.data();
     struct { unsigned char* p; size_t px_bytes; int sky; } bufs[4];
     int nbuf = 0;
     if(bgr)    bufs[nbuf++] = { bgr, 3, HZ_SKY_BGR };
@@ -1815,18 +1825,24 @@ static int resolve_to_host_sparse(hz_dev_t* d, const hz_view_t* view, const floa
     if(index)  bufs[nbuf++] = { (unsigned char*)index, 4, HZ_SKY_INDEX };
     if(z24)    bufs[nbuf++] = { (unsigned char*)z24, 4, HZ_SKY_Z24 };
     hz_copy_pool::batch_t filled = { 0 };
-    for(int b=0; b<sc.nbands; b++) band_left[b].store(nbuf);
-    for(int b=0; b<sc.nbands; b++)
+    std::vector<hz_copy_pool::task_t> tasks;
+    sc.band_rows = (int)(((size_t)4 << 20)/((size_t)SW*4) + 1);
+    const int nbands = (H + sc.band_rows-1)/sc.band_rows;
+    std::vector<std::atomic<int>> band_left(nbands);
+    sc.band_left = band_left.data();
+    for(int b=0; b<nbands; b++)
     {
-        const int y0 = b*sc.band_rows, y1 = (b+1)*sc.band_rows < H ? (b+1)*sc.band_rows : H;
+        const int y0 = b*sc.band_rows, y1 = y0 + sc.band_rows < H ? y0 + sc.band_rows : H;
+        band_left[b].store(nbuf);
         for(int k=0; k<nbuf; k++)
         {
             hz_copy_pool::task_t t = {};
             t.kind = hz_copy_pool::FILL; t.dst = bufs[k].p; t.lo = (size_t)y0*SW*bufs[k].px_bytes; t.n = (size_t)(y1 - y0)*SW*bufs[k].px_bytes;
             t.sky = bufs[k].sky; t.left = &band_left[b];
-            pool->push_task(&filled, t);
+            tasks.push_back(t);
         }
     }
+    pool->push_tasks(&filled, tasks);
     /* from here on the pool's tasks name this frame's variables and the caller's buffers: no return before they are done */
     int rc = 0;
     hipError_t err = hipSuccess;
@@ -1858,6 +1874,7 @@ static int resolve_to_host_sparse(hz_dev_t* d, const hz_view_t* view, const floa
         HZ_TRY(hipMemcpyAsync(d->h_hs_cursor, d->d_hs_cursor, 4*sizeof(unsigned int), hipMemcpyDeviceToHost, d->rstream));
         HZ_TRY(hipEventRecord(d->ev_hs, d->rstream));
         HZ_TRY(hipEventSynchronize(d->ev_hs));
+        t_known = since();
         if(err == hipSuccess && rc == 0)
         {
             total_words = d->h_hs_cursor[0];
@@ -1868,9 +1885,11 @@ static int resolve_to_host_sparse(hz_dev_t* d, const hz_view_t* view, const floa
     const size_t chunk_words = HZ_STAGE_BYTES/4;
     const size_t nc = (err == hipSuccess && rc == 0) ? ((size_t)total_words + chunk_words-1)/chunk_words : 0;
     std::vector<hz_copy_pool::batch_t> done(nc);
-    std::vector<std::vector<size_t>> offs(nc);
     for(size_t k=0; k<nc; k++) done[k].pending = 0;
-    size_t issued = 0;
+    /* (where the blobs of every chunk start: one array for the whole stream) */
+    std::vector<size_t> offs(nc ? (size_t)d->h_hs_cursor[1] + 1 : 0);
+    size_t issued = 0, first = 0, noffs = 0;
+    double t_waited = 0;
     for(size_t k=0; k<nc && err == hipSuccess && rc == 0; k++)
     {
         for(; issued < nc && issued < k + HZ_STAGE_SLOTS - 2 && err == hipSuccess; issued++)
@@ -1883,28 +1902,39 @@ static int resolve_to_host_sparse(hz_dev_t* d, const hz_view_t* view, const floa
             HZ_TRY(hipEventRecord(d->ev_stage[slot], cs));
         }
         const int slot = (int)(k % HZ_STAGE_SLOTS);
+        const double t_w0 = since();
         HZ_TRY(hipEventSynchronize(d->ev_stage[slot]));
         if(err != hipSuccess) break;
+        t_waited += since() - t_w0;
+        if(k == 0) t_first = since();
+        if(k == nc-1) t_arrived = since();
         const size_t w0 = k*chunk_words, nw = (w0 + chunk_words < total_words ? chunk_words : total_words - w0);
         const uint32_t* chunk = (const uint32_t*)d->h_stage[slot];
-        const size_t cap = nw/HZ_BLOB_HDR + 1;
-        offs[k].resize(cap);
-        const size_t nb = hz_blob_walk(chunk, nw, offs[k].data(), cap);
-        if(nb == (size_t)-1) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: chunk %zu of the stream is not a sequence of blobs", k); rc = -1; break; }
+        size_t* const o = offs.data() + noffs;
+        const size_t nb = hz_blob_walk(chunk, nw, first, o, offs.size() - noffs, &first);
+        if(nb == (size_t)-1 || nb > offs.size() - noffs) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: chunk %zu of the stream is not a sequence of blobs", k); rc = -1; break; }
+        noffs += nb;
         /* tasks of ~256 KB of blobs */
         for(size_t b0=0; b0<nb; )
         {
             size_t b1 = b0 + 1;
-            while(b1 < nb && offs[k][b1] - offs[k][b0] < 65536) b1++;
+            while(b1 < nb && o[b1] - o[b0] < 65536) b1++;
             hz_copy_pool::task_t t = {};
-            t.kind = hz_copy_pool::SCATTER; t.sc = &sc; t.chunk = chunk; t.offs = offs[k].data() + b0; t.nblobs = b1 - b0;
-            pool->push_task(&done[k], t);
+            t.kind = hz_copy_pool::SCATTER; t.sc = &sc; t.chunk = chunk; t.offs = o + b0; t.nblobs = b1 - b0;
+            tasks.push_back(t);
             b0 = b1;
         }
+        pool->push_tasks(&done[k], tasks);
     }
     #undef HZ_TRY
-    for(size_t k=0; k<nc; k++) pool->wait(&done[k]);
     pool->wait(&filled);
+    t_sky = since();
+    for(size_t k=0; k<nc; k++) pool->wait(&done[k]);
+    if(d->env.host_times)
+        fprintf(stderr, "hz_hip_resolve_to_host: %.1f MB of blobs (%u) for %.1f MB of results; ms since the call: stream complete on the device %.2f, "
+                        "first chunk here %.2f, last chunk here %.2f (%.2f of that spent waiting for chunks), sky filled in by %.2f at the latest, everything in place %.2f\n",
+                4e-6*total_words, d->h_hs_cursor ? d->h_hs_cursor[1] : 0u, 1e-6*(double)SW*H*((bgr ? 3 : 0) + (ranges ? 4 : 0) + (index ? 4 : 0) + (z24 ? 4 : 0)),
+                t_known, t_first, t_arrived, t_waited, t_sky, since());
     if(err != hipSuccess)
     {
         for(int k=0; k<HZ_COPY_STREAMS; k++) (void)hipStreamSynchronize(d->cstream[k]);

@@ -11,14 +11,15 @@
  *
  * A blob = the terrain pixels of up to 4 image rows x up to 2048 columns, uint32 words:
  *   [0]     first row (top row = 0) | flags << 16   (HZ_BLOB_RANGES | _INDEX | _Z24 | _RED: the arrays it carries)
- *           0xFFFFFFFF: no further blob in this chunk of the stream
  *   [1]     first column     [2..5] terrain pixels T0..T3 of its four rows     [6] size of the blob in words
  *   [7]     columns n (<= 2048)
  *   then    4 x ceil(n/32) mask words (row after row; bit c%32 of word c/32: column c shows terrain)
  *   then    per carried array T0+T1+T2+T3 words, row after row, left to right: float32 ranges, int32 index,
  *           uint32 z24 - and last the shades, one BYTE per terrain pixel (padded to a word)
- * Blobs of tiles without terrain are not sent.  The stream is cut into chunks of HZ_STAGE_BYTES; no blob
- * straddles a chunk boundary.
+ * Blobs of tiles without terrain are not sent.  The stream travels in chunks of HZ_STAGE_BYTES and no blob
+ * straddles a chunk boundary: where a blob would have (the writers take their places with an atomic add), the
+ * stream holds a void instead - word [0] = HZ_BLOB_VOID, word [1] = its length in words - which may reach into
+ * the next chunk.
  */
 #include <stddef.h>
 #include <stdint.h>
@@ -60,19 +61,32 @@ void hz_sky_fill(unsigned char* buf, size_t lo, size_t hi, int kind)
     _mm_sfence();
 }
 
-/* the blobs of one chunk of the stream: their offsets (in words) into `offsets`, at most `max`; returns how many
- * there are, or (size_t)-1 if the chunk is not a sequence of blobs */
-size_t hz_blob_walk(const uint32_t* chunk, size_t nwords, size_t* offsets, size_t max)
+/* the blobs of one chunk of the stream, which starts `first` words into the chunk (what a void at the end of the
+ * chunk before reached over): their offsets (in words) into `offsets`, at most `max`; *beyond = how far the last
+ * void reaches past this chunk's nwords (the next chunk's `first`).  Returns how many blobs there are, or
+ * (size_t)-1 if the chunk is not a sequence of blobs and voids. */
+size_t hz_blob_walk(const uint32_t* chunk, size_t nwords, size_t first, size_t* offsets, size_t max, size_t* beyond)
 {
-    size_t n = 0, at = 0;
-    while(at + 8 <= nwords && chunk[at] != 0xFFFFFFFFu)
+    size_t n = 0, at = first;
+    *beyond = 0;
+    while(at < nwords)
     {
+        if(at + 2 > nwords) return (size_t)-1;
+        if(chunk[at] == HZ_BLOB_VOID)
+        {
+            const size_t size = chunk[at + 1];
+            if(size < 4 || (size & 3)) return (size_t)-1;
+            at += size;
+            continue;
+        }
+        if(at + HZ_BLOB_HDR > nwords) return (size_t)-1;
         const size_t size = chunk[at + 6];
-        if(size < 8 || (size & 3) || at + size > nwords) return (size_t)-1;
+        if(size < HZ_BLOB_HDR || (size & 3) || at + size > nwords) return (size_t)-1;
         if(n < max) offsets[n] = at;
         n++;
         at += size;
     }
+    *beyond = at - nwords;
     return n;
 }
 

@@ -18,7 +18,7 @@ def _lib():
     lib.hz_sky_fill.restype = None
     lib.hz_sky_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
     lib.hz_blob_walk.restype = C.c_size_t
-    lib.hz_blob_walk.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.hz_blob_walk.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.hz_blob_scatter.restype = C.c_int
     lib.hz_blob_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
@@ -100,13 +100,24 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags):
             if t.any():
                 blobs.append(_blob(yo0, x0, n, t, cut(rng, 0), cut(idx, 0), cut(z24, 0), cut(red, 0), flags))
     assert len(blobs) < ((H + 3) // 4) * 3          # (the empty tile sent nothing)
-    # a chunk: the blobs, an end marker, rubbish behind it
-    chunk = np.concatenate(blobs + [np.array([0xFFFFFFFF, 1, 2, 3], np.uint32)])
+    # a chunk: 12 words that a void of the chunk before reaches over, the blobs with a void of 8 words between the first two,
+    # and a void at the end that reaches 20 words beyond the chunk
+    VOID = 0xFFFFFFFE
+    lead = np.array([7] * 12, np.uint32)
+    gap = np.array([VOID, 8, 9, 9, 9, 9, 9, 9], np.uint32)
+    tail = np.array([VOID, 24, 5, 5], np.uint32)
+    chunk = np.concatenate([lead, blobs[0], gap] + blobs[1:] + [tail])
     offs = np.zeros(len(blobs) + 4, np.uint64)
-    assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk), offs.ctypes.data, len(offs)) == len(blobs)
-    assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk) - 5, offs.ctypes.data, len(offs)) == 2**64 - 1       # a cut-off blob is not a blob
-    at = 0
+    beyond = C.c_size_t(99)
+    assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk), 12, offs.ctypes.data, len(offs), C.byref(beyond)) == len(blobs)
+    assert beyond.value == 20
+    assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk) - 9, 12, offs.ctypes.data, len(offs), C.byref(beyond)) == 2**64 - 1       # a cut-off blob is not a blob
+    assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk), 0, offs.ctypes.data, len(offs), C.byref(beyond)) == 2**64 - 1           # nor is rubbish
+    assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk), 12, offs.ctypes.data, len(offs), C.byref(beyond)) == len(blobs)
+    at = 12
     for k, b in enumerate(blobs):
+        if k == 1:
+            at += 8
         assert int(offs[k]) == at
         rc = lib.hz_blob_scatter(chunk[at:].ctypes.data, SW, H,
                                  got["bgr"].ctypes.data if flags & RED else None, got["ranges"].ctypes.data if flags & RANGES else None,
