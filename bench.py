@@ -72,6 +72,10 @@ def parse():
 
 def main():
     args = parse()
+    # never a hang: whatever blocks (a collective that never completes, a stream behind it), the process says where and
+    # leaves with a non-zero code - long before the driver's own limit
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("BENCH_DEADLINE_S", "1500")), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,13 +108,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    import datetime
+    # a collective that does not complete within two minutes is an error with RCCL's text, not a wait for the driver's
+    # half-hour limit: the watchdog of the process group then takes this process down (non-zero), torchrun the others
+    pg_timeout = datetime.timedelta(seconds=float(os.environ.get("BENCH_COLLECTIVE_TIMEOUT_S", "120")))
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only does dmabuf IPC
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
     elif args.exchange_anyway and args.backend == "nccl":
         # the one rank there is, as an RCCL process group of its own: the strips then travel through dist.gather /
         # dist.all_reduce like those of N ranks do (the same calls, the same stream ordering), not through a copy
@@ -119,7 +128,7 @@ def main():
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev, timeout=pg_timeout)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -165,16 +174,19 @@ def main():
     # cells, cells are not square in metres, corners are further away than edges): the layout
     # gives every rank the same share of the work behind the columns - first from the geometry
     # (sharding.azimuth_density), then from what the ranks measure on this scene.  Rank 0 draws a
-    # bit less: it also converts the gathered strips (0.31 ms for 64 Mpix, on the library's second
-    # stream beside its own draw, which that slows by about 0.08 ms; a sector costs about
-    # 0.32 + 1.77*share ms: tools/sector_timing.py).
+    # bit less under --gather root0: it also converts the gathered strips (0.27 ms for 64 Mpix, on the
+    # library's conversion stream beside its own draw, which that slows by about 0.08 ms; a sector's strips
+    # back to back cost about 0.13 + 0.80*share ms: profiles/r3_sector_timing.txt).
     multi = world > 1 or args.exchange_anyway
     NBUF = 2 if multi else 1
     sparse = args.wire == "sparse"
     cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
-    rotate = args.gather == "rotate"
-    weights = gatherer_weights(world, 1.77, 0.08) if world > 1 and not rotate else None
     S = {}                                                               # the current layout and its buffers
+
+    def set_gather(mode):
+        S["rotate"] = mode == "rotate"
+        S["weights"] = gatherer_weights(world, 0.80, 0.08) if world > 1 and mode != "rotate" else None
+    set_gather(args.gather)
 
     def apply_layout(layout):
         S["layout"] = layout
@@ -200,8 +212,8 @@ def main():
         apply_layout([(0, W)])
     else:
         cos_lat = float(np.cos(np.radians(LAT)))
-        apply_layout(balanced_layout(azimuth_density(W, -180.0, 180.0, cos_lat, floor=0.1), world, weights))
-    if world == 1 or rank == 0 or rotate:
+        apply_layout(balanced_layout(azimuth_density(W, -180.0, 180.0, cos_lat, floor=0.1), world, S["weights"]))
+    if True:                                # (every rank: under --gather rotate each assembles panoramas, and both modes run)
         d_img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         d_rng = torch.empty((H, W), dtype=torch.float32, device=dev)
     pending = [None] * NBUF
@@ -250,7 +262,7 @@ def main():
             density = np.where(density > 0.0, np.clip(density, 0.5 * typical, 2.0 * typical), 0.0)
             # columns nobody drew (a rank of weight 0): as costly as the average drawn column
             density[density == 0.0] = density[density > 0.0].mean()
-            apply_layout(balanced_layout(density, world, weights))
+            apply_layout(balanced_layout(density, world, S["weights"]))
 
     def exchange():
         """N > 1, sparse strips: the ranks agree ONCE per layout on how many words a strip sends
@@ -263,7 +275,7 @@ def main():
                 h.sync()
                 words += int(S["d_pk"][0][0].item())
             cap = agree_on_capacity(words, S["HDR"], S["FULL"], cdev)
-            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF, any_dst=rotate,
+            S["ex"] = StripExchange(cap, S["FULL"], S["HDR"], cdev, nslots=NBUF, any_dst=S["rotate"],
                                     collectives_even_alone=args.exchange_anyway and on_gpu)
             S["sent"] = [None] * NBUF
             state["wire_words"] = S["ex"].cap
@@ -314,7 +326,7 @@ def main():
             t0 = time.perf_counter(); slot = state["k"] % NBUF; finish(slot); t1 = time.perf_counter()
             host_us["finish"] += (t1 - t0) * 1e6
         slot = state["k"] % NBUF
-        dst = state["k"] % world if rotate else 0      # the rank that gathers and converts this panorama
+        dst = state["k"] % world if S["rotate"] else 0      # the rank that gathers and converts this panorama
         state["k"] += 1
         if not multi:
             # no wait in between: the library overlaps the readback conversion and the clear of
@@ -456,6 +468,46 @@ def main():
                 "bgr_sha_is_llvmpipe": (hashlib.sha256(img.tobytes()).hexdigest() == g["bgr_sha256"]) if g else None}
 
     last = keep_last(args.zfar)
+
+    # N > 1: the line's `value` is the throughput of --gather's mode (default rotate: panorama k is assembled on rank
+    # k mod N, the panoramas stay spread over the ranks).  Beside it: the other mode (root0: north_star's "gather of the
+    # strips" to ONE place, every panorama assembled on rank 0), and what ONE panorama takes at this N from the call to
+    # the assembled panorama on rank 0 - a draw that is waited for, its gather, its conversion, nothing to overlap with.
+    multi_extra = {}
+    if world > 1 or args.exchange_anyway:
+        def relayout():
+            cos_lat = float(np.cos(np.radians(LAT)))
+            apply_layout(balanced_layout(azimuth_density(W, -180.0, 180.0, cos_lat, floor=0.1), world, S["weights"]))
+            h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+            if world > 1:
+                rebalance()
+        other = "root0" if args.gather == "rotate" else "rotate"
+        set_gather(other)
+        relayout()
+        n2 = max(4, args.steps // 2)
+        dt2, _ = timed(args.zfar, n2, 2)
+        multi_extra["gather_" + other] = {"value": W * H * n2 / dt2 / 1e6, "unit": "Mpix/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+                                          "sector_widths": [c1 - c0 for c0, c1 in S["layout"]],
+                                          "gathered_panorama_equals_single_gpu_render": verify()}
+        if other != "root0":
+            set_gather("root0")
+            relayout()
+        ts = []
+        for k in range(6):
+            drain()
+            fence()
+            t0 = time.perf_counter()
+            step()
+            drain()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts.append(float(t.item()))
+        multi_extra["single_panorama_latency_ms"] = {"value": float(np.median(ts[1:])) * 1e3, "samples_ms": [x * 1e3 for x in ts],
+                                                     "what": "one panorama at this N, gathered to rank 0 and converted there, from the call to the "
+                                                             "assembled BGR8 + float32 range in rank 0's HBM; nothing queued before or behind it "
+                                                             "(max over ranks, median of 5 after one warm-up)"}
     ms_per_step = dt / args.steps * 1e3
     value = W * H * args.steps / dt / 1e6
 
@@ -620,7 +672,7 @@ def main():
                 "sector_widths": [c1 - c0 for c0, c1 in S["layout"]],
                 "wire_bytes_per_rank": (4 * state["wire_words"] if sparse else 4 * H * S["SW_max"]) if multi else 0,
                 "strip_resends": (S["ex"].resends if multi and sparse and S.get("ex") is not None else 0),
-                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to " + ("rank k mod N for panorama k" if rotate else "rank 0") + ", overlapped with the next render; the gathering rank converts them to BGR8 + float32 range" if world > 1 else ""),
+                "parallelism": f"azimuth sectors x{world}" + (" + " + ("RCCL" if args.backend == "nccl" else "gloo (diagnostic, through host memory)") + " gather of " + ("sparse (terrain pixels only + mask)" if sparse else "packed") + " depth+shade strips (4 B/pixel) to " + ("rank k mod N for panorama k" if args.gather == "rotate" else "rank 0") + ", overlapped with the next render; the gathering rank converts them to BGR8 + float32 range" if world > 1 else ""),
                 "gather": args.gather if multi else None,
                 "raster": {0: "auto", 1: "scatter", 2: "march"}.get(args.raster, f"experiment {args.raster}"),
                 "outputs": "BGR8 + float32 range, device-resident",
@@ -648,6 +700,7 @@ def main():
             line["scenes"] = scene_recs
         if verified is not None:
             line["gathered_panorama_equals_single_gpu_render"] = verified
+        line.update(multi_extra)
         if last is not None:
             line["parity"] = {"bgr": last.get("bgr_is_oracle"), "ranges": last.get("ranges_is_oracle"),
                               "bgr_sha_is_llvmpipe": last["bgr_sha_is_llvmpipe"],
@@ -663,6 +716,7 @@ def main():
         gates = [line.get("parity", {}).get(k) for k in ("bgr", "ranges", "bgr_sha_is_llvmpipe")]
         gates.append(extra.get("zfar_40km", {}).get("parity", {}).get("bgr_sha_is_llvmpipe"))
         gates.append(line.get("gathered_panorama_equals_single_gpu_render"))
+        gates += [v.get("gathered_panorama_equals_single_gpu_render") for k, v in multi_extra.items() if k.startswith("gather_")]
         gates.append(host_incl["equals_device_render"] if host_incl is not None else None)
         failed = any(g is False for g in gates)
     h.close()

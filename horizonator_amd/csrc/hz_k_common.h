@@ -81,8 +81,19 @@ __device__ static inline void hz_fb_min(unsigned long long* fb, const hz_params_
         return;
     }
 #endif
-    p.touched[(size_t)py*p.seg_stride + (x >> HZ_SEG_LOG2)] = 1;
-    atomicMin(&fb[(size_t)py*p.SW + x], key);
+    /* A framebuffer is smaller than 4 GB (hz_hip_create: images of up to 2^29 pixels; the reference's own limit,
+     * GL_MAX_RENDERBUFFER_SIZE squared on llvmpipe, is 2^28): byte offsets in 32 bits, so that each of the two
+     * accesses is one multiply-add and a shift on top of a scalar base - the 64-bit form is a 64-bit multiply-add,
+     * two 64-bit shift-adds and a sign extension per address, for every fragment of the draw. */
+    const uint32_t ot = (uint32_t)py*(uint32_t)p.seg_stride + ((uint32_t)x >> HZ_SEG_LOG2);
+    const uint32_t ob = ((uint32_t)py*(uint32_t)p.SW + (uint32_t)x) << 3;
+    *(p.touched + ot) = 1;
+    atomicMin((unsigned long long*)((char*)fb + ob), key);
+}
+/* the framebuffer word of pixel (px, py), for the reads in front of an atomic */
+__device__ static inline const unsigned long long* hz_fb_word(const unsigned long long* fb, const hz_params_t& p, int px, int py)
+{
+    return (const unsigned long long*)((const char*)fb + (((uint32_t)py*(uint32_t)p.SW + (uint32_t)(px - p.col0)) << 3));
 }
 
 /* a set-up triangle as it travels between phases: through LDS inside
@@ -171,6 +182,38 @@ __device__ static inline uint32_t hz_big_chunks(int bw, int bh)
 /* ------------------------------------------------------------------------ */
 /* device helpers                                                            */
 
+/* Inclusive prefix sum / running maximum over the 64 lanes, every lane active.  DPP: within each row of 16 lanes by
+ * row_shr 1, 2, 4, 8 (a lane without a source takes `old` = 0, the identity of both), then lane 15 of rows 0 and 2
+ * into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31) - six VALU operations with the
+ * neighbour read fused in, where __shfl_up() is six ds_bpermute through the LDS crossbar, each with its address
+ * arithmetic and a select (24 against 4 cycles apiece: profiles/valu_issue.json). */
+#define HZ_DPP(v, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xF, false))
+__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
+{
+    (void)lane;
+    v += HZ_DPP(v, 0x111, 0xF);         /* row_shr:1 */
+    v += HZ_DPP(v, 0x112, 0xF);         /* row_shr:2 */
+    v += HZ_DPP(v, 0x114, 0xF);         /* row_shr:4 */
+    v += HZ_DPP(v, 0x118, 0xF);         /* row_shr:8 */
+    v += HZ_DPP(v, 0x142, 0xA);         /* row_bcast:15 -> rows 1, 3 */
+    v += HZ_DPP(v, 0x143, 0xC);         /* row_bcast:31 -> rows 2, 3 */
+    return v;
+}
+__device__ static inline uint32_t mr_scan_max(uint32_t v)
+{
+    #define HZ_MAXU(a, b) ((a) > (b) ? (a) : (b))
+    uint32_t t;
+    t = HZ_DPP(v, 0x111, 0xF); v = HZ_MAXU(v, t);
+    t = HZ_DPP(v, 0x112, 0xF); v = HZ_MAXU(v, t);
+    t = HZ_DPP(v, 0x114, 0xF); v = HZ_MAXU(v, t);
+    t = HZ_DPP(v, 0x118, 0xF); v = HZ_MAXU(v, t);
+    t = HZ_DPP(v, 0x142, 0xA); v = HZ_MAXU(v, t);
+    t = HZ_DPP(v, 0x143, 0xC); v = HZ_MAXU(v, t);
+    #undef HZ_MAXU
+    return v;
+}
+
+
 /* record <- set-up triangle (planes + coverage); the box and the id are the caller's */
 __device__ static inline void hz_rec_from_tri(hz_rec_t& r, const hz_tri_t& t)
 {
@@ -200,7 +243,7 @@ __device__ static inline void hz_emit_rec(unsigned long long* fb, const hz_param
      * read the word first and leave the atomic out where the fragment cannot win */
     if(PRETEST || p.pretest_march)
     {
-        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        if(key < __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             hz_fb_min<HZ_WHO_MARCH>(fb, p, px, py, key);
     }
     else
@@ -221,7 +264,7 @@ __device__ static inline void hz_emit_t(unsigned long long* fb, const hz_params_
     const unsigned long long key = hz_pack(zi, prim, r8);
     if(PRETEST)
     {
-        if(key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        if(key < __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             hz_fb_min(fb, p, px, py, key);
     }
     else

@@ -141,13 +141,7 @@ __device__ static inline bool hiz_chunk_hidden(const hz_tri_t& tri, const hz_par
             const uint32_t v = l2[(size_t)ty*w2 + (tx0 + t)];
             zs = zs > v ? zs : v;
         }
-    #pragma unroll
-    for(int step=32; step>=1; step>>=1)
-    {
-        const uint32_t o = (uint32_t)__shfl_xor((int)zs, step);
-        zs = zs > o ? zs : o;
-    }
-    zs = (uint32_t)__builtin_amdgcn_readfirstlane((int)zs) >> 8;
+    zs = (uint32_t)__builtin_amdgcn_readlane((int)mr_scan_max(zs), 63) >> 8;      /* (the largest over the wave: a running maximum's last lane) */
     uint32_t qmin;
     return hiz_rect_min_depth(tri, px0, px0 + bw - 1, y0, y1, &qmin) && qmin > zs;
 }

@@ -321,7 +321,7 @@ __device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
     const uint32_t rest  = npix > done ? npix - done : 0;
     const uint32_t incl  = mr_scan(rest, lane);
     const uint32_t excl  = incl - rest;
-    const uint32_t total = __shfl(incl, 63);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     for(uint32_t base = 0; base < total; base += 64)
     {
         const uint32_t it = base + lane;
@@ -500,7 +500,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             chunks = hz_big_chunks(r.bw, bh);
         }
         const uint32_t incl  = mr_scan(chunks, lane);
-        const uint32_t total = __shfl(incl, 63);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t nb    = (uint32_t)__popcll(bigmask);
         uint32_t rbase = 0, ibase = 0, ok = 0;
         if(lane == 0)
@@ -514,7 +514,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             if((unsigned long long)rbase + nb <= q.bigrec_capacity && (unsigned long long)ibase + total <= q.bigitem_capacity) ok = 1;
             else atomicMax(&q.counters[2], ~ibase);             /* items from here on are not valid */
         }
-        rbase = __shfl(rbase, 0); ibase = __shfl(ibase, 0); ok = __shfl(ok, 0);
+        rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase); ibase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ibase); ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
         if(is_big)
         {
             if(ok)
@@ -544,7 +544,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     {
         uint32_t mbase = 0;
         if(lane == 0) mbase = atomicAdd(&q.counters[3], (uint32_t)__popcll(midmask));
-        mbase = __shfl(mbase, 0);
+        mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)mbase);
         if(mbase + (uint32_t)__popcll(midmask) <= q.midrec_capacity)
         {
             if(is_mid)
@@ -569,7 +569,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         dbg[4] += (unsigned int)((__builtin_amdgcn_s_memtime() - t1) >> 4);
         return;
     }
-    if(dbg) { const uint32_t tot = __shfl(mr_scan(npix, lane), 63); dbg[4] += tot; }
+    if(dbg) { const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)mr_scan(npix, lane), 63); dbg[4] += tot; }
     mr_distribute(r, npix, lane, fb, p);
 }
 
@@ -581,6 +581,8 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
  * marching waves per SIMD instead of the four that 105 registers allow */
 #ifdef MR_WAVES_PER_EU
 #define MR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MR_WAVES_PER_EU, MR_WAVES_PER_EU)))
+#elif defined(MR_VGPRS)
+#define MR_OCCUPANCY __attribute__((amdgpu_num_vgpr(MR_VGPRS)))
 #else
 #define MR_OCCUPANCY
 #endif

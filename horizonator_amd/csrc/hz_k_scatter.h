@@ -226,18 +226,6 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
     }
 }
 
-/* inclusive prefix sum over the 64 lanes */
-__device__ static inline uint32_t mr_scan(uint32_t v, int lane)
-{
-    #pragma unroll
-    for(int d=1; d<64; d<<=1)
-    {
-        const uint32_t up = __shfl_up(v, d);
-        if(lane >= d) v += up;
-    }
-    return v;
-}
-
 /* 1/d for 1 <= d < 2^31 to within 2^-50 relative: v_rcp_f64's estimate and two
  * Newton steps (each squares the relative error; the estimate is good to 2^-20
  * at the very least).  Not the correctly rounded quotient - hz_floor_div() does
@@ -310,12 +298,27 @@ __device__ static inline uint32_t hz_row_span(const hz_edges_t& e, int row, int3
  * (wave prefix sum) and every lane takes one covered pixel per pass, whatever
  * the shape of the triangle - the long thin slivers next to the viewer cover a
  * quarter of their boxes. */
-__global__ __launch_bounds__(256)
+#ifndef KB_VGPRS
+#define KB_VGPRS 48
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(KB_VGPRS)))
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
            const unsigned int* __restrict__ big_counters,
            unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p, const unsigned int* tile_state)
 {
+    /* per wave: which row's span starts at pixel `base + k` of the current pass (row + 1, 0: none), and each row's
+     * first column minus its exclusive prefix (a pixel's column = its number + that).  A wave's own LDS traffic is
+     * served in program order; KB_LDS_ORDER keeps the compiler from moving or merging it across the points where one
+     * lane reads what another wrote - no barrier, no wait for the atomics in flight.  (Not `volatile` through a
+     * pointer: that loses the address space - flat loads and stores with a wait for every outstanding memory
+     * operation behind each, 660 -> 750 us for the first round's launch beside a marching kernel.) */
+    #define KB_LDS_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
+    __shared__ uint32_t s_start[256/64][64];
+    __shared__ int32_t  s_delta[256/64][64];
+    const int wv = threadIdx.x >> 6;
+    s_start[wv][threadIdx.x & 63] = 0u;
+    KB_LDS_ORDER();
     /* (tile_state: the round's triangles were binned and drawn by screen tile - hz_k_tile.h - unless there were too many) */
     if(tile_state && tile_state[0] == 0) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
@@ -353,7 +356,7 @@ void k_big(unsigned long long* __restrict__ fb,
         /* lane = pixel */
         const uint32_t incl  = mr_scan(count, lane);
         const uint32_t excl  = incl - count;
-        const uint32_t total = __shfl(incl, 63);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         /* Long spans (the triangles next to the viewer: hundreds of pixels a row): row by row, the lanes side by side
          * along the span - row and first column are scalars, no search for the row that owns a pixel (six dependent
          * ds_bpermute per pass below: 40 % of this kernel's instructions).  Worth it from an average of 48 pixels per
@@ -378,7 +381,7 @@ void k_big(unsigned long long* __restrict__ fb,
                         if(hz_tri_fragment(&tri, px, py, &zi, &r8))
                         {
                             const unsigned long long key = hz_pack(zi, prim, r8);
-                            if(!p.pretest || key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                            if(!p.pretest || key < __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                                 hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
                         }
                     }
@@ -386,18 +389,26 @@ void k_big(unsigned long long* __restrict__ fb,
             }
             continue;
         }
+        /* Which row holds pixel k?  The last non-empty row whose exclusive prefix is <= k.  (Round 3 searched for it:
+         * six dependent ds_bpermute per pass, 40 % of the kernel's instructions.)  Every row whose span starts inside
+         * the pass says so at its start's slot - distinct slots, spans of non-empty rows start at distinct pixels -,
+         * every lane reads its slot, and a running maximum over the lanes (the rows come in rising order) carries the
+         * latest start to the pixels behind it; the maximum of a pass carries over to the next. */
+        KB_LDS_ORDER();                                 /* (the reads of the item before) */
+        s_delta[wv][lane] = x0 - (int32_t)excl;
+        uint32_t carry = 0u;
         for(uint32_t base = 0; base < total; base += 64)
         {
             const uint32_t k = base + lane;
-            /* the row that holds pixel k: last lane whose exclusive prefix is <= k */
-            int own = 0;
-            #pragma unroll
-            for(int step=32; step>=1; step>>=1)
-            {
-                const uint32_t v = __shfl(excl, own + step);
-                if(v <= k) own += step;
-            }
-            const int px = __shfl(x0, own) + (int)(k - __shfl(excl, own));
+            if(count > 0u && excl - base < 64u) s_start[wv][excl - base] = (uint32_t)lane + 1u;
+            KB_LDS_ORDER();
+            uint32_t own1 = s_start[wv][lane];
+            KB_LDS_ORDER();
+            if(own1) s_start[wv][lane] = 0u;            /* (clean for the next pass, the next item) */
+            own1 = mr_scan_max(lane == 0 ? (own1 > carry ? own1 : carry) : own1);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
+            const int own = (int)own1 - 1;
+            const int px = (int)k + s_delta[wv][own & 63];
             const int py = row_first + own;
             if(k < total)
             {
@@ -407,7 +418,7 @@ void k_big(unsigned long long* __restrict__ fb,
                     const unsigned long long key = hz_pack(zi, prim, r8);
                     /* p.pretest (views with heavy overdraw, see plan_rounds): look first, and leave the atomic
                      * out where the fragment cannot win - a stale larger value only costs the atomic */
-                    if(!p.pretest || key < __hip_atomic_load(&fb[(size_t)py*p.SW + (px - p.col0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    if(!p.pretest || key < __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                         hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
                 }
             }

@@ -38,6 +38,10 @@ def test_sector_ranks_sharing_one_gpu_assemble_the_single_gpu_panorama(ranks, wi
     assert line["gathered_panorama_equals_single_gpu_render"] is True
     assert len(line["config"]["sector_widths"]) == ranks and sum(line["config"]["sector_widths"]) == 8000
     assert line["value"] > 0 and line["scaling"] == "strong"
+    # the line carries both gather modes (value: --gather's default, rotate) and the latency of one panorama at this N
+    assert line["config"]["gather"] == "rotate"
+    assert line["gather_root0"]["gathered_panorama_equals_single_gpu_render"] is True and line["gather_root0"]["value"] > 0
+    assert line["single_panorama_latency_ms"]["value"] > 0
 
 
 def test_the_rccl_shaped_exchange_with_one_rank():
