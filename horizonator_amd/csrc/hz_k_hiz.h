@@ -135,12 +135,17 @@ __device__ static inline bool hiz_chunk_hidden(const hz_tri_t& tri, const hz_par
     uint32_t zs = 0u;
     const uint32_t* l2 = hiz_level2(p);
     const size_t w2 = hiz_w2(p.SW);
+    /* (not unrolled, 32-bit offsets: the registers this takes are k_big's, two waves of which have to fit beside four marching waves) */
+    #pragma unroll 1
     for(int ty = ty0; ty <= ty1; ty++)
+    {
+        #pragma unroll 1
         for(int t = lane; t < ntx; t += 64)
         {
-            const uint32_t v = l2[(size_t)ty*w2 + (tx0 + t)];
+            const uint32_t v = l2[(uint32_t)ty*(uint32_t)w2 + (uint32_t)(tx0 + t)];
             zs = zs > v ? zs : v;
         }
+    }
     zs = (uint32_t)__builtin_amdgcn_readlane((int)mr_scan_max(zs), 63) >> 8;      /* (the largest over the wave: a running maximum's last lane) */
     uint32_t qmin;
     return hiz_rect_min_depth(tri, px0, px0 + bw - 1, y0, y1, &qmin) && qmin > zs;

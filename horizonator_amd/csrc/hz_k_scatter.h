@@ -298,10 +298,8 @@ __device__ static inline uint32_t hz_row_span(const hz_edges_t& e, int row, int3
  * (wave prefix sum) and every lane takes one covered pixel per pass, whatever
  * the shape of the triangle - the long thin slivers next to the viewer cover a
  * quarter of their boxes. */
-#ifndef KB_VGPRS
-#define KB_VGPRS 48
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(KB_VGPRS)))
+#define KB_LDS_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
+__global__ __launch_bounds__(256)
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
            const unsigned int* __restrict__ big_counters,
@@ -313,7 +311,6 @@ void k_big(unsigned long long* __restrict__ fb,
      * lane reads what another wrote - no barrier, no wait for the atomics in flight.  (Not `volatile` through a
      * pointer: that loses the address space - flat loads and stores with a wait for every outstanding memory
      * operation behind each, 660 -> 750 us for the first round's launch beside a marching kernel.) */
-    #define KB_LDS_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
     __shared__ uint32_t s_start[256/64][64];
     __shared__ int32_t  s_delta[256/64][64];
     const int wv = threadIdx.x >> 6;
