@@ -95,7 +95,47 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
         ulonglong2 k01 = { HZ_FB_CLEAR, HZ_FB_CLEAR }, k23 = k01;
         const size_t o = (size_t)yo*SW + x;
         const bool drawn = *flag != 0;          /* (the same byte for the whole wave) */
-        if(drawn)
+        if(!drawn)
+        {
+            /* Nothing was drawn into this segment - 60 % of the benchmark's: sky, without reading it, and without the
+             * hundred instructions that unpack, convert and pack four words that are known to be all ones.  (Round 3
+             * measured no gain from this: the period of a series of renders was then set by the first round's chain of
+             * kernels; now it is the marching kernel beside which this one runs, and the conversion's instructions are
+             * that kernel's.)  HZ_FRESH: the constants are made where they are stored - kept in registers across the
+             * loop they took the kernel from 44 to 58, and two of its waves no longer fitted beside four marching waves. */
+            #define HZ_FRESH(T, name, value) T name = (value); asm volatile("" : "+v"(name))
+            if(bgr)
+            {
+                /* B,G,R = 255,0,0 four times (reference horizonator-lib.c:185) */
+                HZ_FRESH(uint32_t, w0, 0xFF0000FFu); HZ_FRESH(uint32_t, w1, 0x00FF0000u); HZ_FRESH(uint32_t, w2, 0x0000FF00u);
+                uint32_t* q = (uint32_t*)(bgr + o*3);
+                if(nt) { __builtin_nontemporal_store(w0, q); __builtin_nontemporal_store(w1, q+1); __builtin_nontemporal_store(w2, q+2); }
+                else { q[0] = w0; q[1] = w1; q[2] = w2; }
+            }
+            if(index)
+            {
+                HZ_FRESH(int32_t, m, -1);
+                int32_t* q = index + o;
+                if(nt) { __builtin_nontemporal_store(m, q); __builtin_nontemporal_store(m, q+1); __builtin_nontemporal_store(m, q+2); __builtin_nontemporal_store(m, q+3); }
+                else *(int4*)q = int4{ m, m, m, m };
+            }
+            if(z24)
+            {
+                HZ_FRESH(uint32_t, m, HZ_Z24_MAX);
+                uint32_t* q = z24 + o;
+                if(nt) { __builtin_nontemporal_store(m, q); __builtin_nontemporal_store(m, q+1); __builtin_nontemporal_store(m, q+2); __builtin_nontemporal_store(m, q+3); }
+                else *(uint4*)q = uint4{ m, m, m, m };
+            }
+            if(ranges)
+            {
+                HZ_FRESH(float, m, -1.0f);
+                float* q = ranges + o;
+                if(nt) { __builtin_nontemporal_store(m, q); __builtin_nontemporal_store(m, q+1); __builtin_nontemporal_store(m, q+2); __builtin_nontemporal_store(m, q+3); }
+                else *(float4*)q = float4{ m, m, m, m };
+            }
+            #undef HZ_FRESH
+            continue;
+        }
         {
             k01 = src[0]; k23 = src[1];
             if(CLEAR)
@@ -143,12 +183,7 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
         }
         if(ranges)
         {
-            /* Segments nothing was drawn into - 60 % of the benchmark's - are sky without the terrain's arithmetic (a
-             * double-precision square root per pixel: most of this kernel's instructions).  Round 3 measured no gain from
-             * that: the period of a series was then set by the first round's chain of kernels; now it is the marching
-             * kernel beside which this one runs, and the conversion's instructions are that kernel's. */
             float4 w = { -1.0f, -1.0f, -1.0f, -1.0f };
-            if(drawn)
             {
                 const float tr = tanel[row];
                 w.x = zi[0] == HZ_Z24_MAX ? -1.0f : hz_range_from_z24(zi[0], tr, znear, zfar);
