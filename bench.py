@@ -538,9 +538,7 @@ def main():
     # what actually bounds the dominant kernel: the SIMDs' vector issue slots.
     # Recorded counters of the same workload (profiles/), set against the duration measured now.
     valu = None
-    mix = os.path.join(ROOT, "profiles", "pmc_r3_instruction_mix_cfg3.json")
-    if not os.path.exists(mix):
-        mix = os.path.join(ROOT, "profiles", "pmc_r2_instruction_mix_cfg3.json")
+    mix = next((m for m in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (4, 3, 2)) if os.path.exists(m)), "")
     if args.config == "cfg3" and args.zfar == 600000.0 and world == 1 and args.raster in (0, 2) and os.path.exists(mix):
         try:
             rec = json.load(open(mix))

@@ -102,7 +102,13 @@ def main():
     doc = {"workload": "bench.py cfg3 (7x7 SRTM3 tiles, 16000x4000, 360 degrees, zfar 600 km unless a row says otherwise), 40 renders back to back",
            "how": "python tools/experiments.py on one MI355X; every row: the environment switch (or build flag) that reproduces it",
            "rows": []}
-    for what, env, zfar, note in ROWS:
+    rows, variants = ROWS, VARIANTS
+    if os.environ.get("EXPERIMENTS_QUICK"):     # round 4: the rows that bound what the atomics cost, and the two rounds / coarse depth switches
+        keep = ("as shipped", "one round forced", "k_big: plain stores instead", "k_march: plain stores", "both: plain stores", "k_big looks before",
+                "no coarse depth in a series", "as shipped, zfar 40 km", "k_big: plain stores, zfar 40 km", "north_star's tile-binned", "the same, zfar 40 km")
+        rows = [r for r in ROWS if r[0].startswith(keep)]
+        variants = []
+    for what, env, zfar, note in rows:
         rec = {"what": what, "switch": " ".join(f"{k}={v}" for k, v in env.items()) or "-", "zfar_m": zfar or 600000.0, "note": note}
         if wrong_picture(env):
             rec["build"] = "make -C horizonator_amd/csrc HIPFLAGS_EXTRA=-DHZ_EXPERIMENTS"
@@ -111,7 +117,7 @@ def main():
             rec.update(run(env, zfar=zfar))
         doc["rows"].append(rec)
         print(what, rec.get("median_ms_per_render"), rec.get("serial"), file=sys.stderr, flush=True)
-    for what, name, flags, note in VARIANTS:
+    for what, name, flags, note in variants:
         rec = {"what": what, "switch": "make -C horizonator_amd/csrc HIPFLAGS_EXTRA=" + flags, "zfar_m": 600000.0, "note": note}
         root, err = variant(name, flags)
         if root is None:

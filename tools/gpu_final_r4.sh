@@ -1,0 +1,36 @@
+#!/bin/bash
+# the measurements DESIGN.md and profiles/ quote for round 4: run on the GPU box, results under gpurun_out/final4
+# (tools/collect_profiles_r4.py turns them into the files under profiles/)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/final4; rm -rf $O; mkdir -p $O
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?" >> $O/bench.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host --no-scenes > $O/bench_k20.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-host --no-extra > $O/bench_k40.json 2>> $O/bench.err
+cd /tmp; export TMPDIR=/tmp
+HZ_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/kt_serial -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-host > $GRAFT_REPO_ROOT/$O/kt_serial_bench.json 2>> $GRAFT_REPO_ROOT/$O/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/kt_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-host > $GRAFT_REPO_ROOT/$O/kt_pipelined_bench.json 2>> $GRAFT_REPO_ROOT/$O/bench.err
+cd $GRAFT_REPO_ROOT
+python3 tools/timeline.py $(find $O/kt_pipelined -name "*_kernel_trace.csv" | head -1) > $O/pipelined_timeline.txt 2>&1
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_agent_info.csv" -delete; find $O -name "*_domain_stats.csv" -delete
+HZ_SERIAL=1 bash tools/collect_pmc.sh r4_final > $O/pmc_traffic.txt 2>&1
+cp gpurun_out/pmc_r4_final.json $O/ 2>/dev/null
+HZ_SERIAL=1 bash tools/pmc_groups.sh r4_mix "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT" "SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" -- --no-host --no-scenes > $O/pmc_mix.txt 2>&1
+cp gpurun_out/pmc_r4_mix.json $O/ 2>/dev/null
+mkdir -p $O/scenes
+timeout 900 python tools/scenes.py --counters > $O/scenes/default.json 2> $O/scenes/default.err
+for e in "HZ_NEAR_PX=10" "HZ_NEAR_PX=40" "HZ_TWO_PASS=0"; do env $e timeout 900 python tools/scenes.py > $O/scenes/$e.json 2> $O/scenes/$e.err; done
+for t in default 12 8; do if [ $t = default ]; then python tools/host_inclusive.py; else HZ_COPY_THREADS=$t python tools/host_inclusive.py cfg3; fi; done > $O/host_inclusive.txt 2>&1
+HZ_HOST_DENSE=1 python tools/host_inclusive.py cfg3 >> $O/host_inclusive.txt 2>&1
+HZ_HOST_TIMES=1 python tools/host_inclusive.py cfg3 2>&1 | grep "hz_hip_resolve_to_host" | tail -3 >> $O/host_inclusive.txt
+python tools/sector_timing.py > $O/sector_timing.txt 2>&1
+python tools/sector_b2b.py > $O/sector_b2b.txt 2>&1
+HZ_G=2 python tools/sector_b2b.py >> $O/sector_b2b.txt 2>&1
+timeout 900 python tools/hiz_ab.py cfg3_zoom10 cfg3_zoom45 cfg3_zoom90 cfg3_zoom180 cfg3 cfg3_zfar40km cfg5 --steps 8 --set "HZ_HIZ=0" --set "" > $O/coarse_depth.txt 2> $O/coarse_depth.err
+timeout 900 python tools/hiz_ab.py cfg3_zoom45_summit cfg3_zoom45_valley cfg3_zoom45_rough cfg3_zoom45_east cfg3_zoom45_south cfg3_zoom45 cfg3_zoom10 --steps 10 --set "HZ_NEAR_CELLS=256" --set "" --set "HZ_NEAR_CELLS=512" > $O/coarse_depth_reach.txt 2> $O/coarse_depth_reach.err
+EXPERIMENTS_QUICK=1 timeout 1500 python tools/experiments.py > $O/r4_experiments.json 2> $O/r4_experiments.err
+for g in rotate; do timeout 600 python bench.py --gpus 4 --backend gloo --same-gpu --steps 8 --warmup 2 --no-cpu-baseline --no-host --no-extra --gather $g 2>>$O/multi.err | grep "^{" > $O/multi_4ranks_one_gpu_$g.json; done
+BENCH_HOST_TIMES=1 timeout 300 python bench.py --gpus 1 --exchange-anyway --steps 20 --warmup 4 --no-cpu-baseline --no-host --no-extra 2>>$O/multi.err | grep "^{" > $O/exchange_anyway.json
+ls $O; grep -E "^G=|fixed" $O/sector_timing.txt | cut -c1-330; cat $O/sector_b2b.txt | grep "G="; cat $O/host_inclusive.txt | grep -E "cfg|resolve_to_host" | cut -c1-250; python3 -c "
+import json
+d=json.load(open('$O/bench.json')); print(json.dumps({k:d.get(k) for k in ('value','ms_per_step','parity','host_inclusive','zfar_40km')})[:1500])
+print('k20', json.load(open('$O/bench_k20.json'))['ms_per_step'], 'k40', json.load(open('$O/bench_k40.json'))['ms_per_step'])"

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Where the marching kernel's issue cycles go, by instruction class.
+
+Inputs, all recorded on an MI355X:
+  profiles/pmc_r4_instruction_mix_cfg3.json   rocprofv3 --pmc passes of bench.py (HZ_SERIAL=1): per kernel the hardware's own
+                                              split of SQ_INSTS_VALU into fp32 add / mul / fma, transcendental, int32, int64,
+                                              conversions - and SQ_ACTIVE_INST_VALU, the quad-cycles the vector ALUs were busy
+  profiles/valu_issue.json                    tools/valu_issue.hip: SIMD cycles per wave-instruction of streams of independent
+                                              instructions, by instruction, at 1 / 2 / 4 / 8 waves per SIMD
+  the kernel's code (llvm-objdump of libhorizonator.so)   for the classes the hardware does not count on their own: what the
+                                              "other" instructions of the listing are (compares, selects, min/max, moves,
+                                              DPP, readlane, packed 16-bit)
+
+Output (profiles/r4_k_march_cycles.json): per class the dynamic count, the cycles per instruction that the microbenchmark
+gives it at four waves per SIMD, the product - and the sum of the products against the measured busy cycles.  The sum
+falls short; the last section says which single change of an assumption closes the gap.
+
+    python tools/k_march_cycles.py [kernel key prefix, default k_march_coarse_depth] > profiles/r4_k_march_cycles.json
+"""
+import collections
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# static classes of the listing -> (hardware counter class or "other", cycles at 4 waves/SIMD from valu_issue.json's rows)
+CLASSES = [
+    ("fp32 add/sub/mul/fma/mac",   r"^v_(add|sub|subrev|mul|fma|fmac|mac|mad)_f32", "F32",   "v_fma_f32"),
+    ("fp32 min/max/med3/clamp",    r"^v_(min|max|med3|min3|max3)_f32",              "other", "v_min_f32"),
+    ("transcendental f32",         r"^v_(rcp|rsq|sqrt|exp|log|sin|cos)_f32",        "TRANS", "v_rcp_f32"),
+    ("compares",                   r"^v_cmp",                                       "other", "v_cmp_lt_f32"),
+    ("selects",                    r"^v_cndmask",                                   "other", "v_cndmask_b32_e64 (sgpr cond)"),
+    ("conversions, rounding",      r"^v_(cvt|rndne|floor|ceil|trunc|fract|ldexp)",  "CVT",   "v_cvt_i32_f32"),
+    ("int32 add/sub/logic/ashr",   r"^v_(add|sub|subrev|and|or|xor|not|ashrrev|bfi)_(u32|i32|b32|co_u32)", "INT32", "v_add_u32"),
+    ("int32 shifts, mul, mad, 3-operand", r"^v_(lshlrev|lshrrev|mul_lo|mul_hi|mul_i32|mul_u32|mad_i32|mad_u32|add3|lshl_add|add_lshl|lshl_or|and_or|or3|bfe|alignbit|min_i32|max_i32|min_u32|max_u32|min3|max3|med3|mbcnt)", "INT32", "v_lshlrev_b32"),
+    ("int64",                      r"^v_(mad_i64|mad_u64|lshlrev_b64|lshrrev_b64|ashrrev_i64|lshl_add_u64|add_co|addc_co|subb_co|sub_co)", "INT64", "v_mad_i64_i32"),
+    ("packed 16-bit",              r"^v_pk_",                                       "other", "v_pk_min_i16"),
+    ("cross-lane (readlane, writelane, readfirstlane)", r"^v_(readlane|writelane|readfirstlane)", "other", "v_readlane_b32"),
+    ("moves",                      r"^v_(mov|accvgpr)",                             "other", "v_mov_b32"),
+    ("f64",                        r"^v_.*_f64",                                    "other", "v_mad_i64_i32"),
+]
+
+
+def listing(kernel_fragment):
+    lib = os.path.join(ROOT, "horizonator_amd", "libhorizonator.so")
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, copy)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", copy], check=True, capture_output=True)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f][0]
+        text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", os.path.join(tmp, co)], check=True, capture_output=True, text=True).stdout
+    out, on = [], False
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            on = kernel_fragment in m.group(1)
+            continue
+        if on and line.startswith("\t"):
+            out.append(line.strip().split("//")[0].strip())
+    return out
+
+
+def classify(instr):
+    op = instr.split()[0]
+    dpp = " row_" in instr or " wave_" in instr or "quad_perm" in instr or op.endswith("_dpp")
+    for name, pat, hw, cyc in CLASSES:
+        if re.match(pat, op):
+            return name + (", DPP form" if dpp and not name.startswith("moves") else (" (v_mov_b32_dpp)" if dpp else "")), hw, ("v_mov_b32_dpp wave_shl:1" if dpp else cyc)
+    return "other vector", "other", "v_min_f32"
+
+
+def main():
+    key = sys.argv[1] if len(sys.argv) > 1 else "k_march_coarse_depth"
+    mix = json.load(open(os.path.join(ROOT, "profiles", "pmc_r4_instruction_mix_cfg3.json")))
+    k = max((v for name, v in mix.items() if name.startswith(key + " grid")), key=lambda v: v["SQ_INSTS_VALU"])
+    issue = {}
+    for r in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["rows"]:
+        if r.get("waves_per_simd_asked") == 4:
+            issue[r["instr"]] = r["cycles_per_wave_instr_at_nominal_clock"]
+    one_wave = {r["instr"]: r["cycles_per_wave_instr_at_nominal_clock"] for r in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["rows"] if r.get("waves_per_simd_asked") == 1}
+    two_waves = {r["instr"]: r["cycles_per_wave_instr_at_nominal_clock"] for r in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["rows"] if r.get("waves_per_simd_asked") == 2}
+
+    # the listing's vector instructions by class (static: what kinds of instruction the kernel is made of)
+    frag = "k_marchILb0ELb1E" if key.endswith("coarse_depth") else "k_marchILb0ELb0E"
+    static = collections.Counter()
+    meta = {}
+    for ins in listing(frag):
+        if not ins.startswith("v_"):
+            continue
+        name, hw, cyc = classify(ins)
+        static[name] += 1
+        meta[name] = (hw, cyc)
+    total_static = sum(static.values())
+
+    # dynamic counts: the hardware's classes as counted; inside a hardware class (INT32: cheap adds and 4-cycle shifts/mads
+    # alike; "other": everything the hardware has no counter for) the listing's proportions
+    hw_count = {"F32": k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + k["SQ_INSTS_VALU_FMA_F32"], "TRANS": k["SQ_INSTS_VALU_TRANS_F32"],
+                "INT32": k["SQ_INSTS_VALU_INT32"], "INT64": k["SQ_INSTS_VALU_INT64"], "CVT": k["SQ_INSTS_VALU_CVT"]}
+    hw_count["other"] = k["SQ_INSTS_VALU"] - sum(hw_count.values())
+    static_by_hw = collections.Counter()
+    for name, n in static.items():
+        static_by_hw[meta[name][0]] += n
+    rows = []
+    cycles_sum = 0.0
+    for name, n in sorted(static.items(), key=lambda kv: -kv[1]):
+        hw, cyc_key = meta[name]
+        dyn = hw_count[hw] * n / static_by_hw[hw]
+        cyc = issue.get(cyc_key, 4.3)
+        rows.append({"class": name, "hardware_counter_class": hw, "instructions_in_the_listing": n, "dynamic_count_estimate": round(dyn),
+                     "cycles_per_instruction_microbenchmark_4_waves": cyc, "cycles": round(dyn * cyc)})
+        cycles_sum += dyn * cyc
+    measured_cycles = 4.0 * k["SQ_ACTIVE_INST_VALU"]
+    f32 = hw_count["F32"]
+    out = {
+        "what": "the marching kernel of a series of renders (k_march<false, true>, second round of cfg3: 7x7 SRTM3 tiles, 16000x4000, 360 degrees), "
+                "every kernel alone on the chip (HZ_SERIAL=1): its vector instructions by class, priced with the issue rates tools/valu_issue.hip "
+                "measured for streams of independent instructions at four waves per SIMD",
+        "measured": {"SQ_INSTS_VALU": k["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad_cycles": k["SQ_ACTIVE_INST_VALU"], "busy_cycles": measured_cycles,
+                     "cycles_per_instruction": measured_cycles / k["SQ_INSTS_VALU"],
+                     "hardware_classes": {a: round(b) for a, b in hw_count.items()},
+                     "SQ_WAVE_CYCLES": k.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": k.get("SQ_WAIT_ANY"), "SQ_WAIT_INST_ANY": k.get("SQ_WAIT_INST_ANY")},
+        "listing": {"vector_instructions": total_static, "note": "static: the kinds of instruction the kernel is made of; dynamic counts inside a hardware class "
+                    "(INT32, and 'other' = what the hardware has no counter for) follow the listing's proportions"},
+        "classes": rows,
+        "sum_of_classes": {"cycles": round(cycles_sum), "quad_cycles": round(cycles_sum / 4.0), "of_measured": cycles_sum / measured_cycles},
+        "the_gap": None,
+    }
+    fast = [r for r in rows if r["cycles_per_instruction_microbenchmark_4_waves"] < 3.5]
+    fast_n = sum(r["dynamic_count_estimate"] for r in fast)
+    fast_extra = sum(r["dynamic_count_estimate"] * (4.0 - r["cycles_per_instruction_microbenchmark_4_waves"]) for r in fast)
+    out["the_gap"] = {
+        "cycles_unexplained": round(measured_cycles - cycles_sum),
+        "classes_the_microbenchmark_prices_below_four_cycles": [r["class"] for r in fast],
+        "their_instructions": round(fast_n),
+        "extra_cycles_if_they_took_4_0_like_the_rest": round(fast_extra),
+        "sum_then_of_measured": (cycles_sum + fast_extra) / measured_cycles,
+        "reading": "Three classes are priced below four cycles by the microbenchmark - fp32 add/mul/fma (%.2f cycles at four waves per SIMD, %.2f at two, %.2f "
+                   "for a wave alone), 32-bit integer add/logic and moves: %d M of the kernel's %d M vector instructions.  With those rates the classes add "
+                   "up to %.0f %% of the busy cycles the hardware counted; with four cycles for them like for everything else to %.0f %%.  So inside this "
+                   "kernel the '2-cycle class' does not issue at its 2-cycle rate.  The microbenchmark says why: that rate is reached by SEVERAL waves "
+                   "taking turns (a wave alone issues an independent fp32 instruction every %.1f cycles - it is not instruction-level parallelism within "
+                   "a wave), and the marching kernel's four waves per SIMD wait for %.0f %% of their wave-cycles (SQ_WAIT_ANY: the next row's elevation, "
+                   "LDS, the depths of the early test), so one or two are ready at a time.  Interleaving two vertex rows inside a wave - the obvious "
+                   "remedy for dependent chains - would therefore change nothing; more ready waves would, but a fifth wave per SIMD needs the kernel in "
+                   "96 registers (it has 103; at 96 it spilled and lost 27 %%: profiles/r3_experiments.json).  The lever left is fewer instructions, "
+                   "whatever their class: a cycle is a cycle." % (
+                       issue["v_fma_f32"], two_waves.get("v_fma_f32", 0), one_wave.get("v_fma_f32", 0), round(fast_n / 1e6), round(k["SQ_INSTS_VALU"] / 1e6),
+                       100.0 * cycles_sum / measured_cycles, 100.0 * (cycles_sum + fast_extra) / measured_cycles, one_wave.get("v_fma_f32", 0),
+                       100.0 * (k.get("SQ_WAIT_ANY", 0) / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else 0.0),
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
