@@ -64,7 +64,9 @@ int  hz_hip_device_count(void);
 
 /* Takes over the GL object creation of reference horizonator-lib.c:403-512
  * (VBO/IBO) and :617-666 (FBO): allocates the N x N int16 mosaic and the
- * W x H 64-bit depth/id/colour framebuffer on `device`.  NULL on failure. */
+ * W x H 64-bit depth/id/colour framebuffer on `device`.  NULL on failure.
+ * Images of up to 2^29 pixels (framebuffer words are addressed with 32-bit byte
+ * offsets; the reference's own limit on llvmpipe is 16384^2 = 2^28). */
 hz_dev_t* hz_hip_create(int device, int N, int width, int height);
 void      hz_hip_destroy(hz_dev_t* d);
 
@@ -114,8 +116,11 @@ int  hz_hip_draw(hz_dev_t* d, const hz_view_t* view);
 int  hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                     unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
 
-/* resolve into internal device buffers, then copy to HOST pointers (each may
- * be NULL); synchronous */
+/* The same into HOST pointers (each may be NULL); synchronous.  What crosses
+ * PCIe is the terrain pixels only (hz_scatter.h: 5 bytes each for BGR + range);
+ * host threads fill the caller's buffers with the sky's constants (reference
+ * horizonator-lib.c:185, :1016) while the draw runs and put the terrain in its
+ * places as it arrives - the same bytes as the dense copy (HZ_HOST_DENSE=1). */
 int  hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                             unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
 
