@@ -125,6 +125,7 @@ struct hz_env_t
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
     int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: zoomed views, and every draw of a series */
+    double hiz_far_reaches;         /* HZ_HIZ_FAR_REACHES (default below): whole panoramas of a series keep coarse depth only if the far clip is at least this many reaches of the first round away */
     double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): "zoomed" = a cell at the first round's reach is at least this wide */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -154,6 +155,7 @@ static hz_env_t read_env(void)
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
+    e.hiz_far_reaches  = getenv("HZ_HIZ_FAR_REACHES") ? atof(getenv("HZ_HIZ_FAR_REACHES")) : 0.0;
     e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 25.0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
@@ -1183,7 +1185,12 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
                 const bool zoomed = reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px;
                 /* (azimuth sectors: a half gains 8 %, a quarter loses 4, an eighth 7 - the sweep and the wait do not shrink with the work) */
-                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || (busy && 2*p.SW >= p.W)));
+                /* ... and only where there is enough behind the first round for the tables to pay: with the far clip
+                 * fewer than HZ_HIZ_FAR_REACHES reaches of the first round away (the API's default 40 km over SRTM3: 3.4)
+                 * the second round is short, and the sweep and the wait for it cost more than its tests save */
+                const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
+                const bool far_enough = cells_to_zfar >= (float)d->env.hiz_far_reaches * reach;
+                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || (busy && 2*p.SW >= p.W && far_enough)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight

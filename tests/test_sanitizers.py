@@ -1,6 +1,6 @@
 """the host code under sanitizers.  `make asan` builds libhorizonator_asan.so - hz_dem.c,
-hz_host.c and hz_png.c compiled with -fsanitize=address,undefined (no recovery), linked with the same kernel
-object - and the DEM, PNG, malformed-input and ABI tests run once more through it in a child interpreter
+hz_host.c, hz_png.c and hz_scatter.c compiled with -fsanitize=address,undefined (no recovery), linked with the same kernel
+object - and the DEM, PNG, malformed-input and blob-scatter tests run once more through it in a child interpreter
 (LD_PRELOAD=libasan, HORIZONATOR_AMD_LIB pointing at the sanitized build).  CPU only: neither this
 container nor the GPU pool offers a device-side sanitizer."""
 import os
@@ -30,7 +30,8 @@ def test_host_code_under_address_and_ub_sanitizers():
                HZ_UNDER_SANITIZER="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_dem.py"), os.path.join(ROOT, "tests", "test_png.py"),
-                        os.path.join(ROOT, "tests", "test_malformed_inputs.py")],
+                        os.path.join(ROOT, "tests", "test_malformed_inputs.py"),
+                        os.path.join(ROOT, "tests", "test_scatter.py")],       # (round 4: the host half of results-without-the-sky, hz_scatter.c)
                        cwd=ROOT, env=env, capture_output=True, text=True)
     tail = (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
     assert r.returncode == 0, "tests failed under the sanitizers:\n" + tail
