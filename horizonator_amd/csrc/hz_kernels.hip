@@ -118,6 +118,7 @@ struct hz_env_t
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
+    int    inline_max2;             /* HZ_INLINE_MAX2=n: the second round's marching waves keep boxes of up to n pixels, larger ones up to 64 go to k_mid; 0: the draw decides (64, or 32 with a close far clip) */
     int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
                                      * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
     int    tile_list;               /* HZ_TILE_LIST=n: a tile's list holds n triangles instead of 256 (tests: the fall-back to k_big) */
@@ -125,7 +126,6 @@ struct hz_env_t
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
     int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: zoomed views, and every draw of a series */
-    double hiz_far_reaches;         /* HZ_HIZ_FAR_REACHES (default below): whole panoramas of a series keep coarse depth only if the far clip is at least this many reaches of the first round away */
     double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): "zoomed" = a cell at the first round's reach is at least this wide */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -152,10 +152,10 @@ static hz_env_t read_env(void)
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
+    e.inline_max2      = env_int("HZ_INLINE_MAX2", 0);
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
-    e.hiz_far_reaches  = getenv("HZ_HIZ_FAR_REACHES") ? atof(getenv("HZ_HIZ_FAR_REACHES")) : 0.0;
     e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 25.0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
@@ -1185,12 +1185,9 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
                 const bool zoomed = reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px;
                 /* (azimuth sectors: a half gains 8 %, a quarter loses 4, an eighth 7 - the sweep and the wait do not shrink with the work) */
-                /* ... and only where there is enough behind the first round for the tables to pay: with the far clip
-                 * fewer than HZ_HIZ_FAR_REACHES reaches of the first round away (the API's default 40 km over SRTM3: 3.4)
-                 * the second round is short, and the sweep and the wait for it cost more than its tests save */
-                const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
-                const bool far_enough = cells_to_zfar >= (float)d->env.hiz_far_reaches * reach;
-                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || (busy && 2*p.SW >= p.W && far_enough)));
+                /* (whatever the far clip: with the API's 40 km the tables change nothing - 0.602 / 0.607 ms without / with,
+                 * three alternating pairs -, at 80 km they gain 3 %, at 150 km 4 %: round 4) */
+                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || (busy && 2*p.SW >= p.W)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight
@@ -1208,6 +1205,19 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 near_beside_far = true;         /* "drawn" then has to wait for both rounds: see qstream below */
             /* (the early depth test addresses the framebuffer with 32-bit byte offsets) */
             p.pass = 2; p.early_z = early_z ? 1 : 0;
+            /* A far clip so close that even the farthest cell is four pixels wide (the API's default 40 km at 16000 columns:
+             * 432 cells away, 6 px) leaves the second round a few thousand waves, all of them next to the viewer and all with
+             * medium-sized triangles: the kernel is then as long as its longest wave (0.24 ms alone, 0.58 beside the next first
+             * round).  Boxes beyond 32 pixels go to k_mid there, which spreads them over the chip: 0.585 -> 0.562 ms per
+             * render at 40 km (three alternating triples); where the far field is most of the work the marching waves keep
+             * up to 64 pixels (the headline: 0.815 against 0.822 with 32; a far clip of 80 km, 864 cells: 0.612 / 0.617; 150 km:
+             * 0.636 / 0.661). */
+            {
+                const float ppr = p.halfW * p.u.az_ndc_per_rad;
+                const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
+                if(d->env.inline_max2 > 0) p.inline_max = (unsigned int)d->env.inline_max2;
+                else if(cells_to_zfar <= 0.25f*ppr) p.inline_max = 32;
+            }
             p.hiz = hz.l1;
             /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment
              * cannot win (a stale, larger value only costs the atomic) - where the framebuffer is larger than the

@@ -103,6 +103,15 @@ def main():
     doc = {"workload": "bench.py cfg3 (7x7 SRTM3 tiles, 16000x4000, 360 degrees, zfar 600 km unless a row says otherwise), 40 renders back to back",
            "how": "python tools/experiments.py on one MI355X; every row: the environment switch (or build flag) that reproduces it",
            "rows": []}
+    # the wrong-picture rows run in another build (their branches cost the marching kernel registers, and with them the second
+    # co-resident wave of its neighbours: DESIGN.md section 4): that build, unswitched, is their reference point
+    rec = {"what": "as shipped, built with -DHZ_EXPERIMENTS: the reference point of the WRONG-picture rows", "switch": "-", "zfar_m": 600000.0,
+           "build": "make -C horizonator_amd/csrc HIPFLAGS_EXTRA=-DHZ_EXPERIMENTS", "note": ""}
+    rec.update(run({}, root=exp_root) if exp_root else {"error": exp_err})
+    doc["rows"].append(rec)
+    rec = dict(rec, what="the same, zfar 40 km", zfar_m=40000.0)
+    rec.update(run({}, root=exp_root, zfar=40000.0) if exp_root else {"error": exp_err})
+    doc["rows"].append(rec)
     rows, variants = ROWS, VARIANTS
     if os.environ.get("EXPERIMENTS_QUICK"):     # round 4: the rows that bound what the atomics cost, and the two rounds / coarse depth switches
         keep = ("as shipped", "one round forced", "k_big: plain stores instead", "k_march: plain stores", "both: plain stores", "k_big looks before",
