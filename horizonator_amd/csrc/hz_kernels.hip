@@ -118,6 +118,8 @@ struct hz_env_t
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
+    int    mid, mid_near, mid_cells; /* HZ_MID=1: two-round draws get a middle round (plan_rounds; not the default); HZ_MID_NEAR (256): the first round's reach
+                                     * in draws with a middle round; HZ_MID_CELLS (640): the middle round's */
     int    inline_max2;             /* HZ_INLINE_MAX2=n: the second round's marching waves keep boxes of up to n pixels, larger ones up to 64 go to k_mid; 0: the draw decides (64, or 32 with a close far clip) */
     int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
                                      * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
@@ -152,6 +154,9 @@ static hz_env_t read_env(void)
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
+    e.mid              = env_int("HZ_MID", 0) != 0;
+    e.mid_near         = env_int("HZ_MID_NEAR", 256);
+    e.mid_cells        = env_int("HZ_MID_CELLS", 640);
     e.inline_max2      = env_int("HZ_INLINE_MAX2", 0);
     e.tiles            = env_int("HZ_TILES", 0) != 0;
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
@@ -167,17 +172,18 @@ static hz_env_t read_env(void)
 /* what decides a draw's work lists */
 struct hz_listkey_t
 {
-    hz_view_t view; int col0, col1, two_pass, near_x0, near_x1, near_j0, near_j1, far_rows;
+    hz_view_t view; int col0, col1, two_pass, near_x0, near_x1, near_j0, near_j1, mid_x0, mid_x1, mid_j0, mid_j1, far_rows;
 };
-/* the work lists of sector draws (see strips_behind_columns): [0] first round, [1] second or only round */
+/* the work lists of sector draws (see strips_behind_columns): [0] first round, [1] second or only round, [2] middle round */
+#define HZ_NLISTS 3
 struct hz_worklists_t
 {
-    uint32_t*    d_items[2];
-    uint32_t*    h_items[2][2];         /* pinned; two per list, taken in turn: the host only waits for the copy two lists back */
-    size_t       cap[2];
-    unsigned int n[2];
-    hipEvent_t   ev_copied[2][2];
-    int          turn[2];
+    uint32_t*    d_items[HZ_NLISTS];
+    uint32_t*    h_items[HZ_NLISTS][2]; /* pinned; two per list, taken in turn: the host only waits for the copy two lists back */
+    size_t       cap[HZ_NLISTS];
+    unsigned int n[HZ_NLISTS];
+    hipEvent_t   ev_copied[HZ_NLISTS][2];
+    int          turn[HZ_NLISTS];
     int          valid;                 /* the resident lists are those of `key` */
     hz_listkey_t key;
     std::vector<uint32_t>* scratch;
@@ -312,7 +318,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     if(d->ev_marched) (void)hipEventDestroy(d->ev_marched);
     if(d->ev_near)    (void)hipEventDestroy(d->ev_near);
     for(int i=0; i<HZ_NFB; i++) (void)hipFree(d->d_hiz[i]);
-    for(int k=0; k<2; k++)
+    for(int k=0; k<HZ_NLISTS; k++)
     {
         (void)hipFree(d->lists.d_items[k]);
         for(int t=0; t<2; t++)
@@ -822,13 +828,14 @@ static void list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, do
         mr_segment_rows(zn, seg, &jbeg, &jend);
         int x0 = 0, x1 = nsx-1;
         if(!every_strip && !strips_behind_columns(p, a0, a1, jbeg, jend, nsx, &x0, &x1)) continue;
-        const bool near_rows = jbeg < p.near_j1 && jend > p.near_j0;
+        const bool near_rows = jbeg < p.near_j1 && jend > p.near_j0, mid_rows = jbeg < p.mid_j1 && jend > p.mid_j0;
         for(int sx=x0; sx<=x1; sx++)
         {
-            if(p.pass)
+            if(p.pass)                          /* (as k_march decides it) */
             {
                 const bool near = near_rows && sx >= p.near_x0 && sx <= p.near_x1;
-                if(near != (p.pass == 1)) continue;
+                const bool mid  = mid_rows  && sx >= p.mid_x0  && sx <= p.mid_x1;
+                if(!(p.pass == 1 ? near : p.pass == 2 ? !mid : (mid && !near))) continue;
             }
             out.push_back(MR_ITEM(seg, sx));
         }
@@ -1002,7 +1009,7 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
                         const uint32_t* d_list, unsigned int nlist)
 {
     const int nsx = (pm.N-1 + MR_COLS-1)/MR_COLS;
-    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : (d->env.exp_xcd_pad ? (nsx + 7) & ~7 : nsx), zn.total);
+    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : pm.pass == 3 ? pm.mid_x1 - pm.mid_x0 + 1 : (d->env.exp_xcd_pad ? (nsx + 7) & ~7 : nsx), zn.total);
     pm.worklist = NULL;
     if(d_list)
     {
@@ -1029,8 +1036,8 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
     return 0;
 }
 
-/* the draw's plan: one or two rounds, which strips are "next to the viewer" */
-static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
+/* the draw's plan: rounds (1, 2, or 3: zoomed views), which strips are "next to the viewer", which the middle round's */
+static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
 {
     const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
     /* The first round's reach: the cells that are wider than ~20 pixels on screen - a cell r rows
@@ -1046,12 +1053,38 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
         if(near_cells < 16) near_cells = 16;
         if(near_cells > HZ_NEAR_CELLS_MAX) near_cells = HZ_NEAR_CELLS_MAX;
     }
-    p.near_x0 = (int)floorf((p.u.viewer_cell_i - (float)near_cells)/(float)MR_COLS);
-    p.near_x1 = (int)floorf((p.u.viewer_cell_i + (float)near_cells)/(float)MR_COLS);
-    if(p.near_x0 < 0) p.near_x0 = 0;
-    if(p.near_x1 > nsx-1) p.near_x1 = nsx-1;
-    p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
-    p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
+    /* A MIDDLE ROUND (round 4; HZ_MID=1, not the default).  How far the first round of a zoomed view has to reach for the
+     * ridge that hides most of the view to be in the tables depends on the view (no single reach is
+     * best), and a first round has no early depth test - every cell it is extended by is drawn whatever hides it.  With
+     * HZ_MID=1 the first round stays short (HZ_MID_NEAR), a middle round takes the ring out to HZ_MID_CELLS WITH the early
+     * test against the first round's tables - cheap where the ring is hidden, a round of occluders where it is not -, a
+     * second sweep takes its picture in, and the last round tests against that.  Measured over seven 10 and 45 degree
+     * views (profiles/r4_middle_round.txt): the two whose ridge lies far out gain (summit 2.03 -> 1.64-1.76 ms, valley
+     * 1.54 -> 1.05-1.18), the five others pay the round's fixed cost - a second sweep, another chain of march, clip and
+     * big - with 0.2-0.3 ms each: 10.7 -> 11.0 ms in sum.  Byte-identical (tools/gpu_modes.sh forces it on the suite's
+     * scenes); off unless asked for. */
+    int mid_cells = 0;
+    {
+        const float ppr = p.halfW * p.u.az_ndc_per_rad;
+        const bool zoomed = near_cells > 0 && ppr/(float)near_cells >= (float)d->env.hiz_min_px;
+        (void)zoomed;
+        if(d->env.mid > 0)
+        {
+            mid_cells = d->env.mid_cells;
+            if(d->env.near_cells < 0 && near_cells > d->env.mid_near) near_cells = d->env.mid_near;
+            if(mid_cells <= near_cells) mid_cells = 0;
+        }
+    }
+    auto region = [&](int cells, int* x0, int* x1, int* j0, int* j1)
+    {
+        *x0 = (int)floorf((p.u.viewer_cell_i - (float)cells)/(float)MR_COLS);
+        *x1 = (int)floorf((p.u.viewer_cell_i + (float)cells)/(float)MR_COLS);
+        if(*x0 < 0) *x0 = 0;
+        if(*x1 > nsx-1) *x1 = nsx-1;
+        *j0 = (int)floorf(p.u.viewer_cell_j - (float)cells);
+        *j1 = (int)ceilf (p.u.viewer_cell_j + (float)cells);
+    };
+    region(near_cells, &p.near_x0, &p.near_x1, &p.near_j0, &p.near_j1);
     /* Two rounds pay where there is terrain behind the first round's strips to be hidden by them
      * and enough pixels for the second round's early depth test to save work; a small image is
      * faster in one round (three kernel launches less).  Measured over the scenes of tools/scenes.py
@@ -1064,7 +1097,11 @@ static bool plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p
     const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
     const bool want_two = d->env.two_pass >= 0 ? d->env.two_pass != 0
                              : ((double)p.W*(double)p.H >= d->env.two_pass_min_mpix*1e6 && cells_to_zfar >= 3.0f*(float)near_cells);
-    return want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
+    const bool two = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
+    const bool three = two && mid_cells > 0 && cells_to_zfar >= 1.5f*(float)mid_cells;
+    if(three) region(mid_cells, &p.mid_x0, &p.mid_x1, &p.mid_j0, &p.mid_j1);
+    else { p.mid_x0 = p.near_x0; p.mid_x1 = p.near_x1; p.mid_j0 = p.near_j0; p.mid_j1 = p.near_j1; }
+    return three ? 3 : two ? 2 : 1;
 }
 
 /* Coarse depth of framebuffer `next` (hz_k_hiz.h): the tables of a draw with the geometry of p, allocated on first use */
@@ -1124,7 +1161,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     }
     else
     {
-        const bool two_pass = plan_rounds(d, view, p);
+        const int rounds = plan_rounds(d, view, p);
+        const bool two_pass = rounds >= 2, three = rounds == 3;
         const mr_zones_t zn = mr_make_zones(p, two_pass, d->env.far_rows);
         /* sectors and views of less than the full circle: only the strips behind the drawn columns */
         double a0 = 0, a1 = 0;
@@ -1138,6 +1176,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             memset(&key, 0, sizeof(key));
             key.view = *view; key.col0 = p.col0; key.col1 = p.col1; key.two_pass = two_pass ? 1 : 0;
             key.near_x0 = p.near_x0; key.near_x1 = p.near_x1; key.near_j0 = p.near_j0; key.near_j1 = p.near_j1; key.far_rows = zn.rows[0];
+            key.mid_x0 = p.mid_x0; key.mid_x1 = p.mid_x1; key.mid_j0 = p.mid_j0; key.mid_j1 = p.mid_j1;
             fresh_lists = !d->lists.valid || memcmp(&key, &d->lists.key, sizeof(key)) != 0;
             if(fresh_lists) { d->lists.valid = 0; d->lists.key = key; }
         }
@@ -1187,12 +1226,32 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 /* (azimuth sectors: a half gains 8 %, a quarter loses 4, an eighth 7 - the sweep and the wait do not shrink with the work) */
                 /* (whatever the far clip: with the API's 40 km the tables change nothing - 0.602 / 0.607 ms without / with,
                  * three alternating pairs -, at 80 km they gain 3 %, at 150 km 4 %: round 4) */
-                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || (busy && 2*p.SW >= p.W)));
+                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || three || (busy && 2*p.SW >= p.W)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight
                  * queues the first round's k_big gets the chip earlier and the second round's marching kernel pays for
                  * it: 0.91 -> 1.00 ms per render.  It stays here.) */
+                if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
+            }
+            if(three)
+            {
+                /* The middle round (plan_rounds): the ring between the first round's strips and HZ_MID_CELLS, with the early
+                 * depth test against the tables just taken, its large triangles through the first round's queue set -
+                 * emptied again first: its k_big is done with it - and a second sweep behind it, all on the first round's
+                 * stream.  Same exactness as a second round: the test only ever skips what cannot win a pixel. */
+                HZ_CHECK(hipMemsetAsync(d->d_big_counters_s[HZ_NFB + next], 0, 6*sizeof(unsigned int), d->nstream));
+                hz_params_t pm = p;
+                pm.pass = 3; pm.early_z = early_z ? 1 : 0; pm.hiz = hz.l1; pm.inline_max = HZ_INLINE_MAX_PIX;
+                pm.pretest_march = d->env.pretest_march >= 0 ? d->env.pretest_march
+                                                             : ((unsigned long long)p.SW*(unsigned long long)p.H*8ull > (256ull << 20) ? 1 : 0);
+                if(fresh_lists)
+                {
+                    list_items(pm, zn, a0, a1, *d->lists.scratch);
+                    if(upload_list(d, 2, d->nstream, *d->lists.scratch) != 0) return -1;
+                }
+                if(launch_march(d, d->nstream, qn, zn, pm, listed ? d->lists.d_items[2] : NULL, d->lists.n[2]) != 0) return -1;
+                if(queue_kernels(d, qn, pm, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
                 if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
             }
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
@@ -1253,7 +1312,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
     if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
-    d->last_plan[0] = p.pass == 2 ? 2 : 1; d->last_plan[1] = use_hiz ? 1 : 0;
+    d->last_plan[0] = p.pass == 2 ? (p.mid_j1 - p.mid_j0 > p.near_j1 - p.near_j0 ? 3 : 2) : 1; d->last_plan[1] = use_hiz ? 1 : 0;
     d->last_plan[2] = p.pass == 2 ? (p.near_j1 - p.near_j0)/2 : 0; d->last_plan[3] = p.cull_strips ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
