@@ -64,6 +64,11 @@ def parse():
                     help="N > 1: which rank gathers and converts a panorama's strips - rotate: panorama k goes to rank "
                          "k mod N (every rank converts 1/N of the panoramas; the outputs stay on the rank that assembled "
                          "them); root0: always rank 0, which then draws a narrower sector")
+    ap.add_argument("--loop", default="python", choices=["python", "c"],
+                    help="N > 1 (RCCL, sparse strips): who drives the series - python: this file's loop over torch.distributed "
+                         "(what has run on one GPU with two to four gloo ranks); c: horizonator_rccl_render_series, the same steps as one "
+                         "C call over an RCCL communicator of the library's own (include/horizonator_rccl.h; on one GPU it has run "
+                         "with the one rank there is)")
     ap.add_argument("--wire", default="sparse", choices=["sparse", "packed"],
                     help="N > 1: what a rank sends to rank 0 - sparse: terrain pixels only + mask (default); "
                          "packed: every pixel, 4 bytes")
@@ -124,11 +129,17 @@ def main():
         # the one rank there is, as an RCCL process group of its own: the strips then travel through dist.gather /
         # dist.all_reduce like those of N ranks do (the same calls, the same stream ordering), not through a copy
         import socket
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev, timeout=pg_timeout)
+        for attempt in range(4):
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            try:
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev, timeout=pg_timeout)
+                break
+            except Exception as e:      # (the port found free a moment ago was taken in between: DistNetworkError, EADDRINUSE)
+                if attempt == 3 or "EADDRINUSE" not in str(e):
+                    raise
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -176,16 +187,22 @@ def main():
     # (sharding.azimuth_density), then from what the ranks measure on this scene.  Rank 0 draws a
     # bit less under --gather root0: it also converts the gathered strips (0.27 ms for 64 Mpix, on the
     # library's conversion stream beside its own draw, which that slows by about 0.08 ms; a sector's strips
-    # back to back cost about 0.13 + 0.80*share ms: profiles/r3_sector_timing.txt).
+    # back to back cost about 0.10 + 0.74*share ms: profiles/r4_sector_timing.txt).
     multi = world > 1 or args.exchange_anyway
     NBUF = 2 if multi else 1
     sparse = args.wire == "sparse"
     cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives' tensors live
     S = {}                                                               # the current layout and its buffers
 
+    def drop_series():
+        if S.get("rs") is not None:
+            S["rs"].close()
+        S["rs"] = None
+
     def set_gather(mode):
+        drop_series()
         S["rotate"] = mode == "rotate"
-        S["weights"] = gatherer_weights(world, 0.80, 0.08) if world > 1 and mode != "rotate" else None
+        S["weights"] = gatherer_weights(world, 0.74, 0.08) if world > 1 and mode != "rotate" else None
     set_gather(args.gather)
 
     def apply_layout(layout):
@@ -196,6 +213,7 @@ def main():
         S["MSTRIDE"] = sparse_mask_stride(S["SW_max"])
         S["HDR"] = sparse_header_words(H, S["MSTRIDE"])
         S["ex"] = None
+        drop_series()
         if S["SW"] > 0:
             h.set_sector(S["col0"], S["col1"])
         if multi:
@@ -280,6 +298,42 @@ def main():
             S["sent"] = [None] * NBUF
             state["wire_words"] = S["ex"].cap
         return S["ex"]
+
+    c_loop = args.loop == "c"
+    if c_loop and not (multi and sparse and args.backend == "nccl"):
+        raise SystemExit("--loop c drives the RCCL exchange of sparse strips: N > 1 (or --exchange-anyway), --backend nccl, --wire sparse")
+
+    def c_series():
+        """--loop c: the communicator, strip buffers and bins of horizonator_rccl_render_series for this layout and scene;
+        the ranks agree once on the words a strip sends, as exchange() does"""
+        if S.get("rs") is None:
+            words = S["HDR"]
+            if S["SW"] > 0:
+                h.render_sparse(S["d_pk"][0].data_ptr(), S["MSTRIDE"])
+                h.sync()
+                words += int(S["d_pk"][0][0].item())
+            from horizonator_amd.sharding import RcclSeries
+            cap = agree_on_capacity(words, S["HDR"], S["FULL"], cdev)
+            S["rs"] = RcclSeries(h, S["layout"], H, cap, d_img.data_ptr(), d_rng.data_ptr(), S["rotate"], dev, nslots=NBUF)
+            state["wire_words"] = S["rs"].words
+        return S["rs"]
+
+    def c_run(n, check=False):
+        """n panoramas through the C loop; check: every rank's strip fit the agreed words (else: once more with room for the worst case)"""
+        rs = c_series()
+        first = rs.next
+        fit = rs.run(n, check_fit=check)
+        if check:
+            t = torch.tensor([int(fit)], dtype=torch.int64, device=cdev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if not int(t.item()):
+                drop_series()
+                from horizonator_amd.sharding import RcclSeries
+                S["rs"] = RcclSeries(h, S["layout"], H, S["FULL"], d_img.data_ptr(), d_rng.data_ptr(), S["rotate"], dev, nslots=NBUF)
+                state["wire_words"] = S["rs"].words
+                S["rs"].run(n)
+        state["converted"] += sum(1 for i in range(first, first + n) if (i % world if S["rotate"] else 0) == rank)
 
     def convert(bins):
         """rank 0: the strips of one panorama -> the full-width outputs, on the library's conversion
@@ -404,23 +458,39 @@ def main():
         h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=zfar)
         if multi:
             S["ex"] = None      # another scene: the strips' common capacity is agreed on again (outside the clock)
-        for _ in range(warmup):
-            step()
-        drain()
+            drop_series()
         kern = []
-        fence()
-        for key in host_us:
-            host_us[key] = 0.0
-        t0 = time.perf_counter()
-        for k in range(steps):
-            # HIP events around the kernels of the LAST of the K panoramas only: every event is a packet the command
-            # processor works through between two kernels (profiling all K renders costs 1 % of the throughput)
-            h.set_profiling(k == steps - 1 and os.environ.get("BENCH_NO_KERNEL_EVENTS") is None)
-            step()              # N > 1: nothing in here waits on the host for the device (sharding.StripExchange)
-        drain()                 # every one of the K panoramas is assembled on rank 0 ...
-        h.sync()                # ... and, N = 1, converted ...
-        fence()                 # ... before the clock stops
-        dt = time.perf_counter() - t0
+        if c_loop:
+            c_run(max(warmup, 1), check=True)
+            S["rs"].sync()
+            fence()
+            t0 = time.perf_counter()
+            if steps > 1:
+                c_run(steps - 1)        # one call: returns when the panoramas are queued
+            host_us["c_loop_call_us_per_panorama"] = (time.perf_counter() - t0) * 1e6 / max(steps - 1, 1)
+            h.set_profiling(os.environ.get("BENCH_NO_KERNEL_EVENTS") is None)
+            c_run(1)
+            S["rs"].sync()      # every one of the K panoramas is assembled on its gathering rank ...
+            fence()             # ... before the clock stops
+            dt = time.perf_counter() - t0
+            h.set_profiling(False)
+        else:
+            for _ in range(warmup):
+                step()
+            drain()
+            fence()
+            for key in host_us:
+                host_us[key] = 0.0
+            t0 = time.perf_counter()
+            for k in range(steps):
+                # HIP events around the kernels of the LAST of the K panoramas only: every event is a packet the command
+                # processor works through between two kernels (profiling all K renders costs 1 % of the throughput)
+                h.set_profiling(k == steps - 1 and os.environ.get("BENCH_NO_KERNEL_EVENTS") is None)
+                step()              # N > 1: nothing in here waits on the host for the device (sharding.StripExchange)
+            drain()                 # every one of the K panoramas is assembled on rank 0 ...
+            h.sync()                # ... and, N = 1, converted ...
+            fence()                 # ... before the clock stops
+            dt = time.perf_counter() - t0
         if (not multi or S["SW"] > 0) and h.last_times() is not None:
             kern.append(h.last_times())         # HIP events of the last of the K panoramas
         if world > 1:
@@ -707,6 +777,9 @@ def main():
                                       "every float32 range against oracle/'s render of the same workload (null: --no-cpu-baseline), and the SHA-256 of "
                                       "its BGR bytes against what the reference's vertex/geometry/fragment.glsl drew on Mesa llvmpipe "
                                       "(tests/golden/render_checksums.json; null: no reference render of this workload is committed)"}
+        if c_loop:
+            line["loop"] = {"driver": "horizonator_rccl_render_series (C, include/horizonator_rccl.h)",
+                            "host_us_per_panorama": host_us.get("c_loop_call_us_per_panorama")}
         if os.environ.get("BENCH_HOST_TIMES") and host_us["n"]:
             line["host_us_per_step"] = {k: v / host_us["n"] for k, v in host_us.items() if k != "n"}
         line.update(extra)
@@ -717,6 +790,7 @@ def main():
         gates += [v.get("gathered_panorama_equals_single_gpu_render") for k, v in multi_extra.items() if k.startswith("gather_")]
         gates.append(host_incl["equals_device_render"] if host_incl is not None else None)
         failed = any(g is False for g in gates)
+    drop_series()
     h.close()
     if dist.is_initialized():
         dist.destroy_process_group()

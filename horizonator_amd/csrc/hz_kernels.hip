@@ -116,6 +116,7 @@ struct hz_env_t
     int    host_times;              /* HZ_HOST_TIMES=1 (diagnostics): hz_hip_resolve_to_host says on stderr where a call's time went */
     int    host_dense;              /* HZ_HOST_DENSE=1: results for host memory travel whole (every pixel, as before round 4) instead of without the sky */
     int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
+    int    zone16_rows;             /* HZ_Z16_ROWS: rows per segment where a cell is 1 to 4 pixels wide (experiments); 0: 16, narrow sectors 8 (mr_make_zones) */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
     int    mid, mid_near, mid_cells; /* HZ_MID=1: two-round draws get a middle round (plan_rounds; not the default); HZ_MID_NEAR (256): the first round's reach
@@ -152,6 +153,7 @@ static hz_env_t read_env(void)
     e.host_dense       = env_int("HZ_HOST_DENSE", 0) != 0;
     e.host_times       = env_int("HZ_HOST_TIMES", 0) != 0;
     e.far_rows         = env_int("HZ_FAR_ROWS", 0);
+    e.zone16_rows      = env_int("HZ_Z16_ROWS", 0);
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
     e.mid              = env_int("HZ_MID", 0) != 0;
@@ -629,7 +631,7 @@ extern "C" int hz_hip_wait_for(hz_dev_t* d, void* stream)
 
 /* segment zones of k_march for this view: a cell `r` rows away from the viewer
  * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
-static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first, int far_rows_forced = 0)
+static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first, int far_rows_forced = 0, int zone16_rows_forced = 0)
 {
     const float ppr = p.halfW * p.u.az_ndc_per_rad;
     const int   ncr = p.N-1;                                /* cell rows */
@@ -654,7 +656,15 @@ static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first, int far_r
     if(far_rows < 16) far_rows = 16;
     if(far_rows > 64) far_rows = 64;
     if(far_rows_forced >= 2 && far_rows_forced <= 64) far_rows = far_rows_forced;
-    const int rows[MR_NZONES] = { far_rows, 16, 4, 2, 4, 16, far_rows };
+    /* ... and nearer in (cells of 1 to 4 pixels) a narrow sector's kernel was as long as its longest waves: 16 rows of
+     * 63 cells with a visible triangle in nearly every lane and a flush per row take 100-170 us (tools/wave_timing.py,
+     * HZ_WT_SECTOR=8,0), the whole sector's waves 92 us of the chip - the kernel took 174.  Sectors of less than a sixth
+     * of the image cut that zone into 8-row segments: an eighth's strips back to back 0.198 -> 0.169 ms (the widest),
+     * 0.156 -> 0.153 (the narrowest); a quarter's and the whole image's waves are many enough to hide their longest
+     * (0.273 -> 0.275; profiles/r4_sector_rules.txt). */
+    int z16 = 6*p.SW < p.W ? 8 : 16;
+    if(zone16_rows_forced >= 2 && zone16_rows_forced <= 16) z16 = zone16_rows_forced;
+    const int rows[MR_NZONES] = { far_rows, z16, 4, 2, 4, z16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
      * early and the kernel ends on short ones.  With the early depth test
@@ -1163,7 +1173,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     {
         const int rounds = plan_rounds(d, view, p);
         const bool two_pass = rounds >= 2, three = rounds == 3;
-        const mr_zones_t zn = mr_make_zones(p, two_pass, d->env.far_rows);
+        const mr_zones_t zn = mr_make_zones(p, two_pass, d->env.far_rows, d->env.zone16_rows);
         /* sectors and views of less than the full circle: only the strips behind the drawn columns */
         double a0 = 0, a1 = 0;
         const bool listed = !d->env.no_worklist && azimuths_of_columns(p, &a0, &a1) && zn.total < (1 << (32 - MR_ITEM_SX_BITS))
@@ -1175,7 +1185,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             hz_listkey_t key;
             memset(&key, 0, sizeof(key));
             key.view = *view; key.col0 = p.col0; key.col1 = p.col1; key.two_pass = two_pass ? 1 : 0;
-            key.near_x0 = p.near_x0; key.near_x1 = p.near_x1; key.near_j0 = p.near_j0; key.near_j1 = p.near_j1; key.far_rows = zn.rows[0];
+            key.near_x0 = p.near_x0; key.near_x1 = p.near_x1; key.near_j0 = p.near_j0; key.near_j1 = p.near_j1; key.far_rows = zn.rows[0] | (zn.rows[1] << 8);
             key.mid_x0 = p.mid_x0; key.mid_x1 = p.mid_x1; key.mid_j0 = p.mid_j0; key.mid_j1 = p.mid_j1;
             fresh_lists = !d->lists.valid || memcmp(&key, &d->lists.key, sizeof(key)) != 0;
             if(fresh_lists) { d->lists.valid = 0; d->lists.key = key; }
@@ -1223,10 +1233,12 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
                 const bool zoomed = reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px;
-                /* (azimuth sectors: a half gains 8 %, a quarter loses 4, an eighth 7 - the sweep and the wait do not shrink with the work) */
+                /* (azimuth sectors, round 4 - with k_big's chunk test against the tables: a half gains 8 %, a quarter 6 (strips back to
+                 * back 0.273 -> 0.259, 0.250 -> 0.234 ms), an eighth's widest sector 11 and its narrowest loses 4; beside the 8-row
+                 * segments narrow sectors get (mr_make_zones) an eighth loses 5: from a sixth of the image on.  profiles/r4_sector_rules.txt) */
                 /* (whatever the far clip: with the API's 40 km the tables change nothing - 0.602 / 0.607 ms without / with,
                  * three alternating pairs -, at 80 km they gain 3 %, at 150 km 4 %: round 4) */
-                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || three || (busy && 2*p.SW >= p.W)));
+                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || three || (busy && 6*p.SW >= p.W)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight

@@ -9,6 +9,8 @@ bit-identical to the same pixels of a single-GPU render, and the only exchange
 is one gather of the finished strips to rank 0 (RCCL over xGMI when the process
 group's backend is "nccl"; gloo on CPU in the tests).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -390,6 +392,95 @@ def agree_on_capacity(words, header_words, full_words, device, group=None, margi
         dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
     longest = int(n.item())
     return int(min(full_words, header_words + (longest - header_words) * margin + 1024))
+
+
+# ---- the panorama loop in C (include/horizonator_rccl.h) ---------------------
+
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class _Series(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("rotate", C.c_int), ("nslots", C.c_int),
+                ("d_strips", C.POINTER(C.c_void_p)), ("d_bins", C.POINTER(C.c_void_p)),
+                ("words", C.c_size_t), ("header_words", C.c_size_t), ("mask_stride", C.c_int),
+                ("col0", C.POINTER(C.c_int)), ("ncols", C.POINTER(C.c_int)),
+                ("d_image", C.c_void_p), ("d_ranges", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class RcclSeries:
+    """horizonator_rccl_render_series() for a Python caller: an RCCL communicator of the library's own (the
+    unique id travels through the torch.distributed group that is there anyway), strip buffers and bins per
+    slot, and the loop over a series of panoramas as ONE call into C - no interpreter between two panoramas.
+
+        rs = RcclSeries(h, layout, H, words, d_img, d_rng, rotate=True)   # h: this rank's context, set to its sector
+        rs.run(first, count)        # queues `count` panoramas of the current view; returns at once
+        rs.sync()                   # ... and waits for them
+        rs.close()
+    """
+
+    def __init__(self, h, layout, height, words, d_image, d_ranges, rotate, device, nslots=2, group=None):
+        import os
+        from . import _lib
+        self.world, self.rank = _world_and_rank(group)
+        self.h, self.device = h, device
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        self._rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+        _lib.load()
+        self._hz = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhorizonator_rccl.so"))
+        self._rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        self._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._hz.horizonator_rccl_render_series.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Series), C.c_long, C.c_int, C.c_int]
+        uid = _NcclUniqueId()
+        if self.rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId() failed")
+        if self.world > 1:
+            box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]      # (the raw 128 bytes: .internal as bytes would stop at a NUL)
+            dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.addressof(uid), box[0], 128)
+        self.comm = C.c_void_p()
+        torch.cuda.set_device(device)
+        if self._rccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank) != 0:
+            raise RuntimeError("ncclCommInitRank() failed")
+        self.nslots, self.rotate = int(nslots), bool(rotate)
+        widest = max(c1 - c0 for c0, c1 in layout)
+        self.mask_stride = sparse_mask_stride(widest)
+        self.hdr = sparse_header_words(height, self.mask_stride)
+        self.full = self.hdr + height * widest
+        self.words = int(min(max(int(words), self.hdr + 1), self.full))
+        self.stream = torch.cuda.Stream(device=device)
+        # (torch.empty: the library writes a strip's count word itself, on its own stream)
+        self.strips = [torch.empty(self.full, dtype=torch.int32, device=device) for _ in range(self.nslots)]
+        gathers = self.rotate or self.rank == 0
+        self.bins = [torch.empty(self.words, dtype=torch.int32, device=device) for _ in range(self.nslots * self.world)] if gathers else []
+        self._strips = (C.c_void_p * self.nslots)(*[t.data_ptr() for t in self.strips])
+        self._bins = (C.c_void_p * max(len(self.bins), 1))(*[t.data_ptr() for t in self.bins])
+        self._col0 = (C.c_int * self.world)(*[int(c0) for c0, _ in layout])
+        self._ncols = (C.c_int * self.world)(*[int(c1 - c0) for c0, c1 in layout])
+        self._s = _Series(self.rank, self.world, int(self.rotate), self.nslots,
+                          C.cast(self._strips, C.POINTER(C.c_void_p)), C.cast(self._bins, C.POINTER(C.c_void_p)) if gathers else None,
+                          self.words, self.hdr, self.mask_stride, C.cast(self._col0, C.POINTER(C.c_int)), C.cast(self._ncols, C.POINTER(C.c_int)),
+                          int(d_image) if d_image else None, int(d_ranges) if d_ranges else None, self.stream.cuda_stream)
+        self.next = 0
+
+    def run(self, count, check_fit=False):
+        """queue `count` more panoramas; with check_fit: wait for the last strip and return True if it fit the agreed words"""
+        rc = self._hz.horizonator_rccl_render_series(C.byref(self.h._ctx), self.comm, C.byref(self._s), self.next, int(count), int(bool(check_fit)))
+        if rc < 0:
+            raise RuntimeError("horizonator_rccl_render_series() failed (message on stderr)")
+        self.next += int(count)
+        return rc == 0
+
+    def sync(self):
+        self.stream.synchronize()
+        self.h.sync()
+
+    def close(self):
+        if self.comm:
+            self.sync()
+            self._rccl.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
 
 
 # ---- a batch of viewpoints (BASELINE.json configs[3]) --------------------------

@@ -42,6 +42,45 @@ int horizonator_rccl_broadcast_mosaic(void* comm, int root, int16_t* d_mosaic, i
 int horizonator_rccl_gather_strips(const horizonator_context_t* ctx, void* comm, int rank, int world, int root,
                                    const uint32_t* d_send, size_t words, uint32_t* const* d_recv, void* stream);
 
+/* A series of panoramas of the context's current view without the host in their way: what bench.py's Python loop
+ * does per panorama (sharding.StripExchange: draw the sector, queue the gather behind the strip's conversion, convert
+ * the gathered strips on the gathering rank) as one C call - five library calls and one ncclGroup per panorama, no
+ * interpreter, no tensor bookkeeping (profiles/r4_c_loop_host_time.txt).  Nothing in it waits on the host for the
+ * device; the caller synchronises `stream` and the context (horizonator_amd_sync) when it wants the results.
+ *
+ *   rank, world     as in the communicator
+ *   rotate          0: every panorama is gathered and converted on rank 0; 1: panorama i on rank i % world
+ *   nslots          strip buffers (and sets of bins) used in turn, 1..4: panorama i uses slot i % nslots, and is
+ *                   ordered on the device behind the exchange that last read that slot
+ *   d_strips        [nslots]        this rank's strip buffers (DEVICE; horizonator_amd_render_sparse's d_out)
+ *   d_bins          [nslots*world]  where a gathering rank receives rank r's strip of a panorama in slot s:
+ *                                   d_bins[s*world + r], `words` uint32 each; NULL on a rank that never gathers
+ *   words           what every rank sends per strip - all ranks agree on it (the longest strip + a margin)
+ *   header_words    1 + H + H*mask_stride (the strips' header; for the check below)
+ *   col0, ncols     [world] the layout: rank r draws image columns [col0[r], col0[r]+ncols[r]) - this context is
+ *                   set to its own (horizonator_amd_set_sector); ncols[rank] == 0: it draws nothing and sends filler
+ *   d_image, d_ranges  the gathering ranks' full-width outputs (DEVICE; either may be NULL)
+ *   first, count    panoramas first .. first+count-1 (the index decides slot and gathering rank: a caller that
+ *                   splits a series over several calls passes where it is)
+ *   check_fit       != 0: after the last panorama is queued, wait for this rank's last strip and look at its length
+ * Returns 0; 1 if check_fit and this rank's strip was longer than `words` (the panoramas gathered are then
+ * incomplete: agree on more words and repeat); -1 on an error (message on stderr). */
+typedef struct
+{
+    int rank, world, rotate, nslots;
+    uint32_t* const* d_strips;
+    uint32_t* const* d_bins;
+    size_t words, header_words;
+    int mask_stride;
+    const int* col0;
+    const int* ncols;
+    void* d_image;
+    float* d_ranges;
+    void* stream;
+} horizonator_rccl_series_t;
+int horizonator_rccl_render_series(const horizonator_context_t* ctx, void* comm, const horizonator_rccl_series_t* s,
+                                   long first, int count, int check_fit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,7 @@ def test_rccl_library_exports_what_its_header_declares():
     library of its own so that libhorizonator.so does not depend on RCCL)"""
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "horizonator_rccl.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(horizonator_rccl_[a-z0-9_]+)\s*\(", text))
-    assert declared == {"horizonator_rccl_broadcast_mosaic", "horizonator_rccl_gather_strips"}
+    assert declared == {"horizonator_rccl_broadcast_mosaic", "horizonator_rccl_gather_strips", "horizonator_rccl_render_series"}
     _lib.load()                                     # libhorizonator.so first: the rccl library links against it
     lib = C.CDLL(os.path.join(ROOT, "horizonator_amd", "libhorizonator_rccl.so"))
     for name in declared:

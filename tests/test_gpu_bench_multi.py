@@ -48,3 +48,10 @@ def test_the_rccl_shaped_exchange_with_one_rank():
     line = _bench("--gpus", "1", "--exchange-anyway")
     assert line["gathered_panorama_equals_single_gpu_render"] is True
     assert isinstance(line["config"]["strip_resends"], int)
+
+
+def test_the_series_driven_from_c_with_one_rank():
+    """--loop c: horizonator_rccl_render_series over an RCCL communicator of the library's own instead of the Python loop"""
+    line = _bench("--gpus", "1", "--exchange-anyway", "--loop", "c")
+    assert line["gathered_panorama_equals_single_gpu_render"] is True
+    assert line["loop"]["host_us_per_panorama"] > 0

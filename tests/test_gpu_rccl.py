@@ -73,3 +73,68 @@ def test_strips_through_rccl_convert_to_the_same_panorama():
     finally:
         h.close()
         rccl.ncclCommDestroy(comm)
+
+
+def _series_case(sector=None):
+    import torch
+    import horizonator_amd
+    from horizonator_amd.sharding import RcclSeries
+    LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
+    R, W, H = 300, 1000, 250
+    dev = torch.device("cuda:0")
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
+    rs = None
+    try:
+        image, ranges = h.render(-180, 180, zfar=30000.0)
+        c0, c1 = sector if sector else (0, W)
+        h.set_sector(c0, c1)
+        d_img = torch.full((H, W, 3), 77, dtype=torch.uint8, device=dev)
+        d_rng = torch.full((H, W), -7.0, dtype=torch.float32, device=dev)
+        terrain = int((ranges[:, c0:c1] > 0).sum())
+        yield h, image, ranges, d_img, d_rng, terrain, (c0, c1), dev
+    finally:
+        h.close()
+
+
+def test_a_series_of_panoramas_driven_from_c_gives_the_same_panorama():
+    """horizonator_rccl_render_series (include/horizonator_rccl.h): draw, gather through RCCL and conversion of the gathered
+    strip for several panoramas in one C call, two strip buffers in turn - the panorama left in the outputs is the plain render"""
+    import torch
+    from horizonator_amd.sharding import RcclSeries
+    for rotate in (False, True):
+        for h, image, ranges, d_img, d_rng, terrain, (c0, c1), dev in _series_case():
+            H, W = ranges.shape
+            rs = RcclSeries(h, [(0, W)], H, 10**9, d_img.data_ptr(), d_rng.data_ptr(), rotate, dev, nslots=2)
+            try:
+                assert rs.run(3)                        # (returns at once: nothing waits on the host)
+                assert rs.run(2, check_fit=True)
+                rs.sync()
+                assert [int(t[0]) for t in rs.strips] == [terrain, terrain]
+                assert np.array_equal(d_img.cpu().numpy(), image)
+                assert np.array_equal(d_rng.cpu().numpy(), ranges)
+            finally:
+                rs.close()
+
+
+def test_a_series_reports_a_strip_that_did_not_fit_and_a_sector_lands_in_its_columns():
+    import torch
+    from horizonator_amd.sharding import RcclSeries, sparse_header_words, sparse_mask_stride
+    for h, image, ranges, d_img, d_rng, terrain, (c0, c1), dev in _series_case(sector=(300, 700)):
+        H, W = ranges.shape
+        hdr = sparse_header_words(H, sparse_mask_stride(c1 - c0))
+        assert terrain > 2000
+        rs = RcclSeries(h, [(c0, c1)], H, hdr + terrain - 1000, d_img.data_ptr(), d_rng.data_ptr(), False, dev, nslots=2)
+        try:
+            assert rs.run(3, check_fit=True) is False           # 1000 words short: reported, nothing hangs
+        finally:
+            rs.close()
+        d_img.fill_(77); d_rng.fill_(-7.0)
+        rs = RcclSeries(h, [(c0, c1)], H, hdr + terrain + 16, d_img.data_ptr(), d_rng.data_ptr(), False, dev, nslots=1)
+        try:
+            assert rs.run(4, check_fit=True) is True
+            rs.sync()
+            got_img, got_rng = d_img.cpu().numpy(), d_rng.cpu().numpy()
+            assert np.array_equal(got_img[:, c0:c1], image[:, c0:c1]) and np.array_equal(got_rng[:, c0:c1], ranges[:, c0:c1])
+            assert (got_img[:, :c0] == 77).all() and (got_rng[:, c1:] == -7.0).all()     # (nothing outside the strip's columns is touched)
+        finally:
+            rs.close()

@@ -6,7 +6,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # renders: split at k_resolve4 ends
-res = [i for i, n in enumerate(names) if "k_resolve4" in n]
+split = "k_resolve4"
+if "--split" in sys.argv:                               # (sectors end in k_pack_sparse)
+    i = sys.argv.index("--split"); split = sys.argv[i + 1]; del sys.argv[i:i + 2]
+res = [i for i, n in enumerate(names) if split in n]
 mid = len(res)//2
 lo, hi = res[mid-2], res[mid+1]
 if len(sys.argv) > 2 and sys.argv[2] == "--last":      # the last N renders and the drain

@@ -11,7 +11,13 @@ ZFAR = float(os.environ.get("HZ_WT_ZFAR", "600000"))
 AZ = [float(x) for x in os.environ.get("HZ_WT_AZ", "-180,180").split(",")]
 h.set_view(AZ[0], AZ[1], zfar=ZFAR)
 import torch
-img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda"); rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
+SW = W
+if os.environ.get("HZ_WT_SECTOR"):                  # "G,r": the waves of sector r of G (one GPU's share of the panorama)
+    from horizonator_amd.sharding import sector_columns
+    G, r = [int(x) for x in os.environ["HZ_WT_SECTOR"].split(",")]
+    c0, c1 = sector_columns(W, G, r); h.set_sector(c0, c1); SW = c1 - c0
+    print("sector", r, "of", G, "columns", c0, c1)
+img = torch.empty((H, SW, 3), dtype=torch.uint8, device="cuda"); rng = torch.empty((H, SW), dtype=torch.float32, device="cuda")
 for _ in range(2):
     h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
 import ctypes as C
