@@ -12,9 +12,11 @@ R, W, H = 4200, 16000, 4000
 d = hzutil.dem_dir_for(LAT, LON, R)
 od = oracle.Dem(LAT, LON, d, radius_cells=R)
 m = od.mosaic()
-v = od.view(LAT, LON, W, H, -180, 180, zfar=600000.0)
+AZ = [float(x) for x in os.environ.get("HZ_BQ_AZ", "-180,180").split(",")]      # (HZ_BQ_AZ=-22.5,22.5: a zoomed view)
+v = od.view(LAT, LON, W, H, AZ[0], AZ[1], zfar=600000.0)
 with hzutil.HipDev(m, W, H, raster=2) as dev:
     out = dev.render(v)
+    print("view", AZ, "terrain pixels %.1f M of %.1f M" % ((out["ranges"] > 0).sum() / 1e6, W * H / 1e6))
     lib = dev.lib
     for which in (0, 1):
         cnt = (C.c_uint * 6)()
