@@ -1,51 +1,49 @@
 /* hz_k_tile.h - part of hz_kernels.hip (included there, after hz_k_scatter.h; one translation unit):
  * the large triangles of a round rasterised by screen tile, each tile's depth in LDS.
  *
- * BASELINE north_star's "tile-binned software rasteriser ... per-bin depth": the triangles k_march and k_clip
- * queued for k_big are binned by the 64 x 32 pixel tiles of the image they can cover; one workgroup OWNS a
- * tile - it is the only writer of those pixels while it runs (the kernels that wrote them before are earlier
- * on its stream, the second round and the conversion wait for it) -, takes the tile's 2048 framebuffer words
- * into LDS, draws the tile's triangles with LDS atomic minima, and writes the tile back with plain stores: one
- * store per pixel where k_big issues one device-scope atomic per FRAGMENT into a framebuffer that is larger
- * than the last-level cache.  Same fragments (hz_row_span, hz_tri_fragment), same keys, a minimum either way:
- * the same bytes (the GPU parity suite is green under HZ_TILES=1).
+ * BASELINE north_star's "tile-binned software rasteriser ... per-bin depth".  k_big issues one 64-bit atomic minimum per
+ * FRAGMENT, and the chip does 173 G of those a second whatever their scope (tools/atomic_scope.hip,
+ * profiles/r4_atomic_scope.json): where a round's large triangles lie hills behind hills - the first round of a zoomed
+ * view: 131 M fragments for 54 M pixels - k_big runs at 90 % of that rate and three times as long as its arithmetic
+ * needs (0.88 ms; 0.29 with plain stores, 0.25 with the fragments dropped: profiles/r4_tile_batches.txt).  Here the
+ * triangles queued for k_big are binned by the 64 x 64 pixel tiles of the image they can cover; a workgroup takes a
+ * BATCH of up to TL_BATCH triangles of one tile, draws them into 32 KB of LDS with LDS atomic minima (the tile starts
+ * out cleared: nothing is read from the framebuffer) and merges what it drew into the framebuffer with one atomic
+ * minimum per touched PIXEL.  Same fragments (hz_row_span, hz_tri_fragment), same keys, a minimum of minima: the
+ * same bytes (the GPU parity suite under HZ_TILES=1).
  *
- * NOT THE DEFAULT (HZ_TILES=1 switches it on; profiles/r3_experiments.json): as built it is slower than k_big
- * wherever it was measured - 16000x4000, every kernel alone: k_tile_bin 42-58 us + k_tile_raster 417 us for the
- * first round where k_big takes 310, 246 us for the second round where k_big takes 62; pipelined 1.00 -> 1.28 ms
- * per render; 40 km far clip 0.68 -> 0.75-0.83; a 45 degree view 2.85 -> 3.45 - and the most a perfect one could
- * gain is what plain stores instead of k_big's atomics gain (2.6 % of the headline render, 19 % with the 40 km
- * far clip: same file).  Why: a tile is one workgroup's job and the tiles are not alike - those along the horizon
- * hold a thousand and more small triangles (256 per tile was not enough for the benchmark scene), each costing the
- * wave its row spans and a pass of its own, four waves working through them one after the other, while k_big
- * deals its row chunks over the whole chip; the second round's large triangles are few and scattered, so that
- * most of a tile's 32 KB round trip carries nothing.  A rasteriser of this kind that wins needs a second path
- * for small triangles inside a tile (a lane each) and larger tiles for the largest - k_big with LDS in front of
- * it, not instead of it.  Kept as the measured answer to "why not LDS depth bins".
+ * Round 3's version gave a whole tile to one workgroup, which owned it (plain stores, the tile read first): the tiles
+ * along the horizon hold a thousand and more triangles, the others a dozen, and it lost to k_big everywhere (header
+ * of that version: git history; 126 + 770 us against 854 for the first round above).  Batches make the units of work
+ * alike and need no ownership - any kernel may draw into the same pixels meanwhile - at the price of atomics for the
+ * merge; a tile's batches resolve the overdraw among their own triangles only.
  *
  * k_tile_bin     one pass over the round's queue (a lane per triangle, the wave for those that touch many tiles):
  *                the triangle's number goes into the list of every tile of its box that an edge test does not
- *                rule out.  A tile's list holds TL_LIST (2048) numbers; one tile with more sends the whole round back to
- *                k_big (flag) - no counting pass, no prefix sum (a single-workgroup scan over the 31 K tiles of a
- *                16000x4000 image alone took 82 us per round)
- * k_tile_raster  one workgroup per tile with at least one triangle
+ *                rule out; the first entry of every batch of a list registers a unit of work (tile, batch).  A
+ *                tile's list holds TL_LIST numbers, the unit list TL_UNITS_PER_TILE x tiles; one overflow sends
+ *                the whole round back to k_big (flag) - no counting pass, no prefix sum
+ * k_tile_raster  one workgroup per unit of work, the units dealt round the launch
  */
 #pragma once
 
 #define TL_W 64
-#define TL_H 32
+#define TL_H 64
 
 #define TL_LIST 2048                /* triangles a tile's list holds */
+#define TL_BATCH 64                 /* triangles a workgroup draws into its LDS tile before it merges the tile into the framebuffer */
+#define TL_ROW_MIN 24               /* average pixels per non-empty row, within the tile, from which a triangle is drawn row by row (16..48: the same within 5 %) */
+#define TL_UNITS_PER_TILE 4         /* room in the unit list, per tile of the image (busy tiles are a fraction, most of them with one batch) */
 
 /* what the tile kernels share: per queue set, allocated with the context */
 struct tl_bins_t
 {
-    unsigned int* cursor;           /* [ntiles]: triangles listed for the tile (all zero between rounds: k_tile_raster zeroes its own) */
+    unsigned int* cursor;           /* [ntiles]: triangles listed for the tile (zeroed in front of k_tile_bin)                        */
     unsigned int* pairs;            /* [ntiles][TL_LIST]: record numbers                                                          */
-    unsigned int* state;            /* [0] 1 = some tile's list overflowed: k_tile_raster stands down, k_big draws the round;
-                                     * [1] tiles with a list (both zeroed in front of k_tile_bin)                                 */
-    unsigned int* busy;             /* [ntiles]: the numbers of the tiles with a list (an empty workgroup still costs its dispatch:
-                                     * 31 K of them - one per tile of a 16000x4000 image - 0.25 ms)                              */
+    unsigned int* state;            /* [0] 1 = a list (or the unit list) overflowed: k_tile_raster stands down, k_big draws the round;
+                                     * [1] units of work (both zeroed in front of k_tile_bin)                                     */
+    unsigned int* busy;             /* [TL_UNITS_PER_TILE*ntiles]: the units of work, tile | batch << 24                          */
+    unsigned int  units_cap;
     int           tiles_x, tiles_y;
     unsigned int  list_cap;         /* <= TL_LIST (tests make it small: HZ_TILE_LIST) */
 };
@@ -75,8 +73,16 @@ __device__ static inline void tl_visit(const hz_bigrec_t& br, int k, int tx0, in
         return;
     const int tile = ty*tb.tiles_x + tx;
     const unsigned int at = atomicAdd(&tb.cursor[tile], 1u);
-    if(at == 0) tb.busy[atomicAdd(&tb.state[1], 1u)] = (unsigned int)tile;
-    if(at < tb.list_cap) tb.pairs[(size_t)tile*TL_LIST + at] = rec;
+    if(at < tb.list_cap)
+    {
+        tb.pairs[(size_t)tile*TL_LIST + at] = rec;
+        if(at % TL_BATCH == 0)                                  /* the first of a batch: a unit of work */
+        {
+            const unsigned int u = atomicAdd(&tb.state[1], 1u);
+            if(u < tb.units_cap) tb.busy[u] = (unsigned int)tile | ((at / TL_BATCH) << 24);
+            else tb.state[0] = 1u;
+        }
+    }
     else tb.state[0] = 1u;                                      /* (any number of writers, one value) */
 }
 
@@ -125,77 +131,102 @@ __global__ __launch_bounds__(256)
 void k_tile_raster(unsigned long long* __restrict__ fb, const hz_bigrec_t* __restrict__ bigrec, tl_bins_t tb, hz_params_t p)
 {
     __shared__ unsigned long long tile[TL_H][TL_W];
-    const unsigned int nbusy = tb.state[1];
-    const bool stand_down = tb.state[0] != 0;                     /* some tile's list overflowed: k_big draws this round */
-    for(unsigned int b = blockIdx.x; b < nbusy; b += gridDim.x)
+    /* per wave, as in k_big: which row's span starts at pixel `base + k` of the current pass, each row's first column
+     * minus its exclusive prefix */
+    __shared__ uint32_t s_start[256/64][64];
+    __shared__ int32_t  s_delta[256/64][64];
+    if(tb.state[0] != 0) return;                                    /* an overflow: k_big draws this round */
+    const unsigned int nunits = tb.state[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_start[wave][lane] = 0u;
+    for(unsigned int b = blockIdx.x; b < nunits; b += gridDim.x)
     {
-        const int t = (int)tb.busy[b];
-        const unsigned int n = tb.cursor[t];
-        __syncthreads();                                            /* (everybody has read the count; the tile of the turn before is stored) */
-        if(threadIdx.x == 0) tb.cursor[t] = 0u;                     /* the list is empty again for the round that takes this queue set next */
-        if(stand_down) continue;
+        const unsigned int unit = tb.busy[b];
+        const int t = (int)(unit & 0xFFFFFFu);
+        const unsigned int k0 = (unit >> 24)*TL_BATCH;
+        const unsigned int n = min(tb.cursor[t], tb.list_cap);
+        const unsigned int k1 = min(n, k0 + TL_BATCH);
         const size_t first = (size_t)t*TL_LIST;
         const int tx = t % tb.tiles_x, ty = t / tb.tiles_x;
         const int X0 = tx*TL_W, Y0 = ty*TL_H;                       /* tile origin: column relative to the sector, GL row */
         const int wcols = min(TL_W, p.SW - X0), hrows = min(TL_H, p.H - Y0);
-        for(int k = threadIdx.x; k < TL_W*TL_H; k += 256)
+        const int xt = X0 + p.col0;                                 /* image column of the tile's column 0 */
+        __syncthreads();                                            /* (the tile of the turn before is merged) */
         {
-            const int r = k/TL_W, c = k%TL_W;
-            tile[r][c] = (r < hrows && c < wcols) ? fb[(size_t)(Y0 + r)*p.SW + X0 + c] : HZ_FB_CLEAR;
+            ulonglong2* t2 = (ulonglong2*)&tile[0][0];
+            const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
+            for(int k = threadIdx.x; k < TL_W*TL_H/2; k += 256) t2[k] = ones;
         }
         __syncthreads();
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         /* (the next record is requested before the current one is drawn: its latency hides behind the pixel work) */
         hz_bigrec_t rec_next = {};
-        if((unsigned int)wave < n) rec_next = bigrec[__builtin_amdgcn_readfirstlane(tb.pairs[first + wave])];
-        for(unsigned int k = wave; k < n; k += 4)
+        if(k0 + wave < k1) rec_next = bigrec[__builtin_amdgcn_readfirstlane(tb.pairs[first + k0 + wave])];
+        for(unsigned int k = k0 + wave; k < k1; k += 4)
         {
             const hz_bigrec_t br = rec_next;
-            if(k + 4 < n) rec_next = bigrec[__builtin_amdgcn_readfirstlane(tb.pairs[first + k + 4])];
+            if(k + 4 < k1) rec_next = bigrec[__builtin_amdgcn_readfirstlane(tb.pairs[first + k + 4])];
             hz_tri_t tri;
             hz_planes_from_rec(tri, br.r);
             const uint32_t prim = br.r.prim;
-            /* lane = row of the tile (the upper half of the wave has none) */
-            const int row = Y0 + (lane & (TL_H-1));
+            /* lane = row of the tile */
+            const int row = Y0 + lane;
             const int xlo = max(br.r.px0, X0 + p.col0), xhi = min(br.r.px0 + br.r.bw - 1, X0 + p.col0 + wcols - 1);
             int32_t x0 = xlo;
             const uint32_t span = hz_row_span(br.r.e, row, xlo, xhi, &x0);
-            const uint32_t count = (lane < TL_H && row >= br.r.py0 && row < br.r.py0 + br.bh && row < Y0 + hrows) ? span : 0u;
+            const uint32_t count = (row >= br.r.py0 && row < br.r.py0 + br.bh && lane < hrows) ? span : 0u;
             /* lane = pixel, as k_big */
             const uint32_t incl  = mr_scan(count, lane);
             const uint32_t excl  = incl - count;
-            const uint32_t total = __shfl(incl, 63);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            unsigned long long rows_left = __ballot(count > 0u);
+            if(total >= (uint32_t)TL_ROW_MIN*(uint32_t)__popcll(rows_left))
+            {
+                /* long spans (a tile holds at most 64 pixels of a row): row by row, the lanes side by side */
+                while(rows_left)
+                {
+                    const int r = (int)__builtin_ctzll(rows_left);
+                    rows_left &= rows_left - 1ull;
+                    const int rx0 = __builtin_amdgcn_readlane(x0, r);
+                    const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)count, r);
+                    if((uint32_t)lane < rc)
+                    {
+                        const int px = rx0 + lane, py = Y0 + r;
+                        uint32_t zi, r8;
+                        if(hz_tri_fragment(&tri, px, py, &zi, &r8)) atomicMin(&tile[r][px - xt], hz_pack(zi, prim, r8));
+                    }
+                }
+                continue;
+            }
+            KB_LDS_ORDER();                                         /* (the reads of the triangle before) */
+            s_delta[wave][lane] = x0 - (int32_t)excl;
+            uint32_t carry = 0u;
             for(uint32_t base = 0; base < total; base += 64)
             {
                 const uint32_t q = base + lane;
-                int own = 0;
-                #pragma unroll
-                for(int step=TL_H/2; step>=1; step>>=1)
-                {
-                    const uint32_t v = __shfl(excl, own + step);
-                    if(v <= q) own += step;
-                }
-                const int px = __shfl(x0, own) + (int)(q - __shfl(excl, own));
+                if(count > 0u && excl - base < 64u) s_start[wave][excl - base] = (uint32_t)lane + 1u;
+                KB_LDS_ORDER();
+                uint32_t own1 = s_start[wave][lane];
+                KB_LDS_ORDER();
+                if(own1) s_start[wave][lane] = 0u;
+                own1 = mr_scan_max(lane == 0 ? (own1 > carry ? own1 : carry) : own1);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
+                const int own = (int)own1 - 1;
+                const int px = (int)q + s_delta[wave][own & 63];
                 const int py = Y0 + own;
                 if(q < total)
                 {
                     uint32_t zi, r8;
-                    if(hz_tri_fragment(&tri, px, py, &zi, &r8))
-                        atomicMin(&tile[own][px - p.col0 - X0], hz_pack(zi, prim, r8));
+                    if(hz_tri_fragment(&tri, px, py, &zi, &r8)) atomicMin(&tile[own & 63][px - xt], hz_pack(zi, prim, r8));
                 }
             }
         }
         __syncthreads();
+        /* what the batch drew, into the framebuffer: a minimum of minima */
         for(int k = threadIdx.x; k < TL_W*TL_H; k += 256)
         {
             const int r = k/TL_W, c = k%TL_W;
-            if(r < hrows && c < wcols)
-            {
-                const unsigned long long v = tile[r][c];
-                if(v != HZ_FB_CLEAR) fb[(size_t)(Y0 + r)*p.SW + X0 + c] = v;
-            }
+            const unsigned long long v = tile[r][c];
+            if(v != HZ_FB_CLEAR) hz_fb_min<HZ_WHO_BIG>(fb, p, xt + c, Y0 + r, v);
         }
-        /* something was (or may have been) drawn into these rows' segment: the conversion has to look */
-        if(threadIdx.x < hrows) p.touched[(size_t)(Y0 + threadIdx.x)*p.seg_stride + (X0 >> HZ_SEG_LOG2)] = 1;
     }
 }

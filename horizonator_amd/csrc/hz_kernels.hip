@@ -122,8 +122,8 @@ struct hz_env_t
     int    mid, mid_near, mid_cells; /* HZ_MID=1: two-round draws get a middle round (plan_rounds; not the default); HZ_MID_NEAR (256): the first round's reach
                                      * in draws with a middle round; HZ_MID_CELLS (640): the middle round's */
     int    inline_max2;             /* HZ_INLINE_MAX2=n: the second round's marching waves keep boxes of up to n pixels, larger ones up to 64 go to k_mid; 0: the draw decides (64, or 32 with a close far clip) */
-    int    tiles;                   /* HZ_TILES=1: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics:
-                                     * byte-identical, slower as built (profiles/r3_experiments.json) - not the default */
+    int    tiles;                   /* HZ_TILES: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics, byte-identical:
+                                     * 1 every round, 2 first (and middle) rounds, 0 never; default -1: the first round of zoomed views (draw_impl) */
     int    tile_list;               /* HZ_TILE_LIST=n: a tile's list holds n triangles instead of 256 (tests: the fall-back to k_big) */
     int    resolve_nt;              /* HZ_RESOLVE_NT=0: the conversion's results leave with plain instead of non-temporal stores */
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
@@ -160,7 +160,7 @@ static hz_env_t read_env(void)
     e.mid_near         = env_int("HZ_MID_NEAR", 256);
     e.mid_cells        = env_int("HZ_MID_CELLS", 640);
     e.inline_max2      = env_int("HZ_INLINE_MAX2", 0);
-    e.tiles            = env_int("HZ_TILES", 0) != 0;
+    e.tiles            = env_int("HZ_TILES", -1);
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
     e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 25.0;
@@ -233,6 +233,7 @@ struct hz_dev
     /* coarse depth of each framebuffer (hz_k_hiz.h), allocated by the first draw that wants it */
     uint32_t*           d_hiz[HZ_NFB];
     int                 hiz_unavailable;        /* their allocation failed once: not tried again with every draw */
+    int                 tiles_unavailable;      /* ... the tile bins' (tile_bins) */
     int                 last_plan[4];           /* the last draw (hz_hip_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
@@ -363,6 +364,30 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
 
 static mr_queue_t queue_set(const hz_dev_t* d, int k);
 
+/* the tile bins of queue set `set` (hz_k_tile.h): 8 KB of list per 64 x 64 pixel tile of the image - 129 MB per set at
+ * 16000 x 4000 -, allocated when a round first draws by tile.  Returns 0, or 1 if there is no memory for them (not tried
+ * again: the rounds stay with k_big). */
+static int tile_bins(hz_dev_t* d, int set)
+{
+    tl_bins_t& tb = d->tiles_s[set];
+    if(tb.cursor) return 0;
+    if(d->tiles_unavailable) return 1;
+    const size_t ntiles = (size_t)((d->W + TL_W-1)/TL_W)*((d->H + TL_H-1)/TL_H);
+    hipError_t e = hipMalloc(&tb.pairs, ntiles*TL_LIST*sizeof(unsigned int));
+    if(e == hipSuccess) e = hipMalloc(&tb.state, 2*sizeof(unsigned int));
+    if(e == hipSuccess) e = hipMalloc(&tb.busy, TL_UNITS_PER_TILE*ntiles*sizeof(unsigned int));
+    if(e == hipSuccess) e = hipMalloc(&tb.cursor, ntiles*sizeof(unsigned int));
+    if(e != hipSuccess)
+    {
+        (void)hipGetLastError();
+        (void)hipFree(tb.pairs); (void)hipFree(tb.state); (void)hipFree(tb.busy); (void)hipFree(tb.cursor);
+        tb.pairs = tb.state = tb.busy = tb.cursor = NULL;
+        d->tiles_unavailable = 1;
+        return 1;
+    }
+    return 0;
+}
+
 static int create_impl(hz_dev_t* d)
 {
     HZ_ON_DEVICE(d);
@@ -431,17 +456,9 @@ static int create_impl(hz_dev_t* d)
         HZ_CHECK(hipMalloc(&d->d_clip_s[i],    (size_t)q.clip_capacity*sizeof(uint32_t)));
         HZ_CHECK(hipMalloc(&d->d_big_counters_s[i], HZ_NCOUNTERS*sizeof(unsigned int)));
         HZ_CHECK(hipMemset(d->d_big_counters_s[i], 0, HZ_NCOUNTERS*sizeof(unsigned int)));
-        if(d->env.tiles > 0)                /* (the tile bins exist only where HZ_TILES=1 asks for them) */
-        {
-            tl_bins_t& tb = d->tiles_s[i];
-            const size_t ntiles = (size_t)((d->W + TL_W-1)/TL_W)*((d->H + TL_H-1)/TL_H);
-            HZ_CHECK(hipMalloc(&tb.cursor, ntiles*sizeof(unsigned int)));
-            HZ_CHECK(hipMalloc(&tb.pairs,  ntiles*TL_LIST*sizeof(unsigned int)));
-            HZ_CHECK(hipMalloc(&tb.state,  2*sizeof(unsigned int)));
-            HZ_CHECK(hipMalloc(&tb.busy,   ntiles*sizeof(unsigned int)));
-            HZ_CHECK(hipMemset(tb.cursor, 0, ntiles*sizeof(unsigned int)));
-            HZ_CHECK(hipMemset(tb.state, 0, 2*sizeof(unsigned int)));
-        }
+        /* (the tile bins of the rounds that use them whatever the view - HZ_TILES=1: all, 2: the first rounds' queue sets;
+         * by default they are made when a zoomed view first asks for them: tile_bins()) */
+        if((d->env.tiles == 1 || (d->env.tiles == 2 && i >= HZ_NFB)) && tile_bins(d, i) != 0) return -1;
     }
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
@@ -999,7 +1016,9 @@ static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp
         tl_bins_t tb = d->tiles_s[set];
         tb.tiles_x = (pp.SW + TL_W-1)/TL_W; tb.tiles_y = (pp.H + TL_H-1)/TL_H;
         tb.list_cap = d->env.tile_list > 0 && d->env.tile_list < TL_LIST ? (unsigned int)d->env.tile_list : TL_LIST;
+        tb.units_cap = (unsigned int)(TL_UNITS_PER_TILE*(size_t)((d->W + TL_W-1)/TL_W)*((d->H + TL_H-1)/TL_H));
         HZ_CHECK(hipMemsetAsync(tb.state, 0, 2*sizeof(unsigned int), st));
+        HZ_CHECK(hipMemsetAsync(tb.cursor, 0, (size_t)tb.tiles_x*tb.tiles_y*sizeof(unsigned int), st));
         hipLaunchKernelGGL(k_tile_bin, dim3(1024), dim3(256), 0, st, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
                            (const unsigned int*)q.counters, q.bigrec_capacity, tb, pp);
         hipLaunchKernelGGL(k_tile_raster, dim3(2048), dim3(256), 0, st, d->d_fb, (const hz_bigrec_t*)q.bigrec, tb, pp);
@@ -1152,10 +1171,12 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     const int next = d->fbi;
 
     const mr_queue_t q = queue_set(d, next);        /* one-round draw, or second round */
-    /* large triangles by screen tile instead of by k_big's atomics (HZ_TILES; hz_k_tile.h).  A tile's workgroup must be
-     * the only writer of its pixels: the kernels before it on its stream are done, and the second round of a two-round
-     * draw then always waits for the first (a second round beside its first would write the same framebuffer). */
-    const bool by_tile = d->env.tiles > 0 && d->raster != HZ_RASTER_SCATTER;
+    /* large triangles by screen tile instead of by k_big's atomics (HZ_TILES; hz_k_tile.h): in every round (1), or in first
+     * and middle rounds - where the large triangles lie hills behind hills and k_big is bound by its atomics - always (2)
+     * or when the view is zoomed (the default; decided below).  The tiles merge into the framebuffer with atomic minima:
+     * no ownership, nothing else has to wait. */
+    const bool by_tile = d->env.tiles == 1 && d->raster != HZ_RASTER_SCATTER;
+    bool by_tile_first = (d->env.tiles == 1 || d->env.tiles == 2) && d->raster != HZ_RASTER_SCATTER;
     bool near_beside_far = false;                   /* the second round did not wait for the first */
     bool waited_near = false;                       /* ... or it did */
     bool use_hiz = false;                           /* the second round keeps coarse depth (hz_k_hiz.h) */
@@ -1208,7 +1229,13 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             }
             if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
-            if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
+            {
+                /* (zoomed: as for coarse depth below - a cell at the first round's reach still hz_min_px pixels wide) */
+                const float ppr = p.halfW * p.u.az_ndc_per_rad;
+                const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
+                if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px && tile_bins(d, HZ_NFB + next) == 0) by_tile_first = true;
+            }
+            if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile_first) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
              * finds the marching kernel of the draw before it finished (a single render, or
@@ -1238,7 +1265,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                  * segments narrow sectors get (mr_make_zones) an eighth loses 5: from a sixth of the image on.  profiles/r4_sector_rules.txt) */
                 /* (whatever the far clip: with the API's 40 km the tables change nothing - 0.602 / 0.607 ms without / with,
                  * three alternating pairs -, at 80 km they gain 3 %, at 150 km 4 %: round 4) */
-                use_hiz = early_z && !by_tile && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || three || (busy && 6*p.SW >= p.W)));
+                use_hiz = early_z && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || three || (busy && 6*p.SW >= p.W)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight
@@ -1263,11 +1290,11 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                     if(upload_list(d, 2, d->nstream, *d->lists.scratch) != 0) return -1;
                 }
                 if(launch_march(d, d->nstream, qn, zn, pm, listed ? d->lists.d_items[2] : NULL, d->lists.n[2]) != 0) return -1;
-                if(queue_kernels(d, qn, pm, d->nstream, HZ_NFB + next, by_tile) != 0) return -1;
+                if(queue_kernels(d, qn, pm, d->nstream, HZ_NFB + next, by_tile_first) != 0) return -1;
                 if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
             }
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
-            if(use_hiz || d->env.always_wait_near || by_tile || busy)
+            if(use_hiz || d->env.always_wait_near || busy)
             {
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
                 waited_near = true;             /* (the first round itself waited for the framebuffer: no second wait for that below) */

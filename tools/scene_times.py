@@ -9,7 +9,10 @@ for name in sys.argv[1:]:
     R, W, H = sc["R"], sc["W"], sc["H"]
     h = horizonator_amd.horizonator(scenes.LAT, scenes.LON, W, H, dir_dems=hzutil.dem_dir_for(scenes.LAT, scenes.LON, R, rough=sc.get("rough", False)), render_radius_cells=R)
     az0, az1 = sc.get("az", (-180.0, 180.0))
-    h.set_view(az0, az1, znear=100.0, zfar=sc.get("zfar", 600000.0))
+    lat, lon = scenes.LAT, scenes.LON
+    if sc.get("viewpoint"):
+        lat, lon, _ = scenes._extreme_viewpoint(h, sc["viewpoint"])
+    h.set_view(az0, az1, lat=lat, lon=lon, znear=100.0, zfar=sc.get("zfar", 600000.0))
     h.set_profiling(True)
     d_img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda"); d_rng = torch.empty((H, W), dtype=torch.float32, device="cuda")
     for k in range(3):
