@@ -32,8 +32,13 @@
  * a narrow view's frustum is narrow in elevation too, little of the nearest terrain is inside it, and the ridge
  * that hides most of the view tends to lie further out - seven 10 and 45 degree views (three viewpoints, four
  * directions, the rough DEM; tools/hiz_ab.py, profiles/r3_coarse_depth.txt) take 14.5 ms in sum with a reach of 256
- * cells, 11.0 with 384, 11.1 with 512 (five gain up to 2x, two lose 8 %). */
-#define HZ_NEAR_CELLS_MAX 384
+ * cells, 11.0 with 384, 11.1 with 512 (five gain up to 2x, two lose 8 %).  Round 4: with the first round's large
+ * triangles drawn by screen tile (hz_k_tile.h) a longer first round costs less - the same views 9.7 ms with 384, 9.8 with
+ * 448, 9.5 with 512, 9.8 with 576, 10.3 with 640, and the slowest of them 2.03 / 1.95 / 1.72 / 1.69 / 1.80
+ * (profiles/r4_tile_batches.txt): views that are still "zoomed" at 512 cells (a cell there HZ_HIZ_MIN_PX pixels wide:
+ * up to 70 degrees at 16000 columns) reach that far, the others 384 as before (a 90 degree view with 509: 1.06 -> 1.21). */
+#define HZ_NEAR_CELLS_WIDE 384
+#define HZ_NEAR_CELLS_MAX  512
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the

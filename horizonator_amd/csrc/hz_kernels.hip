@@ -129,6 +129,7 @@ struct hz_env_t
     int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
     double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
     int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: zoomed views, and every draw of a series */
+    double tiles_min_px;            /* HZ_TILES_MIN_PX (default 35): from this width of a cell at the first round's reach on, that round's large triangles go by tile */
     double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): "zoomed" = a cell at the first round's reach is at least this wide */
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -163,6 +164,7 @@ static hz_env_t read_env(void)
     e.tiles            = env_int("HZ_TILES", -1);
     e.tile_list        = env_int("HZ_TILE_LIST", 0);
     e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
+    e.tiles_min_px     = getenv("HZ_TILES_MIN_PX") ? atof(getenv("HZ_TILES_MIN_PX")) : 35.0;
     e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 25.0;
     e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
     e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
@@ -1072,7 +1074,7 @@ static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
     /* The first round's reach: the cells that are wider than ~20 pixels on screen - a cell r rows
      * from the viewer is about ppr/r pixels wide (ppr = pixels per radian of azimuth), so r = ppr/20:
      * 127 cells for a 16000-wide panorama (where 32..256 were timed: hz_k_march.h), 64 for 8000, 260
-     * for 32768, at most HZ_NEAR_CELLS_MAX (zoomed views: see there).
+     * for 32768, at most HZ_NEAR_CELLS_WIDE - and HZ_NEAR_CELLS_MAX for views zoomed far enough (see there).
      * profiles/r3_scenes.json holds the sweep over the scenes of tools/scenes.py. */
     int near_cells = d->env.near_cells;
     if(near_cells < 0)
@@ -1080,7 +1082,8 @@ static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
         const float ppr = p.halfW * p.u.az_ndc_per_rad;
         near_cells = (int)(ppr / (float)d->env.near_px + 0.5f);
         if(near_cells < 16) near_cells = 16;
-        if(near_cells > HZ_NEAR_CELLS_MAX) near_cells = HZ_NEAR_CELLS_MAX;
+        if(near_cells > HZ_NEAR_CELLS_WIDE) near_cells = HZ_NEAR_CELLS_WIDE;
+        if(ppr/(float)HZ_NEAR_CELLS_MAX >= (float)d->env.hiz_min_px) near_cells = HZ_NEAR_CELLS_MAX;       /* (zoomed even at that reach: hz_k_march.h) */
     }
     /* A MIDDLE ROUND (round 4; HZ_MID=1, not the default).  How far the first round of a zoomed view has to reach for the
      * ridge that hides most of the view to be in the tables depends on the view (no single reach is
@@ -1230,10 +1233,11 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists.d_items[0] : NULL, d->lists.n[0]) != 0) return -1;
             {
-                /* (zoomed: as for coarse depth below - a cell at the first round's reach still hz_min_px pixels wide) */
+                /* (zoomed further than coarse depth asks for: a cell at the first round's reach still HZ_TILES_MIN_PX = 35 pixels wide - a 45
+                 * degree view of 16000 columns: 40; a 90 degree view, 26, is better off with k_big: 0.92 against 1.08 ms) */
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
-                if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px && tile_bins(d, HZ_NFB + next) == 0) by_tile_first = true;
+                if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= (float)d->env.tiles_min_px && tile_bins(d, HZ_NFB + next) == 0) by_tile_first = true;
             }
             if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile_first) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
