@@ -198,6 +198,7 @@ def _open(path, selftest):
     sig("horizonator_amd_stream_waits_for_outputs", b, ctxp, vp)
     sig("horizonator_amd_waits_for_stream", b, ctxp, vp)
     sig("hz_hip_last_plan", i, vp, vp)
+    sig("hz_hip_last_queue_counts", i, vp, vp)
     sig("hz_hip_last_error", C.c_char_p)
     if selftest:
         sig("hz_hip_check_fastmath", i, i, i, C.c_uint64, C.c_uint64, P(C.c_uint64), vp)
@@ -233,7 +234,7 @@ DECLARED_SYMBOLS = [
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
     "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
-    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_last_plan", "hz_hip_last_error",
+    "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_last_plan", "hz_hip_last_queue_counts", "hz_hip_last_error",
 ]
 # include/hz_selftest.h: what libhorizonator_selftest.so exports on top of those (and libhorizonator.so must not)
 SELFTEST_SYMBOLS = ["hz_hip_check_fastmath", "hz_hip_check_exactness", "hz_hip_debug_bigqueue", "hz_hip_debug_wave_timing",

@@ -35,8 +35,10 @@
  * cells, 11.0 with 384, 11.1 with 512 (five gain up to 2x, two lose 8 %).  Round 4: with the first round's large
  * triangles drawn by screen tile (hz_k_tile.h) a longer first round costs less - the same views 9.7 ms with 384, 9.8 with
  * 448, 9.5 with 512, 9.8 with 576, 10.3 with 640, and the slowest of them 2.03 / 1.95 / 1.72 / 1.69 / 1.80
- * (profiles/r4_tile_batches.txt): views that are still "zoomed" at 512 cells (a cell there HZ_HIZ_MIN_PX pixels wide:
- * up to 70 degrees at 16000 columns) reach that far, the others 384 as before (a 90 degree view with 509: 1.06 -> 1.21). */
+ * (profiles/r4_tile_batches.txt) - but it is two of the seven that gain (summit, valley: 0.3-0.4 ms each) and five
+ * that lose 0.1.  So views that are still "zoomed" at 512 cells (a cell there HZ_HIZ_MIN_PX pixels wide: up to 70
+ * degrees at 16000 columns) MAY reach that far: they do when the draws of the same view before them say it pays
+ * (hz_kernels.hip, adapt: what the second round had to queue), the others and every first draw of a view 384. */
 #define HZ_NEAR_CELLS_WIDE 384
 #define HZ_NEAR_CELLS_MAX  512
 

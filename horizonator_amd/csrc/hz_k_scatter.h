@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256)
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
            const unsigned int* __restrict__ big_counters,
-           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p, const unsigned int* tile_state)
+           unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p, const unsigned int* tile_state,
+           unsigned int* report)
 {
     /* per wave: which row's span starts at pixel `base + k` of the current pass (row + 1, 0: none), and each row's
      * first column minus its exclusive prefix (a pixel's column = its number + that).  A wave's own LDS traffic is
@@ -313,6 +314,8 @@ void k_big(unsigned long long* __restrict__ fb,
      * operation behind each, 660 -> 750 us for the first round's launch beside a marching kernel.) */
     __shared__ uint32_t s_start[256/64][64];
     __shared__ int32_t  s_delta[256/64][64];
+    /* (report: pinned host memory - what this round queued, for the host's choice of the next first round's reach: hz_kernels.hip, adapt) */
+    if(report && blockIdx.x == 0 && threadIdx.x == 0) { report[0] = big_counters[0]; report[1] = big_counters[1]; }
     const int wv = threadIdx.x >> 6;
     s_start[wv][threadIdx.x & 63] = 0u;
     KB_LDS_ORDER();

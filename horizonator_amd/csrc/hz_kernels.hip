@@ -119,6 +119,8 @@ struct hz_env_t
     int    zone16_rows;             /* HZ_Z16_ROWS: rows per segment where a cell is 1 to 4 pixels wide (experiments); 0: 16, narrow sectors 8 (mr_make_zones) */
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
+    int    adapt, adapt_hi;         /* HZ_ADAPT=0/1/2 (default 1): the first round of a zoomed view may reach HZ_NEAR_CELLS_MAX instead of HZ_NEAR_CELLS_WIDE cells: never / when the draws
+                                     * of the same view before it say so (from HZ_ADAPT_HI = 500000 work items for k_big in the second round on) / always */
     int    mid, mid_near, mid_cells; /* HZ_MID=1: two-round draws get a middle round (plan_rounds; not the default); HZ_MID_NEAR (256): the first round's reach
                                      * in draws with a middle round; HZ_MID_CELLS (640): the middle round's */
     int    inline_max2;             /* HZ_INLINE_MAX2=n: the second round's marching waves keep boxes of up to n pixels, larger ones up to 64 go to k_mid; 0: the draw decides (64, or 32 with a close far clip) */
@@ -158,6 +160,8 @@ static hz_env_t read_env(void)
     e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
     e.mid              = env_int("HZ_MID", 0) != 0;
+    e.adapt            = env_int("HZ_ADAPT", 1);
+    e.adapt_hi         = env_int("HZ_ADAPT_HI", 500000);
     e.mid_near         = env_int("HZ_MID_NEAR", 256);
     e.mid_cells        = env_int("HZ_MID_CELLS", 640);
     e.inline_max2      = env_int("HZ_INLINE_MAX2", 0);
@@ -236,6 +240,26 @@ struct hz_dev
     uint32_t*           d_hiz[HZ_NFB];
     int                 hiz_unavailable;        /* their allocation failed once: not tried again with every draw */
     int                 tiles_unavailable;      /* ... the tile bins' (tile_bins) */
+    /* The first round's reach of a zoomed view follows what the second round had to draw (plan_rounds, draw_impl): how
+     * far the first round has to reach for the ridge that hides most of the view to be in its picture depends on the
+     * view, and what a reach was worth shows in what the second round still had to queue for k_big.  The second round's
+     * queue counters are copied to the host behind its queue kernels; a later draw of the SAME view that finds the copy
+     * complete looks at them: many work items behind a short first round (HZ_ADAPT_HI) - the next draws try the long
+     * reach; if that leaves fewer than 70 % of them, they stay with it, else they go back for good.  A new view starts
+     * short.  The bytes do not depend on the reach. */
+    struct
+    {
+        unsigned int* h_counts[HZ_NFB];     /* pinned, 6 words each: the second round's queue counters */
+        hipEvent_t    ev[HZ_NFB];
+        int           pending[HZ_NFB], long_of[HZ_NFB], reach_of[HZ_NFB];
+        unsigned int  serial_of[HZ_NFB];
+        hz_view_t     view; int col0, col1, have_view;     /* the view the observations are about */
+        unsigned int  serial;               /* ... its number */
+        unsigned int  items_short;          /* what its second round queued behind a short first round (0: not seen yet) */
+        int           tried_long;
+        int           long_reach;           /* the choice for its next draw */
+        int           seen_reach; unsigned int seen_records, seen_items;   /* the last observation (hz_hip_last_queue_counts) */
+    } adapt;
     int                 last_plan[4];           /* the last draw (hz_hip_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
@@ -352,6 +376,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_index);
     (void)hipFree(d->d_z24);
     for(int k=0; k<10; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    for(int k=0; k<HZ_NFB; k++) { if(d->adapt.ev[k]) (void)hipEventDestroy(d->adapt.ev[k]); if(d->adapt.h_counts[k]) (void)hipHostFree(d->adapt.h_counts[k]); }
     if(d->ev_drawn)   (void)hipEventDestroy(d->ev_drawn);
     for(int i=0; i<HZ_NFB; i++) if(d->ev_free[i]) (void)hipEventDestroy(d->ev_free[i]);
     if(d->ev_readers) (void)hipEventDestroy(d->ev_readers);
@@ -467,6 +492,11 @@ static int create_impl(hz_dev_t* d)
     d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
     d->tanel_resident = 0;
     for(int k=0; k<10; k++) HZ_CHECK(hipEventCreate(&d->ev[k]));
+    for(int k=0; k<HZ_NFB; k++)
+    {
+        HZ_CHECK(hipHostMalloc((void**)&d->adapt.h_counts[k], 6*sizeof(unsigned int), hipHostMallocDefault));
+        HZ_CHECK(hipEventCreateWithFlags(&d->adapt.ev[k], hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -999,7 +1029,7 @@ static mr_queue_t queue_set(const hz_dev_t* d, int k)
 }
 
 /* what the marching waves queued: clipper, medium boxes, large boxes */
-static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st, int set, bool by_tile)
+static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st, int set, bool by_tile, unsigned int* report = NULL)
 {
     hipLaunchKernelGGL(k_clip, dim3(1024), dim3(64), 0, st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
     HZ_CHECK(hipGetLastError());
@@ -1029,7 +1059,7 @@ static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp
     }
     hipLaunchKernelGGL(k_big, dim3(4096), dim3(256), 0, st,
                        d->d_fb, (const hz_bigrec_t*)q.bigrec, (const hz_bigitem_t*)q.bigitem,
-                       q.counters, q.bigrec_capacity, q.bigitem_capacity, pp, tile_state);
+                       q.counters, q.bigrec_capacity, q.bigitem_capacity, pp, tile_state, report);
     HZ_CHECK(hipGetLastError());
     return 0;
 }
@@ -1083,7 +1113,8 @@ static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
         near_cells = (int)(ppr / (float)d->env.near_px + 0.5f);
         if(near_cells < 16) near_cells = 16;
         if(near_cells > HZ_NEAR_CELLS_WIDE) near_cells = HZ_NEAR_CELLS_WIDE;
-        if(ppr/(float)HZ_NEAR_CELLS_MAX >= (float)d->env.hiz_min_px) near_cells = HZ_NEAR_CELLS_MAX;       /* (zoomed even at that reach: hz_k_march.h) */
+        /* (zoomed even at the long reach: there, if the draws before say so - hz_k_march.h, adapt) */
+        if(ppr/(float)HZ_NEAR_CELLS_MAX >= (float)d->env.hiz_min_px && (d->env.adapt == 2 || (d->env.adapt == 1 && d->adapt.long_reach))) near_cells = HZ_NEAR_CELLS_MAX;
     }
     /* A MIDDLE ROUND (round 4; HZ_MID=1, not the default).  How far the first round of a zoomed view has to reach for the
      * ridge that hides most of the view to be in the tables depends on the view (no single reach is
@@ -1170,6 +1201,31 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     hz_params_t p = make_params(d, view);
     const bool prof = d->profiling != 0;
     d->last_view = *view; d->have_view = 1; d->fb_consumed = 0;
+    /* what the second rounds of the draws before had to queue (adapt): those of this view whose copy has arrived */
+    if(!d->adapt.have_view || memcmp(view, &d->adapt.view, sizeof(*view)) != 0 || d->adapt.col0 != d->col0 || d->adapt.col1 != d->col1)
+    {
+        d->adapt.view = *view; d->adapt.col0 = d->col0; d->adapt.col1 = d->col1; d->adapt.have_view = 1;
+        d->adapt.serial++; d->adapt.items_short = 0; d->adapt.tried_long = 0; d->adapt.long_reach = 0;
+    }
+    for(int k=0; k<HZ_NFB; k++)
+        if(d->adapt.pending[k] && hipEventQuery(d->adapt.ev[k]) == hipSuccess)
+        {
+            d->adapt.pending[k] = 0;
+            const unsigned int items = d->adapt.h_counts[k][1];
+            d->adapt.seen_reach = d->adapt.reach_of[k]; d->adapt.seen_records = d->adapt.h_counts[k][0]; d->adapt.seen_items = items;
+            if(d->adapt.serial_of[k] != d->adapt.serial) continue;                  /* (about another view) */
+            if(!d->adapt.long_of[k])
+            {
+                d->adapt.items_short = items;
+                if(!d->adapt.tried_long && items > (unsigned int)d->env.adapt_hi) d->adapt.long_reach = 1;
+            }
+            else
+            {
+                d->adapt.tried_long = 1;
+                if(!(d->adapt.items_short && (unsigned long long)items*10ull < (unsigned long long)d->adapt.items_short*7ull)) d->adapt.long_reach = 0;
+            }
+        }
+    (void)hipGetLastError();                /* (hipErrorNotReady from a query is not an error) */
     if(next_framebuffer(d, p) != 0) return -1;
     const int next = d->fbi;
 
@@ -1353,8 +1409,21 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * second round's queue kernels only as long as the second round itself waited for the first */
     if(near_beside_far) HZ_CHECK(hipStreamWaitEvent(d->qstream, d->ev_near, 0));
     if(prof) HZ_CHECK(hipEventRecord(d->ev[8], d->qstream));
-    if(queue_kernels(d, q, p, d->qstream, next, by_tile) != 0) return -1;
+    /* (adapt: k_big itself leaves the round's queue counters in pinned host memory - no copy in front of ev_drawn) */
+    unsigned int* report = NULL;
+    if(d->env.adapt == 1 && d->env.near_cells < 0 && p.pass == 2 && d->adapt.h_counts[next] && !d->adapt.pending[next])
+    {
+        const float ppr = p.halfW * p.u.az_ndc_per_rad;
+        if(ppr/(float)HZ_NEAR_CELLS_MAX >= (float)d->env.hiz_min_px) report = d->adapt.h_counts[next];        /* (a view whose reach has the choice) */
+    }
+    if(queue_kernels(d, q, p, d->qstream, next, by_tile, report) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
+    if(report)
+    {
+        HZ_CHECK(hipEventRecord(d->adapt.ev[next], d->qstream));
+        d->adapt.pending[next] = 1; d->adapt.reach_of[next] = (p.near_j1 - p.near_j0)/2;
+        d->adapt.long_of[next] = d->adapt.reach_of[next] > HZ_NEAR_CELLS_WIDE ? 1 : 0; d->adapt.serial_of[next] = d->adapt.serial;
+    }
     d->last_plan[0] = p.pass == 2 ? (p.mid_j1 - p.mid_j0 > p.near_j1 - p.near_j0 ? 3 : 2) : 1; d->last_plan[1] = use_hiz ? 1 : 0;
     d->last_plan[2] = p.pass == 2 ? (p.near_j1 - p.near_j0)/2 : 0; d->last_plan[3] = p.cull_strips ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
@@ -2343,6 +2412,13 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
 /* what the last draw was (bench.py records it beside every timing, tests assert on it) - out[0] rounds (1 / 2),
  * [1] its second round kept coarse depth (hz_k_hiz.h), [2] the first round's reach in cells (0: one round), [3] only
  * the strips behind the drawn columns were launched (sectors, views of less than the full circle) */
+extern "C" int hz_hip_last_queue_counts(hz_dev_t* d, unsigned int* out)
+{
+    if(!d || !out) return -1;
+    out[0] = (unsigned int)d->adapt.seen_reach; out[1] = d->adapt.seen_records; out[2] = d->adapt.seen_items; out[3] = (unsigned int)d->adapt.long_reach;
+    return 0;
+}
+
 extern "C" int hz_hip_last_plan(hz_dev_t* d, int* out)
 {
     if(!d || !out) return -1;

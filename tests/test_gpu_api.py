@@ -402,6 +402,43 @@ def test_which_draws_keep_coarse_depth(monkeypatch):
         h.set_view(-10, 10, zfar=200000.0)          # a 20 degree view: ppr = 22900, the reach hits its cap
         h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
         rounds, coarse, reach, listed = plan()
-        assert (rounds, coarse, listed) == (2, 1, 1) and reach == 512, plan()     # (zoomed even at 512 cells: 45 px a cell there)
+        assert (rounds, coarse, listed) == (2, 1, 1) and reach == 384, plan()     # (the first draw of a view: the short reach; hz_kernels.hip, adapt)
+    finally:
+        h.close()
+
+
+def test_the_reach_of_a_zoomed_view_follows_the_draws_before(monkeypatch):
+    """hz_kernels.hip, adapt: the first draw of a zoomed view reaches HZ_NEAR_CELLS_WIDE cells; a later draw of the same view
+    that finds the second round's queue counters of a draw before it on the host tries the long reach if they were large
+    (HZ_ADAPT_HI, here 0: always), keeps it if it paid and goes back for good if not; another view starts short again.
+    The bytes never depend on it."""
+    import torch
+    import horizonator_amd
+    for k in [k for k in os.environ if k.startswith("HZ_") and k != "HZ_TEST_DEM_DIR"]:
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("HZ_TWO_PASS", "1")
+    monkeypatch.setenv("HZ_ADAPT_HI", "0")
+    R, W, H = 1000, 8000, 2000
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
+    try:
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
+        rng = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
+
+        def draw():
+            h.render_device(img.data_ptr(), rng.data_ptr()); h.sync()
+            return h.last_plan()["reach_cells"], img.cpu().numpy().copy(), rng.cpu().numpy().copy()
+
+        h.set_view(-10, 10, zfar=200000.0)
+        reach, img0, rng0 = draw()
+        assert reach == 384
+        reaches = []
+        for _ in range(5):
+            reach, i, r = draw()
+            reaches.append(reach)
+            assert np.array_equal(i, img0) and np.array_equal(r, rng0)
+        assert reaches[0] == 512                        # the first draw's counters were there: the long reach is tried
+        assert len(set(reaches[2:])) == 1, reaches      # ... and kept, or given up for good
+        h.set_view(-12, 8, zfar=200000.0)               # another view: short again
+        assert draw()[0] == 384
     finally:
         h.close()

@@ -5,6 +5,7 @@
     python tools/hiz_ab.py [scene ...]  [--set "HZ_HIZ=1 HZ_NEAR_CELLS=512" ...]
 """
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -56,13 +57,16 @@ def run(name, settings, steps):
     h.sync()
     one = (time.perf_counter() - t0) * 1e3
     digest = hashlib.sha256(d_img.cpu().numpy().tobytes() + d_rng.cpu().numpy().tobytes()).hexdigest()[:16]
+    qc = (C.c_uint * 4)()
+    h._lib.hz_hip_last_queue_counts(h._lib.horizonator_amd_device(C.byref(h._ctx)), qc)
     cnt = scenes.wave_counters(h)
     h.close()
     del d_img, d_rng
     torch.cuda.empty_cache()
     return {"scene": name, "settings": settings, "ms_per_render": round(ms, 4), "one_render_waited_for_ms": round(one, 4), "sha": digest,
             "kill_rate": cnt and cnt["early_z_kill_rate"], "set_up": cnt and cnt["triangles_set_up"], "to_k_big": cnt and cnt["to_k_big"],
-            "pixel_centres": cnt and cnt["pixel_centres_tested_in_the_waves"]}
+            "pixel_centres": cnt and cnt["pixel_centres_tested_in_the_waves"],
+            "second_round_queue": {"reach": int(qc[0]), "records": int(qc[1]), "items": int(qc[2]), "next_reach_long": int(qc[3])}}
 
 
 def main():

@@ -5,6 +5,6 @@ for l in sys.stdin:
         continue
     d = json.loads(l)
     if "settings" in d:
-        print(d["scene"], "|", d["settings"], "|", d["ms_per_render"], d["one_render_waited_for_ms"], d["sha"], d["kill_rate"])
+        print(d["scene"], "|", d["settings"], "|", d["ms_per_render"], d["one_render_waited_for_ms"], d["sha"], d["kill_rate"], d.get("second_round_queue"))
     else:
         print(d)
