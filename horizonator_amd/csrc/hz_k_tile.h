@@ -17,6 +17,12 @@
  * of that version: git history; 126 + 770 us against 854 for the first round above).  Batches make the units of work
  * alike and need no ownership - any kernel may draw into the same pixels meanwhile - at the price of atomics for the
  * merge; a tile's batches resolve the overdraw among their own triangles only.
+ * Where it runs (draw_impl; HZ_TILES): the first round of views zoomed so far that a cell at that round's reach is
+ * HZ_TILES_MIN_PX = 35 pixels wide - 71 + 522 us against k_big's 876 on the 45 degree view towards the east, seven such
+ * views 10.5 -> 9.8 ms in sum (9.0 with the reach following the draws before).  Not second rounds (their large
+ * triangles are few and scattered: +5..140 %), not the first round of a whole panorama (small triangles along the
+ * horizon: 0.92 -> 1.14 ms).  What is left in k_tile_raster: 1.33 vector instructions per fragment - k_big's own
+ * arithmetic, and a triangle's row spans once per tile it touches; the merge is 50 of its 507 us.
  *
  * k_tile_bin     one pass over the round's queue (a lane per triangle, the wave for those that touch many tiles):
  *                the triangle's number goes into the list of every tile of its box that an edge test does not
