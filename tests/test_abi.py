@@ -126,3 +126,18 @@ def test_product_does_not_touch_the_oracle():
                 if re.search(r"(#include\s*[\"<].*oracle|import\s+oracle|from\s+oracle|liboracle|orc_)", text):
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+def test_series_struct_of_the_rccl_header_matches_c_compiler(tmp_path):
+    """sharding._Series (what RcclSeries hands to horizonator_rccl_render_series) agrees with what gcc makes of
+    horizonator_rccl_series_t: size and the offset of every field"""
+    import subprocess
+    from horizonator_amd.sharding import _Series
+    fields = [f for f, _ in _Series._fields_]
+    body = 'printf("%zu ", sizeof(horizonator_rccl_series_t));' + "".join(f'printf("%zu ", offsetof(horizonator_rccl_series_t, {f}));' for f in fields)
+    src = tmp_path / "series.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "horizonator_rccl.h"\nint main(void){' + body + 'return 0;}\n')
+    exe = tmp_path / "series"
+    subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_Series)] + [getattr(_Series, f).offset for f in fields]
