@@ -141,3 +141,34 @@ def test_series_struct_of_the_rccl_header_matches_c_compiler(tmp_path):
     subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [C.sizeof(_Series)] + [getattr(_Series, f).offset for f in fields]
+
+
+def test_series_rejects_bad_arguments_without_a_gpu():
+    """horizonator_rccl_render_series checks its arguments before it touches the device: no context, no communicator,
+    a rank outside the communicator, too many slots, fewer words than a header - -1 each, nothing queued"""
+    from horizonator_amd.sharding import _Series
+    _lib.load()
+    lib = C.CDLL(os.path.join(ROOT, "horizonator_amd", "libhorizonator_rccl.so"))
+    lib.horizonator_rccl_render_series.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Series), C.c_long, C.c_int, C.c_int]
+    ctx = _lib.Context()
+    fake_comm = C.c_void_p(1)
+    strips = (C.c_void_p * 2)(8, 16)
+    col0 = (C.c_int * 1)(0)
+    ncols = (C.c_int * 1)(100)
+
+    def series(**kw):
+        v = dict(rank=0, world=1, rotate=0, nslots=2, d_strips=C.cast(strips, C.POINTER(C.c_void_p)), d_bins=C.cast(strips, C.POINTER(C.c_void_p)),
+                 words=1000, header_words=10, mask_stride=4, col0=C.cast(col0, C.POINTER(C.c_int)), ncols=C.cast(ncols, C.POINTER(C.c_int)),
+                 d_image=None, d_ranges=None, stream=None)
+        v.update(kw)
+        return _Series(**v)
+
+    call = lib.horizonator_rccl_render_series
+    assert call(None, fake_comm, C.byref(series()), 0, 1, 0) == -1
+    assert call(C.byref(ctx), None, C.byref(series()), 0, 1, 0) == -1
+    assert call(C.byref(ctx), fake_comm, None, 0, 1, 0) == -1
+    assert call(C.byref(ctx), fake_comm, C.byref(series(rank=1)), 0, 1, 0) == -1
+    assert call(C.byref(ctx), fake_comm, C.byref(series(nslots=5)), 0, 1, 0) == -1
+    assert call(C.byref(ctx), fake_comm, C.byref(series(words=10)), 0, 1, 0) == -1
+    assert call(C.byref(ctx), fake_comm, C.byref(series(d_bins=None)), 0, 1, 0) == -1       # rank 0 gathers: it needs bins
+    assert call(C.byref(ctx), fake_comm, C.byref(series()), -1, 1, 0) == -1
