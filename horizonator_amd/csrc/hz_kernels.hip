@@ -120,7 +120,7 @@ struct hz_env_t
     int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
     int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
     int    adapt, adapt_hi;         /* HZ_ADAPT=0/1/2 (default 1): the first round of a zoomed view may reach HZ_NEAR_CELLS_MAX instead of HZ_NEAR_CELLS_WIDE cells: never / when the draws
-                                     * of the same view before it say so (from HZ_ADAPT_HI = 500000 work items for k_big in the second round on) / always */
+                                     * of the same view before it say so (from HZ_ADAPT_HI work items for k_big in the second round on; default: 500000 per 64 Mpix of image) / always */
     int    mid, mid_near, mid_cells; /* HZ_MID=1: two-round draws get a middle round (plan_rounds; not the default); HZ_MID_NEAR (256): the first round's reach
                                      * in draws with a middle round; HZ_MID_CELLS (640): the middle round's */
     int    inline_max2;             /* HZ_INLINE_MAX2=n: the second round's marching waves keep boxes of up to n pixels, larger ones up to 64 go to k_mid; 0: the draw decides (64, or 32 with a close far clip) */
@@ -161,7 +161,7 @@ static hz_env_t read_env(void)
     e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
     e.mid              = env_int("HZ_MID", 0) != 0;
     e.adapt            = env_int("HZ_ADAPT", 1);
-    e.adapt_hi         = env_int("HZ_ADAPT_HI", 500000);
+    e.adapt_hi         = env_int("HZ_ADAPT_HI", -1);
     e.mid_near         = env_int("HZ_MID_NEAR", 256);
     e.mid_cells        = env_int("HZ_MID_CELLS", 640);
     e.inline_max2      = env_int("HZ_INLINE_MAX2", 0);
@@ -1217,7 +1217,10 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(!d->adapt.long_of[k])
             {
                 d->adapt.items_short = items;
-                if(!d->adapt.tried_long && items > (unsigned int)d->env.adapt_hi) d->adapt.long_reach = 1;
+                /* (500 K work items at 16000 x 4000 - the views that gain had 750 K and more, the others 320 K and fewer -, in
+                 * proportion to the image's pixels elsewhere: a triangle's pixels, hence what counts as large, go with them) */
+                const double hi = d->env.adapt_hi >= 0 ? (double)d->env.adapt_hi : 500000.0*((double)(d->col1 - d->col0)*(double)d->H/64.0e6);
+                if(!d->adapt.tried_long && (double)items > hi) d->adapt.long_reach = 1;
             }
             else
             {
