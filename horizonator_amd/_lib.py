@@ -188,8 +188,8 @@ def _open(path, selftest):
     sig("hz_hip_resolve", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_resolve_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_read_depth", i, vp, i, i, P(C.c_uint32))
-    sig("hz_hip_link_cells", i, vp, P(View), vp, d, d, i, i, i, i, i, vp, vp)
-    sig("hz_hip_poi_visibility", i, vp, P(View), vp, d, d, d, i, vp, i, vp, vp, vp)
+    sig("hz_hip_link_cells", i, vp, P(View), vp, vp, vp, vp, d, d, d, i, i, i, i, vp, vp)
+    sig("hz_hip_poi_visibility", i, vp, P(View), vp, i, vp, i, vp, vp, vp)
     sig("hz_hip_sync", i, vp)
     sig("hz_hip_last_times", i, vp, P(Times))
     sig("hz_hip_stream", vp, vp)

@@ -973,6 +973,9 @@ bool horizonator_amd_link_cells_size(const horizonator_context_t* ctx, int cell_
     return true;
 }
 
+/* reference annotator.c:228-264.  What depends on the cell's column and row alone - sinf / cosf of the azimuth,
+ * cos of the elevation, reference horizonator-lib.c:1181-1195 - is evaluated here, with the C library the
+ * reference calls; the device does the rest (IEEE arithmetic only): the same bits as the reference's loop. */
 bool horizonator_amd_link_cells(const horizonator_context_t* ctx, int cell_width, int cell_height,
                                 int cut_off_bottom_px, float* lat, float* lon)
 {
@@ -982,30 +985,70 @@ bool horizonator_amd_link_cells(const horizonator_context_t* ctx, int cell_width
         return false;
     if(nx == 0 || ny == 0) return true;
     fill_tanel(s);
-    if(0 != hz_hip_link_cells(s->dev, &s->view, s->tanel, (double)ctx->viewer_lat, (double)ctx->viewer_lon,
-                              cell_width, cell_height, cut_off_bottom_px, nx, ny, lat, lon))
+    const int    width = s->width, height = s->height;
+    const double az_deg0 = (double)s->view.az_deg0, az_deg1 = (double)s->view.az_deg1;
+    float*  sin_az = (float*) malloc((size_t)nx*sizeof(float));
+    float*  cos_az = (float*) malloc((size_t)nx*sizeof(float));
+    double* cos_el = (double*)malloc((size_t)ny*sizeof(double));
+    bool ok = sin_az != NULL && cos_az != NULL && cos_el != NULL;
+    if(ok)
     {
-        MSG("%s", hz_hip_last_error());
-        return false;
+        for(int cx=0; cx<nx; cx++)
+        {
+            const int x = cx*cell_width + cell_width/2;
+            /* reference horizonator-lib.c:1183-1184: mixed float/double on purpose */
+            float az_ndc = ((float)x + 0.5f) / (float)width * 2.f - 1.f;
+            float az     = (az_ndc * (az_deg1-az_deg0) / 2.f + (az_deg1+az_deg0)/2.f) * M_PI/180.0f;
+            sin_az[cx] = sinf(az);
+            cos_az[cx] = cosf(az);
+        }
+        for(int cy=0; cy<ny; cy++)
+        {
+            const int y = cy*cell_height + cell_height/2;
+            double aspect = (double)width / (double)height;
+            double el_ndc = ((double)y + 0.5) / (double)height * 2. - 1.;
+            double el     = el_ndc * (az_deg1-az_deg0) / 2. / aspect * M_PI/180.0;
+            cos_el[cy] = cos(el);
+        }
+        const double viewer_lat = (double)ctx->viewer_lat;
+        if(0 != hz_hip_link_cells(s->dev, &s->view, s->tanel, sin_az, cos_az, cos_el,
+                                  viewer_lat, cos(viewer_lat * M_PI/180.), (double)ctx->viewer_lon,
+                                  cell_width, cell_height, nx, ny, lat, lon))
+        {
+            MSG("%s", hz_hip_last_error());
+            ok = false;
+        }
     }
-    return true;
+    free(sin_az); free(cos_az); free(cos_el);
+    return ok;
 }
 
+/* reference annotator.c:280-348.  The projection of each point (reference horizonator_project: atan2 and sqrt in
+ * double) is made here, with the C library the reference calls; the device searches the range image. */
 bool horizonator_amd_poi_visibility(const horizonator_context_t* ctx, int cut_off_bottom_px,
                                     const hz_poi_t* pois, int npois,
                                     unsigned char* visible, float* label_x, float* label_y)
 {
     hz_state_t* s = live_state(ctx);
-    if(s == NULL) return false;
+    if(s == NULL || npois < 0) return false;
+    if(npois == 0) return true;
     fill_tanel(s);
-    if(0 != hz_hip_poi_visibility(s->dev, &s->view, s->tanel,
-                                  (double)ctx->viewer_lat, (double)ctx->viewer_lon, (double)s->view.viewer_z,
-                                  cut_off_bottom_px, pois, npois, visible, label_x, label_y))
+    hz_poi_proj_t* proj = (hz_poi_proj_t*)malloc((size_t)npois*sizeof(*proj));
+    if(proj == NULL) return false;
+    const double lat = (double)ctx->viewer_lat, lon = (double)ctx->viewer_lon, ele = (double)s->view.viewer_z;
+    const double cos_lat = cos(lat * M_PI/180.);
+    const double az_rad0 = (double)s->view.az_deg0 * M_PI/180., az_rad1 = (double)s->view.az_deg1 * M_PI/180.;
+    for(int k=0; k<npois; k++)
     {
-        MSG("%s", hz_hip_last_error());
-        return false;
+        if(!horizonator_project(&proj[k].x, &proj[k].y, &proj[k].range, lat, cos_lat, lon, ele,
+                                (double)pois[k].lat, (double)pois[k].lon, (double)pois[k].ele_m,
+                                az_rad0, az_rad1, s->width, s->height))
+            proj[k].x = proj[k].y = 0.0, proj[k].range = -1.0;
     }
-    return true;
+    const bool ok = 0 == hz_hip_poi_visibility(s->dev, &s->view, s->tanel, cut_off_bottom_px, proj, npois, visible, label_x, label_y);
+    if(!ok) MSG("%s", hz_hip_last_error());
+    free(proj);
+    return ok;
 }
 
 bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic)

@@ -2230,30 +2230,28 @@ __device__ static inline float hz_range_of(unsigned long long key, float tanel_r
     return (float)sqrt((double)len*(double)len + (double)zt*(double)zt);
 }
 
-/* reference horizonator_unproject (horizonator-lib.c:1157-1213), range_enh given */
-__device__ static inline void hz_unproject_enh(float* lat, float* lon, int x, int y, double range_enh,
-                                               double lat_viewer, double cos_lat_viewer, double lon_viewer,
-                                               double az_deg0, double az_deg1, int width, int height)
+/* reference horizonator_unproject (horizonator-lib.c:1157-1213), range_enh given.  The transcendental functions in it
+ * depend on the pixel's column (sinf / cosf of its azimuth) and on its row (cos of its elevation) only: the host
+ * evaluates them with the C library the reference itself calls (hz_host.c: horizonator_amd_link_cells) and the kernel
+ * is left with IEEE multiplications and divisions - the same bits as the reference's loop, not "within a tolerance". */
+__device__ static inline void hz_unproject_enh(float* lat, float* lon, double range_enh,
+                                               float sin_az, float cos_az, double cos_el,
+                                               double lat_viewer, double cos_lat_viewer, double lon_viewer)
 {
     const float Rearth = 6371000.0;
-    float az_ndc = ((float)x + 0.5f) / (float)width * 2.f - 1.f;
-    float az     = (az_ndc * (az_deg1-az_deg0) / 2.f + (az_deg1+az_deg0)/2.f) * M_PI/180.0f;
-    double aspect = (double)width / (double)height;
-    double el_ndc = ((double)y + 0.5) / (double)height * 2. - 1.;
-    double el     = el_ndc * (az_deg1-az_deg0) / 2. / aspect * M_PI/180.0;
-    double range_en = cos(el) * range_enh;
-    float e = range_en * sinf(az);
-    float n = range_en * cosf(az);
+    double range_en = cos_el * range_enh;
+    float e = range_en * sin_az;
+    float n = range_en * cos_az;
     *lon = lon_viewer + e / Rearth / M_PI * 180. / cos_lat_viewer;
     *lat = lat_viewer + n / Rearth / M_PI * 180.;
 }
 
 __global__ __launch_bounds__(256)
 void k_link_cells(const unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
+                  const float* __restrict__ sin_az, const float* __restrict__ cos_az, const double* __restrict__ cos_el,
                   float* __restrict__ lat, float* __restrict__ lon,
                   int W, int H, int cell_w, int cell_h, int nx, int ny,
-                  float znear, float zfar, double viewer_lat, double cos_viewer_lat, double viewer_lon,
-                  double az_deg0, double az_deg1)
+                  float znear, float zfar, double viewer_lat, double cos_viewer_lat, double viewer_lon)
 {
     const int c = blockIdx.x*blockDim.x + threadIdx.x;
     if(c >= nx*ny) return;
@@ -2263,53 +2261,25 @@ void k_link_cells(const unsigned long long* __restrict__ fb, const float* __rest
     const float range = hz_range_of(fb[(size_t)row*W + x], tanel[row], znear, zfar);
     float la = __builtin_nanf(""), lo = __builtin_nanf("");
     if(range > 0.0f)                                    /* reference annotator.c:236-238 */
-        hz_unproject_enh(&la, &lo, x + cell_w/2, y + cell_h/2, (double)range,
-                         viewer_lat, cos_viewer_lat, viewer_lon, az_deg0, az_deg1, W, H);
+        hz_unproject_enh(&la, &lo, (double)range, sin_az[cx], cos_az[cx], cos_el[cy],
+                         viewer_lat, cos_viewer_lat, viewer_lon);
     lat[c] = la; lon[c] = lo;
 }
 
-/* reference horizonator-lib.c:1053-1095 */
-__device__ static inline double hz_unwrap_d(double x, double near)
-{
-    const double d = (x - near) / (2.*M_PI);
-    return (d - round(d)) * 2.*M_PI + near;
-}
-
+/* reference annotator.c:297-347: the search of the range image around a projected point of interest.  The projection
+ * itself (reference horizonator_project, horizonator-lib.c:1097-1155: atan2, sqrt, in double) is the host's, made with
+ * the C library the reference calls (hz_host.c: horizonator_amd_poi_visibility); proj[k].range < 0: outside the view. */
 __global__ __launch_bounds__(256)
 void k_poi(const unsigned long long* __restrict__ fb, const float* __restrict__ tanel,
-           const hz_poi_t* __restrict__ pois, int npois,
+           const hz_poi_proj_t* __restrict__ proj, int npois,
            unsigned char* __restrict__ visible, float* __restrict__ label_x, float* __restrict__ label_y,
-           int W, int H, int height_out, float znear, float zfar,
-           double lat_viewer, double cos_lat_viewer, double lon_viewer, double ele_viewer,
-           double az_rad0, double az_rad1)
+           int W, int H, int height_out, float znear, float zfar)
 {
     const int k = blockIdx.x*blockDim.x + threadIdx.x;
     if(k >= npois) return;
     visible[k] = 0; label_x[k] = 0.f; label_y[k] = 0.f;
-
-    /* reference horizonator_project (horizonator-lib.c:1097-1155) */
-    const float Rearth = 6371000.0;
-    const double dlat = ((double)pois[k].lat - lat_viewer)*M_PI/180;
-    const double dlon = ((double)pois[k].lon - lon_viewer)*M_PI/180;
-    const double east  = dlon * Rearth * cos_lat_viewer;
-    const double north = dlat * Rearth;
-    const double d2    = east*east + north*north;
-    double a1 = hz_unwrap_d(az_rad1-az_rad0, M_PI) + az_rad0;
-    const double center = (az_rad0 + a1)/2.;
-    const double az = hz_unwrap_d(atan2(east, north), center);
-    const double kk = 2.0 / (a1 - az_rad0);
-    const double az_ndc = (az - center) * kk;
-    if(!(-1. <= az_ndc && az_ndc <= 1.)) return;
-    const double cx = (az_ndc + 1.)/2.*W - 0.5;
-    const double h = (double)pois[k].ele_m - ele_viewer;
-    const double d_ne = sqrt(d2);
-    const double range_have = sqrt(d2 + h*h);
-    const double aspect = (double)W / (double)H;
-    const double el_ndc = atan2(h, d_ne) * aspect * kk;
-    if(!(-1. <= el_ndc && el_ndc <= 1.)) return;
-    const double cy = (-el_ndc + 1.)/2.*H - 0.5;
-
-    /* reference annotator.c:297-347 */
+    const double cx = proj[k].x, cy = proj[k].y, range_have = proj[k].range;
+    if(!(range_have >= 0.0)) return;
     if(range_have < 500.0 || range_have > 100000.0) return;
     int    fuzz_nearest = 0;
     double err_nearest  = 1.7976931348623157e308;
@@ -2336,43 +2306,50 @@ void k_poi(const unsigned long long* __restrict__ fb, const float* __restrict__ 
 }
 
 extern "C" int hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float* tanel,
-                                 double viewer_lat, double viewer_lon,
-                                 int cell_w, int cell_h, int cut_off_bottom_px,
-                                 int nx, int ny, float* lat, float* lon)
+                                 const float* sin_az, const float* cos_az, const double* cos_el,
+                                 double viewer_lat, double cos_viewer_lat, double viewer_lon,
+                                 int cell_w, int cell_h, int nx, int ny, float* lat, float* lon)
 {
     HZ_ON_DEVICE(d);
     if(fb_refill(d) != 0) return -1;
     HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_drawn, 0));      /* the last draw finishes on qstream */
     d->stream_reads_fb = 1;
-    if(d->col0 != 0 || d->col1 != d->W || cell_w <= 0 || cell_h <= 0 || nx <= 0 || ny <= 0)
+    if(d->col0 != 0 || d->col1 != d->W || cell_w <= 0 || cell_h <= 0 || nx <= 0 || ny <= 0 || !sin_az || !cos_az || !cos_el)
     {
-        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells: needs a full-width context and positive sizes");
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells: needs a full-width context, positive sizes and the three tables");
         return -1;
     }
-    (void)cut_off_bottom_px;
     if(upload_tanel(d, tanel) != 0) return -1;
-    float *d_lat = NULL, *d_lon = NULL;
     const size_t n = (size_t)nx*ny;
-    HZ_CHECK(hipMalloc(&d_lat, n*sizeof(float)));
-    HZ_CHECK(hipMalloc(&d_lon, n*sizeof(float)));
-    hipLaunchKernelGGL(k_link_cells, dim3((unsigned)((n + 255)/256)), dim3(256), 0, d->stream,
-                       (const unsigned long long*)d->d_fb, (const float*)d->d_tanel, d_lat, d_lon,
-                       d->W, d->H, cell_w, cell_h, nx, ny, view->znear, view->zfar,
-                       viewer_lat, cos(viewer_lat * M_PI/180.), viewer_lon,
-                       (double)view->az_deg0, (double)view->az_deg1);
-    int rc = hipGetLastError() == hipSuccess ? 0 : -1;
+    /* one allocation: lat, lon, then the tables */
+    const size_t bytes = 2*n*sizeof(float) + 2*(size_t)nx*sizeof(float) + (size_t)ny*sizeof(double) + 16;
+    unsigned char* buf = NULL;
+    HZ_CHECK(hipMalloc(&buf, bytes));
+    double* d_cos_el = (double*)buf;
+    float* d_lat = (float*)(d_cos_el + ny), * d_lon = d_lat + n, * d_sin = d_lon + n, * d_cos = d_sin + nx;
+    int rc = 0;
+    if(hipMemcpyAsync(d_cos_el, cos_el, (size_t)ny*sizeof(double), hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0 && hipMemcpyAsync(d_sin, sin_az, (size_t)nx*sizeof(float), hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0 && hipMemcpyAsync(d_cos, cos_az, (size_t)nx*sizeof(float), hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = -1;
+    if(rc == 0)
+    {
+        hipLaunchKernelGGL(k_link_cells, dim3((unsigned)((n + 255)/256)), dim3(256), 0, d->stream,
+                           (const unsigned long long*)d->d_fb, (const float*)d->d_tanel,
+                           (const float*)d_sin, (const float*)d_cos, (const double*)d_cos_el, d_lat, d_lon,
+                           d->W, d->H, cell_w, cell_h, nx, ny, view->znear, view->zfar,
+                           viewer_lat, cos_viewer_lat, viewer_lon);
+        if(hipGetLastError() != hipSuccess) rc = -1;
+    }
     if(rc == 0 && hipMemcpyAsync(lat, d_lat, n*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
     if(rc == 0 && hipMemcpyAsync(lon, d_lon, n*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
     if(hipStreamSynchronize(d->stream) != hipSuccess) rc = -1;
-    (void)hipFree(d_lat); (void)hipFree(d_lon);
+    (void)hipFree(buf);
     if(rc != 0) snprintf(g_last_error, sizeof(g_last_error), "hz_hip_link_cells failed");
     return rc;
 }
 
 extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const float* tanel,
-                                     double viewer_lat, double viewer_lon, double viewer_ele_m,
-                                     int cut_off_bottom_px,
-                                     const hz_poi_t* pois, int npois,
+                                     int cut_off_bottom_px, const hz_poi_proj_t* proj, int npois,
                                      unsigned char* visible, float* label_x, float* label_y)
 {
     HZ_ON_DEVICE(d);
@@ -2386,28 +2363,26 @@ extern "C" int hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const f
     }
     if(npois == 0) return 0;
     if(upload_tanel(d, tanel) != 0) return -1;
-    hz_poi_t* d_pois = NULL; unsigned char* d_vis = NULL; float *d_x = NULL, *d_y = NULL;
-    HZ_CHECK(hipMalloc(&d_pois, (size_t)npois*sizeof(hz_poi_t)));
+    hz_poi_proj_t* d_proj = NULL; unsigned char* d_vis = NULL; float *d_x = NULL, *d_y = NULL;
+    HZ_CHECK(hipMalloc(&d_proj, (size_t)npois*sizeof(hz_poi_proj_t)));
     HZ_CHECK(hipMalloc(&d_vis, (size_t)npois));
     HZ_CHECK(hipMalloc(&d_x, (size_t)npois*sizeof(float)));
     HZ_CHECK(hipMalloc(&d_y, (size_t)npois*sizeof(float)));
     int rc = 0;
-    if(hipMemcpyAsync(d_pois, pois, (size_t)npois*sizeof(hz_poi_t), hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = -1;
+    if(hipMemcpyAsync(d_proj, proj, (size_t)npois*sizeof(hz_poi_proj_t), hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = -1;
     if(rc == 0)
     {
         hipLaunchKernelGGL(k_poi, dim3((unsigned)((npois + 255)/256)), dim3(256), 0, d->stream,
                            (const unsigned long long*)d->d_fb, (const float*)d->d_tanel,
-                           (const hz_poi_t*)d_pois, npois, d_vis, d_x, d_y,
-                           d->W, d->H, d->H - cut_off_bottom_px, view->znear, view->zfar,
-                           viewer_lat, cos(viewer_lat * M_PI/180.), viewer_lon, viewer_ele_m,
-                           (double)view->az_deg0 * M_PI/180., (double)view->az_deg1 * M_PI/180.);
+                           (const hz_poi_proj_t*)d_proj, npois, d_vis, d_x, d_y,
+                           d->W, d->H, d->H - cut_off_bottom_px, view->znear, view->zfar);
         if(hipGetLastError() != hipSuccess) rc = -1;
     }
     if(rc == 0 && hipMemcpyAsync(visible, d_vis, (size_t)npois, hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
     if(rc == 0 && hipMemcpyAsync(label_x, d_x, (size_t)npois*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
     if(rc == 0 && hipMemcpyAsync(label_y, d_y, (size_t)npois*sizeof(float), hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = -1;
     if(hipStreamSynchronize(d->stream) != hipSuccess) rc = -1;
-    (void)hipFree(d_pois); (void)hipFree(d_vis); (void)hipFree(d_x); (void)hipFree(d_y);
+    (void)hipFree(d_proj); (void)hipFree(d_vis); (void)hipFree(d_x); (void)hipFree(d_y);
     if(rc != 0) snprintf(g_last_error, sizeof(g_last_error), "hz_hip_poi_visibility failed");
     return rc;
 }

@@ -135,27 +135,33 @@ int  hz_hip_read_depth(hz_dev_t* d, int x, int y, uint32_t* z24);
  * the GPU for them. */
 
 /* For every cell of cell_w x cell_h pixels (x = 0, cell_w, ... < W-cell_w;
- * y likewise below height_out = H - cut_off_bottom_px) whose top-left pixel
- * shows terrain: latitude/longitude under the cell centre (reference
- * horizonator_unproject with range_enh = range of that pixel).  lat/lon are
- * HOST arrays [ny][nx]; NaN where the cell has no terrain.  Full-width
- * contexts only (sector = whole image). */
+ * y likewise below height_out = H - cut_off_bottom_px: nx x ny of them) whose
+ * top-left pixel shows terrain: latitude/longitude under the cell centre
+ * (reference horizonator_unproject with range_enh = range of that pixel).
+ * The transcendental functions of that formula belong to the caller (the C
+ * library the reference calls; the device's own sinf/cosf differ in the last
+ * bit): HOST tables sin_az[nx], cos_az[nx] - sinf / cosf of the azimuth of
+ * the centre column of cell column cx, reference horizonator-lib.c:1181-1183 -
+ * and cos_el[ny] - cos of the elevation of the centre row of cell row cy,
+ * :1190-1195.  lat/lon are HOST arrays [ny][nx]; NaN where the cell has no
+ * terrain.  Full-width contexts only (sector = whole image). */
 int  hz_hip_link_cells(hz_dev_t* d, const hz_view_t* view, const float* tanel,
-                       double viewer_lat, double viewer_lon,
-                       int cell_w, int cell_h, int cut_off_bottom_px,
-                       int nx, int ny, float* lat, float* lon);
+                       const float* sin_az, const float* cos_az, const double* cos_el,
+                       double viewer_lat, double cos_viewer_lat, double viewer_lon,
+                       int cell_w, int cell_h, int nx, int ny, float* lat, float* lon);
 
 typedef struct { float lat, lon, ele_m; } hz_poi_t;
+/* a point of interest projected into the image (reference horizonator_project,
+ * horizonator-lib.c:1097-1155): pixel coordinates and range; range < 0: not in the view */
+typedef struct { double x, y, range; } hz_poi_proj_t;
 
-/* For every point of interest: is it visible in the last draw, and where does
- * its label crosshair go (reference annotator.c:280-348: project, distance
+/* For every projected point of interest: is it visible in the last draw, and
+ * where does its label crosshair go (reference annotator.c:297-347: distance
  * window 500 m .. 100 km, vertical search of +-6 pixels in the range image for
  * the range closest to the expected one, accepted within 500 m).  Outputs are
  * HOST arrays of npois: visible (0/1), label_x, label_y (pixels). */
 int  hz_hip_poi_visibility(hz_dev_t* d, const hz_view_t* view, const float* tanel,
-                           double viewer_lat, double viewer_lon, double viewer_ele_m,
-                           int cut_off_bottom_px,
-                           const hz_poi_t* pois, int npois,
+                           int cut_off_bottom_px, const hz_poi_proj_t* proj, int npois,
                            unsigned char* visible, float* label_x, float* label_y);
 
 /* Multi-GPU gather in 4 instead of 7 bytes per pixel: hz_hip_pack() writes the

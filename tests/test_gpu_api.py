@@ -77,14 +77,19 @@ def test_pick_inverts_the_projection(scene):
     got = h.pick(x, y)
     assert got is not None
     # reference horizonator-lib.c:1285-1295: unproject the depth as a horizontal distance
-    lib = h._lib
+    # ... the expectation from the ORACLE's restatement of it (oracle_annot.c: orc_unproject), not from the library under test
     lat, lon = C.c_float(), C.c_float()
     v = h.view()
     depth = np.float32(np.float64(z24[y, x]) * (1.0 / 16777215.0))
     range_en = float(depth * np.float32(v["zfar"] - v["znear"]) + np.float32(v["znear"]))
-    assert lib.horizonator_unproject(C.byref(lat), C.byref(lon), x, y, -1.0, range_en, np.float32(LAT),
-                                     v["cos_viewer_lat"], np.float32(LON), v["az_deg0"], v["az_deg1"], W, H)
+    assert oracle.load().orc_unproject(C.byref(lat), C.byref(lon), x, y, -1.0, range_en, np.float32(LAT),
+                                       v["cos_viewer_lat"], np.float32(LON), v["az_deg0"], v["az_deg1"], W, H)
     assert got == (lat.value, lon.value)
+    # (and the library's own horizonator_unproject says the same)
+    lat2, lon2 = C.c_float(), C.c_float()
+    assert h._lib.horizonator_unproject(C.byref(lat2), C.byref(lon2), x, y, -1.0, range_en, np.float32(LAT),
+                                        v["cos_viewer_lat"], np.float32(LON), v["az_deg0"], v["az_deg1"], W, H)
+    assert (lat2.value, lon2.value) == (lat.value, lon.value)
     # and the picked point is the visible cell, to within a cell or two
     cell = index[y, x] >> 1
     N = 2 * h.radius_cells
