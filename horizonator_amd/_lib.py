@@ -165,6 +165,7 @@ def _open(path, selftest):
     sig("horizonator_amd_get_view", b, ctxp, P(View))
     sig("horizonator_amd_device", vp, ctxp)
     sig("horizonator_amd_get_mosaic", b, ctxp, vp)
+    sig("horizonator_amd_build_id", C.c_char_p)
     sig("horizonator_amd_link_cells_size", b, ctxp, i, i, i, P(i), P(i))
     sig("horizonator_amd_link_cells", b, ctxp, i, i, i, vp, vp)
     sig("horizonator_amd_poi_visibility", b, ctxp, i, vp, i, vp, vp, vp)
@@ -229,7 +230,7 @@ DECLARED_SYMBOLS = [
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
     "horizonator_amd_get_mosaic", "horizonator_amd_link_cells_size", "horizonator_amd_link_cells",
-    "horizonator_amd_poi_visibility",
+    "horizonator_amd_poi_visibility", "horizonator_amd_build_id",
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",

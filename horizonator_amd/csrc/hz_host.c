@@ -1051,6 +1051,9 @@ bool horizonator_amd_poi_visibility(const horizonator_context_t* ctx, int cut_of
     return ok;
 }
 
+#include "hz_build_id.h"         /* made by the Makefile: HZ_BUILD_ID */
+const char* horizonator_amd_build_id(void) { return HZ_BUILD_ID; }
+
 bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic)
 {
     hz_state_t* s = live_state(ctx);

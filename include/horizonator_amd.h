@@ -151,6 +151,10 @@ bool horizonator_amd_poi_visibility(const horizonator_context_t* ctx, int cut_of
                                     const hz_poi_t* pois, int npois,
                                     unsigned char* visible, float* label_x, float* label_y);
 
+/* A digest of the sources this library was built from (16 hex digits).  A program linked against the library can
+ * record it at link time and compare at run time (tests/caller_stubs: the reference's CLI does). */
+const char* horizonator_amd_build_id(void);
+
 /* copy of the N x N int16 mosaic as it sits in HBM (tests) */
 bool horizonator_amd_get_mosaic(const horizonator_context_t* ctx, int16_t* mosaic);
 

@@ -146,6 +146,10 @@ int orc_draw_triangles(const float* tris, int ntri, int W, int H, const orc_tex_
 
 /* ---- annotator passes over the range image ("next" row N2) ----------------- */
 
+/* reference horizonator-lib.c:1006-1047 alone: z24_gl[H][W] raw 24-bit depth in GL row order -> ranges[H][W], top row first */
+void orc_ranges_from_z24(float* ranges, const uint32_t* z24_gl, int W, int H,
+                         float az_deg0, float az_deg1, float znear, float zfar);
+
 /* reference horizonator-lib.c:1097-1155 / :1157-1213; return 1 on success */
 int orc_project(double* x, double* y, double* range,
                 double lat_viewer, double cos_lat_viewer, double lon_viewer, double ele_viewer,

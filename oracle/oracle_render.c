@@ -585,6 +585,17 @@ void orc_tanel(float* tanel, int W, int H, float az_deg0, float az_deg1)
     }
 }
 
+/* one pixel of the readback conversion (reference horizonator-lib.c:1013-1025) */
+static float range_of_z24(uint32_t zi, float tanel_row, float znear, float zfar)
+{
+    /* glReadPixels(GL_DEPTH_COMPONENT, GL_FLOAT) of a Z24 buffer */
+    float depth = (float)((double)zi * (1.0/16777215.0));
+    if(depth == 1.0f) return -1.0f;                         /* reference :1016 */
+    float length_en = depth * (zfar - znear) + znear;       /* :1018 */
+    float zt = tanel_row * length_en;                       /* :1023 */
+    return hypotf(length_en, zt);                           /* :1024 */
+}
+
 int orc_render(const int16_t* mosaic, int N, const orc_view_t* v,
                int W, int H, int col0, int col1,
                uint8_t* bgr, float* ranges, int32_t* index, uint32_t* z24,
@@ -751,21 +762,30 @@ int orc_render_tex(const int16_t* mosaic, int N, const orc_view_t* v, const orc_
             if(z24)   z24[o]   = zi;
             if(ranges)
             {
-                /* glReadPixels(GL_DEPTH_COMPONENT, GL_FLOAT) of a Z24 buffer */
-                float depth = (float)((double)zi * (1.0/16777215.0));
-                if(depth == 1.0f) ranges[o] = -1.0f;        /* reference :1016 */
-                else
-                {
-                    float length_en = depth * (v->zfar - v->znear) + v->znear;  /* :1018 */
-                    float zt = tanel[row] * length_en;                          /* :1023 */
-                    ranges[o] = hypotf(length_en, zt);                          /* :1024 */
-                }
+                ranges[o] = range_of_z24(zi, tanel[row], v->znear, v->zfar);
             }
         }
     }
 
     free(fb.depth); free(fb.prim); free(fb.red); free(fb.color); free(vert); free(vst); free(tanel);
     return 0;
+}
+
+/* The readback conversion alone (reference horizonator-lib.c:1006-1047) on a depth image given as raw 24-bit values in
+ * GL row order (row 0 = bottom); ranges come out top row first.  tests/test_naive_host_math.py compares it with a
+ * third, independent restatement. */
+void orc_ranges_from_z24(float* ranges, const uint32_t* z24_gl, int W, int H,
+                         float az_deg0, float az_deg1, float znear, float zfar)
+{
+    float* tanel = malloc((size_t)H*sizeof(float));
+    orc_tanel(tanel, W, H, az_deg0, az_deg1);
+    for(int yo=0; yo<H; yo++)
+    {
+        const int row = H-1-yo;
+        for(int x=0; x<W; x++)
+            ranges[(size_t)yo*W + x] = range_of_z24(z24_gl[(size_t)row*W + x], tanel[row], znear, zfar);
+    }
+    free(tanel);
 }
 
 /* ---- workload statistics (design aid, not part of any comparison) -------- */

@@ -10,6 +10,18 @@
 #include "libswscale/swscale.h"
 
 static int something;
+
+/* which build of the library this program was linked against (HZ_BUILD_ID: horizonator_amd/csrc/build/hz_build_id.h at
+ * link time, tests/caller_stubs/Makefile), said on request: tests/test_gpu_standalone.py compares it with what the
+ * library it finds at run time says of itself - a binary left over from an older tree does not pass for a current one */
+#include <stdlib.h>
+#ifndef HZ_BUILD_ID
+#define HZ_BUILD_ID "unknown"
+#endif
+__attribute__((constructor)) static void say_build_id(void)
+{
+    if(getenv("HZ_SHOW_BUILD_ID")) fprintf(stderr, "standalone_ref: linked against libhorizonator build %s\n", HZ_BUILD_ID);
+}
 /* FreeImage: the one stand-in that does something - FreeImage_Save() writes what the caller handed to
  * FreeImage_ConvertFromRawBitsEx() to the named file as it is ("HZRAW width height bytes_per_pixel\n", then
  * the rows top first, pitch removed), so that a test can look at the image the reference's CLI produced */

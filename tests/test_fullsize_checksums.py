@@ -167,3 +167,75 @@ def test_hip_all_256_viewpoints_batch_equals_one_render_each():
             assert _sha(d_img[vp].cpu().numpy()) == c["viewpoints"][str(vp)]["bgr_sha256"], vp
     finally:
         h.close()
+
+
+def _api_render(lat, lon, R, W, H, az0, az1, view_lat, view_lon, znear, zfar, viewer_z=None):
+    """one render through the reference's own API surface (include/horizonator.h: init, pan_zoom, move, set_zextents,
+    then the build's four-output render): hz_host.c's uniform derivation and fill_tanel are in the path, nothing
+    computed by the oracle is handed to the library"""
+    import ctypes as C
+    import horizonator_amd
+    d = hzutil.dem_dir_for(lat, lon, R)
+    h = horizonator_amd.horizonator(lat, lon, W, H, dir_dems=d, render_radius_cells=R)
+    try:
+        ctx, lib = C.byref(h._ctx), h._lib
+        vz = C.c_float(-1.0 if viewer_z is None else viewer_z)
+        assert lib.horizonator_pan_zoom(ctx, az0, az1)
+        assert lib.horizonator_move(ctx, C.byref(vz), view_lat, view_lon)
+        assert lib.horizonator_set_zextents(ctx, znear, zfar, znear, zfar)
+        image = np.empty((H, W, 3), np.uint8); ranges = np.empty((H, W), np.float32)
+        index = np.empty((H, W), np.int32); z24 = np.empty((H, W), np.uint32)
+        assert lib.horizonator_amd_render(ctx, image.ctypes.data, ranges.ctypes.data, index.ctypes.data, z24.ctypes.data)
+        # ... and the reference's own two-output call gives the same two
+        image2 = np.empty((H, W, 3), np.uint8); ranges2 = np.empty((H, W), np.float32)
+        assert lib.horizonator_render_offscreen(ctx, image2.ctypes.data, ranges2.ctypes.data)
+        assert np.array_equal(image, image2) and np.array_equal(ranges, ranges2)
+        return image, ranges, index, z24, h.view()
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLD))
+def test_api_full_size_is_the_reference_render(name):
+    """every full-size scene once through the API (the shim-level tests above feed the kernels
+    oracle-computed uniforms and tanel tables; here the library derives both itself)"""
+    c = GOLD[name]
+    _inputs(c)                                      # (the DEM is the one the hashes were made on)
+    image, ranges, index, z24, v = _api_render(c["lat"], c["lon"], c["R"], c["W"], c["H"], c["az_deg0"], c["az_deg1"],
+                                               c["view_lat"], c["view_lon"], c["znear"], c["zfar"], c.get("kw", {}).get("viewer_z"))
+    assert {k: float(np.float32(v[k])) for k in c["view"]} == c["view"]
+    assert _sha(image) == c["bgr_sha256"]
+    assert _sha(z24) == c["z24_sha256"]
+    assert abs(float((index >= 0).mean()) - c["terrain_fraction"]) < 1e-12
+    # the ranges: the naive restatement of reference horizonator-lib.c:1006-1047 on a band of rows around the horizon
+    import naive_host_math as nv
+    H, W = c["H"], c["W"]
+    rows = [r for r in (0, H // 2 - 1, H // 2, H - 1) if 0 <= r < H]
+    cols = slice(0, W, max(1, W // 97))
+    for yo in rows:
+        row = H - 1 - yo
+        y = row if row < H - H // 2 else H - 1 - row
+        t = nv.get_tanel(y, W, H, v["az_deg0"], v["az_deg1"])
+        for x in range(W)[cols]:
+            zi = z24[yo, x]
+            if zi == 0xFFFFFF:
+                assert ranges[yo, x] == -1.0
+                continue
+            depth = np.float32(np.float64(zi) / np.float64(16777215.0))
+            length_en = depth * (np.float32(v["zfar"]) - np.float32(v["znear"])) + np.float32(v["znear"])
+            assert ranges[yo, x] == nv.hypotf(length_en, np.float32(t) * length_en), (yo, x)
+
+
+@pytest.mark.gpu
+def test_api_cfg1_is_the_reference_render():
+    """BASELINE.json configs[0] (one tile, 2000x500) through the API against the committed llvmpipe render"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_G3_cfg1.npz"))
+    W, H = int(g["W"]), int(g["H"])
+    image, ranges, index, z24, v = _api_render(hzutil.VIEW_LAT, hzutil.VIEW_LON, 600, W, H, -180.0, 180.0,
+                                               hzutil.VIEW_LAT, hzutil.VIEW_LON, 100.0, 40000.0)
+    for k in oracle.VIEW_FIELDS:
+        assert np.float32(v[k]) == np.float32(g["u_" + k]), k
+    assert np.array_equal(image, g["bgr"])
+    orc = oracle.render(g["mosaic"], oracle.make_view(**{k: float(g["u_" + k]) for k in oracle.VIEW_FIELDS}), W, H)
+    hzutil.assert_same_render(dict(bgr=image, ranges=ranges, index=index, z24=z24), orc, "cfg1 through the API")

@@ -35,6 +35,14 @@ def test_the_reference_cli_renders_through_this_library(tmp_path):
                "where /root/reference exists (python -c 'import __graft_entry__ as g; g.build()' in the build container)")
         print("\n" + why, flush=True)
         pytest.skip(why)
+    # the binary is the one linked against THIS build of the library (it is untracked and travels with the tree)
+    from horizonator_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    lib.horizonator_amd_build_id.restype = ctypes.c_char_p
+    build_id = lib.horizonator_amd_build_id().decode()
+    r = subprocess.run([EXE, "--help"], capture_output=True, text=True, timeout=60, env=dict(os.environ, HZ_SHOW_BUILD_ID="1"))
+    assert f"linked against libhorizonator build {build_id}" in r.stderr, (build_id, r.stderr[-300:])
     lat, lon, W, H, zfar, azc, azr = hzutil.VIEW_LAT, hzutil.VIEW_LON, 1200, 300, 20000.0, 35.0, 70.0
     # radius given in metres (reference standalone.c:438: radius_cells = -1, radius_m = zfar)
     R = int(round(zfar / (6371000.0 * np.pi / 180.0 * np.cos(np.radians(np.float32(lat))) / 1200)))
