@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import RASTER_AUTO, RASTER_MARCH, RASTER_SCATTER, Times, View  # noqa: F401
+from ._lib import RASTER_AUTO, RASTER_MARCH, RASTER_SCATTER, Options, Times, View  # noqa: F401
 
 HORIZONATOR_ZNEAR_DEFAULT = 100.0
 HORIZONATOR_ZFAR_DEFAULT = 40000.0
@@ -369,6 +369,25 @@ class horizonator:
     def set_raster(self, which):
         if not self._lib.horizonator_amd_set_raster(C.byref(self._ctx), int(which)):
             raise RuntimeError("horizonator_amd_set_raster() failed")
+
+    def options(self):
+        """the context's tunables (include/hz_hip.h: hz_options_t) as a dict"""
+        o = Options()
+        if not self._lib.horizonator_amd_get_options(C.byref(self._ctx), C.byref(o)):
+            raise RuntimeError("horizonator_amd_get_options() failed")
+        return {n: getattr(o, n) for n, _ in Options._fields_}
+
+    def set_options(self, **kw):
+        """change some of the tunables, e.g. set_options(rounds=1, host_sectors=4): none changes a byte of a result"""
+        o = Options()
+        if not self._lib.horizonator_amd_get_options(C.byref(self._ctx), C.byref(o)):
+            raise RuntimeError("horizonator_amd_get_options() failed")
+        for k, v in kw.items():
+            if k not in dict(Options._fields_):
+                raise TypeError("no such option: %s" % k)
+            setattr(o, k, int(v))
+        if not self._lib.horizonator_amd_set_options(C.byref(self._ctx), C.byref(o)):
+            raise RuntimeError("horizonator_amd_set_options() failed")
 
     def set_profiling(self, on=True):
         self._lib.horizonator_amd_set_profiling(C.byref(self._ctx), bool(on))

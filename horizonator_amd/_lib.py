@@ -68,6 +68,13 @@ class View(C.Structure):
         "az_deg0", "az_deg1", "aspect", "znear", "zfar", "znear_color", "zfar_color")]
 
 
+class Options(C.Structure):
+    """hz_options_t (include/hz_hip.h): the tunables of a context"""
+    _fields_ = [(n, C.c_int) for n in (
+        "serial", "rounds", "near_cells", "coarse_depth", "tiles", "tile_list", "adapt", "adapt_hi", "pretest_march",
+        "worklists", "fast_math", "resolve_clears", "queue_capacity", "host_dense", "host_sectors", "host_times")]
+
+
 class Times(C.Structure):
     """hz_times_t (include/hz_hip.h)"""
     _fields_ = [(n, C.c_float) for n in ("clear_ms", "raster_ms", "big_ms", "resolve_ms", "total_ms", "near_ms")]
@@ -161,6 +168,8 @@ def _open(path, selftest):
     sig("horizonator_amd_set_sector", b, ctxp, i, i)
     sig("horizonator_amd_set_raster", b, ctxp, i)
     sig("horizonator_amd_set_profiling", b, ctxp, b)
+    sig("horizonator_amd_get_options", b, ctxp, P(Options))
+    sig("horizonator_amd_set_options", b, ctxp, P(Options))
     sig("horizonator_amd_last_times", b, ctxp, P(Times))
     sig("horizonator_amd_get_view", b, ctxp, P(View))
     sig("horizonator_amd_device", vp, ctxp)
@@ -179,6 +188,8 @@ def _open(path, selftest):
     sig("hz_hip_set_sector", i, vp, i, i)
     sig("hz_hip_set_raster", i, vp, i)
     sig("hz_hip_set_profiling", i, vp, i)
+    sig("hz_hip_get_options", i, vp, P(Options))
+    sig("hz_hip_set_options", i, vp, P(Options))
     sig("hz_hip_set_texture", i, vp, P(TexParams), vp)
     sig("hz_hip_pack", i, vp, vp)
     sig("hz_hip_resolve_packed", i, vp, P(View), vp, vp, i, i, i, vp, vp)
@@ -228,13 +239,14 @@ DECLARED_SYMBOLS = [
     "horizonator_amd_resolve_sparse_strips",
     "horizonator_amd_sync", "horizonator_amd_stream_waits_for_outputs", "horizonator_amd_waits_for_stream", "horizonator_amd_texture_layout", "horizonator_amd_set_texture",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
+    "horizonator_amd_get_options", "horizonator_amd_set_options",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
     "horizonator_amd_get_mosaic", "horizonator_amd_link_cells_size", "horizonator_amd_link_cells",
     "horizonator_amd_poi_visibility", "horizonator_amd_build_id",
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
-    "hz_hip_set_profiling", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
+    "hz_hip_set_profiling", "hz_hip_get_options", "hz_hip_set_options", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
     "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_last_plan", "hz_hip_last_queue_counts", "hz_hip_last_error",
 ]
 # include/hz_selftest.h: what libhorizonator_selftest.so exports on top of those (and libhorizonator.so must not)

@@ -933,6 +933,17 @@ bool horizonator_amd_set_raster(const horizonator_context_t* ctx, int which)
     return s != NULL && 0 == hz_hip_set_raster(s->dev, which);
 }
 
+bool horizonator_amd_get_options(const horizonator_context_t* ctx, hz_options_t* options)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && options != NULL && 0 == hz_hip_get_options(s->dev, options);
+}
+bool horizonator_amd_set_options(const horizonator_context_t* ctx, const hz_options_t* options)
+{
+    hz_state_t* s = live_state(ctx);
+    return s != NULL && options != NULL && 0 == hz_hip_set_options(s->dev, options);
+}
+
 bool horizonator_amd_set_profiling(const horizonator_context_t* ctx, bool on)
 {
     hz_state_t* s = live_state(ctx);

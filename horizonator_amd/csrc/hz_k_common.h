@@ -26,18 +26,14 @@ struct hz_params_t
      * whether it tests its survivors against the depth already in the framebuffer */
     const uint32_t* worklist;          /* k_march: the (segment, strip column) pairs of this launch, one per workgroup; NULL = the launch grid says it */
     int   cull_strips;                 /* k_march: strips whose four corners lie outside the drawn columns leave at once (sectors, views < 360 degrees) */
-    int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 those beyond the middle region, 3 the middle region's */
+    int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 all the others */
     int   near_x0, near_x1;            /* strip columns [x0,x1] and                                             */
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
-    int   mid_x0, mid_x1;              /* ... and the larger region around it that a middle round takes (zoomed views:  */
-    int   mid_j0, mid_j1;              /* draw_impl); the same region again where a draw has no middle round           */
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
-    int   pretest;                     /* k_big: read a framebuffer word before the atomic and skip fragments that cannot win */
     int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
 #ifdef HZ_EXPERIMENTS
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
 #endif
-    int   nsx;                         /* strip columns of the mosaic; a launch grid may be wider (HZ_EXP_XCD_PAD) */
     const uint32_t* hiz;               /* mr_flush, k_big: coarse depth (hz_k_hiz.h: level 1, level 2 behind it; second rounds of zoomed views), or NULL.
                                         * (One pointer, the rest follows from SW and H: every scalar register k_march holds costs it lane spills in its loop.) */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */

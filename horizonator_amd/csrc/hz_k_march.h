@@ -617,8 +617,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         const uint32_t item = p.worklist[blockIdx.x];
         sx = (int)(item & ((1u << MR_ITEM_SX_BITS) - 1u)); seg = (int)(item >> MR_ITEM_SX_BITS);
     }
-    else { sx = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : p.pass == 3 ? p.mid_x0 : 0); seg = (int)blockIdx.y; }
-    if(sx >= p.nsx) return;                             /* (a launch grid padded beyond the mosaic: HZ_EXP_XCD_PAD) */
+    else { sx = (int)blockIdx.x + (p.pass == 1 ? p.near_x0 : 0); seg = (int)blockIdx.y; }
     const int i0   = sx*MR_COLS;
     const int i    = i0 + lane;
     int jbeg, jend;                                     /* vertex rows jbeg..jend, cell rows jbeg..jend-1 */
@@ -626,8 +625,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     if(p.pass)
     {
         const bool near = sx >= p.near_x0 && sx <= p.near_x1 && jbeg < p.near_j1 && jend > p.near_j0;
-        const bool mid  = sx >= p.mid_x0  && sx <= p.mid_x1  && jbeg < p.mid_j1  && jend > p.mid_j0;
-        if(!(p.pass == 1 ? near : p.pass == 2 ? !mid : (mid && !near))) return;
+        if((p.pass == 1) != near) return;
     }
     const bool has_vertex = i < p.N;
     const bool has_cell   = lane < MR_COLS && i < p.N-1;

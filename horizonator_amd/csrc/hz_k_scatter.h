@@ -381,8 +381,7 @@ void k_big(unsigned long long* __restrict__ fb,
                         if(hz_tri_fragment(&tri, px, py, &zi, &r8))
                         {
                             const unsigned long long key = hz_pack(zi, prim, r8);
-                            if(!p.pretest || key < __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
+                            hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
                         }
                     }
                 }
@@ -416,10 +415,9 @@ void k_big(unsigned long long* __restrict__ fb,
                 if(hz_tri_fragment(&tri, px, py, &zi, &r8))
                 {
                     const unsigned long long key = hz_pack(zi, prim, r8);
-                    /* p.pretest (views with heavy overdraw, see plan_rounds): look first, and leave the atomic
-                     * out where the fragment cannot win - a stale larger value only costs the atomic */
-                    if(!p.pretest || key < __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
+                    /* (a look at the word before the atomic - leave it out where the fragment cannot win - lost here
+                     * on every scene: rounds 3 and 4, removed in round 5) */
+                    hz_fb_min<HZ_WHO_BIG>(fb, p, px, py, key);
                 }
             }
         }

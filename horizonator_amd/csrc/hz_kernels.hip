@@ -96,94 +96,73 @@ struct hz_device_guard
 /* ------------------------------------------------------------------------ */
 /* host side of the C-ABI                                                    */
 
-/* the HZ_* environment switches (diagnostics, tests), read once when a context is created */
-struct hz_env_t
-{
-    int    serial;                  /* HZ_SERIAL=1: the four streams are one (per-kernel times of a trace are then those of each kernel alone) */
-    int    queue_capacity;          /* HZ_QUEUE_CAPACITY: tests shrink the queues to exercise the overflow paths; 0 = default sizes */
-    int    resolve_clears;          /* HZ_RESOLVE_CLEARS=0 switches the fused clear of the conversion off */
-#ifdef HZ_EXPERIMENTS
-    int    march_debug;             /* HZ_MARCH_DEBUG: timing splits (wrong pictures), see hz_params_t::debug */
-    int    exp_fb_march, exp_fb_big;/* HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG = 1 | 2: experiments with wrong pictures, see hz_fb_min */
-#endif
-    int    no_fast_math;            /* HZ_NO_FAST_MATH=1: the unabridged transform everywhere */
-    int    two_pass;                /* HZ_TWO_PASS=0/1 forces one / two rounds; -1: the draw decides */
-    int    near_cells;              /* HZ_NEAR_CELLS: the first round's reach in cells; -1: from the view (plan_rounds) */
-    double two_pass_min_mpix;       /* HZ_TWO_PASS_MIN_MPIX (default 6) */
-    int    always_wait_near;        /* HZ_ALWAYS_WAIT_NEAR=1: a second round never starts beside its first */
-    int    no_worklist;             /* HZ_NO_WORKLIST=1: sectors launch the whole grid of strips (as before round 3) */
-    int    plain_copy;              /* HZ_PLAIN_COPY=1: hipMemcpy into the caller's memory as it is */
-    int    host_times;              /* HZ_HOST_TIMES=1 (diagnostics): hz_hip_resolve_to_host says on stderr where a call's time went */
-    int    host_dense;              /* HZ_HOST_DENSE=1: results for host memory travel whole (every pixel, as before round 4) instead of without the sky */
-    int    far_rows;                /* HZ_FAR_ROWS: rows per segment far from the viewer (experiments); 0: by the sector's width */
-    int    zone16_rows;             /* HZ_Z16_ROWS: rows per segment where a cell is 1 to 4 pixels wide (experiments); 0: 16, narrow sectors 8 (mr_make_zones) */
-    int    pretest;                 /* HZ_PRETEST=0/1: k_big looks before its atomics never / always; -1: the draw decides */
-    int    pretest_march;           /* HZ_PRETEST_MARCH=0/1: the second round's waves never / always read a word before the atomic; -1: the draw decides */
-    int    adapt, adapt_hi;         /* HZ_ADAPT=0/1/2 (default 1): the first round of a zoomed view may reach HZ_NEAR_CELLS_MAX instead of HZ_NEAR_CELLS_WIDE cells: never / when the draws
-                                     * of the same view before it say so (from HZ_ADAPT_HI work items for k_big in the second round on; default: 500000 per 64 Mpix of image) / always */
-    int    mid, mid_near, mid_cells; /* HZ_MID=1: two-round draws get a middle round (plan_rounds; not the default); HZ_MID_NEAR (256): the first round's reach
-                                     * in draws with a middle round; HZ_MID_CELLS (640): the middle round's */
-    int    inline_max2;             /* HZ_INLINE_MAX2=n: the second round's marching waves keep boxes of up to n pixels, larger ones up to 64 go to k_mid; 0: the draw decides (64, or 32 with a close far clip) */
-    int    tiles;                   /* HZ_TILES: the large triangles by screen tile with depth in LDS (hz_k_tile.h) instead of by k_big's atomics, byte-identical:
-                                     * 1 every round, 2 first (and middle) rounds, 0 never; default -1: the first round of zoomed views (draw_impl) */
-    int    tile_list;               /* HZ_TILE_LIST=n: a tile's list holds n triangles instead of 256 (tests: the fall-back to k_big) */
-    int    resolve_nt;              /* HZ_RESOLVE_NT=0: the conversion's results leave with plain instead of non-temporal stores */
-    int    exp_xcd_pad;             /* HZ_EXP_XCD_PAD=1: the launch grid padded to a multiple of 8 strip columns (one XCD per column) */
-    double near_px;                 /* HZ_NEAR_PX (default 20): the first round takes the strips whose cells are wider than this many pixels */
-    int    hiz;                     /* HZ_HIZ=0/1: second rounds never / always keep coarse depth for the early test of larger boxes (hz_k_hiz.h); -1: zoomed views, and every draw of a series */
-    double tiles_min_px;            /* HZ_TILES_MIN_PX (default 35): from this width of a cell at the first round's reach on, that round's large triangles go by tile */
-    double hiz_min_px;              /* HZ_HIZ_MIN_PX (default 25): "zoomed" = a cell at the first round's reach is at least this wide */
-};
+/* The tunables of a context (include/hz_hip.h: hz_options_t, hz_hip_set_options).  Every one of them changes how a
+ * picture is made, none what is in it.  The environment is a debugging override read HERE and nowhere else, once,
+ * when a context is created: HZ_<NAME IN CAPITALS>=value for each field of the struct. */
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static hz_env_t read_env(void)
+static hz_options_t default_options(void)
 {
-    hz_env_t e;
-    e.serial           = env_int("HZ_SERIAL", 0) != 0;
-    e.queue_capacity   = env_int("HZ_QUEUE_CAPACITY", 0);
-    e.resolve_clears   = env_int("HZ_RESOLVE_CLEARS", 1) != 0;
+    hz_options_t o;
+    o.serial         = 0;
+    o.rounds         = 0;
+    o.near_cells     = -1;
+    o.coarse_depth   = -1;
+    o.tiles          = -1;
+    o.tile_list      = 0;
+    o.adapt          = 1;
+    o.adapt_hi       = -1;
+    o.pretest_march  = -1;
+    o.worklists      = 1;
+    o.fast_math      = 1;
+    o.resolve_clears = 1;
+    o.queue_capacity = 0;
+    o.host_dense     = 0;
+    o.host_sectors   = 0;
+    o.host_times     = 0;
+    return o;
+}
+static hz_options_t options_from_env(void)
+{
+    hz_options_t o = default_options();
+    o.serial         = env_int("HZ_SERIAL", o.serial) != 0;
+    if(getenv("HZ_TWO_PASS")) o.rounds = env_int("HZ_TWO_PASS", 0) != 0 ? 2 : 1;
+    o.near_cells     = env_int("HZ_NEAR_CELLS", o.near_cells);
+    if(getenv("HZ_HIZ")) o.coarse_depth = env_int("HZ_HIZ", 0) != 0;
+    o.tiles          = env_int("HZ_TILES", o.tiles);
+    o.tile_list      = env_int("HZ_TILE_LIST", o.tile_list);
+    o.adapt          = env_int("HZ_ADAPT", o.adapt);
+    o.adapt_hi       = env_int("HZ_ADAPT_HI", o.adapt_hi);
+    if(getenv("HZ_PRETEST_MARCH")) o.pretest_march = env_int("HZ_PRETEST_MARCH", 0) != 0;
+    o.worklists      = env_int("HZ_NO_WORKLIST", 0) == 0;
+    o.fast_math      = env_int("HZ_NO_FAST_MATH", 0) == 0;
+    o.resolve_clears = env_int("HZ_RESOLVE_CLEARS", o.resolve_clears) != 0;
+    o.queue_capacity = env_int("HZ_QUEUE_CAPACITY", o.queue_capacity);
+    o.host_dense     = env_int("HZ_HOST_DENSE", o.host_dense) != 0;
+    o.host_sectors   = env_int("HZ_HOST_SECTORS", o.host_sectors);
+    o.host_times     = env_int("HZ_HOST_TIMES", o.host_times) != 0;
+    return o;
+}
 #ifdef HZ_EXPERIMENTS                   /* (switches that draw wrong pictures exist in builds with -DHZ_EXPERIMENTS only: tools/experiments.py) */
-    e.march_debug      = env_int("HZ_MARCH_DEBUG", 0);
-    e.exp_fb_march     = env_int("HZ_EXP_FB_MARCH", 0);
-    e.exp_fb_big       = env_int("HZ_EXP_FB_BIG", 0);
-#endif
-    e.no_fast_math     = env_int("HZ_NO_FAST_MATH", 0) != 0;
-    e.two_pass         = getenv("HZ_TWO_PASS") ? (env_int("HZ_TWO_PASS", 0) != 0) : -1;
-    e.near_cells       = getenv("HZ_NEAR_CELLS") ? env_int("HZ_NEAR_CELLS", 0) : -1;
-    e.two_pass_min_mpix= getenv("HZ_TWO_PASS_MIN_MPIX") ? atof(getenv("HZ_TWO_PASS_MIN_MPIX")) : 6.0;
-    e.always_wait_near = getenv("HZ_ALWAYS_WAIT_NEAR") != NULL;
-    e.no_worklist      = env_int("HZ_NO_WORKLIST", 0) != 0;
-    e.plain_copy       = env_int("HZ_PLAIN_COPY", 0) != 0;
-    e.host_dense       = env_int("HZ_HOST_DENSE", 0) != 0;
-    e.host_times       = env_int("HZ_HOST_TIMES", 0) != 0;
-    e.far_rows         = env_int("HZ_FAR_ROWS", 0);
-    e.zone16_rows      = env_int("HZ_Z16_ROWS", 0);
-    e.exp_xcd_pad      = env_int("HZ_EXP_XCD_PAD", 0) != 0;
-    e.resolve_nt       = env_int("HZ_RESOLVE_NT", 1) != 0;
-    e.mid              = env_int("HZ_MID", 0) != 0;
-    e.adapt            = env_int("HZ_ADAPT", 1);
-    e.adapt_hi         = env_int("HZ_ADAPT_HI", -1);
-    e.mid_near         = env_int("HZ_MID_NEAR", 256);
-    e.mid_cells        = env_int("HZ_MID_CELLS", 640);
-    e.inline_max2      = env_int("HZ_INLINE_MAX2", 0);
-    e.tiles            = env_int("HZ_TILES", -1);
-    e.tile_list        = env_int("HZ_TILE_LIST", 0);
-    e.hiz              = getenv("HZ_HIZ") ? (env_int("HZ_HIZ", 0) != 0) : -1;
-    e.tiles_min_px     = getenv("HZ_TILES_MIN_PX") ? atof(getenv("HZ_TILES_MIN_PX")) : 35.0;
-    e.hiz_min_px       = getenv("HZ_HIZ_MIN_PX") ? atof(getenv("HZ_HIZ_MIN_PX")) : 25.0;
-    e.pretest_march    = getenv("HZ_PRETEST_MARCH") ? (env_int("HZ_PRETEST_MARCH", 0) != 0) : -1;
-    e.pretest          = getenv("HZ_PRETEST") ? (env_int("HZ_PRETEST", 0) != 0) : -1;
-    e.near_px          = getenv("HZ_NEAR_PX") ? atof(getenv("HZ_NEAR_PX")) : 20.0;
-    if(!(e.near_px >= 0.5)) e.near_px = 20.0;
+struct hz_experiments_t { int march_debug, exp_fb_march, exp_fb_big; };
+static hz_experiments_t experiments_from_env(void)
+{
+    hz_experiments_t e = { env_int("HZ_MARCH_DEBUG", 0), env_int("HZ_EXP_FB_MARCH", 0), env_int("HZ_EXP_FB_BIG", 0) };
     return e;
 }
+#endif
+/* constants that used to be switches (each was swept: DESIGN.md section 4, docs/history/) */
+#define HZ_NEAR_PX            20.0f     /* the first round takes the strips whose cells are wider than this many pixels */
+#define HZ_TWO_ROUNDS_MIN_PIX 6.0e6     /* two rounds from this many pixels on */
+#define HZ_TILES_MIN_PX       35.0f     /* from this width of a cell at the first round's reach on, that round's large triangles go by screen tile */
+#define HZ_HIZ_MIN_PX         25.0f     /* "zoomed" = a cell at the first round's reach is at least this wide */
 
 /* what decides a draw's work lists */
 struct hz_listkey_t
 {
-    hz_view_t view; int col0, col1, two_pass, near_x0, near_x1, near_j0, near_j1, mid_x0, mid_x1, mid_j0, mid_j1, far_rows;
+    hz_view_t view; int col0, col1, two_pass, near_x0, near_x1, near_j0, near_j1, far_rows;
 };
-/* the work lists of sector draws (see strips_behind_columns): [0] first round, [1] second or only round, [2] middle round */
-#define HZ_NLISTS 3
+/* the work lists of sector draws (see strips_behind_columns): [0] first round, [1] second or only round */
+#define HZ_NLISTS 2
 struct hz_worklists_t
 {
     uint32_t*    d_items[HZ_NLISTS];
@@ -200,7 +179,10 @@ struct hz_worklists_t
 struct hz_dev
 {
     int device;
-    hz_env_t env;
+    hz_options_t env;                   /* (the options; "env" from the time when the environment was the only way to set them) */
+#ifdef HZ_EXPERIMENTS
+    hz_experiments_t exp;
+#endif
     int N, W, H;
     int col0, col1;
     int raster;
@@ -418,7 +400,10 @@ static int tile_bins(hz_dev_t* d, int set)
 static int create_impl(hz_dev_t* d)
 {
     HZ_ON_DEVICE(d);
-    d->env = read_env();
+    d->env = options_from_env();
+#ifdef HZ_EXPERIMENTS
+    d->exp = experiments_from_env();
+#endif
     d->lists.scratch = new std::vector<uint32_t>();
     HZ_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     if(d->env.serial) d->rstream = d->stream;
@@ -485,7 +470,7 @@ static int create_impl(hz_dev_t* d)
         HZ_CHECK(hipMemset(d->d_big_counters_s[i], 0, HZ_NCOUNTERS*sizeof(unsigned int)));
         /* (the tile bins of the rounds that use them whatever the view - HZ_TILES=1: all, 2: the first rounds' queue sets;
          * by default they are made when a zoomed view first asks for them: tile_bins()) */
-        if((d->env.tiles == 1 || (d->env.tiles == 2 && i >= HZ_NFB)) && tile_bins(d, i) != 0) return -1;
+        if(d->env.tiles > 0 && i >= HZ_NFB && tile_bins(d, i) != 0) return -1;
     }
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
@@ -660,6 +645,25 @@ extern "C" int hz_hip_set_texture(hz_dev_t* d, const hz_texparams_t* params, con
 }
 
 extern "C" int hz_hip_set_profiling(hz_dev_t* d, int on) { d->profiling = on; return 0; }
+
+extern "C" int hz_hip_get_options(hz_dev_t* d, hz_options_t* o)
+{
+    if(!d || !o) return -1;
+    *o = d->env;
+    return 0;
+}
+extern "C" int hz_hip_set_options(hz_dev_t* d, const hz_options_t* o)
+{
+    if(!d || !o) return -1;
+    HZ_ON_DEVICE(d);
+    HZ_CHECK(sync_all(d));
+    const int serial = d->env.serial, queue_capacity = d->env.queue_capacity;       /* (streams and queues exist already) */
+    d->env = *o;
+    d->env.serial = serial; d->env.queue_capacity = queue_capacity;
+    d->lists.valid = 0;
+    d->adapt.have_view = 0;
+    return 0;
+}
 extern "C" void* hz_hip_stream(hz_dev_t* d) { return (void*)d->rstream; }
 
 extern "C" int hz_hip_wait_outputs(hz_dev_t* d, void* stream)
@@ -680,7 +684,7 @@ extern "C" int hz_hip_wait_for(hz_dev_t* d, void* stream)
 
 /* segment zones of k_march for this view: a cell `r` rows away from the viewer
  * is about ppr/r pixels wide (ppr = pixels per radian of azimuth) */
-static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first, int far_rows_forced = 0, int zone16_rows_forced = 0)
+static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first)
 {
     const float ppr = p.halfW * p.u.az_ndc_per_rad;
     const int   ncr = p.N-1;                                /* cell rows */
@@ -704,15 +708,13 @@ static mr_zones_t mr_make_zones(const hz_params_t& p, bool near_first, int far_r
     int far_rows = 64*p.SW/p.W;
     if(far_rows < 16) far_rows = 16;
     if(far_rows > 64) far_rows = 64;
-    if(far_rows_forced >= 2 && far_rows_forced <= 64) far_rows = far_rows_forced;
     /* ... and nearer in (cells of 1 to 4 pixels) a narrow sector's kernel was as long as its longest waves: 16 rows of
      * 63 cells with a visible triangle in nearly every lane and a flush per row take 100-170 us (tools/wave_timing.py,
      * HZ_WT_SECTOR=8,0), the whole sector's waves 92 us of the chip - the kernel took 174.  Sectors of less than a sixth
      * of the image cut that zone into 8-row segments: an eighth's strips back to back 0.198 -> 0.169 ms (the widest),
      * 0.156 -> 0.153 (the narrowest); a quarter's and the whole image's waves are many enough to hide their longest
      * (0.273 -> 0.275; profiles/r4_sector_rules.txt). */
-    int z16 = 6*p.SW < p.W ? 8 : 16;
-    if(zone16_rows_forced >= 2 && zone16_rows_forced <= 16) z16 = zone16_rows_forced;
+    const int z16 = 6*p.SW < p.W ? 8 : 16;
     const int rows[MR_NZONES] = { far_rows, z16, 4, 2, 4, z16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
@@ -776,14 +778,12 @@ static hz_params_t make_params(const hz_dev_t* d, const hz_view_t* v)
     p.z_hide_k = 1.03f * p.z_guard * 16777215.f;
     /* (0 = no cell is ever culled the short way: tiny images, and sides that do not fit the packed 16-bit pixel boxes) */
     p.quad_max_dx = d->W >= 64 && d->W <= 65535 && d->H <= 65535 ? 256*(d->W/16 - 1) : 0;
-    p.pretest = d->env.pretest > 0 ? 1 : 0;
 #ifdef HZ_EXPERIMENTS
-    p.exp_fb[HZ_WHO_MARCH] = d->env.exp_fb_march; p.exp_fb[HZ_WHO_BIG] = d->env.exp_fb_big;
-    p.debug   = d->env.march_debug;
+    p.exp_fb[HZ_WHO_MARCH] = d->exp.exp_fb_march; p.exp_fb[HZ_WHO_BIG] = d->exp.exp_fb_big;
+    p.debug   = d->exp.march_debug;
 #endif
-    p.nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
     p.pretest_march = 0;                /* (the second round of a two-round draw may switch it on: draw_impl) */
-    p.fast_ok = hzf_draw_ok(&p.u) && !d->env.no_fast_math;
+    p.fast_ok = hzf_draw_ok(&p.u) && d->env.fast_math;
     return p;
 }
 
@@ -887,14 +887,13 @@ static void list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, do
         mr_segment_rows(zn, seg, &jbeg, &jend);
         int x0 = 0, x1 = nsx-1;
         if(!every_strip && !strips_behind_columns(p, a0, a1, jbeg, jend, nsx, &x0, &x1)) continue;
-        const bool near_rows = jbeg < p.near_j1 && jend > p.near_j0, mid_rows = jbeg < p.mid_j1 && jend > p.mid_j0;
+        const bool near_rows = jbeg < p.near_j1 && jend > p.near_j0;
         for(int sx=x0; sx<=x1; sx++)
         {
             if(p.pass)                          /* (as k_march decides it) */
             {
                 const bool near = near_rows && sx >= p.near_x0 && sx <= p.near_x1;
-                const bool mid  = mid_rows  && sx >= p.mid_x0  && sx <= p.mid_x1;
-                if(!(p.pass == 1 ? near : p.pass == 2 ? !mid : (mid && !near))) continue;
+                if((p.pass == 1) != near) continue;
             }
             out.push_back(MR_ITEM(seg, sx));
         }
@@ -1070,7 +1069,7 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
                         const uint32_t* d_list, unsigned int nlist)
 {
     const int nsx = (pm.N-1 + MR_COLS-1)/MR_COLS;
-    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : pm.pass == 3 ? pm.mid_x1 - pm.mid_x0 + 1 : (d->env.exp_xcd_pad ? (nsx + 7) & ~7 : nsx), zn.total);
+    dim3 grid(pm.pass == 1 ? pm.near_x1 - pm.near_x0 + 1 : nsx, zn.total);
     pm.worklist = NULL;
     if(d_list)
     {
@@ -1097,7 +1096,7 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
     return 0;
 }
 
-/* the draw's plan: rounds (1, 2, or 3: zoomed views), which strips are "next to the viewer", which the middle round's */
+/* the draw's plan: one round or two, and which strips are "next to the viewer" */
 static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
 {
     const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
@@ -1105,49 +1104,26 @@ static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
      * from the viewer is about ppr/r pixels wide (ppr = pixels per radian of azimuth), so r = ppr/20:
      * 127 cells for a 16000-wide panorama (where 32..256 were timed: hz_k_march.h), 64 for 8000, 260
      * for 32768, at most HZ_NEAR_CELLS_WIDE - and HZ_NEAR_CELLS_MAX for views zoomed far enough (see there).
-     * profiles/r3_scenes.json holds the sweep over the scenes of tools/scenes.py. */
+     * profiles/r3_scenes.json holds the sweep over the scenes of tools/scenes.py.
+     * (A middle round between the two - the ring out to 640 cells with the early test against the first round's
+     * tables - was built and measured in round 4: two of seven zoomed views gained, five paid its fixed cost, 10.7 ->
+     * 11.0 ms in sum; removed in round 5, profiles/r4_middle_round.txt.) */
     int near_cells = d->env.near_cells;
     if(near_cells < 0)
     {
         const float ppr = p.halfW * p.u.az_ndc_per_rad;
-        near_cells = (int)(ppr / (float)d->env.near_px + 0.5f);
+        near_cells = (int)(ppr / HZ_NEAR_PX + 0.5f);
         if(near_cells < 16) near_cells = 16;
         if(near_cells > HZ_NEAR_CELLS_WIDE) near_cells = HZ_NEAR_CELLS_WIDE;
         /* (zoomed even at the long reach: there, if the draws before say so - hz_k_march.h, adapt) */
-        if(ppr/(float)HZ_NEAR_CELLS_MAX >= (float)d->env.hiz_min_px && (d->env.adapt == 2 || (d->env.adapt == 1 && d->adapt.long_reach))) near_cells = HZ_NEAR_CELLS_MAX;
+        if(ppr/(float)HZ_NEAR_CELLS_MAX >= HZ_HIZ_MIN_PX && (d->env.adapt == 2 || (d->env.adapt == 1 && d->adapt.long_reach))) near_cells = HZ_NEAR_CELLS_MAX;
     }
-    /* A MIDDLE ROUND (round 4; HZ_MID=1, not the default).  How far the first round of a zoomed view has to reach for the
-     * ridge that hides most of the view to be in the tables depends on the view (no single reach is
-     * best), and a first round has no early depth test - every cell it is extended by is drawn whatever hides it.  With
-     * HZ_MID=1 the first round stays short (HZ_MID_NEAR), a middle round takes the ring out to HZ_MID_CELLS WITH the early
-     * test against the first round's tables - cheap where the ring is hidden, a round of occluders where it is not -, a
-     * second sweep takes its picture in, and the last round tests against that.  Measured over seven 10 and 45 degree
-     * views (profiles/r4_middle_round.txt): the two whose ridge lies far out gain (summit 2.03 -> 1.64-1.76 ms, valley
-     * 1.54 -> 1.05-1.18), the five others pay the round's fixed cost - a second sweep, another chain of march, clip and
-     * big - with 0.2-0.3 ms each: 10.7 -> 11.0 ms in sum.  Byte-identical (tools/gpu_modes.sh forces it on the suite's
-     * scenes); off unless asked for. */
-    int mid_cells = 0;
-    {
-        const float ppr = p.halfW * p.u.az_ndc_per_rad;
-        const bool zoomed = near_cells > 0 && ppr/(float)near_cells >= (float)d->env.hiz_min_px;
-        (void)zoomed;
-        if(d->env.mid > 0)
-        {
-            mid_cells = d->env.mid_cells;
-            if(d->env.near_cells < 0 && near_cells > d->env.mid_near) near_cells = d->env.mid_near;
-            if(mid_cells <= near_cells) mid_cells = 0;
-        }
-    }
-    auto region = [&](int cells, int* x0, int* x1, int* j0, int* j1)
-    {
-        *x0 = (int)floorf((p.u.viewer_cell_i - (float)cells)/(float)MR_COLS);
-        *x1 = (int)floorf((p.u.viewer_cell_i + (float)cells)/(float)MR_COLS);
-        if(*x0 < 0) *x0 = 0;
-        if(*x1 > nsx-1) *x1 = nsx-1;
-        *j0 = (int)floorf(p.u.viewer_cell_j - (float)cells);
-        *j1 = (int)ceilf (p.u.viewer_cell_j + (float)cells);
-    };
-    region(near_cells, &p.near_x0, &p.near_x1, &p.near_j0, &p.near_j1);
+    p.near_x0 = (int)floorf((p.u.viewer_cell_i - (float)near_cells)/(float)MR_COLS);
+    p.near_x1 = (int)floorf((p.u.viewer_cell_i + (float)near_cells)/(float)MR_COLS);
+    if(p.near_x0 < 0) p.near_x0 = 0;
+    if(p.near_x1 > nsx-1) p.near_x1 = nsx-1;
+    p.near_j0 = (int)floorf(p.u.viewer_cell_j - (float)near_cells);
+    p.near_j1 = (int)ceilf (p.u.viewer_cell_j + (float)near_cells);
     /* Two rounds pay where there is terrain behind the first round's strips to be hidden by them
      * and enough pixels for the second round's early depth test to save work; a small image is
      * faster in one round (three kernel launches less).  Measured over the scenes of tools/scenes.py
@@ -1155,16 +1131,11 @@ static int plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p)
      * 4000x1000 0.224 / 0.225, 8000x2000 0.353 / 0.316 (a batch of viewpoints of that size 0.512 /
      * 0.465), 16000x4000 1.33 / 1.12, with the API's 40 km far clip 0.752 / 0.725, 32768x8192 12.5 /
      * 11.1 - so: from 6 Mpix on, and a far clip at least three reaches of the first round away.
-     * (Round 2 drew this line at 24 Mpix and 12 reaches, from the benchmark scene alone.)  Azimuth
-     * sectors decide by the size of the whole image: their renders overlap just the same. */
+     * Azimuth sectors decide by the size of the whole image: their renders overlap just the same. */
     const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
-    const bool want_two = d->env.two_pass >= 0 ? d->env.two_pass != 0
-                             : ((double)p.W*(double)p.H >= d->env.two_pass_min_mpix*1e6 && cells_to_zfar >= 3.0f*(float)near_cells);
-    const bool two = want_two && near_cells > 0 && p.near_x1 >= p.near_x0;
-    const bool three = two && mid_cells > 0 && cells_to_zfar >= 1.5f*(float)mid_cells;
-    if(three) region(mid_cells, &p.mid_x0, &p.mid_x1, &p.mid_j0, &p.mid_j1);
-    else { p.mid_x0 = p.near_x0; p.mid_x1 = p.near_x1; p.mid_j0 = p.near_j0; p.mid_j1 = p.near_j1; }
-    return three ? 3 : two ? 2 : 1;
+    const bool want_two = d->env.rounds > 0 ? d->env.rounds == 2
+                             : ((double)p.W*(double)p.H >= HZ_TWO_ROUNDS_MIN_PIX && cells_to_zfar >= 3.0f*(float)near_cells);
+    return want_two && near_cells > 0 && p.near_x1 >= p.near_x0 ? 2 : 1;
 }
 
 /* Coarse depth of framebuffer `next` (hz_k_hiz.h): the tables of a draw with the geometry of p, allocated on first use */
@@ -1237,8 +1208,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
      * and middle rounds - where the large triangles lie hills behind hills and k_big is bound by its atomics - always (2)
      * or when the view is zoomed (the default; decided below).  The tiles merge into the framebuffer with atomic minima:
      * no ownership, nothing else has to wait. */
-    const bool by_tile = d->env.tiles == 1 && d->raster != HZ_RASTER_SCATTER;
-    bool by_tile_first = (d->env.tiles == 1 || d->env.tiles == 2) && d->raster != HZ_RASTER_SCATTER;
+    bool by_tile_first = d->env.tiles > 0 && d->raster != HZ_RASTER_SCATTER;
     bool near_beside_far = false;                   /* the second round did not wait for the first */
     bool waited_near = false;                       /* ... or it did */
     bool use_hiz = false;                           /* the second round keeps coarse depth (hz_k_hiz.h) */
@@ -1254,12 +1224,11 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     }
     else
     {
-        const int rounds = plan_rounds(d, view, p);
-        const bool two_pass = rounds >= 2, three = rounds == 3;
-        const mr_zones_t zn = mr_make_zones(p, two_pass, d->env.far_rows, d->env.zone16_rows);
+        const bool two_pass = plan_rounds(d, view, p) == 2;
+        const mr_zones_t zn = mr_make_zones(p, two_pass);
         /* sectors and views of less than the full circle: only the strips behind the drawn columns */
         double a0 = 0, a1 = 0;
-        const bool listed = !d->env.no_worklist && azimuths_of_columns(p, &a0, &a1) && zn.total < (1 << (32 - MR_ITEM_SX_BITS))
+        const bool listed = d->env.worklists && azimuths_of_columns(p, &a0, &a1) && zn.total < (1 << (32 - MR_ITEM_SX_BITS))
                             && (p.N-1 + MR_COLS-1)/MR_COLS <= (1 << MR_ITEM_SX_BITS);
         p.cull_strips = (p.col0 > 0 || p.col1 < p.W || listed) ? 1 : 0;
         bool fresh_lists = false;
@@ -1269,7 +1238,6 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             memset(&key, 0, sizeof(key));
             key.view = *view; key.col0 = p.col0; key.col1 = p.col1; key.two_pass = two_pass ? 1 : 0;
             key.near_x0 = p.near_x0; key.near_x1 = p.near_x1; key.near_j0 = p.near_j0; key.near_j1 = p.near_j1; key.far_rows = zn.rows[0] | (zn.rows[1] << 8);
-            key.mid_x0 = p.mid_x0; key.mid_x1 = p.mid_x1; key.mid_j0 = p.mid_j0; key.mid_j1 = p.mid_j1;
             fresh_lists = !d->lists.valid || memcmp(&key, &d->lists.key, sizeof(key)) != 0;
             if(fresh_lists) { d->lists.valid = 0; d->lists.key = key; }
         }
@@ -1296,7 +1264,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                  * degree view of 16000 columns: 40; a 90 degree view, 26, is better off with k_big: 0.92 against 1.08 ms) */
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
-                if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= (float)d->env.tiles_min_px && tile_bins(d, HZ_NFB + next) == 0) by_tile_first = true;
+                if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= HZ_TILES_MIN_PX) by_tile_first = true;
+                if(by_tile_first && tile_bins(d, HZ_NFB + next) != 0) by_tile_first = false;       /* (no memory for the bins: k_big) */
             }
             if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile_first) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
@@ -1322,13 +1291,13 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             {
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
-                const bool zoomed = reach > 0.f && ppr/reach >= (float)d->env.hiz_min_px;
+                const bool zoomed = reach > 0.f && ppr/reach >= HZ_HIZ_MIN_PX;
                 /* (azimuth sectors, round 4 - with k_big's chunk test against the tables: a half gains 8 %, a quarter 6 (strips back to
                  * back 0.273 -> 0.259, 0.250 -> 0.234 ms), an eighth's widest sector 11 and its narrowest loses 4; beside the 8-row
                  * segments narrow sectors get (mr_make_zones) an eighth loses 5: from a sixth of the image on.  profiles/r4_sector_rules.txt) */
                 /* (whatever the far clip: with the API's 40 km the tables change nothing - 0.602 / 0.607 ms without / with,
                  * three alternating pairs -, at 80 km they gain 3 %, at 150 km 4 %: round 4) */
-                use_hiz = early_z && (d->env.hiz >= 0 ? d->env.hiz != 0 : (zoomed || three || (busy && 6*p.SW >= p.W)));
+                use_hiz = early_z && (d->env.coarse_depth >= 0 ? d->env.coarse_depth != 0 : (zoomed || (busy && 6*p.SW >= p.W)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight
@@ -1336,28 +1305,8 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
                  * it: 0.91 -> 1.00 ms per render.  It stays here.) */
                 if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
             }
-            if(three)
-            {
-                /* The middle round (plan_rounds): the ring between the first round's strips and HZ_MID_CELLS, with the early
-                 * depth test against the tables just taken, its large triangles through the first round's queue set -
-                 * emptied again first: its k_big is done with it - and a second sweep behind it, all on the first round's
-                 * stream.  Same exactness as a second round: the test only ever skips what cannot win a pixel. */
-                HZ_CHECK(hipMemsetAsync(d->d_big_counters_s[HZ_NFB + next], 0, 6*sizeof(unsigned int), d->nstream));
-                hz_params_t pm = p;
-                pm.pass = 3; pm.early_z = early_z ? 1 : 0; pm.hiz = hz.l1; pm.inline_max = HZ_INLINE_MAX_PIX;
-                pm.pretest_march = d->env.pretest_march >= 0 ? d->env.pretest_march
-                                                             : ((unsigned long long)p.SW*(unsigned long long)p.H*8ull > (256ull << 20) ? 1 : 0);
-                if(fresh_lists)
-                {
-                    list_items(pm, zn, a0, a1, *d->lists.scratch);
-                    if(upload_list(d, 2, d->nstream, *d->lists.scratch) != 0) return -1;
-                }
-                if(launch_march(d, d->nstream, qn, zn, pm, listed ? d->lists.d_items[2] : NULL, d->lists.n[2]) != 0) return -1;
-                if(queue_kernels(d, qn, pm, d->nstream, HZ_NFB + next, by_tile_first) != 0) return -1;
-                if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
-            }
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
-            if(use_hiz || d->env.always_wait_near || busy)
+            if(use_hiz || busy)
             {
                 HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_near, 0));
                 waited_near = true;             /* (the first round itself waited for the framebuffer: no second wait for that below) */
@@ -1376,8 +1325,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
             {
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
-                if(d->env.inline_max2 > 0) p.inline_max = (unsigned int)d->env.inline_max2;
-                else if(cells_to_zfar <= 0.25f*ppr) p.inline_max = 32;
+                if(cells_to_zfar <= 0.25f*ppr) p.inline_max = 32;
             }
             p.hiz = hz.l1;
             /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment
@@ -1417,9 +1365,9 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
     if(d->env.adapt == 1 && d->env.near_cells < 0 && p.pass == 2 && d->adapt.h_counts[next] && !d->adapt.pending[next])
     {
         const float ppr = p.halfW * p.u.az_ndc_per_rad;
-        if(ppr/(float)HZ_NEAR_CELLS_MAX >= (float)d->env.hiz_min_px) report = d->adapt.h_counts[next];        /* (a view whose reach has the choice) */
+        if(ppr/(float)HZ_NEAR_CELLS_MAX >= HZ_HIZ_MIN_PX) report = d->adapt.h_counts[next];        /* (a view whose reach has the choice) */
     }
-    if(queue_kernels(d, q, p, d->qstream, next, by_tile, report) != 0) return -1;
+    if(queue_kernels(d, q, p, d->qstream, next, false, report) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     if(report)
     {
@@ -1427,7 +1375,7 @@ static int draw_impl(hz_dev_t* d, const hz_view_t* view)
         d->adapt.pending[next] = 1; d->adapt.reach_of[next] = (p.near_j1 - p.near_j0)/2;
         d->adapt.long_of[next] = d->adapt.reach_of[next] > HZ_NEAR_CELLS_WIDE ? 1 : 0; d->adapt.serial_of[next] = d->adapt.serial;
     }
-    d->last_plan[0] = p.pass == 2 ? (p.mid_j1 - p.mid_j0 > p.near_j1 - p.near_j0 ? 3 : 2) : 1; d->last_plan[1] = use_hiz ? 1 : 0;
+    d->last_plan[0] = p.pass == 2 ? 2 : 1; d->last_plan[1] = use_hiz ? 1 : 0;
     d->last_plan[2] = p.pass == 2 ? (p.near_j1 - p.near_j0)/2 : 0; d->last_plan[3] = p.cull_strips ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
@@ -1518,11 +1466,11 @@ static int resolve_impl(hz_dev_t* d, const hz_view_t* view, const float* tanel,
             if(clears)
                 hipLaunchKernelGGL(k_resolve4<true>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
                                    bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride,
-                                   k == 0 ? qa : (unsigned int*)NULL, qb, yo0, yo1, d->env.resolve_nt);
+                                   k == 0 ? qa : (unsigned int*)NULL, qb, yo0, yo1, 1);
             else
                 hipLaunchKernelGGL(k_resolve4<false>, grid, dim3(256), 0, d->rstream, d->d_fb, (const float*)d->d_tanel,
                                    bgr, ranges, index, z24, SW, d->H, view->znear, view->zfar, d->d_touched[d->fbi], d->seg_stride,
-                                   (unsigned int*)NULL, (unsigned int*)NULL, yo0, yo1, d->env.resolve_nt);
+                                   (unsigned int*)NULL, (unsigned int*)NULL, yo0, yo1, 1);
             HZ_CHECK(hipGetLastError());
             if(ev_band) HZ_CHECK(hipEventRecord(ev_band[k], d->rstream));
         }
@@ -2155,7 +2103,7 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
     HZ_ON_DEVICE(d);
     /* without the sky, unless: a textured colour (three bytes per terrain pixel that are not the shade), an image too
      * large for a blob's 16-bit row field, nothing asked for, or a switch says so */
-    if(!d->env.host_dense && !d->env.plain_copy && !(d->tex_on && bgr) && (bgr || ranges || index || z24) &&
+    if(!d->env.host_dense && !(d->tex_on && bgr) && (bgr || ranges || index || z24) &&
        d->H <= 65535 && (d->col1 - d->col0) >= 1)
     {
         if(ensure_staging(d) != 0) return -1;
@@ -2175,7 +2123,7 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
     if(index)  { dst[nbuf] = (unsigned char*)index;  src[nbuf] = (const unsigned char*)d->d_index;    row_bytes[nbuf++] = (size_t)SW*sizeof(int32_t); }
     if(z24)    { dst[nbuf] = (unsigned char*)z24;    src[nbuf] = (const unsigned char*)d->d_z24;      row_bytes[nbuf++] = (size_t)SW*sizeof(uint32_t); }
     /* the draw is in flight (asynchronous): while it runs, the pool maps the caller's pages */
-    hz_copy_pool* pool = d->env.plain_copy ? NULL : copy_pool();
+    hz_copy_pool* pool = copy_pool();
     hz_copy_pool::batch_t mapped = { 0 };
     if(pool) for(int b=0; b<nbuf; b++) pool->push(&mapped, dst[b], NULL, row_bytes[b]*d->H, (size_t)4 << 20);
     int band_rows = d->H;
@@ -2184,13 +2132,6 @@ extern "C" int hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const 
     const int nbands = resolve_impl(d, view, tanel, bgr ? d->d_bgr : NULL, ranges ? d->d_ranges : NULL,
                                     index ? d->d_index : NULL, z24 ? d->d_z24 : NULL, want_bands, d->ev_band, &band_rows);
     int rc = nbands < 0 ? -1 : 0;
-    if(rc == 0 && !pool)                                /* diagnostics: hipMemcpy into the caller's memory as it is */
-    {
-        for(int b=0; b<nbuf && rc == 0; b++)
-            if(hipMemcpyAsync(dst[b], src[b], row_bytes[b]*d->H, hipMemcpyDeviceToHost, d->rstream) != hipSuccess) rc = -1;
-        if(hipStreamSynchronize(d->rstream) != hipSuccess) rc = -1;
-        return rc;
-    }
     if(rc == 0 && pool) rc = copy_out(d, nbuf, dst, src, row_bytes, d->H, nbands, band_rows, pool);
     if(pool) pool->wait(&mapped);                       /* (its tasks name the caller's buffers: none may outlive this call) */
     return rc;

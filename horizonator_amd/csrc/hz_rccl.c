@@ -115,6 +115,11 @@ int horizonator_rccl_render_series(const horizonator_context_t* ctx, void* comm,
     if(check_fit && draws && last_slot >= 0)
     {
         uint32_t terrain = 0;
+        /* (the exchange stream too: the last panoramas' send/receive groups may still be in flight on THIS communicator,
+         * and a caller that now agrees on the fit over ANOTHER communicator - bench.py's all_reduce over torch's - would
+         * have collectives of two communicators in flight on one device, which RCCL documents as deadlock-prone) */
+        hipError_t es = hipStreamSynchronize((hipStream_t)s->stream);
+        if(es != hipSuccess) { MSG("hipStreamSynchronize -> %s", hipGetErrorString(es)); return -1; }
         if(!horizonator_amd_sync(ctx)) return -1;
         hipError_t e = hipMemcpy(&terrain, s->d_strips[last_slot], sizeof(terrain), hipMemcpyDeviceToHost);
         if(e != hipSuccess) { MSG("hipMemcpy -> %s", hipGetErrorString(e)); return -1; }

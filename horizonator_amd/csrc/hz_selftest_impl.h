@@ -418,13 +418,12 @@ extern "C" long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view
 {
     hz_dev_t* d = (hz_dev_t*)calloc(1, sizeof(*d));
     if(!d) return -1;
-    d->env = read_env();
-    const int far_rows = d->env.far_rows, zone16_rows = d->env.zone16_rows;
+    d->env = options_from_env();
     d->N = N; d->W = W; d->H = H; d->col0 = col0; d->col1 = col1;
     d->seg_stride = (W + HZ_SEG-1)/HZ_SEG;
     hz_params_t p = make_params(d, view);
     (void)plan_rounds(d, view, p);
-    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0, far_rows, zone16_rows);
+    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0);
     free(d);
     p.pass = round & 3;
     double a0 = 0, a1 = 0;

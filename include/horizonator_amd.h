@@ -133,6 +133,10 @@ bool horizonator_amd_set_sector(const horizonator_context_t* ctx, int col0, int 
 /* HZ_RASTER_* of hz_hip.h */
 bool horizonator_amd_set_raster(const horizonator_context_t* ctx, int which);
 
+/* the context's tunables (hz_hip.h: hz_options_t; none of them changes a byte of any result) */
+bool horizonator_amd_get_options(const horizonator_context_t* ctx, hz_options_t* options);
+bool horizonator_amd_set_options(const horizonator_context_t* ctx, const hz_options_t* options);
+
 bool horizonator_amd_set_profiling(const horizonator_context_t* ctx, bool on);
 bool horizonator_amd_last_times(const horizonator_context_t* ctx, hz_times_t* times);
 

@@ -62,7 +62,8 @@ int horizonator_rccl_gather_strips(const horizonator_context_t* ctx, void* comm,
  *   d_image, d_ranges  the gathering ranks' full-width outputs (DEVICE; either may be NULL)
  *   first, count    panoramas first .. first+count-1 (the index decides slot and gathering rank: a caller that
  *                   splits a series over several calls passes where it is)
- *   check_fit       != 0: after the last panorama is queued, wait for this rank's last strip and look at its length
+ *   check_fit       != 0: after the last panorama is queued, wait for `stream` and the context (no exchange of this
+ *                   series is in flight when the call returns) and look at the length of this rank's last strip
  * Returns 0; 1 if check_fit and this rank's strip was longer than `words` (the panoramas gathered are then
  * incomplete: agree on more words and repeat); -1 on an error (message on stderr). */
 typedef struct

@@ -96,6 +96,35 @@ int  hz_hip_set_sector(hz_dev_t* d, int col0, int col1);
 int  hz_hip_set_raster(hz_dev_t* d, int which);
 int  hz_hip_set_profiling(hz_dev_t* d, int on);
 
+/* The tunables of a context.  Every one of them changes HOW a picture is made, none WHAT is in it (the GPU suite runs
+ * under each of them: tools/gpu_modes.sh).  -1 / 0 = "the draw decides" where noted.  A context starts with the
+ * defaults below, overridden - for debugging only - by environment variables read once when it is created
+ * (HZ_SERIAL, HZ_TWO_PASS=0|1, HZ_NEAR_CELLS, HZ_HIZ, HZ_TILES, HZ_TILE_LIST, HZ_ADAPT, HZ_ADAPT_HI, HZ_PRETEST_MARCH,
+ * HZ_NO_WORKLIST, HZ_NO_FAST_MATH, HZ_RESOLVE_CLEARS, HZ_QUEUE_CAPACITY, HZ_HOST_DENSE, HZ_HOST_SECTORS,
+ * HZ_HOST_TIMES); hz_hip_set_options() replaces them (queued work is waited for first; `serial` and
+ * `queue_capacity` only take effect at creation). */
+typedef struct
+{
+    int serial;           /* 0    1: one stream instead of four (per-kernel times of a trace are then those of each kernel alone) */
+    int rounds;           /* 0    1 / 2: every draw in one round / in two (first the strips next to the viewer); 0: by image size and far clip */
+    int near_cells;       /* -1   the first round's reach in cells; -1: from the view (cells wider than ~20 px, at most 384, zoomed views 512) */
+    int coarse_depth;     /* -1   0 / 1: second rounds never / always test larger boxes against coarse depth (k_hiz); -1: zoomed views and series of renders */
+    int tiles;            /* -1   first rounds' large triangles by screen tile with depth in LDS (k_tile_*): 0 never, 1 always, -1 zoomed views */
+    int tile_list;        /* 0    triangles a tile's list holds (tests: small values exercise the fall-back to k_big); 0: 2048 */
+    int adapt;            /* 1    the first round's reach of a zoomed view: 0 always short, 2 always long, 1 by what the draws before had to queue */
+    int adapt_hi;         /* -1   ... from this many work items in the second round on; -1: 500 000 per 64 Mpix */
+    int pretest_march;    /* -1   0 / 1: second rounds' marching waves never / always read a word before the atomic; -1: framebuffers beyond the 256 MB last-level cache */
+    int worklists;        /* 1    0: sectors and narrow views launch the whole grid of strips instead of a host-built list */
+    int fast_math;        /* 1    0: the unabridged division / square-root sequences everywhere (same bits) */
+    int resolve_clears;   /* 1    0: framebuffers are cleared by a memset instead of by the conversion that reads them last */
+    int queue_capacity;   /* 0    records per queue between the kernels of a draw (tests: small values exercise the overflow paths); 0: by image size */
+    int host_dense;       /* 0    1: results for host memory travel whole (every pixel) instead of without the sky */
+    int host_sectors;     /* 0    azimuth sectors a call that delivers into host memory is drawn and shipped in (draw of sector s+1 beside the transfer of sector s); 0: by image size */
+    int host_times;       /* 0    1: such a call says on stderr where its time went */
+} hz_options_t;
+int  hz_hip_get_options(hz_dev_t* d, hz_options_t* o);
+int  hz_hip_set_options(hz_dev_t* d, const hz_options_t* o);
+
 /* Takes over glClear + glDrawElements (reference horizonator-lib.c:896-897)
  * and with it vertex.glsl / geometry.glsl / fragment.glsl and the fixed
  * function raster + depth test.  Asynchronous: queued on the context's streams (marching kernel, queue kernels and

@@ -331,7 +331,7 @@ def test_random_views_bit_exact_vs_oracle_and_vs_reference(seed):
 @pytest.mark.parametrize("capacity", [None, 3])
 def test_tile_binned_rasteriser_draws_the_same_bytes(capacity, monkeypatch):
     """HZ_TILES=1 (hz_k_tile.h: BASELINE north_star's tile-binned rasteriser with per-bin depth in LDS, for the large
-    triangles of both rounds): a whole image, a sector and a zoomed view against the oracle on every output; with tile lists
+    triangles of every first round instead of those of zoomed views only): a whole image, a sector and a zoomed view against the oracle on every output; with tile lists
     of three triangles some tile's list overflows and the round must fall back to k_big - same bytes either way"""
     monkeypatch.setenv("HZ_TILES", "1")
     monkeypatch.setenv("HZ_TWO_PASS", "1")

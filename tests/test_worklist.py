@@ -127,37 +127,6 @@ def test_rounds_partition_the_one_round_list():
         assert cover[jb:je, sx].all()
 
 
-def test_three_rounds_of_a_zoomed_view_partition_its_list(monkeypatch):
-    """with HZ_MID=1 a draw has three rounds (first, middle, last: DESIGN.md appendix C): their lists are disjoint and together
-    cover the one-round list; the middle one is the ring between the first round's reach and HZ_MID_CELLS"""
-    for k in ("HZ_MID", "HZ_MID_NEAR", "HZ_MID_CELLS", "HZ_NEAR_CELLS", "HZ_TWO_PASS", "HZ_HIZ", "HZ_TILES"):
-        monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("HZ_MID", "1")               # (a middle round is an option: HZ_MID=1)
-    rng = np.random.default_rng(3)
-    N, W, H = 2400, 16000, 4000
-    v = _view(rng, N, W, H, -22.5, 22.5)
-    v.viewer_cell_i, v.viewer_cell_j = 1200.3, 1190.7
-    lists = {}
-    for rnd in (1, 3, 2):
-        n, items = _listed(N, W, H, v, 0, W, rnd)
-        assert n > 0, rnd
-        lists[rnd] = {tuple(int(t) for t in r) for r in items}
-    assert not (lists[1] & lists[3]) and not (lists[1] & lists[2]) and not (lists[3] & lists[2])
-    # rows of the first round within 256 cells of the viewer, of the middle round within 640, the last beyond
-    for sx, jb, je in lists[1]:
-        assert je > 1190.7 - 257 and jb < 1190.7 + 257 and (sx + 1) * MR_COLS > 1200.3 - 257 - MR_COLS and sx * MR_COLS < 1200.3 + 257 + MR_COLS
-    for sx, jb, je in lists[3]:
-        assert je > 1190.7 - 641 and jb < 1190.7 + 641
-    assert any(jb < 1190.7 - 700 or je > 1190.7 + 700 for _, jb, je in lists[2])
-    cover = np.zeros((N, (N - 1 + MR_COLS - 1) // MR_COLS), bool)
-    for sx, jb, je in lists[1] | lists[3] | lists[2]:
-        assert not cover[jb:je, sx].any()
-        cover[jb:je, sx] = True
-    n0, i0 = _listed(N, W, H, v, 0, W, 0)
-    for sx, jb, je in i0:
-        assert cover[jb:je, sx].all()
-
-
 def test_full_circle_launches_the_grid():
     rng = np.random.default_rng(2)
     v = _view(rng, 600, 2000, 500, -180.0, 180.0)

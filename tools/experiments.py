@@ -66,17 +66,10 @@ ROWS = [
      "upper bound of what the marching waves' atomics cost"),
     ("k_march: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2"}, None, "the same with the store kept"),
     ("both: plain stores (WRONG picture)", {"HZ_EXP_FB_MARCH": "2", "HZ_EXP_FB_BIG": "2"}, None, "no atomic anywhere"),
-    ("k_big looks before its atomics", {"HZ_PRETEST": "1"}, None, "reads the word first, skips fragments that cannot win"),
     ("the second round's waves do not look before their atomics", {"HZ_PRETEST_MARCH": "0"}, None, "round 2's behaviour: every fragment of the marching waves is an atomic (default for framebuffers of up to 256 MB)"),
     ("north_star's tile-binned rasteriser with depth in LDS for the large triangles (hz_k_tile.h)", {"HZ_TILES": "1"}, None,
-     "64x32-pixel tiles owned by one workgroup each: LDS atomic minima, one plain store per pixel; byte-identical"),
+     "64x64-pixel tiles: batches of up to 64 triangles drawn into 32 KB of LDS (LDS atomic minima) and merged into the framebuffer with one atomic minimum per touched pixel; first rounds only; byte-identical"),
     ("the same, zfar 40 km", {"HZ_TILES": "1"}, 40000.0, "where the near field is most of the work"),
-    ("the conversion stores its results the plain way", {"HZ_RESOLVE_NT": "0"}, None, "default: non-temporal stores (448 MB per panorama that nobody on the chip reads)"),
-    ("launch grid padded to a multiple of 8 strip columns", {"HZ_EXP_XCD_PAD": "1"}, None,
-     "all segments of a strip column on one XCD (workgroups are dealt to the XCDs round-robin): L2 locality against balance"),
-    ("first round reaches cells wider than 10 px", {"HZ_NEAR_PX": "10"}, None, "default 20"),
-    ("first round reaches cells wider than 40 px", {"HZ_NEAR_PX": "40"}, None, "default 20"),
-    ("second round always waits for the first", {"HZ_ALWAYS_WAIT_NEAR": "1"}, None, ""),
     ("no coarse depth in a series of renders", {"HZ_HIZ": "0"}, None,
      "the second rounds without the tables of hz_k_hiz.h (default: zoomed views always, whole panoramas when they are part of a series): the build before them"),
     ("coarse depth forced", {"HZ_HIZ": "1"}, None, "in a series the same as shipped; it differs for the first renders only"),
