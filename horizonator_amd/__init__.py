@@ -217,6 +217,23 @@ class horizonator:
             raise RuntimeError("horizonator_render_offscreen() failed")
 
     # -- build-side additions ------------------------------------------------
+    def render_begin(self, image=None, ranges=None):
+        """the first half of render_into(): queues the draw of the current view into the caller's arrays and returns;
+        render_end() returns when they hold the panorama.  Two panoramas may be in flight (each with arrays of its own):
+        the device draws one while the other crosses PCIe.  The arrays must stay alive and untouched until the matching end."""
+        c0, c1 = self.sector
+        H, W = self._ctx.offscreen.height, c1 - c0
+        for a, shape, dt in ((image, (H, W, 3), np.uint8), (ranges, (H, W), np.float32)):
+            if a is not None and (a.shape != shape or a.dtype != dt or not a.flags.c_contiguous):
+                raise ValueError("render_begin() wants C-contiguous %s arrays of shape %s" % (np.dtype(dt).name, shape))
+        if not self._lib.horizonator_amd_render_begin(C.byref(self._ctx), image.ctypes.data if image is not None else None,
+                                                      ranges.ctypes.data if ranges is not None else None):
+            raise RuntimeError("horizonator_amd_render_begin() failed")
+
+    def render_end(self):
+        if not self._lib.horizonator_amd_render_end(C.byref(self._ctx)):
+            raise RuntimeError("horizonator_amd_render_end() failed")
+
     def render_full(self, az_deg0, az_deg1, lat=-1000.0, lon=-1000.0,
                     az_extents_use_pixel_centers=False,
                     znear=HORIZONATOR_ZNEAR_DEFAULT, zfar=HORIZONATOR_ZFAR_DEFAULT,

@@ -168,6 +168,8 @@ def _open(path, selftest):
     sig("horizonator_amd_set_sector", b, ctxp, i, i)
     sig("horizonator_amd_set_raster", b, ctxp, i)
     sig("horizonator_amd_set_profiling", b, ctxp, b)
+    sig("horizonator_amd_render_begin", b, ctxp, vp, vp)
+    sig("horizonator_amd_render_end", b, ctxp)
     sig("horizonator_amd_get_options", b, ctxp, P(Options))
     sig("horizonator_amd_set_options", b, ctxp, P(Options))
     sig("horizonator_amd_last_times", b, ctxp, P(Times))
@@ -199,6 +201,9 @@ def _open(path, selftest):
     sig("hz_hip_draw", i, vp, P(View))
     sig("hz_hip_resolve", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_resolve_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
+    sig("hz_hip_render_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
+    sig("hz_hip_host_begin", i, vp, P(View), vp, vp, vp, vp, vp)
+    sig("hz_hip_host_end", i, vp)
     sig("hz_hip_read_depth", i, vp, i, i, P(C.c_uint32))
     sig("hz_hip_link_cells", i, vp, P(View), vp, vp, vp, vp, d, d, d, i, i, i, i, vp, vp)
     sig("hz_hip_poi_visibility", i, vp, P(View), vp, i, vp, i, vp, vp, vp)
@@ -239,14 +244,14 @@ DECLARED_SYMBOLS = [
     "horizonator_amd_resolve_sparse_strips",
     "horizonator_amd_sync", "horizonator_amd_stream_waits_for_outputs", "horizonator_amd_waits_for_stream", "horizonator_amd_texture_layout", "horizonator_amd_set_texture",
     "horizonator_amd_set_sector", "horizonator_amd_set_raster", "horizonator_amd_set_profiling",
-    "horizonator_amd_get_options", "horizonator_amd_set_options",
+    "horizonator_amd_get_options", "horizonator_amd_set_options", "horizonator_amd_render_begin", "horizonator_amd_render_end",
     "horizonator_amd_last_times", "horizonator_amd_get_view", "horizonator_amd_device",
     "horizonator_amd_get_mosaic", "horizonator_amd_link_cells_size", "horizonator_amd_link_cells",
     "horizonator_amd_poi_visibility", "horizonator_amd_build_id",
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
-    "hz_hip_set_profiling", "hz_hip_get_options", "hz_hip_set_options", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host",
+    "hz_hip_set_profiling", "hz_hip_get_options", "hz_hip_set_options", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host", "hz_hip_render_to_host", "hz_hip_host_begin", "hz_hip_host_end",
     "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_last_plan", "hz_hip_last_queue_counts", "hz_hip_last_error",
 ]
 # include/hz_selftest.h: what libhorizonator_selftest.so exports on top of those (and libhorizonator.so must not)

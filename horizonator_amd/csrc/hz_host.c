@@ -631,14 +631,45 @@ static bool render_common(const horizonator_context_t* ctx, bool to_host,
         MSG("Prior to calling horizonator_render_offscreen(), the context must have been inited for offscreen rendering with horizonator_init(use_glut=true, offscreen_width,height > 0)");
         return false;
     }
-    if(!horizonator_redraw(ctx)) return false;
     if(ranges != NULL) fill_tanel(s);
-    const int rc = to_host
-        ? hz_hip_resolve_to_host(s->dev, &s->view, s->tanel, image, ranges, index, z24)
-        : hz_hip_resolve        (s->dev, &s->view, s->tanel, image, ranges, index, z24);
+    int rc;
+    if(to_host)
+        /* glClear + glDrawElements + the two glReadPixels and the conversion (reference horizonator-lib.c:896-897,
+         * 936-1048) as one call: the HIP side draws and ships the panorama sector by sector (hz_hostpath.cpp) */
+        rc = hz_hip_render_to_host(s->dev, &s->view, s->tanel, image, ranges, index, z24);
+    else
+    {
+        if(!horizonator_redraw(ctx)) return false;
+        rc = hz_hip_resolve(s->dev, &s->view, s->tanel, image, ranges, index, z24);
+    }
     if(rc != 0)
     {
-        MSG("resolve failed: %s", hz_hip_last_error());
+        MSG("render failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool horizonator_amd_render_begin(const horizonator_context_t* ctx, char* image, float* ranges)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(!ctx->offscreen.inited) { MSG("the context must have been inited for offscreen rendering"); return false; }
+    if(ranges != NULL) fill_tanel(s);
+    if(0 != hz_hip_host_begin(s->dev, &s->view, s->tanel, (unsigned char*)image, ranges, NULL, NULL))
+    {
+        MSG("render failed: %s", hz_hip_last_error());
+        return false;
+    }
+    return true;
+}
+bool horizonator_amd_render_end(const horizonator_context_t* ctx)
+{
+    hz_state_t* s = live_state(ctx);
+    if(s == NULL) return false;
+    if(0 != hz_hip_host_end(s->dev))
+    {
+        MSG("render failed: %s", hz_hip_last_error());
         return false;
     }
     return true;

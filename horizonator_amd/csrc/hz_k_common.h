@@ -5,55 +5,6 @@
 /* ------------------------------------------------------------------------ */
 /* kernel parameters                                                         */
 
-/* coarse depth (hz_k_hiz.h): the largest upper half of a framebuffer word per 8 x 4 (l1) and 32 x 16 (l2) pixels,
- * w1 / w2 tiles per row; l1 == NULL: the draw has none */
-struct hz_hiz_t { uint32_t* l1; uint32_t* l2; int w1, w2; };
-
-struct hz_params_t
-{
-    hz_xform_t u;
-    float halfW, halfH;
-    int   N;                /* samples per mosaic axis                  */
-    int   W, H;             /* full image size                          */
-    int   col0, col1;       /* sector [col0,col1)                       */
-    int   SW;               /* col1-col0, row stride of fb              */
-    unsigned long long* wave_cycles;   /* diagnostics: per-wave duration of k_march, or NULL */
-    unsigned int inline_max;           /* k_march: boxes up to this many pixels are rasterised by the marching wave */
-    unsigned int big_min;              /* k_march: boxes above this many pixels go to k_big (tiles), between: k_mid  */
-    float far_dd;                      /* k_march: squared horizontal distance beyond which a vertex is surely past zfar */
-    int   far_strips;                  /* some vertex of the mosaic lies beyond that: whole strips may (k_march asks) */
-    /* two-pass draw (see hz_hip_draw): which strips a k_march launch takes, and
-     * whether it tests its survivors against the depth already in the framebuffer */
-    const uint32_t* worklist;          /* k_march: the (segment, strip column) pairs of this launch, one per workgroup; NULL = the launch grid says it */
-    int   cull_strips;                 /* k_march: strips whose four corners lie outside the drawn columns leave at once (sectors, views < 360 degrees) */
-    int   pass;                        /* 0 every strip, 1 only the strips next to the viewer, 2 all the others */
-    int   near_x0, near_x1;            /* strip columns [x0,x1] and                                             */
-    int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
-    int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
-    int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
-#ifdef HZ_EXPERIMENTS
-    int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
-#endif
-    const uint32_t* hiz;               /* mr_flush, k_big: coarse depth (hz_k_hiz.h: level 1, level 2 behind it; second rounds of zoomed views), or NULL.
-                                        * (One pointer, the rest follows from SW and H: every scalar register k_march holds costs it lane spills in its loop.) */
-    float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */
-    float z_hide_k;                    /* hz_tri_hidden(): 1.03 * z_guard * (2^24-1)                            */
-    int   fast_ok;                     /* hzf_draw_ok(): the uniforms allow the abridged division/sqrt sequences */
-    int   quad_max_dx;                 /* k_march: 256*(W/16 - 1): see the cull of whole cells                  */
-#ifdef HZ_EXPERIMENTS
-    int   debug;                       /* HZ_MARCH_DEBUG (timing splits, wrong pictures): 1 survivors are dropped,
-                                        * 2 survivors are dropped after the early depth test */
-#endif
-    /* one byte per HZ_SEG consecutive pixels of a framebuffer row (row stride
-     * seg_stride): nonzero once anything was drawn there.  Every write to the
-     * framebuffer sets it (hz_fb_min); the conversion skips reading - and
-     * clearing - segments nothing touched: the sky, 62 % of the benchmark's
-     * pixels.  A stale nonzero byte only costs the read. */
-    unsigned char* touched;
-    int   seg_stride;
-};
-#define HZ_SEG_LOG2 8
-#define HZ_SEG      (1 << HZ_SEG_LOG2)
 
 /* the one place fragments enter the framebuffer.
  * Builds with -DHZ_EXPERIMENTS only (tools/experiments.py; never the library that ships): p.exp_fb
@@ -94,33 +45,6 @@ __device__ static inline const unsigned long long* hz_fb_word(const unsigned lon
     return (const unsigned long long*)((const char*)fb + (((uint32_t)py*(uint32_t)p.SW + (uint32_t)(px - p.col0)) << 3));
 }
 
-/* a set-up triangle as it travels between phases: through LDS inside
- * k_scatter (stride 23 dwords = odd, conflict-free), through HBM to k_mid and
- * k_big.  Coverage as hz_edges_t: what the pixel loops need, ready made. */
-struct hz_rec_t
-{
-    hz_edges_t e;
-    float    z_org, dzdx, dzdy, r_org, drdx, drdy;
-    int32_t  px0, py0, bw;
-    float    inv_bw;
-    uint32_t prim;
-};
-struct hz_bigrec_t { hz_rec_t r; int32_t bh; };
-
-/* work item of the large-triangle pass: 64 tiles of one triangle */
-struct hz_bigitem_t { uint32_t rec; uint32_t chunk; };
-
-/* the HBM queues between the kernels of one draw */
-struct mr_queue_t
-{
-    hz_bigrec_t*  bigrec;           /* set-up triangles for k_big                                */
-    hz_bigitem_t* bigitem;          /* ... and their work items                                  */
-    hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
-    uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
-    unsigned int* counters;         /* [0] big records [1] big items [2] ~(first invalid big item)
-                                     * [3] mid records [4] clip ids [5] ~(first invalid mid record) */
-    unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
-};
 
 /* triangles that cross a plane of the view volume: their ids go to k_clip.
  * One atomic per wave.  Ids that do not fit are not stored, but still counted:
@@ -137,8 +61,6 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
     if(at < q.clip_capacity) q.clip[at] = prim;
 }
 
-#define HZ_NCOUNTERS 16
-#define HZ_CNT_LAST  8                  /* [8..14): the counters as the last draw left them (diagnostics) */
 /* An empty queue set is all zeros ([2] and [5] hold the COMPLEMENT of the first
  * invalid index, raised with atomicMax).  The queue sets of a framebuffer are
  * emptied together with it: by the conversion that clears behind itself (one
@@ -151,14 +73,6 @@ __device__ static inline void hz_counters_consume(unsigned int* a, unsigned int*
     #pragma unroll
     for(int k=0; k<6; k++) { a[HZ_CNT_LAST + k] = a[k]; a[k] = 0u; b[HZ_CNT_LAST + k] = b[k]; b[k] = 0u; }
 }
-#ifndef HZ_NFB
-#define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
-#endif
-#define HZ_STAGE_SLOTS 8                /* pinned staging chunks in flight between device and caller memory */
-#define HZ_STAGE_BYTES ((size_t)16 << 20)
-#define HZ_COPY_STREAMS 2               /* device -> host copies alternate between that many streams (copy engines) */
-#define HZ_HOST_BANDS  4                /* the conversion runs in that many bands of rows when its results go to the host */
-#define HZ_INLINE_MAX_PIX  64       /* k_scatter: boxes up to this many pixel centres are rasterised in the block */
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
 /* k_big walks a triangle's box in chunks of pixel rows, one wave per chunk

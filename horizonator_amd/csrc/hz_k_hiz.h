@@ -20,19 +20,6 @@
  * scenes run under HZ_HIZ=1 in tools/gpu_modes.sh. */
 #pragma once
 
-#define HIZ1_W_LOG2 3
-#define HIZ1_H_LOG2 2
-#define HIZ2_W_LOG2 5
-#define HIZ2_H_LOG2 4
-#define HIZ_UNIT_ROWS 16                /* one wave sweeps 256 columns (a segment of hz_params_t::touched) x 16 rows */
-
-/* tiles per row / rows of tiles of the two levels of a framebuffer of SW x H */
-__host__ __device__ static inline size_t hiz_w1(int SW) { return (size_t)((SW + (1 << HIZ1_W_LOG2) - 1) >> HIZ1_W_LOG2); }
-__host__ __device__ static inline size_t hiz_w2(int SW) { return (size_t)((SW + (1 << HIZ2_W_LOG2) - 1) >> HIZ2_W_LOG2); }
-__host__ __device__ static inline size_t hiz_h1(int H)  { return (size_t)((H  + (1 << HIZ1_H_LOG2) - 1) >> HIZ1_H_LOG2); }
-__host__ __device__ static inline size_t hiz_h2(int H)  { return (size_t)((H  + (1 << HIZ2_H_LOG2) - 1) >> HIZ2_H_LOG2); }
-/* words of both levels for an image of W x H (level 2 behind level 1) */
-__host__ __device__ static inline size_t hiz_words(int W, int H) { return hiz_w1(W)*hiz_h1(H) + hiz_w2(W)*hiz_h2(H); }
 /* level 2 of the tables a draw's parameters point to */
 __device__ static inline const uint32_t* hiz_level2(const hz_params_t& p) { return p.hiz + hiz_w1(p.SW)*hiz_h1(p.H); }
 

@@ -21,26 +21,9 @@
  * Workgroup = one wave, so nothing ever waits for another wave.
  */
 
-#define MR_COLS   63
 #define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
 #define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
-/* round 1 of a draw takes the strips within ppr/20 cells of the viewer (draw_impl: plan_rounds); timed at 16000x4000,
- * round 2: 32 cells 1.085 ms per render, 64: 1.063, 96: 1.056, 128: 1.052, 192: 1.064, 256: 1.12 */
-/* The cap of the first round's reach (zoomed views and panoramas wider than 49000 columns hit it), and what the first
- * rounds' queue sets are sized for (or HZ_NEAR_CELLS, if larger).  256 until zoomed views got coarse depth (hz_k_hiz.h):
- * a narrow view's frustum is narrow in elevation too, little of the nearest terrain is inside it, and the ridge
- * that hides most of the view tends to lie further out - seven 10 and 45 degree views (three viewpoints, four
- * directions, the rough DEM; tools/hiz_ab.py, profiles/r3_coarse_depth.txt) take 14.5 ms in sum with a reach of 256
- * cells, 11.0 with 384, 11.1 with 512 (five gain up to 2x, two lose 8 %).  Round 4: with the first round's large
- * triangles drawn by screen tile (hz_k_tile.h) a longer first round costs less - the same views 9.7 ms with 384, 9.8 with
- * 448, 9.5 with 512, 9.8 with 576, 10.3 with 640, and the slowest of them 2.03 / 1.95 / 1.72 / 1.69 / 1.80
- * (profiles/r4_tile_batches.txt) - but it is two of the seven that gain (summit, valley: 0.3-0.4 ms each) and five
- * that lose 0.1.  So views that are still "zoomed" at 512 cells (a cell there HZ_HIZ_MIN_PX pixels wide: up to 70
- * degrees at 16000 columns) MAY reach that far: they do when the draws of the same view before them say it pays
- * (hz_kernels.hip, adapt: what the second round had to queue), the others and every first draw of a view 384. */
-#define HZ_NEAR_CELLS_WIDE 384
-#define HZ_NEAR_CELLS_MAX  512
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the
@@ -116,43 +99,6 @@ __device__ static inline hz_wvert_t mr_load_vert_pos(const mr_lds_t& L, int slot
     return v;
 }
 
-/* The strips are cut into segments of rows; the segment length depends on the
- * distance (in rows) from the viewer's row so that every wave gets a comparable
- * amount of pixel work: zones south->north with 64, 16, 4, 2, 4, 16, 64 rows
- * per segment.  Built on the host per draw (mr_make_zones).  Measured: with
- * uniform 64-row segments the waves next to the viewer run 10-50x longer than
- * the median and set the kernel time. */
-#define MR_NZONES 7
-struct mr_zones_t
-{
-    int row0[MR_NZONES+1];          /* first cell row of each zone; row0[MR_NZONES] = N-1 */
-    int rows[MR_NZONES];            /* cell rows per segment                              */
-    int seg0[MR_NZONES];            /* number of the zone's first segment                 */
-    int nseg[MR_NZONES];            /* segments in the zone                               */
-    int total;                      /* all segments = gridDim.y                           */
-    int near_first;                 /* dispatch order: segments nearest to the viewer's row first */
-};
-
-/* cell rows [jbeg, jend) of segment `seg` (= blockIdx.y of a grid launch, or the
- * segment field of a work-list item); vertex rows jbeg..jend.  Device and host
- * (the work lists of draw_impl) use the same function. */
-HZ_HD void mr_segment_rows(const mr_zones_t& zn, int seg, int* jbeg, int* jend)
-{
-    int zone = 0;
-    #pragma unroll
-    for(int z=1; z<MR_NZONES; z++)
-        if(seg >= zn.seg0[z] && seg < zn.seg0[z] + zn.nseg[z]) zone = z;
-    int sseg = seg - zn.seg0[zone];
-    if(zn.near_first && zone < MR_NZONES/2) sseg = zn.nseg[zone]-1 - sseg;      /* south of the viewer: northernmost first */
-    const int jb = zn.row0[zone] + sseg*zn.rows[zone];
-    const int je = jb + zn.rows[zone];
-    *jbeg = jb;
-    *jend = je < zn.row0[zone+1] ? je : zn.row0[zone+1];
-}
-
-/* a work-list item: one marching wave = (segment, strip column) */
-#define MR_ITEM_SX_BITS 12
-#define MR_ITEM(seg, sx) (((uint32_t)(seg) << MR_ITEM_SX_BITS) | (uint32_t)(sx))
 
 /* value held by the lane one to the east (lane+1): DPP wave shift, one VALU
  * move instead of an LDS-crossbar permute (gfx9 family: wave_shl:1).  Lane 63,

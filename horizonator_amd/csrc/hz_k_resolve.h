@@ -204,26 +204,18 @@ void k_resolve4(unsigned long long* __restrict__ fb, const float* __restrict__ t
  * and what lies between this kernel and the caller's buffers is PCIe: 448 MB per 16000 x 4000 panorama at ~55 GB/s
  * was 8 of the 10.9 ms a call took.  62 % of those bytes say "sky".  This conversion writes the terrain pixels only,
  * as a stream of blobs (hz_scatter.h / hz_scatter.c: a blob = the terrain pixels of 4 rows x <= 2048 columns, with a
- * mask; tiles without terrain send nothing), 5 bytes per terrain pixel for BGR + range - the shade and the float32
- * range, computed here exactly as k_resolve4 computes it - and the host threads put them in their places between
- * the sky constants they filled in while the draw was running.
+ * mask; tiles without terrain send nothing), 4 bytes per terrain pixel - z24<<8 | red8, the word the multi-GPU strips
+ * carry too: the host threads make the BGR bytes, the depth and the float32 range of it (hz_scatter.c, the same IEEE
+ * operations as k_resolve4's; round 4 sent range + shade, 5 bytes) and put them in their places between the sky
+ * constants they filled in while the draw was running.  col_off: what to add to a column of the framebuffer (a
+ * sector's) to get the column of the caller's image.
  * One workgroup per blob, one wave per row, the tile's words kept in registers between the count and the write-out
  * (as k_pack_sparse); a blob takes its place in the stream with one atomic add (and another if the place straddles
  * two of the chunks the stream travels in). */
-struct hz_hostpack_t
-{
-    uint32_t*     out;              /* the stream                                                              */
-    unsigned int* cursor;           /* [0] words of the stream in use, [1] blobs, [2] nonzero: a blob did not fit */
-    unsigned int  capacity;         /* words                                                                   */
-    unsigned int  chunk_words;      /* no blob straddles a multiple of this                                    */
-    uint32_t      flags;            /* HZ_BLOB_*: the arrays a blob carries                                    */
-};
-#define HP_NONE 0xFFFFFFFFu
 
 template<bool CLEAR>
 __global__ __launch_bounds__(64*HZ_BLOB_ROWS)
-void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const float* __restrict__ tanel,
-                 int SW, int H, float znear, float zfar,
+void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, int SW, int H, int col_off,
                  unsigned char* __restrict__ touched, int seg_stride, unsigned int* qa, unsigned int* qb)
 {
     static_assert(HZ_SEG == 256 && HZ_BLOB_COLS == 8*HZ_SEG && HZ_BLOB_ROWS == 4, "k_pack_host: a wave = a row of eight segments");
@@ -267,7 +259,7 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const flo
     for(int m=32; m>=1; m>>=1) count += __shfl_xor(count, m);
     if(lane == 0) s_count[wave] = count;
     __syncthreads();
-    const uint32_t words_per_pixel = ((o.flags & HZ_BLOB_RANGES) ? 1u : 0u) + ((o.flags & HZ_BLOB_INDEX) ? 1u : 0u) + ((o.flags & HZ_BLOB_Z24) ? 1u : 0u);
+    const uint32_t words_per_pixel = ((o.flags & HZ_BLOB_PACKED) ? 1u : 0u) + ((o.flags & HZ_BLOB_INDEX) ? 1u : 0u);
     const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
     if(threadIdx.x == 0)
     {
@@ -291,7 +283,7 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const flo
             if(start != HP_NONE)
             {
                 uint32_t* b = o.out + start;
-                b[0] = (uint32_t)yo0 | (o.flags << 16); b[1] = (uint32_t)x0;
+                b[0] = (uint32_t)yo0 | (o.flags << 16); b[1] = (uint32_t)(x0 + col_off);
                 b[2] = s_count[0]; b[3] = s_count[1]; b[4] = s_count[2]; b[5] = s_count[3];
                 b[6] = size; b[7] = (uint32_t)n;
             }
@@ -305,15 +297,13 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const flo
         uint32_t* blob = o.out + start;
         uint32_t* mask = blob + HZ_BLOB_HDR + wave*mw;
         uint32_t* p = blob + HZ_BLOB_HDR + HZ_BLOB_ROWS*mw;
-        float*    d_rng = NULL; int32_t* d_idx = NULL; uint32_t* d_z = NULL; unsigned char* d_red = NULL;
-        if(o.flags & HZ_BLOB_RANGES) { d_rng = (float*)p;   p += total; }
+        uint32_t* d_pk = NULL; int32_t* d_idx = NULL; unsigned char* d_red = NULL;
+        if(o.flags & HZ_BLOB_PACKED) { d_pk  = p;           p += total; }
         if(o.flags & HZ_BLOB_INDEX)  { d_idx = (int32_t*)p; p += total; }
-        if(o.flags & HZ_BLOB_Z24)    { d_z   = p;           p += total; }
         if(o.flags & HZ_BLOB_RED)    { d_red = (unsigned char*)p; }
         uint32_t at = 0;
         #pragma unroll
         for(int w=0; w<HZ_BLOB_ROWS; w++) if(w < wave) at += s_count[w];
-        const float tan_row = tanel ? tanel[glrow] : 0.f;
         const unsigned long long lt = (1ull << lane) - 1ull;
         #pragma unroll
         for(int it=0; it<8; it++)
@@ -334,10 +324,8 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, const flo
                     if((nib >> k) & 1u)
                     {
                         const unsigned long long kk = key[it][k];
-                        const uint32_t zi = (uint32_t)(kk >> 40);
-                        if(d_rng) d_rng[q] = hz_range_from_z24(zi, tan_row, znear, zfar);
+                        if(d_pk)  d_pk[q]  = ((uint32_t)(kk >> 40) << 8) | (uint32_t)(kk & 0xFFu);     /* z24 << 8 | red8 */
                         if(d_idx) d_idx[q] = (int32_t)(uint32_t)(kk >> 8);
-                        if(d_z)   d_z[q]   = zi;
                         if(d_red) d_red[q] = (unsigned char)(kk & 0xFFu);       /* reference fragment.glsl:15-16: colour = (red,0,0) */
                         q++;
                     }
@@ -451,9 +439,6 @@ void k_resolve_packed(const uint32_t* __restrict__ packed, int stride, int ncols
  * L2).  Segments nothing was drawn into (`touched`) are sky without being read.
  * The four rows of a workgroup take their place in the data with ONE atomic
  * (same-address atomics are serialised at ~10 ns each). */
-#define SP_WAVES  4                     /* rows per workgroup                            */
-#define SP_STEPS  8                     /* steps whose words stay in registers           */
-#define SP_MAXIT  256                   /* steps per row: sectors up to 65536 columns    */
 
 /* one step of one row: loads, terrain bits (nibble per lane), mask words */
 __device__ static inline uint32_t sp_step(const unsigned long long* row, int SW, int it, int lane, bool flagged,
@@ -616,12 +601,6 @@ void k_pack_sparse(unsigned long long* __restrict__ fb, uint32_t* __restrict__ o
  * launch (blockIdx.y = strip); a thread takes four neighbouring OUTPUT pixels
  * whose first column is a multiple of four, so that its results leave as one
  * 12-byte and one 16-byte store whatever column the strip starts at. */
-#define HZ_MAX_STRIPS 16
-struct hz_strips_t
-{
-    const uint32_t* in[HZ_MAX_STRIPS];
-    int ncols[HZ_MAX_STRIPS], col0[HZ_MAX_STRIPS];
-};
 
 __global__ __launch_bounds__(256)
 void k_resolve_sparse(hz_strips_t st, int mask_stride,

@@ -21,11 +21,6 @@
  *            ~15% lane utilisation here)
  */
 
-#define SC_CX 64
-#define SC_CY 4
-#define SC_VX (SC_CX+1)
-#define SC_VY (SC_CY+1)
-#define SC_THREADS (SC_CX*SC_CY)
 #define SC_REC_STRIDE 23
 
 static_assert(sizeof(hz_rec_t) == SC_REC_STRIDE*4, "record layout");

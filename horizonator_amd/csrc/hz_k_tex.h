@@ -67,8 +67,6 @@ __device__ static inline void hz_prim_cverts(const int16_t* __restrict__ mosaic,
  *   C  lane = pixel: planes of its run from LDS, evaluate, sample, blend, store
  * Next to the viewer a chunk holds a handful of runs; at the skyline every pixel
  * is its own run and the scheme falls back to one set-up per pixel. */
-#define TX_SUB   4                      /* sub-spans of 64 pixels per chunk */
-#define TX_CHUNK (64*TX_SUB)
 #define TX_MAXCLIP 4                    /* clipped triangles per chunk whose pieces are kept in LDS */
 #define TX_PIECES  (HZ_MAX_CLIPPED-2)
 struct tx_lds_t

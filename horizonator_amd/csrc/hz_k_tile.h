@@ -33,26 +33,6 @@
  */
 #pragma once
 
-#define TL_W 64
-#define TL_H 64
-
-#define TL_LIST 2048                /* triangles a tile's list holds */
-#define TL_BATCH 64                 /* triangles a workgroup draws into its LDS tile before it merges the tile into the framebuffer */
-#define TL_ROW_MIN 24               /* average pixels per non-empty row, within the tile, from which a triangle is drawn row by row (16..48: the same within 5 %) */
-#define TL_UNITS_PER_TILE 4         /* room in the unit list, per tile of the image (busy tiles are a fraction, most of them with one batch) */
-
-/* what the tile kernels share: per queue set, allocated with the context */
-struct tl_bins_t
-{
-    unsigned int* cursor;           /* [ntiles]: triangles listed for the tile (zeroed in front of k_tile_bin)                        */
-    unsigned int* pairs;            /* [ntiles][TL_LIST]: record numbers                                                          */
-    unsigned int* state;            /* [0] 1 = a list (or the unit list) overflowed: k_tile_raster stands down, k_big draws the round;
-                                     * [1] units of work (both zeroed in front of k_tile_bin)                                     */
-    unsigned int* busy;             /* [TL_UNITS_PER_TILE*ntiles]: the units of work, tile | batch << 24                          */
-    unsigned int  units_cap;
-    int           tiles_x, tiles_y;
-    unsigned int  list_cap;         /* <= TL_LIST (tests make it small: HZ_TILE_LIST) */
-};
 
 /* can edge m have a covered pixel centre inside the tile [x0,x1] x [y0,y1]?  (its function g + dx*py - dy*px is
  * linear: the maximum over the tile is at a corner) */

@@ -10,12 +10,16 @@
  * the same bytes in the caller's buffers as the dense copy, a third to a fifth of the bytes over PCIe.
  *
  * A blob = the terrain pixels of up to 4 image rows x up to 2048 columns, uint32 words:
- *   [0]     first row (top row = 0) | flags << 16   (HZ_BLOB_RANGES | _INDEX | _Z24 | _RED: the arrays it carries)
- *   [1]     first column     [2..5] terrain pixels T0..T3 of its four rows     [6] size of the blob in words
- *   [7]     columns n (<= 2048)
+ *   [0]     first row (top row = 0) | flags << 16   (HZ_BLOB_PACKED | _INDEX | _RED: the arrays it carries)
+ *   [1]     first column (of the IMAGE: a sector's blobs carry their sector's offset)
+ *   [2..5]  terrain pixels T0..T3 of its four rows     [6] size of the blob in words     [7] columns n (<= 2048)
  *   then    4 x ceil(n/32) mask words (row after row; bit c%32 of word c/32: column c shows terrain)
- *   then    per carried array T0+T1+T2+T3 words, row after row, left to right: float32 ranges, int32 index,
- *           uint32 z24 - and last the shades, one BYTE per terrain pixel (padded to a word)
+ *   then    per carried array T0+T1+T2+T3 entries, row after row, left to right:
+ *             PACKED  a word z24<<8 | red8 - the 24-bit depth and the shade, from which this file makes the BGR
+ *                     bytes, the raw depth and the float32 range (reference horizonator-lib.c:1013-1025) exactly
+ *                     as the device's conversions make them: 4 bytes over PCIe where range + shade took 5
+ *             INDEX   a word: the id of the triangle that owns the pixel
+ *             RED     a BYTE: the shade alone (callers that want the image only), padded to a word
  * Blobs of tiles without terrain are not sent.  The stream travels in chunks of HZ_STAGE_BYTES and no blob
  * straddles a chunk boundary: where a blob would have (the writers take their places with an atomic add), the
  * stream holds a void instead - word [0] = HZ_BLOB_VOID, word [1] = its length in words - which may reach into
@@ -26,6 +30,7 @@
 #include <string.h>
 
 #include <emmintrin.h>
+#include <immintrin.h>
 
 #include "hz_scatter.h"
 
@@ -107,39 +112,116 @@ static void expand_scalar(unsigned char* dst, const unsigned char* red, int n)
     for(int k=0; k<n; k++) { dst[3*k] = 0; dst[3*k+1] = 0; dst[3*k+2] = red[k]; }
 }
 
-static int have_ssse3 = -1;
-
-/* one blob into the caller's buffers (any of them may be NULL; [H][SW] pixels, top row first).  Returns 0, or -1
- * if the blob does not describe pixels of a SW x H image. */
-int hz_blob_scatter(const uint32_t* blob, int SW, int H, unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
+/* what this machine's vector unit can do, found out once when the library is loaded (not lazily by whichever pool
+ * thread comes first) */
+static int cpu_ssse3, cpu_avx2;
+__attribute__((constructor)) static void hz_scatter_probe_cpu(void)
 {
-    if(have_ssse3 < 0) have_ssse3 = __builtin_cpu_supports("ssse3") ? 1 : 0;
+    __builtin_cpu_init();
+    cpu_ssse3 = __builtin_cpu_supports("ssse3") ? 1 : 0;
+    cpu_avx2  = __builtin_cpu_supports("avx2") ? 1 : 0;
+}
+
+/* ---- depth -> range on the host ------------------------------------------------------------------------------
+ * reference horizonator-lib.c:1013-1025:  depth = float(z24 / (2^24-1))   (what glReadPixels hands out)
+ *                                         length_en = depth*(zfar-znear) + znear;  z = tanel*length_en;
+ *                                         range = hypotf(length_en, z)
+ * hypotf of two floats is the correctly rounded double square root of the exact sum of squares, rounded to float (the
+ * squares of floats are exact in double): the form the device kernels use (hz_k_resolve.h) and the one used here, with the
+ * IEEE operations in the same order - no fused multiply-add (this file is built with -ffp-contract=off and the vector
+ * version spells out every operation). */
+static inline float range_of_packed(uint32_t w, float tan_row, float znear, float span)
+{
+    const float depth = (float)((double)(w >> 8) * (1.0/16777215.0));
+    const float len   = depth * span + znear;
+    const float zt    = tan_row * len;
+    return (float)__builtin_sqrt((double)len*(double)len + (double)zt*(double)zt);
+}
+
+__attribute__((target("avx2")))
+static void ranges_avx2(float* out, const uint32_t* packed, size_t n, float tan_row, float znear, float span)
+{
+    const __m256d inv = _mm256_set1_pd(1.0/16777215.0);
+    const __m128  vspan = _mm_set1_ps(span), vnear = _mm_set1_ps(znear), vtan = _mm_set1_ps(tan_row);
+    size_t k = 0;
+    for(; k + 4 <= n; k += 4)
+    {
+        const __m128i zi    = _mm_srli_epi32(_mm_loadu_si128((const __m128i*)(packed + k)), 8);
+        const __m128  depth = _mm256_cvtpd_ps(_mm256_mul_pd(_mm256_cvtepi32_pd(zi), inv));
+        const __m128  len   = _mm_add_ps(_mm_mul_ps(depth, vspan), vnear);
+        const __m128  zt    = _mm_mul_ps(vtan, len);
+        const __m256d l = _mm256_cvtps_pd(len), z = _mm256_cvtps_pd(zt);
+        const __m256d r = _mm256_sqrt_pd(_mm256_add_pd(_mm256_mul_pd(l, l), _mm256_mul_pd(z, z)));
+        _mm_storeu_ps(out + k, _mm256_cvtpd_ps(r));
+    }
+    for(; k < n; k++) out[k] = range_of_packed(packed[k], tan_row, znear, span);
+}
+
+void hz_ranges_from_packed(float* out, const uint32_t* packed, size_t n, float tan_row, float znear, float zfar)
+{
+    const float span = zfar - znear;
+    if(cpu_avx2) { ranges_avx2(out, packed, n, tan_row, znear, span); return; }
+    for(size_t k=0; k<n; k++) out[k] = range_of_packed(packed[k], tan_row, znear, span);
+}
+
+/* one blob into the caller's buffers.  Returns 0, or -1 if the blob does not describe pixels of dst's image - decided
+ * BEFORE anything is written: the columns and rows lie inside the image, every row's mask has exactly the bits its count
+ * says and none beyond the blob's columns, and the arrays those counts imply fit the size the blob declares. */
+int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
+{
+    const int W = dst->W, H = dst->H;
     const uint32_t flags = blob[0] >> 16;
-    const int yo0 = (int)(blob[0] & 0xFFFFu), x0 = (int)blob[1], n = (int)blob[7];
-    if(n < 1 || n > HZ_BLOB_COLS || x0 < 0 || x0 + n > SW || yo0 >= H) return -1;
+    const int yo0 = (int)(blob[0] & 0xFFFFu), n = (int)blob[7];
+    if(flags & ~(HZ_BLOB_PACKED | HZ_BLOB_INDEX | HZ_BLOB_RED)) return -1;
+    if(n < 1 || n > HZ_BLOB_COLS || blob[1] > (uint32_t)W || (int)blob[1] + n > W || yo0 >= H) return -1;
+    const int x0 = (int)blob[1];
     const int mw = (n + 31) >> 5;
+    const uint32_t* mask = blob + HZ_BLOB_HDR;
     size_t total = 0;
-    for(int r=0; r<HZ_BLOB_ROWS; r++) total += blob[2 + r];
-    const uint32_t* mask = blob + 8;
+    for(int r=0; r<HZ_BLOB_ROWS; r++)
+    {
+        const uint32_t* m = mask + (size_t)r*mw;
+        uint32_t bits = 0;
+        for(int w=0; w<mw; w++) bits += (uint32_t)__builtin_popcount(m[w]);
+        if(bits != blob[2 + r]) return -1;
+        if((n & 31) && (m[mw-1] >> (n & 31))) return -1;
+        if(yo0 + r >= H && bits) return -1;
+        total += bits;
+    }
     const uint32_t* p = mask + (size_t)HZ_BLOB_ROWS*mw;
-    const float*    src_rng = NULL; const int32_t* src_idx = NULL; const uint32_t* src_z = NULL; const unsigned char* src_red = NULL;
-    if(flags & HZ_BLOB_RANGES) { src_rng = (const float*)p;   p += total; }
+    const uint32_t* src_pk = NULL; const int32_t* src_idx = NULL; const unsigned char* src_red = NULL;
+    if(flags & HZ_BLOB_PACKED) { src_pk  = p;                 p += total; }
     if(flags & HZ_BLOB_INDEX)  { src_idx = (const int32_t*)p; p += total; }
-    if(flags & HZ_BLOB_Z24)    { src_z   = p;                 p += total; }
     if(flags & HZ_BLOB_RED)    { src_red = (const unsigned char*)p; p += (total + 3) >> 2; }
     if((size_t)(p - blob) > blob[6]) return -1;
-    if(!src_rng) ranges = NULL;
-    if(!src_idx) index = NULL;
-    if(!src_z)   z24 = NULL;
-    if(!src_red) bgr = NULL;
+    unsigned char* bgr    = (src_pk || src_red) ? dst->bgr : NULL;
+    float*         ranges = src_pk ? dst->ranges : NULL;
+    uint32_t*      z24    = src_pk ? dst->z24 : NULL;
+    int32_t*       index  = src_idx ? dst->index : NULL;
+    if(ranges && !dst->tanel) return -1;
+
     size_t k = 0;                                   /* terrain pixels of the blob so far */
     for(int r=0; r<HZ_BLOB_ROWS; r++)
     {
         const int yo = yo0 + r;
+        const size_t T = blob[2 + r];
+        if(T == 0) continue;
         const uint32_t* m = mask + (size_t)r*mw;
-        if(yo >= H) { if(blob[2 + r]) return -1; continue; }
-        const size_t row = (size_t)yo*SW + x0;
-        size_t seen = 0;
+        /* the row's terrain pixels, converted where they lie together: ranges, depths, shades */
+        float         rng[HZ_BLOB_COLS];
+        uint32_t      zz[HZ_BLOB_COLS];
+        unsigned char shade[HZ_BLOB_COLS + 16];
+        const unsigned char* red = src_red ? src_red + k : shade;
+        if(src_pk)
+        {
+            const uint32_t* w = src_pk + k;
+            if(ranges) hz_ranges_from_packed(rng, w, T, dst->tanel[H-1 - yo], dst->znear, dst->zfar);
+            if(z24) for(size_t q=0; q<T; q++) zz[q] = w[q] >> 8;
+            if(bgr) for(size_t q=0; q<T; q++) shade[q] = (unsigned char)w[q];     /* reference fragment.glsl:15-16: colour = (red,0,0) */
+        }
+        const int32_t* idx = src_idx ? src_idx + k : NULL;
+        const size_t row = (size_t)yo*W + x0;
+        size_t q = 0;                               /* terrain pixels of the row so far */
         for(int w=0; w<mw; w++)
         {
             uint32_t bits = m[w];
@@ -148,29 +230,29 @@ int hz_blob_scatter(const uint32_t* blob, int SW, int H, unsigned char* bgr, flo
             if(bits == 0xFFFFFFFFu)
             {
                 /* 32 terrain pixels in a row: below the horizon that is nearly every word */
-                if(ranges) memcpy(ranges + o, src_rng + k, 128);
-                if(index)  memcpy(index + o,  src_idx + k, 128);
-                if(z24)    memcpy(z24 + o,    src_z + k,   128);
+                if(ranges) memcpy(ranges + o, rng + q, 128);
+                if(index)  memcpy(index + o,  idx + q, 128);
+                if(z24)    memcpy(z24 + o,    zz + q,  128);
                 if(bgr)
                 {
-                    if(have_ssse3) { expand16_ssse3(bgr + 3*o, src_red + k); expand16_ssse3(bgr + 3*o + 48, src_red + k + 16); }
-                    else expand_scalar(bgr + 3*o, src_red + k, 32);
+                    if(cpu_ssse3) { expand16_ssse3(bgr + 3*o, red + q); expand16_ssse3(bgr + 3*o + 48, red + q + 16); }
+                    else expand_scalar(bgr + 3*o, red + q, 32);
                 }
-                k += 32; seen += 32;
+                q += 32;
                 continue;
             }
             while(bits)
             {
                 const int c = __builtin_ctz(bits);
                 bits &= bits - 1;
-                if(ranges) ranges[o + c] = src_rng[k];
-                if(index)  index[o + c]  = src_idx[k];
-                if(z24)    z24[o + c]    = src_z[k];
-                if(bgr)    { unsigned char* q = bgr + 3*(o + c); q[0] = 0; q[1] = 0; q[2] = src_red[k]; }
-                k++; seen++;
+                if(ranges) ranges[o + c] = rng[q];
+                if(index)  index[o + c]  = idx[q];
+                if(z24)    z24[o + c]    = zz[q];
+                if(bgr)    { unsigned char* b3 = bgr + 3*(o + c); b3[0] = 0; b3[1] = 0; b3[2] = red[q]; }
+                q++;
             }
         }
-        if(seen != blob[2 + r]) return -1;
+        k += T;
     }
     return 0;
 }

@@ -418,19 +418,19 @@ extern "C" long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view
 {
     hz_dev_t* d = (hz_dev_t*)calloc(1, sizeof(*d));
     if(!d) return -1;
-    d->env = options_from_env();
+    d->env = hz_options_from_env();
     d->N = N; d->W = W; d->H = H; d->col0 = col0; d->col1 = col1;
     d->seg_stride = (W + HZ_SEG-1)/HZ_SEG;
-    hz_params_t p = make_params(d, view);
-    (void)plan_rounds(d, view, p);
-    const mr_zones_t zn = mr_make_zones(p, (round & 3) != 0);
+    hz_params_t p = hz_make_params(d, view);
+    (void)hz_plan_rounds(d, view, p);
+    const mr_zones_t zn = hz_make_zones(p, (round & 3) != 0);
     free(d);
     p.pass = round & 3;
     double a0 = 0, a1 = 0;
     const bool every_strip = (round & 256) != 0;
-    if(!every_strip && !azimuths_of_columns(p, &a0, &a1)) return -1;
+    if(!every_strip && !hz_azimuths_of_columns(p, &a0, &a1)) return -1;
     std::vector<uint32_t> items;
-    list_items(p, zn, a0, a1, items, every_strip);
+    hz_list_items(p, zn, a0, a1, items, every_strip);
     for(size_t k=0; k<items.size() && k<capacity_items; k++)
     {
         int jbeg, jend;
@@ -448,15 +448,15 @@ extern "C" long hz_hip_debug_worklist(int N, int W, int H, const hz_view_t* view
 extern "C" int hz_hip_debug_wave_timing(hz_dev_t* d, const hz_view_t* view, unsigned long long* out, size_t capacity_words, unsigned int* grid)
 {
     HZ_ON_DEVICE(d);
-    HZ_CHECK(sync_all(d));
+    HZ_CHECK(hz_sync_all(d));
     unsigned long long* d_cycles = NULL;
     HZ_CHECK(hipMalloc(&d_cycles, capacity_words*sizeof(unsigned long long)));
     HZ_CHECK(hipMemset(d_cycles, 0, capacity_words*sizeof(unsigned long long)));
     d->wave_timing.d_cycles = d_cycles; d->wave_timing.capacity = capacity_words;
     d->wave_timing.grid_x = d->wave_timing.grid_y = 0;
-    int rc = draw_impl(d, view);
+    int rc = hz_draw_impl(d, view);
     d->wave_timing.d_cycles = NULL; d->wave_timing.capacity = 0;
-    if(rc == 0 && sync_all(d) != hipSuccess) rc = -1;
+    if(rc == 0 && hz_sync_all(d) != hipSuccess) rc = -1;
     grid[0] = d->wave_timing.grid_x; grid[1] = d->wave_timing.grid_y;
     if(rc == 0 && hipMemcpy(out, d_cycles, (size_t)grid[0]*grid[1]*4*sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
     (void)hipFree(d_cycles);

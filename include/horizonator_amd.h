@@ -46,6 +46,15 @@ bool horizonator_amd_render(const horizonator_context_t* ctx,
                             char* image, float* ranges,
                             int32_t* index, uint32_t* z24);
 
+/* horizonator_render_offscreen() in two halves, for a caller that renders a series: _begin queues the draw of the
+ * current view and returns; _end returns when image and ranges (HOST pointers as horizonator_render_offscreen's, either
+ * may be NULL) hold the panorama.  Two panoramas may be between their begin and their end - each into buffers of its
+ * own, ended in the order begun: the device then draws one while the other crosses PCIe, and a panorama of a series
+ * costs what the link takes (hz_hip.h: hz_hip_host_begin).  The view may be changed (move, pan_zoom, set_zextents)
+ * between a begin and the next; the buffers belong to the library until the matching end returns.  Untextured. */
+bool horizonator_amd_render_begin(const horizonator_context_t* ctx, char* image, float* ranges);
+bool horizonator_amd_render_end(const horizonator_context_t* ctx);
+
 /* Draw + resolve into DEVICE buffers owned by the caller (e.g. torch tensors
  * that an RCCL gather then moves); asynchronous (queued on the context's streams; consecutive renders overlap),
  * follow with horizonator_amd_sync(). */

@@ -145,13 +145,28 @@ int  hz_hip_draw(hz_dev_t* d, const hz_view_t* view);
 int  hz_hip_resolve(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                     unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
 
-/* The same into HOST pointers (each may be NULL); synchronous.  What crosses
- * PCIe is the terrain pixels only (hz_scatter.h: 5 bytes each for BGR + range);
- * host threads fill the caller's buffers with the sky's constants (reference
- * horizonator-lib.c:185, :1016) while the draw runs and put the terrain in its
- * places as it arrives - the same bytes as the dense copy (HZ_HOST_DENSE=1). */
+/* The same into HOST pointers (each may be NULL); synchronous.  What crosses PCIe is the terrain pixels only, 4 bytes
+ * each (hz_scatter.h: z24<<8 | red8 - the host makes BGR bytes, depth and range of them with the reference's own
+ * arithmetic, reference horizonator-lib.c:1013-1025); host threads fill the caller's buffers with the sky's constants
+ * (reference :185, :1016) while the device draws and put the terrain in its places as it arrives - the same bytes as
+ * the dense copy (hz_options_t::host_dense).
+ *   hz_hip_resolve_to_host   the conversion of the draw already queued (hz_hip_draw)
+ *   hz_hip_render_to_host    draw + conversion: glClear, glDrawElements and the two glReadPixels of reference
+ *                            horizonator-lib.c:896-897, 936-1048 in one call.  Whole images of 12 Mpix and more are
+ *                            drawn and shipped in azimuth sectors (hz_options_t::host_sectors), sector s+1 drawn while
+ *                            sector s crosses PCIe; same bytes.
+ *   hz_hip_host_begin / hz_hip_host_end   that call in two halves: begin queues the draw and starts the sky, end moves
+ *                            the results and returns when they are in place.  Up to two panoramas may be between their
+ *                            begin and their end (each with buffers of its own; ended in the order begun): the device
+ *                            draws the second while the first crosses PCIe, and a series pays the link alone.  The
+ *                            buffers handed to begin are the library's until end returns. */
 int  hz_hip_resolve_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                             unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
+int  hz_hip_render_to_host(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                           unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
+int  hz_hip_host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel,
+                       unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
+int  hz_hip_host_end(hz_dev_t* d);
 
 /* 24-bit depth of image pixel (x, y), y = 0 top row, from the last draw
  * (reference horizonator-lib.c:1268-1270) */

@@ -102,8 +102,8 @@ def hip_available():
 
 class HipDev:
     """one device context of the C-ABI shim (include/hz_hip.h), reusable for several draws:
-    hz_hip_create / upload_mosaic, then render(view, col0, col1) = set_sector / draw /
-    resolve_to_host as often as wanted"""
+    hz_hip_create / upload_mosaic, then render(view, col0, col1) = set_sector / render_to_host
+    (or draw / resolve_to_host) as often as wanted"""
 
     def __init__(self, mosaic, W, H, raster=0):
         self.lib = hzlib.load()
@@ -158,9 +158,16 @@ class HipDev:
         tanel = np.ascontiguousarray(tanel, np.float32)
         out = {"bgr": np.empty((H, SW, 3), np.uint8), "ranges": np.empty((H, SW), np.float32),
                "index": np.empty((H, SW), np.int32), "z24": np.empty((H, SW), np.uint32)}
-        assert lib.hz_hip_draw(self.dev, C.byref(v)) == 0, lib.hz_hip_last_error()
-        rc = lib.hz_hip_resolve_to_host(self.dev, C.byref(v), tanel.ctypes.data, out["bgr"].ctypes.data,
-                                        out["ranges"].ctypes.data, out["index"].ctypes.data, out["z24"].ctypes.data)
+        # draw + delivery into host memory as one call (hz_hostpath.cpp: in azimuth sectors where the image is large or the
+        # context's host_sectors option says so); every other call the two-step form, hz_hip_draw then hz_hip_resolve_to_host
+        self.calls = getattr(self, "calls", 0) + 1
+        if self.calls % 2:
+            rc = lib.hz_hip_render_to_host(self.dev, C.byref(v), tanel.ctypes.data, out["bgr"].ctypes.data,
+                                           out["ranges"].ctypes.data, out["index"].ctypes.data, out["z24"].ctypes.data)
+        else:
+            assert lib.hz_hip_draw(self.dev, C.byref(v)) == 0, lib.hz_hip_last_error()
+            rc = lib.hz_hip_resolve_to_host(self.dev, C.byref(v), tanel.ctypes.data, out["bgr"].ctypes.data,
+                                            out["ranges"].ctypes.data, out["index"].ctypes.data, out["z24"].ctypes.data)
         assert rc == 0, lib.hz_hip_last_error()
         return out
 

@@ -1,0 +1,117 @@
+"""horizonator_render_offscreen() as the reference's callers see it - results in HOST memory (reference
+horizonator-lib.c:911-1051) - through hz_hostpath.cpp: the panorama drawn and shipped in azimuth sectors, 4 bytes per terrain
+pixel over PCIe, the readback conversion (reference :1006-1047) on the host's vector unit, the sky filled in by host threads.
+Whatever the number of sectors, the outputs asked for and the order of begin / end, the caller's buffers hold the bytes the
+oracle computes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hzutil
+import oracle
+
+pytestmark = pytest.mark.gpu
+LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
+
+
+@pytest.fixture(scope="module")
+def scene():
+    import horizonator_amd
+    R, W, H = 500, 3001, 750                                    # an odd width: sector edges and blobs that do not end on a multiple of 4
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    yield h, od, W, H
+    h.close()
+
+
+def _want(od, W, H, az0, az1, zfar, lat=LAT, lon=LON):
+    return oracle.render(od.mosaic(), od.view(lat, lon, W, H, az0, az1, zfar=zfar), W, H)
+
+
+@pytest.mark.parametrize("sectors", [1, 2, 3, 4, 8])
+def test_any_number_of_sectors_delivers_the_oracles_bytes(scene, sectors):
+    h, od, W, H = scene
+    h.set_options(host_sectors=sectors)
+    try:
+        for az0, az1, zfar in ((-180.0, 180.0, 200000.0), (20.0, 140.0, 40000.0)):
+            want = _want(od, W, H, az0, az1, zfar)
+            image, ranges, index, z24 = h.render_full(az0, az1, zfar=zfar)
+            hzutil.assert_same_render(dict(bgr=image, ranges=ranges, index=index, z24=z24), want, f"{sectors} sectors, az [{az0},{az1}]")
+            # the reference's own call: image + ranges; and each alone (other blob formats: the shade only, no index)
+            image2, ranges2 = h.render(az0, az1, zfar=zfar)
+            assert np.array_equal(image2, want["bgr"]) and np.array_equal(ranges2, want["ranges"])
+            assert np.array_equal(h.render(az0, az1, zfar=zfar, return_range=False), want["bgr"])
+            assert np.array_equal(h.render(az0, az1, zfar=zfar, return_image=False), want["ranges"])
+        # readers of the framebuffer after a sectored call see the whole view (the last sector's framebuffer is not it)
+        ys, xs = np.nonzero(index >= 0)
+        for k in (0, len(ys) // 3, len(ys) - 1):
+            assert h.pick(int(xs[k]), int(ys[k])) is not None
+        sky = np.argwhere(index < 0)[0]
+        assert h.pick(int(sky[1]), int(sky[0])) is None
+    finally:
+        h.set_options(host_sectors=0)
+
+
+def test_two_panoramas_in_flight(scene):
+    """begin k+1 before end k: different views, buffers of their own, ended in the order begun"""
+    h, od, W, H = scene
+    views = [(-180.0, 180.0, 200000.0, LAT, LON), (-100.0, 100.0, 60000.0, LAT + 0.02, LON - 0.03), (-180.0, 180.0, 9000.0, LAT - 0.01, LON)]
+    for sectors in (0, 3):
+        h.set_options(host_sectors=sectors)
+        bufs = [(np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32)) for _ in views]
+        try:
+            pending = []
+            for k, (az0, az1, zfar, lat, lon) in enumerate(views):
+                h.set_view(az0, az1, lat=lat, lon=lon, zfar=zfar)
+                h.render_begin(*bufs[k])
+                pending.append(k)
+                if len(pending) == 2:
+                    h.render_end(); pending.pop(0)
+            while pending:
+                h.render_end(); pending.pop(0)
+            with pytest.raises(RuntimeError):
+                h.render_end()                                  # nothing is in flight
+            for k, (az0, az1, zfar, lat, lon) in enumerate(views):
+                want = _want(od, W, H, az0, az1, zfar, lat, lon)
+                assert np.array_equal(bufs[k][0], want["bgr"]), (sectors, k)
+                assert np.array_equal(bufs[k][1], want["ranges"]), (sectors, k)
+            # a third begin while two are in flight is refused, and a synchronous render while one is
+            h.render_begin(*bufs[0]); h.render_begin(*bufs[1])
+            with pytest.raises(RuntimeError):
+                h.render_begin(*bufs[2])
+            with pytest.raises(RuntimeError):
+                h.render(-180.0, 180.0)
+            h.render_end(); h.render_end()
+        finally:
+            h.set_options(host_sectors=0)
+    h.set_view(-180.0, 180.0, lat=LAT, lon=LON)
+
+
+def test_sectors_of_a_sector_context_and_small_images(scene):
+    """a context that is itself one sector of a panorama (multi-GPU) is not cut further; its buffers have the sector's width"""
+    h, od, W, H = scene
+    want = _want(od, W, H, -180.0, 180.0, 200000.0)
+    h.set_options(host_sectors=4)
+    h.set_sector(701, 1502)
+    try:
+        image, ranges, index, z24 = h.render_full(-180.0, 180.0, zfar=200000.0)
+        assert image.shape == (H, 801, 3)
+        for k, a in (("bgr", image), ("ranges", ranges), ("index", index), ("z24", z24)):
+            assert np.array_equal(a, want[k][:, 701:1502]), k
+    finally:
+        h.set_sector(0, W)
+        h.set_options(host_sectors=0)
+
+
+def test_options_round_trip(scene):
+    h, _, _, _ = scene
+    o = h.options()
+    assert set(o) >= {"host_sectors", "adapt", "fast_math", "rounds"}
+    h.set_options(rounds=2, near_cells=40)
+    assert h.options()["rounds"] == 2 and h.options()["near_cells"] == 40
+    h.set_options(rounds=o["rounds"], near_cells=o["near_cells"])
+    assert h.options() == o
+    with pytest.raises(TypeError):
+        h.set_options(no_such_thing=1)

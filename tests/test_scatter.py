@@ -10,7 +10,13 @@ import pytest
 from horizonator_amd import _lib as hzlib
 
 ROWS, COLS = 4, 2048
-RANGES, INDEX, Z24, RED = 1, 2, 4, 8
+PACKED, INDEX, RED = 1, 2, 8
+
+
+class Dst(C.Structure):
+    """hz_scatter_dst_t (hz_scatter.h)"""
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("bgr", C.c_void_p), ("ranges", C.c_void_p), ("index", C.c_void_p), ("z24", C.c_void_p),
+                ("tanel", C.c_void_p), ("znear", C.c_float), ("zfar", C.c_float)]
 
 
 def _lib():
@@ -20,8 +26,19 @@ def _lib():
     lib.hz_blob_walk.restype = C.c_size_t
     lib.hz_blob_walk.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.hz_blob_scatter.restype = C.c_int
-    lib.hz_blob_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hz_blob_scatter.argtypes = [C.c_void_p, C.POINTER(Dst)]
+    lib.hz_ranges_from_packed.restype = None
+    lib.hz_ranges_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float]
     return lib
+
+
+def _ranges(z24, tan_row, znear, zfar):
+    """reference horizonator-lib.c:1013-1025 in numpy: float32 steps, hypotf as the rounded double square root"""
+    f = np.float32
+    depth = (z24.astype(np.float64) * (1.0 / 16777215.0)).astype(f)
+    length = depth * (f(zfar) - f(znear)) + f(znear)
+    zt = (np.asarray(tan_row, f) * length).astype(f)
+    return np.sqrt(length.astype(np.float64) ** 2 + zt.astype(np.float64) ** 2).astype(f)
 
 
 SKY = {0: np.array([255, 0, 0], np.uint8).tobytes(), 1: np.float32(-1.0).tobytes(), 2: np.int32(-1).tobytes(), 3: np.uint32(0xFFFFFF).tobytes()}
@@ -46,7 +63,7 @@ def test_sky_fill_writes_the_constant_into_exactly_the_bytes_asked_for(kind):
         assert (raw[:off] == 0x5A).all() and (raw[off + n:] == 0x5A).all()
 
 
-def _blob(yo0, x0, n, terrain, rng, idx, z24, red, flags):
+def _blob(yo0, x0, n, terrain, idx, z24, red, flags):
     """terrain: bool[4, n]; the value arrays [4, n]"""
     mw = (n + 31) // 32
     masks = np.zeros((ROWS, mw * 32), bool)
@@ -54,9 +71,8 @@ def _blob(yo0, x0, n, terrain, rng, idx, z24, red, flags):
     words = np.packbits(masks.reshape(ROWS, mw, 32), axis=2, bitorder="little").view(np.uint32).reshape(ROWS, mw)
     T = terrain.sum(axis=1)
     body = [words.ravel()]
-    if flags & RANGES: body.append(rng[terrain].view(np.uint32))
+    if flags & PACKED: body.append((z24[terrain] << 8) | red[terrain])
     if flags & INDEX:  body.append(idx[terrain].view(np.uint32))
-    if flags & Z24:    body.append(z24[terrain])
     if flags & RED:
         r = red[terrain]
         r = np.concatenate([r, np.zeros((-len(r)) % 4, np.uint8)])
@@ -68,23 +84,51 @@ def _blob(yo0, x0, n, terrain, rng, idx, z24, red, flags):
     return np.concatenate([hdr, body, np.zeros(pad, np.uint32)])
 
 
-@pytest.mark.parametrize("flags", [RANGES | RED, RANGES | INDEX | Z24 | RED, RED, RANGES, INDEX | Z24])
-def test_blobs_land_where_the_dense_copy_would_put_them(flags):
+def test_host_ranges_are_the_reference_conversion_bit_for_bit():
+    """hz_ranges_from_packed (AVX2 where the machine has it, scalar tail) against the numpy restatement: every length 0..70
+    (vector body and tail), depths over the whole 24-bit range, several rows and z extents"""
+    lib = _lib()
+    g = np.random.default_rng(11)
+    for trial in range(200):
+        n = trial if trial <= 70 else int(g.integers(71, 2049))
+        z24 = g.integers(0, 0xFFFFFF, n).astype(np.uint32)
+        if n > 3:
+            z24[:3] = (0, 1, 0xFFFFFE)
+        red = g.integers(0, 256, n).astype(np.uint32)
+        packed = np.ascontiguousarray((z24 << 8) | red, np.uint32)
+        tan_row = np.float32(g.uniform(-0.6, 0.6))
+        znear, zfar = float(g.choice([1.0, 100.0, 500.0])), float(g.choice([2000.0, 40000.0, 600000.0]))
+        raw = np.full(n + 8, np.float32(123.0), np.float32)
+        lib.hz_ranges_from_packed(raw.ctypes.data, packed.ctypes.data, n, tan_row, znear, zfar)
+        assert np.array_equal(raw[:n], _ranges(z24, tan_row, znear, zfar)), (trial, n)
+        assert (raw[n:] == 123.0).all()
+
+
+@pytest.mark.parametrize("flags", [PACKED, PACKED | INDEX, RED, INDEX, RED | INDEX])
+@pytest.mark.parametrize("col0", [0, 1000])
+def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0):
+    """col0: the blobs are those of an azimuth sector that starts at image column col0 (their x0 carries the offset)"""
     lib = _lib()
     g = np.random.default_rng(flags)
     SW, H = 5000, 23                      # a last tile of 904 columns, a last blob of 3 rows
+    W = SW + col0 + 37
+    znear, zfar = 100.0, 40000.0
+    tanel = np.tan(np.linspace(-0.5, 0.5, H)).astype(np.float32)           # per GL row (row 0 = bottom)
     terrain = g.random((H, SW)) < 0.6
     terrain[:, 100:400] = True            # whole mask words of terrain ...
     terrain[:, 2048:2048 + 64] = True
     terrain[4:8, :2048] = False           # ... and a tile without any: no blob
-    rng = g.random((H, SW)).astype(np.float32) * 1e5
     idx = g.integers(0, 2**31 - 1, (H, SW)).astype(np.int32)
     z24 = g.integers(0, 0xFFFFFF, (H, SW)).astype(np.uint32)
     red = g.integers(0, 256, (H, SW)).astype(np.uint8)
-    want = {"bgr": np.zeros((H, SW, 3), np.uint8), "ranges": np.where(terrain, rng, np.float32(-1)).astype(np.float32),
-            "index": np.where(terrain, idx, -1).astype(np.int32), "z24": np.where(terrain, z24, 0xFFFFFF).astype(np.uint32)}
-    want["bgr"][..., 0] = np.where(terrain, 0, 255); want["bgr"][..., 2] = np.where(terrain, red, 0)
-    got = {"bgr": np.empty((H, SW, 3), np.uint8), "ranges": np.empty((H, SW), np.float32), "index": np.empty((H, SW), np.int32), "z24": np.empty((H, SW), np.uint32)}
+    rng = _ranges(z24, tanel[::-1][:, None], znear, zfar)
+    full = np.zeros((H, W), bool); full[:, col0:col0 + SW] = terrain
+    def place(a, fill):
+        out = np.full((H, W), fill, a.dtype); out[:, col0:col0 + SW] = a; return out
+    want = {"bgr": np.zeros((H, W, 3), np.uint8), "ranges": np.where(full, place(rng, 0), np.float32(-1)).astype(np.float32),
+            "index": np.where(full, place(idx, 0), -1).astype(np.int32), "z24": np.where(full, place(z24, 0), 0xFFFFFF).astype(np.uint32)}
+    want["bgr"][..., 0] = np.where(full, 0, 255); want["bgr"][..., 2] = np.where(full, place(red, 0), 0)
+    got = {"bgr": np.empty((H, W, 3), np.uint8), "ranges": np.empty((H, W), np.float32), "index": np.empty((H, W), np.int32), "z24": np.empty((H, W), np.uint32)}
     for kind, k in enumerate(("bgr", "ranges", "index", "z24")):
         lib.hz_sky_fill(got[k].ctypes.data, 0, got[k].nbytes, kind)
     blobs = []
@@ -98,7 +142,7 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags):
                 return out
             t = cut(terrain, False)
             if t.any():
-                blobs.append(_blob(yo0, x0, n, t, cut(rng, 0), cut(idx, 0), cut(z24, 0), cut(red, 0), flags))
+                blobs.append(_blob(yo0, col0 + x0, n, t, cut(idx, 0), cut(z24, 0), cut(red, 0), flags))
     assert len(blobs) < ((H + 3) // 4) * 3          # (the empty tile sent nothing)
     # a chunk: 12 words that a void of the chunk before reaches over, the blobs with a void of 8 words between the first two,
     # and a void at the end that reaches 20 words beyond the chunk
@@ -114,32 +158,57 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags):
     assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk) - 9, 12, offs.ctypes.data, len(offs), C.byref(beyond)) == 2**64 - 1       # a cut-off blob is not a blob
     assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk), 0, offs.ctypes.data, len(offs), C.byref(beyond)) == 2**64 - 1           # nor is rubbish
     assert lib.hz_blob_walk(chunk.ctypes.data, len(chunk), 12, offs.ctypes.data, len(offs), C.byref(beyond)) == len(blobs)
+    dst = Dst(W, H, got["bgr"].ctypes.data, got["ranges"].ctypes.data, got["index"].ctypes.data, got["z24"].ctypes.data,
+              tanel.ctypes.data, znear, zfar)
     at = 12
     for k, b in enumerate(blobs):
         if k == 1:
             at += 8
         assert int(offs[k]) == at
-        rc = lib.hz_blob_scatter(chunk[at:].ctypes.data, SW, H,
-                                 got["bgr"].ctypes.data if flags & RED else None, got["ranges"].ctypes.data if flags & RANGES else None,
-                                 got["index"].ctypes.data if flags & INDEX else None, got["z24"].ctypes.data if flags & Z24 else None)
-        assert rc == 0
+        assert lib.hz_blob_scatter(chunk[at:].ctypes.data, C.byref(dst)) == 0
         at += len(b)
-    for k, f in (("bgr", RED), ("ranges", RANGES), ("index", INDEX), ("z24", Z24)):
-        if flags & f:
+    carried = {"bgr": flags & (PACKED | RED), "ranges": flags & PACKED, "z24": flags & PACKED, "index": flags & INDEX}
+    for k in ("bgr", "ranges", "index", "z24"):
+        if carried[k]:
             assert np.array_equal(got[k], want[k]), k
         else:                                       # a buffer the blobs do not carry stays sky
-            sky = np.frombuffer(SKY[("bgr", "ranges", "index", "z24").index(k)] * (got[k].nbytes // len(SKY[("bgr", "ranges", "index", "z24").index(k)])), np.uint8)
+            kind = ("bgr", "ranges", "index", "z24").index(k)
+            sky = np.frombuffer(SKY[kind] * (got[k].nbytes // len(SKY[kind])), np.uint8)
             assert np.array_equal(got[k].view(np.uint8).ravel(), sky), k
 
 
-def test_a_blob_that_is_not_one_is_refused():
+def test_a_blob_that_is_not_one_is_refused_before_anything_is_written():
     lib = _lib()
-    t = np.ones((ROWS, 64), bool)
-    z = np.zeros((ROWS, 64))
-    b = _blob(0, 0, 64, t, z.astype(np.float32), z.astype(np.int32), z.astype(np.uint32), z.astype(np.uint8), RANGES | RED)
-    out = np.zeros((8, 64), np.float32)
-    img = np.zeros((8, 64, 3), np.uint8)
-    assert lib.hz_blob_scatter(b.ctypes.data, 64, 8, img.ctypes.data, out.ctypes.data, None, None) == 0
-    for field, value in ((1, 32), (7, 4096), (0, 8 | ((RANGES | RED) << 16)), (2, 63)):     # beyond the image's columns, too wide, below the image, a count the mask does not have
+    g = np.random.default_rng(4)
+    n = 70                                                       # (a last mask word with 6 columns in use)
+    t = g.random((ROWS, n)) < 0.7
+    t[1] = True
+    z = g.integers(0, 0xFFFFFF, (ROWS, n))
+    b = _blob(0, 0, n, t, z.astype(np.int32), z.astype(np.uint32), (z & 255).astype(np.uint8), PACKED | INDEX)
+    W, H = 80, 8
+    tanel = np.zeros(H, np.float32)
+    def run(blob, W=W, H=H):
+        out = {"bgr": np.full((H, W, 3), 7, np.uint8), "ranges": np.full((H, W), 7, np.float32), "index": np.full((H, W), 7, np.int32), "z24": np.full((H, W), 7, np.uint32)}
+        guard = np.full(4096, 0x5A5A5A5A, np.uint32)            # what lies behind the blob: a refused blob must not be read beyond its size
+        buf = np.concatenate([blob, guard])
+        dst = Dst(W, H, out["bgr"].ctypes.data, out["ranges"].ctypes.data, out["index"].ctypes.data, out["z24"].ctypes.data, tanel.ctypes.data, 100.0, 40000.0)
+        rc = lib.hz_blob_scatter(buf.ctypes.data, C.byref(dst))
+        touched = any((a != 7).any() for a in out.values())
+        return rc, touched
+    assert run(b) == (0, True)
+    mw = (n + 31) // 32
+    cases = {
+        "first column beyond the image": (1, W - n + 1),
+        "too wide": (7, 4096),
+        "below the image": (0, 8 | ((PACKED | INDEX) << 16)),
+        "a count the mask does not have": (2, int(b[2]) - 1),
+        "an unknown array": (0, (64 | PACKED) << 16),
+        "arrays that do not fit the declared size": (6, 8 + 4 * mw + 3),
+        "a mask bit beyond the blob's columns": (8 + mw - 1, int(b[8 + mw - 1]) | (1 << 31)),
+        "a mask bit more in a row (beyond its count)": (8 + mw, int(b[8 + mw]) & ~1),
+    }
+    for what, (field, value) in cases.items():
         bad = b.copy(); bad[field] = value
-        assert lib.hz_blob_scatter(bad.ctypes.data, 64, 8, img.ctypes.data, out.ctypes.data, None, None) == -1, field
+        assert run(bad) == (-1, False), what
+    # terrain in a row below the image
+    assert run(b, H=3) == (-1, False)
