@@ -776,9 +776,9 @@ static mr_queue_t queue_set(const hz_dev_t* d, int k)
 }
 
 /* what the marching waves queued: clipper, medium boxes, large boxes */
-static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st, int set, bool by_tile, unsigned int* report = NULL)
+static int queue_kernels(hz_dev_t* d, const mr_queue_t& q, const hz_params_t& pp, hipStream_t st, int set, bool by_tile, bool zoomed, unsigned int* report = NULL)
 {
-    hzk_clip(dim3(1024), dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
+    hzk_clip(zoomed, dim3(1024), dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, pp);
     HZ_CHECK(hipGetLastError());
     if(d->raster != HZ_RASTER_SCATTER && pp.inline_max < pp.big_min)      /* else nothing is ever queued for it */
     {
@@ -954,6 +954,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
     bool near_beside_far = false;                   /* the second round did not wait for the first */
     bool waited_near = false;                       /* ... or it did */
     bool use_hiz = false;                           /* the second round keeps coarse depth (hz_k_hiz.h) */
+    bool zoomed_view = false;                       /* a cell at the first round's reach is still HZ_HIZ_MIN_PX pixels wide */
 
     if(d->raster == HZ_RASTER_SCATTER)
     {
@@ -1015,10 +1016,11 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                  * degree view of 16000 columns: 40; a 90 degree view, 26, is better off with k_big: 0.92 against 1.08 ms) */
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
+                zoomed_view = reach > 0.f && ppr/reach >= HZ_HIZ_MIN_PX;
                 if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= HZ_TILES_MIN_PX) by_tile_first = true;
                 if(by_tile_first && tile_bins(d, HZ_NFB + next) != 0) by_tile_first = false;       /* (no memory for the bins: k_big) */
             }
-            if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile_first) != 0) return -1;
+            if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile_first, zoomed_view) != 0) return -1;
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
              * finds the marching kernel of the draw before it finished (a single render, or
@@ -1040,9 +1042,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
             const bool early_z = true;        /* (the early depth test addresses the framebuffer with 32-bit byte offsets: every framebuffer is below 4 GB, hz_hip_create) */
             hz_hiz_t hz = {};
             {
-                const float ppr = p.halfW * p.u.az_ndc_per_rad;
-                const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
-                const bool zoomed = reach > 0.f && ppr/reach >= HZ_HIZ_MIN_PX;
+                const bool zoomed = zoomed_view;
                 /* (azimuth sectors, round 4 - with k_big's chunk test against the tables: a half gains 8 %, a quarter 6 (strips back to
                  * back 0.273 -> 0.259, 0.250 -> 0.234 ms), an eighth's widest sector 11 and its narrowest loses 4; beside the 8-row
                  * segments narrow sectors get (mr_make_zones) an eighth loses 5: from a sixth of the image on.  profiles/r4_sector_rules.txt) */
@@ -1118,7 +1118,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
         const float ppr = p.halfW * p.u.az_ndc_per_rad;
         if(ppr/(float)HZ_NEAR_CELLS_MAX >= HZ_HIZ_MIN_PX) report = d->adapt.h_counts[next];        /* (a view whose reach has the choice) */
     }
-    if(queue_kernels(d, q, p, d->qstream, next, false, report) != 0) return -1;
+    if(queue_kernels(d, q, p, d->qstream, next, false, zoomed_view, report) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     if(report)
     {

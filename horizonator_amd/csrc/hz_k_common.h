@@ -196,9 +196,12 @@ __device__ static inline hz_wvert_t hz_vertex_at(const hz_params_t& p, const int
 
 /* clip one triangle of the grid (by id) and hand its pieces on: to the k_big
  * queue, or - `inline_ok` and no room - straight into the framebuffer */
+/* (jobs, njobs: the work items of pieces with more than HZ_CLIP_JOB_MIN chunks are left to the caller - 3 words per piece:
+ * first item, record, chunks - instead of being written here, one after the other by this thread: k_clip<true>) */
+#define HZ_CLIP_JOB_MIN 32
 __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long long* fb, const mr_queue_t& q,
                                         const hz_params_t& p, uint32_t prim, bool inline_ok,
-                                        hz_cvert_t* bufa, hz_cvert_t* bufb)
+                                        hz_cvert_t* bufa, hz_cvert_t* bufb, uint32_t (*jobs)[3] = NULL, int* njobs = NULL)
 {
     const uint32_t cell = prim >> 1;
     const int t = prim & 1;
@@ -259,7 +262,8 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
         br.bh = box.py1 - box.py0 + 1;
         const uint32_t chunks = hz_big_chunks(br.r.bw, br.bh);
         q.bigrec[ri] = br;
-        for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+        if(jobs && chunks > HZ_CLIP_JOB_MIN) { uint32_t* job = jobs[*njobs]; job[0] = ii; job[1] = ri; job[2] = chunks; (*njobs)++; }
+        else for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
         ri++; ii += chunks;
     }
 }
@@ -279,21 +283,56 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
  * waited ~0.7 ms to be placed.  HZ_CLIP_LANES lanes of a block clip, the
  * others leave at once. */
 #define HZ_CLIP_LANES 4
+/* WAVE_ITEMS (round 5; zoomed views: draw_impl): the work items of a clipped triangle's large pieces are written by the whole
+ * wave.  A triangle next to the viewer of a zoomed view is clipped into pieces thousands of rows high and as wide as the
+ * image - one row to a chunk, so thousands of work items apiece -, and the one thread that clipped it wrote them one after
+ * the other: the kernel took 90-150 us for 2000 triangles whose average wave needed 9; with the wave writing them 154 -> 21 us,
+ * the 45 degree view towards the east 1.31 -> 1.17 ms (profiles/r4_ab_kclip_items.txt).  The 60 lanes that do not clip cost
+ * nothing while they wait - a wave's registers are allocated whatever its lanes do.  A whole panorama's clipped triangles
+ * have no such pieces, and its draws keep the instance they were tuned with: the same machine code as before, to the byte
+ * (round 4 measured 0.8 % on the headline with the one kernel serving both - its first round's k_big then starts 17 us
+ * earlier beside the second round of the panorama before). */
+template<bool WAVE_ITEMS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb, mr_queue_t q, hz_params_t p)
 {
     __shared__ hz_cvert_t polygon[HZ_CLIP_LANES][2][HZ_MAX_CLIPPED+1];
-    if(threadIdx.x >= HZ_CLIP_LANES) return;
-    hz_cvert_t* poly0 = polygon[threadIdx.x][0];
-    hz_cvert_t* poly1 = polygon[threadIdx.x][1];
+    __shared__ uint32_t s_job[WAVE_ITEMS ? HZ_CLIP_LANES : 1][WAVE_ITEMS ? HZ_MAX_CLIPPED : 1][3];
+    __shared__ int      s_njobs[HZ_CLIP_LANES];
+    const bool clipper = threadIdx.x < HZ_CLIP_LANES;
+    if(!WAVE_ITEMS && !clipper) return;
+    const int  cl = clipper ? (int)threadIdx.x : 0;
+    hz_cvert_t* poly0 = polygon[cl][0];
+    hz_cvert_t* poly1 = polygon[cl][1];
     const unsigned int n = q.counters[4];
     const unsigned int me = blockIdx.x*HZ_CLIP_LANES + threadIdx.x, stride = gridDim.x*HZ_CLIP_LANES;
     if(n <= q.clip_capacity)
     {
-        for(unsigned int k = me; k < n; k += stride)
-            hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, poly0, poly1);
+        if(!WAVE_ITEMS)
+        {
+            for(unsigned int k = me; k < n; k += stride)
+                hz_clip_and_draw(mosaic, fb, q, p, q.clip[k], true, poly0, poly1);
+            return;
+        }
+        for(unsigned int k0 = blockIdx.x*HZ_CLIP_LANES; k0 < n; k0 += stride)        /* (the same trips for every lane) */
+        {
+            int njobs = 0;
+            if(clipper && k0 + cl < n) hz_clip_and_draw(mosaic, fb, q, p, q.clip[k0 + cl], true, poly0, poly1, s_job[cl], &njobs);
+            /* (most trips have none - pieces of a few chunks are written by their thread as before: no LDS, no barrier) */
+            if(__ballot(njobs > 0) == 0ull) continue;
+            if(clipper) s_njobs[cl] = njobs;
+            __syncthreads();
+            for(int c=0; c<HZ_CLIP_LANES; c++)
+                for(int jb=0; jb<s_njobs[c]; jb++)
+                {
+                    const uint32_t ii = s_job[c][jb][0], ri = s_job[c][jb][1], chunks = s_job[c][jb][2];
+                    for(uint32_t c2 = threadIdx.x; c2 < chunks; c2 += 64u) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+                }
+            __syncthreads();
+        }
         return;
     }
+    if(!clipper) return;
     const size_t ncells = (size_t)(p.N-1)*(p.N-1);
     for(size_t cell = me; cell < ncells; cell += stride)
     {

@@ -164,9 +164,10 @@ void k_poi(const unsigned long long* __restrict__ fb, const float* __restrict__ 
 
 #include "hz_launch.h"
 
-void hzk_clip(dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, hz_params_t p)
+void hzk_clip(bool wave_items, dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, hz_params_t p)
 {
-    hipLaunchKernelGGL(k_clip, grid, block, 0, stream, mosaic, fb, q, p);
+    if(wave_items) hipLaunchKernelGGL(k_clip<true>, grid, block, 0, stream, mosaic, fb, q, p);
+    else hipLaunchKernelGGL(k_clip<false>, grid, block, 0, stream, mosaic, fb, q, p);
 }
 
 void hzk_hiz(dim3 grid, dim3 block, hipStream_t stream, const unsigned long long* fb, const unsigned char* touched, int seg_stride, int SW, int H, hz_hiz_t hz, unsigned int nunits)

@@ -8,7 +8,7 @@
 
 #include "hz_types.h"
 
-void hzk_clip(dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, hz_params_t p);
+void hzk_clip(bool wave_items, dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, hz_params_t p);
 void hzk_hiz(dim3 grid, dim3 block, hipStream_t stream, const unsigned long long* fb, const unsigned char* touched, int seg_stride, int SW, int H, hz_hiz_t hz, unsigned int nunits);
 void hzk_mid(dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, const hz_rec_t* midrec, const unsigned int* counters, unsigned int midrec_capacity, hz_params_t p);
 void hzk_march(bool counters, bool hiz, dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, mr_zones_t zn, hz_params_t p);
