@@ -594,16 +594,20 @@ def main():
     algo_bytes = 2 * N * N + 7 * S["SW_max"] * H
     achieved = algo_bytes / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
     traffic = None
+    traffic_by_kernel = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             if rec.get("config") == args.config and rec.get("zfar") == args.zfar and world == 1:
-                traffic = rec.get("hbm_bytes_per_launch")
+                # the whole render's HBM bytes (every kernel of one panorama of a series), and who moved them
+                traffic = rec.get("hbm_bytes_per_render_all_kernels")
+                traffic_by_kernel = {k: v.get("hbm_bytes_per_render") for k, v in rec.get("kernels", {}).items() if v.get("hbm_bytes_per_render")}
         except Exception:
             traffic = None
-    traffic_note = ("RECORDED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, "
-                    "profiles/pmc_latest.json") if traffic is not None else None
+    traffic_note = ("RECORDED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command (FETCH_SIZE doubled: the "
+                    "gfx950 correction, checked on the conversion's known reads), profiles/pmc_latest.json; `traffic` = HBM bytes of ALL kernels of one "
+                    "render of a series, `traffic_by_kernel` says whose they are (the dominant kernel's own: k_march_far_round)") if traffic is not None else None
 
     # what actually bounds the dominant kernel: the SIMDs' vector issue slots.
     # Recorded counters of the same workload (profiles/), set against the duration measured now.
@@ -778,7 +782,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_by_kernel": traffic_by_kernel, "traffic_source": traffic_note,
                 "kernel": "k_scatter" if args.raster == 1 else "k_march", "kernel_ms": raster_ms,
                 "kernel_launch": ("second round of a two-round draw: every strip but those next to the viewer (the first round's "
                                   "k_march is in other_kernels_ms.round1_near_viewer with its queue kernels)") if near_ms > 0.05 else "the draw's only k_march launch",

@@ -50,7 +50,7 @@ SCENES = {
     "cfg4_32":       dict(R=3000, W=8000, H=2000, batch=32, what="BASELINE configs[3]: viewpoints of the 16x16 lattice over 5x5 tiles, 8000x2000 BGR each, one batch"),
     "cfg5":          dict(R=19800, W=32768, H=8192, srtm1=True, steps=3, what="BASELINE configs[4]: 11x11 SRTM1 tiles (3.1 G triangles), 32768x8192"),
 }
-DEFAULT = ["cfg3", "cfg3_rough", "cfg3_summit", "cfg3_valley", "cfg3_zoom45", "cfg2", "cfg4_32", "cfg5"]
+DEFAULT = ["cfg3", "cfg3_rough", "cfg3_summit", "cfg3_valley", "cfg3_zoom45", "cfg1", "cfg2", "cfg4_32", "cfg5"]
 
 
 def _extreme_viewpoint(h, which, half_span_deg=0.3):
