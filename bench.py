@@ -502,6 +502,11 @@ def main():
     if world > 1:
         h.set_view(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
         rebalance()
+    # The headline is the COLD draw: every vertex of every panorama transformed in full, as for a viewer that moves with
+    # every render.  The library's vertex cache (hz_options_t::vertex_cache: from the second draw from a viewpoint on, the
+    # view-independent half of the transform is read back from HBM) would serve K renders of one view from the cache: it is
+    # switched off for `value` and measured beside it ("same_viewpoint").
+    h.set_options(vertex_cache=0)
     dt, kern = timed(args.zfar, args.steps, args.warmup)
     verified = verify()
 
@@ -538,6 +543,21 @@ def main():
                 "bgr_sha_is_llvmpipe": (hashlib.sha256(img.tobytes()).hexdigest() == g["bgr_sha256"]) if g else None}
 
     last = keep_last(args.zfar)
+
+    same_viewpoint = None
+    if world == 1 and not args.no_extra and not args.exchange_anyway and args.raster != 1:
+        h.set_options(vertex_cache=1)
+        dt_c, _ = timed(args.zfar, args.steps, max(args.warmup, 3))
+        plan_c = h.last_plan()
+        img_c = d_img.cpu().numpy()
+        same_viewpoint = {"ms_per_step": dt_c / args.steps * 1e3, "value": W * H * args.steps / dt_c / 1e6, "unit": "Mpix/s",
+                          "from_vertex_cache": bool(plan_c.get("vertex_cache")),
+                          "equals_the_cold_render": bool(last is not None and np.array_equal(img_c, last["img"]) and np.array_equal(d_rng.cpu().numpy(), last["rng"])),
+                          "what": "the same K renders with the library's default: the viewer has not moved, so from the second draw on the "
+                                  "view-independent half of every vertex's transform (two atan, two square roots; 16 B per vertex, %.2f GB) "
+                                  "is read from HBM instead of computed - what a caller that turns or zooms sees; `value` above is the cold draw" % (16.0 * N * N / 1e9)}
+        del img_c
+        h.set_options(vertex_cache=0)
 
     # N > 1: the line's `value` is the throughput of --gather's mode (default rotate: panorama k is assembled on rank
     # k mod N, the panoramas stay spread over the ranks).  Beside it: the other mode (root0: north_star's "gather of the
@@ -796,6 +816,8 @@ def main():
             "cpu_baseline": cpu,
             "reference_llvmpipe_recorded": ref_rec,
         }
+        if same_viewpoint is not None:
+            line["same_viewpoint"] = same_viewpoint
         if host_incl is not None:
             line["host_inclusive"] = host_incl
         if scene_recs is not None:
@@ -823,6 +845,7 @@ def main():
         gates.append(line.get("gathered_panorama_equals_single_gpu_render"))
         gates += [v.get("gathered_panorama_equals_single_gpu_render") for k, v in multi_extra.items() if k.startswith("gather_")]
         gates.append(host_incl["equals_device_render"] if host_incl is not None else None)
+        gates.append(same_viewpoint["equals_the_cold_render"] if same_viewpoint is not None and last is not None else None)
         gates.append(host_incl["two_in_flight_equals_device_render"] if host_incl is not None else None)
         failed = any(g is False for g in gates)
     drop_series()

@@ -418,11 +418,12 @@ class horizonator:
     def last_plan(self):
         """what the last draw was: {"rounds": 1 | 2, "coarse_depth": its second round kept coarse depth (zoomed views, the
         draws of a series), "reach_cells": the first round's reach, "work_list": only the strips behind the drawn columns
-        were launched} (include/hz_hip.h: hz_hip_last_plan)"""
-        out = (C.c_int * 4)()
+        were launched, "vertex_cache": its vertices came from the vertex cache} (include/hz_hip.h: hz_hip_last_plan)"""
+        out = (C.c_int * 5)()
         if self._lib.hz_hip_last_plan(self._lib.horizonator_amd_device(C.byref(self._ctx)), out) != 0:
             raise RuntimeError("hz_hip_last_plan() failed")
-        return {"rounds": int(out[0]), "coarse_depth": bool(out[1]), "reach_cells": int(out[2]), "work_list": bool(out[3])}
+        return {"rounds": int(out[0]), "coarse_depth": bool(out[1]), "reach_cells": int(out[2]), "work_list": bool(out[3]),
+                "vertex_cache": bool(out[4])}
 
     def view(self):
         v = View()

@@ -72,7 +72,7 @@ class Options(C.Structure):
     """hz_options_t (include/hz_hip.h): the tunables of a context"""
     _fields_ = [(n, C.c_int) for n in (
         "serial", "rounds", "near_cells", "coarse_depth", "tiles", "tile_list", "adapt", "adapt_hi", "pretest_march",
-        "worklists", "fast_math", "resolve_clears", "queue_capacity", "host_dense", "host_sectors", "host_times")]
+        "worklists", "fast_math", "resolve_clears", "queue_capacity", "host_dense", "host_sectors", "host_times", "vertex_cache")]
 
 
 class Times(C.Structure):

@@ -155,7 +155,9 @@ struct hz_dev
         int           long_reach;           /* the choice for its next draw */
         int           seen_reach; unsigned int seen_records, seen_items;   /* the last observation (hz_hip_last_queue_counts) */
     } adapt;
-    int                 last_plan[4];           /* the last draw (hz_hip_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
+    /* the vertex cache (hz_draw.cpp: vertex_cache): the view-independent half of every vertex's transform for the viewpoint `key` */
+    struct { hz_polar_t* d_polar; hz_xform_t key; int state /* 0 nothing, 1 the viewpoint has been drawn once, 2 filled */; int unavailable; hipEvent_t ev_filled; } vc;
+    int                 last_plan[5];           /* the last draw (hz_hip_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */
     hz_bigrec_t*        d_bigrec_s[2*HZ_NFB];          /* [0..NFB) one-round draws and second rounds, [NFB..2 NFB) first rounds */
     hz_bigitem_t*       d_bigitem_s[2*HZ_NFB];

@@ -40,6 +40,7 @@ static hz_options_t default_options(void)
     o.host_dense     = 0;
     o.host_sectors   = 0;
     o.host_times     = 0;
+    o.vertex_cache   = 1;
     return o;
 }
 hz_options_t hz_options_from_env(void)
@@ -61,6 +62,7 @@ hz_options_t hz_options_from_env(void)
     o.host_dense     = env_int("HZ_HOST_DENSE", o.host_dense) != 0;
     o.host_sectors   = env_int("HZ_HOST_SECTORS", o.host_sectors);
     o.host_times     = env_int("HZ_HOST_TIMES", o.host_times) != 0;
+    o.vertex_cache   = env_int("HZ_VERTEX_CACHE", o.vertex_cache) != 0;
     return o;
 }
 #ifdef HZ_EXPERIMENTS                   /* (switches that draw wrong pictures exist in builds with -DHZ_EXPERIMENTS only: tools/experiments.py) */
@@ -129,6 +131,8 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
     hz_hostpath_destroy(d);
+    (void)hipFree(d->vc.d_polar);
+    if(d->vc.ev_filled) (void)hipEventDestroy(d->vc.ev_filled);
     for(int k=0; k<10; k++) if(d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     for(int k=0; k<HZ_NFB; k++) { if(d->adapt.ev[k]) (void)hipEventDestroy(d->adapt.ev[k]); if(d->adapt.h_counts[k]) (void)hipHostFree(d->adapt.h_counts[k]); }
     if(d->ev_drawn)   (void)hipEventDestroy(d->ev_drawn);
@@ -288,6 +292,7 @@ extern "C" int hz_hip_upload_mosaic(hz_dev_t* d, const int16_t* mosaic)
     HZ_CHECK(hipMemcpyAsync(d->d_mosaic, mosaic, (size_t)d->N*d->N*sizeof(int16_t), hipMemcpyHostToDevice, d->stream));
     HZ_CHECK(hipStreamSynchronize(d->stream));
     d->adapt.have_view = 0;         /* (what the draws of the old terrain had to queue says nothing about the new one) */
+    d->vc.state = 0;                /* ... and the vertex cache held the old terrain's heights */
     return 0;
 }
 
@@ -827,14 +832,11 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
         if((size_t)grid.x*grid.y*4 > d->wave_timing.capacity) { snprintf(g_last_error, sizeof(g_last_error), "wave timing buffer too small"); return -1; }
         pm.wave_cycles = d->wave_timing.d_cycles;
         d->wave_timing.grid_x = grid.x; d->wave_timing.grid_y = grid.y;
-        hzk_march(true, true, grid, dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+        hzk_march(true, true, false, grid, dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     }
     else
 #endif
-    if(pm.hiz)
-        hzk_march(false, true, grid, dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
-    else
-        hzk_march(false, false, grid, dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
+    hzk_march(false, pm.hiz != NULL, pm.vcache != NULL, grid, dim3(64), st, (const int16_t*)d->d_mosaic, d->d_fb, q, zn, pm);
     HZ_CHECK(hipGetLastError());
     return 0;
 }
@@ -909,6 +911,60 @@ static int hiz_sweep(hz_dev_t* d, hipStream_t st, int next, const hz_params_t& p
     return 0;
 }
 
+/* ---- the vertex cache ------------------------------------------------------------------------------------------------
+ * The expensive half of the vertex transform (reference vertex.glsl:133-134, 154, 156: two atan, two square roots - 42 % of
+ * the marching kernel's instructions, and that kernel is bound by instruction issue at a tenth of the chip's memory bandwidth)
+ * depends on where the viewer stands and on nothing else.  A caller that turns, zooms or changes the depth extents
+ * (horizonator_pan_zoom, horizonator_set_zextents - the reference's interactive use, and every render of a series from one
+ * viewpoint) redraws the same vertices from the same place: the second draw from a viewpoint writes that half of every
+ * vertex into HBM (k_polar_fill: 16 bytes per vertex, 1.13 GB for the 7x7-tile mosaic - 288 GB are there to be used), and
+ * the draws after it read it back (k_march<.., VCACHE>) instead of computing it.  The FIRST draw from a viewpoint is what it
+ * always was - a viewer that moves with every draw (BASELINE configs[3]) never pays for a fill it would not use.
+ * Same operations on the same numbers in the same order: the bytes drawn do not depend on it (tests/test_gpu_sequences.py
+ * interleaves cached and cold draws with moves).  Dropped by horizonator_move (a new key), by a new mosaic, with the
+ * context; off where memory is short or hz_options_t::vertex_cache says so. */
+static bool same_viewpoint(const hz_xform_t& a, const hz_xform_t& b)
+{
+    return a.viewer_cell_i == b.viewer_cell_i && a.viewer_cell_j == b.viewer_cell_j && a.viewer_z == b.viewer_z &&
+           a.cos_viewer_lat == b.cos_viewer_lat && a.deg_per_cell == b.deg_per_cell;
+}
+static int vertex_cache(hz_dev_t* d, hz_params_t& p)
+{
+    p.vcache = NULL;
+    if(!d->env.vertex_cache || d->vc.unavailable) return 0;
+    if(!d->vc.state || !same_viewpoint(d->vc.key, p.u))
+    {
+        d->vc.key = p.u; d->vc.state = 1;           /* seen once: this draw computes everything, as always */
+        return 0;
+    }
+    if(d->vc.state == 1)
+    {
+        /* the second draw from here: fill.  On the first round's stream, behind everything that may still read the cache of
+         * the viewpoint before (first rounds: that stream itself; second rounds: ev_marched), in front of both rounds of this draw. */
+        if(!d->vc.d_polar)
+        {
+            const size_t bytes = (size_t)d->N*d->N*sizeof(hz_polar_t);
+            size_t free_b = 0, total_b = 0;
+            if(hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2*bytes + ((size_t)4 << 30) ||
+               hipMalloc(&d->vc.d_polar, bytes) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                d->vc.d_polar = NULL; d->vc.unavailable = 1;        /* memory is short: every draw computes everything */
+                return 0;
+            }
+            HZ_CHECK(hipEventCreateWithFlags(&d->vc.ev_filled, hipEventDisableTiming));
+        }
+        HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_marched, 0));
+        hzk_polar_fill(dim3((unsigned)((d->N + 255)/256), 1024), dim3(256), d->nstream, (const int16_t*)d->d_mosaic, d->vc.d_polar, d->N, p.u);
+        HZ_CHECK(hipGetLastError());
+        HZ_CHECK(hipEventRecord(d->vc.ev_filled, d->nstream));
+        HZ_CHECK(hipStreamWaitEvent(d->stream, d->vc.ev_filled, 0));
+        d->vc.state = 2;
+    }
+    p.vcache = d->vc.d_polar;
+    return 0;
+}
+
 int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
 {
     hz_params_t p = hz_make_params(d, view);
@@ -944,6 +1000,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
     (void)hipGetLastError();                /* (hipErrorNotReady from a query is not an error) */
     if(next_framebuffer(d, p) != 0) return -1;
     const int next = d->fbi;
+    if(d->raster != HZ_RASTER_SCATTER && vertex_cache(d, p) != 0) return -1;
 
     const mr_queue_t q = queue_set(d, next);        /* one-round draw, or second round */
     /* large triangles by screen tile instead of by k_big's atomics (HZ_TILES; hz_k_tile.h): in every round (1), or in first
@@ -1128,6 +1185,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
     }
     d->last_plan[0] = p.pass == 2 ? 2 : 1; d->last_plan[1] = use_hiz ? 1 : 0;
     d->last_plan[2] = p.pass == 2 ? (p.near_j1 - p.near_j0)/2 : 0; d->last_plan[3] = p.cull_strips ? 1 : 0;
+    d->last_plan[4] = p.vcache ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
     return 0;
@@ -1497,7 +1555,7 @@ extern "C" int hz_hip_last_queue_counts(hz_dev_t* d, unsigned int* out)
 extern "C" int hz_hip_last_plan(hz_dev_t* d, int* out)
 {
     if(!d || !out) return -1;
-    for(int k=0; k<4; k++) out[k] = d->last_plan[k];
+    for(int k=0; k<5; k++) out[k] = d->last_plan[k];
     return 0;
 }
 

@@ -140,23 +140,33 @@ __device__ static inline float hzf_atan2(float y, float x)
 /* hz_transform_en() under the range conditions: e, n in [2^-30, 2^30] in
  * magnitude (not zero), h = fz - viewer_z zero or in that range, the depth and
  * colour extents and their spans in that range (hzf_draw_ok) */
-__device__ static inline hz_vertex_t hzf_transform_en(const hz_xform_t* u, const hzf_const_t* c, float e, float n, float fz)
+/* (in two halves, as hz_num.h's: hzf_polar_en() is what depends on the viewer's position alone, hzf_finish() the rest) */
+__device__ static inline hz_polar_t hzf_polar_en(const hz_xform_t* u, float e, float n, float fz)
+{
+    hz_polar_t q;
+    const float h = fz - u->viewer_z;
+    const float nn = n*n, ee = e*e;
+    q.d_ne  = hzf_sqrt(nn + ee);
+    q.az    = hzf_atan2<false>(e, n);
+    q.el    = hzf_atan2<true>(h, q.d_ne);
+    q.d_enh = hzf_sqrt(h*h + nn + ee);
+    return q;
+}
+__device__ static inline hz_vertex_t hzf_finish(const hz_xform_t* u, const hzf_const_t* c, hz_polar_t q)
 {
     hz_vertex_t v;
-    const float h = fz - u->viewer_z;
-
-    const float nn = n*n, ee = e*e;
-    const float d_ne = hzf_sqrt(nn + ee);
-    const float az   = hzf_atan2<false>(e, n);
-
-    const float d = hzf_div_by(az + -u->az_center, HZ_TWO_PI, c->rr_two_pi);
+    const float d = hzf_div_by(q.az + -u->az_center, HZ_TWO_PI, c->rr_two_pi);
     v.x = (HZ_TWO_PI*(d - hz_roundeven(d))) * u->az_ndc_per_rad;
-    v.y = hzf_atan2<true>(h, d_ne) * u->aspect * u->az_ndc_per_rad;
-    v.z = hzf_div_by(hzf_sqrt(h*h + nn + ee) - u->znear, c->zrange, c->rr_zrange) * 2.0f + -1.0f;
+    v.y = q.el * u->aspect * u->az_ndc_per_rad;
+    v.z = hzf_div_by(q.d_enh - u->znear, c->zrange, c->rr_zrange) * 2.0f + -1.0f;
 
-    const float r = hzf_div_by(d_ne - u->znear_color, c->crange, c->rr_crange);
+    const float r = hzf_div_by(q.d_ne - u->znear_color, c->crange, c->rr_crange);
     v.red = hz_min(hz_max(r, 0.0f), 1.0f);
     return v;
+}
+__device__ static inline hz_vertex_t hzf_transform_en(const hz_xform_t* u, const hzf_const_t* c, float e, float n, float fz)
+{
+    return hzf_finish(u, c, hzf_polar_en(u, e, n, fz));
 }
 
 #endif /* __HIPCC__ */

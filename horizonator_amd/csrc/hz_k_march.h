@@ -542,7 +542,12 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
 /* HIZ: the instance for draws that keep coarse depth (hz_k_hiz.h; zoomed views).  The test of the larger boxes is
  * ~100 instructions in each of the four places the flush is inlined and a dozen scalars held across the marching
  * loop: compiled into the one kernel it cost whole panoramas, which never use it, 2 % more instructions per render. */
-template<bool COUNTERS, bool HIZ>
+/* VCACHE (round 5): the instance for draws whose viewer stands where the draw before stood.  The expensive half of the
+ * transform - two atan, two square roots: 42 % of this kernel's instructions - depends on the viewer's position alone;
+ * a context keeps its four numbers per vertex (p.vcache, 16 bytes each, written by k_polar_fill when a viewpoint is drawn
+ * a second time) and this instance reads them instead of the elevation: a 16-byte load and the ~30 instructions of
+ * hz_finish() per vertex where the cold instance spends ~155.  Same operations on the same numbers: same bits. */
+template<bool COUNTERS, bool HIZ, bool VCACHE>
 __global__ __launch_bounds__(64) MR_OCCUPANCY
 void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
              mr_queue_t q, mr_zones_t zn, hz_params_t p)
@@ -651,7 +656,9 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
      * (mr_vcull_t) and the same combined with the vertex one lane to the east */
     mr_rowstate_t prev = {};
     bool prev_simple = false;
-    int16_t z_next = mosaic[(size_t)jbeg*p.N + ic];
+    int16_t z_next = VCACHE ? (int16_t)0 : mosaic[(size_t)jbeg*p.N + ic];
+    hz_polar_t q_next = {};
+    if(VCACHE) q_next = p.vcache[(size_t)jbeg*p.N + ic];
     /* rows whose 64 vertices all lie safely beyond zfar (by horizontal distance
      * alone, 0.1% margin): their triangles can only be far-clipped, so a vertex
      * row is transformed only if it or a neighbouring row is not such a row.
@@ -663,7 +670,12 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     {
         const int rel = j - jbeg;
         const float z = (float)z_next;
-        if(j < jend) z_next = mosaic[(size_t)(j+1)*p.N + ic];
+        const hz_polar_t q_cur = q_next;
+        if(j < jend)
+        {
+            if(VCACHE) q_next = p.vcache[(size_t)(j+1)*p.N + ic];
+            else z_next = mosaic[(size_t)(j+1)*p.N + ic];
+        }
         const float n_next   = (j == jend) ? 0.f : north_of(rel+1);
         const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
         const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
@@ -673,7 +685,8 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         if(skip_row) continue;
 
         const bool fast = fast_strip && (rel >= 64 ? hzf_in_range(n) : (int)((fast_rows >> rel) & 1ull));
-        const hz_vertex_t vtx = fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z);
+        const hz_vertex_t vtx = VCACHE ? (fast ? hzf_finish(&p.u, &fc, q_cur) : hz_finish(&p.u, q_cur))
+                                       : (fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z));
 
         bool in_volume, in_guard;
         hz_wvert_t cur = mr_window(vtx, p, &in_volume, &in_guard);

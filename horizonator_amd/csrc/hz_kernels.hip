@@ -160,6 +160,22 @@ void k_poi(const unsigned long long* __restrict__ fb, const float* __restrict__ 
 }
 
 /* ------------------------------------------------------------------------ */
+/* the vertex cache: the view-independent half of every vertex's transform    */
+
+/* one thread per vertex, a wave = 64 consecutive columns of a row: q[j][i] = hz_polar_en() of vertex (i, j) for the viewer of u
+ * (the unabridged sequences: the abridged ones of hz_fast.h give the same bits where they apply, and this kernel runs once
+ * per viewpoint) */
+__global__ __launch_bounds__(256)
+void k_polar_fill(const int16_t* __restrict__ mosaic, hz_polar_t* __restrict__ q, int N, hz_xform_t u)
+{
+    const int i = (int)(blockIdx.x*blockDim.x + threadIdx.x);
+    if(i >= N) return;
+    const float e = hz_east(&u, (float)i);
+    for(int j = (int)blockIdx.y; j < N; j += (int)gridDim.y)
+        q[(size_t)j*N + i] = hz_polar_en(&u, e, hz_north(&u, (float)j), (float)mosaic[(size_t)j*N + i]);
+}
+
+/* ------------------------------------------------------------------------ */
 /* the launchers (hz_launch.h): what the host translation units call          */
 
 #include "hz_launch.h"
@@ -180,14 +196,25 @@ void hzk_mid(dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, 
     hipLaunchKernelGGL(k_mid, grid, block, 0, stream, fb, midrec, counters, midrec_capacity, p);
 }
 
-void hzk_march(bool counters, bool hiz, dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, mr_zones_t zn, hz_params_t p)
+void hzk_march(bool counters, bool hiz, bool vcache, dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, mr_zones_t zn, hz_params_t p)
 {
 #ifdef HZ_SELFTEST
-    if(counters) { hipLaunchKernelGGL((k_march<true, true>), grid, block, 0, stream, mosaic, fb, q, zn, p); return; }
+    if(counters) { hipLaunchKernelGGL((k_march<true, true, false>), grid, block, 0, stream, mosaic, fb, q, zn, p); return; }
 #endif
     (void)counters;
-    if(hiz) hipLaunchKernelGGL((k_march<false, true>), grid, block, 0, stream, mosaic, fb, q, zn, p);
-    else hipLaunchKernelGGL((k_march<false, false>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+    if(vcache)
+    {
+        if(hiz) hipLaunchKernelGGL((k_march<false, true, true>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+        else hipLaunchKernelGGL((k_march<false, false, true>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+        return;
+    }
+    if(hiz) hipLaunchKernelGGL((k_march<false, true, false>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+    else hipLaunchKernelGGL((k_march<false, false, false>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+}
+
+void hzk_polar_fill(dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, hz_polar_t* q, int N, hz_xform_t u)
+{
+    hipLaunchKernelGGL(k_polar_fill, grid, block, 0, stream, mosaic, q, N, u);
 }
 
 void hzk_resolve(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, const float* tanel, unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24, int SW, int H, float znear, float zfar, unsigned int* qa, unsigned int* qb)

@@ -113,26 +113,45 @@ HZ_HD float hz_north(const hz_xform_t* u, float fj)
     return (fj - u->viewer_cell_j) * HZ_REARTH_PI * u->deg_per_cell / 180.0f;
 }
 
-HZ_HD hz_vertex_t hz_transform_en(const hz_xform_t* u, float e, float n, float fz)
-{
-    hz_vertex_t v;
-    const float h = fz - u->viewer_z;                       /* vertex.glsl:131 */
+/* The transform in two halves.  What is expensive in it - two atan, two square roots (vertex.glsl:133-134, 154, 156) -
+ * depends on where the viewer stands (e, n, h) and on nothing else: not on the azimuth extents, the aspect ratio or
+ * the depth and colour extents.  hz_polar_en() is that half; hz_finish() turns its four numbers into gl_Position and
+ * the colour for a given view.  A context may keep the four numbers of every vertex from one draw to the next
+ * (hz_draw.cpp: the vertex cache - 16 bytes per vertex) and redo only the second half while the viewer stays put: the
+ * same operations in the same order, hence the same bits. */
+typedef struct { float az, d_ne, el, d_enh; } hz_polar_t;
 
+HZ_HD hz_polar_t hz_polar_en(const hz_xform_t* u, float e, float n, float fz)
+{
+    hz_polar_t q;
+    const float h = fz - u->viewer_z;                       /* vertex.glsl:131 */
     /* vertex.glsl:133-134 */
     const float nn = n*n, ee = e*e;
-    const float d_ne = hz_sqrt(nn + ee);
-    const float az   = hz_atan2(e, n);
+    q.d_ne  = hz_sqrt(nn + ee);
+    q.az    = hz_atan2(e, n);
+    q.el    = hz_atan2(h, q.d_ne);                          /* vertex.glsl:154 */
+    q.d_enh = hz_sqrt(h*h + nn + ee);                       /* vertex.glsl:156 */
+    return q;
+}
 
+HZ_HD hz_vertex_t hz_finish(const hz_xform_t* u, hz_polar_t q)
+{
+    hz_vertex_t v;
     /* vertex.glsl:148-156 */
-    const float d = (az + -u->az_center) / HZ_TWO_PI;
+    const float d = (q.az + -u->az_center) / HZ_TWO_PI;
     v.x = (HZ_TWO_PI*(d - hz_roundeven(d))) * u->az_ndc_per_rad;
-    v.y = hz_atan2(h, d_ne) * u->aspect * u->az_ndc_per_rad;
-    v.z = (hz_sqrt(h*h + nn + ee) - u->znear) / (u->zfar - u->znear) * 2.0f + -1.0f;
+    v.y = q.el * u->aspect * u->az_ndc_per_rad;
+    v.z = (q.d_enh - u->znear) / (u->zfar - u->znear) * 2.0f + -1.0f;
 
     /* vertex.glsl:159-160 */
-    const float r = (d_ne - u->znear_color) / (u->zfar_color - u->znear_color);
+    const float r = (q.d_ne - u->znear_color) / (u->zfar_color - u->znear_color);
     v.red = hz_min(hz_max(r, 0.0f), 1.0f);
     return v;
+}
+
+HZ_HD hz_vertex_t hz_transform_en(const hz_xform_t* u, float e, float n, float fz)
+{
+    return hz_finish(u, hz_polar_en(u, e, n, fz));
 }
 
 /* fi,fj: grid indices as float; fz: elevation as float (the reference feeds

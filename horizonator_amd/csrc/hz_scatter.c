@@ -114,12 +114,51 @@ static void expand_scalar(unsigned char* dst, const unsigned char* red, int n)
 
 /* what this machine's vector unit can do, found out once when the library is loaded (not lazily by whichever pool
  * thread comes first) */
-static int cpu_ssse3, cpu_avx2;
+static int cpu_ssse3, cpu_avx2, cpu_avx512;
 __attribute__((constructor)) static void hz_scatter_probe_cpu(void)
 {
     __builtin_cpu_init();
     cpu_ssse3 = __builtin_cpu_supports("ssse3") ? 1 : 0;
     cpu_avx2  = __builtin_cpu_supports("avx2") ? 1 : 0;
+    cpu_avx512 = (cpu_avx2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl")) ? 1 : 0;
+}
+
+/* 8 ranges at a time where the machine has 512-bit vectors (the double-precision square root is what the conversion
+ * costs: 8 per instruction instead of 4) */
+__attribute__((target("avx512f,avx512vl,avx2")))
+static inline __m256 ranges8_avx512(const uint32_t* w, __m256 vspan, __m256 vnear, __m256 vtan)
+{
+    const __m256i zi    = _mm256_srli_epi32(_mm256_loadu_si256((const __m256i*)w), 8);
+    const __m256  depth = _mm512_cvtpd_ps(_mm512_mul_pd(_mm512_cvtepi32_pd(zi), _mm512_set1_pd(1.0/16777215.0)));
+    const __m256  len   = _mm256_add_ps(_mm256_mul_ps(depth, vspan), vnear);
+    const __m256  zt    = _mm256_mul_ps(vtan, len);
+    const __m512d l = _mm512_cvtps_pd(len), z = _mm512_cvtps_pd(zt);
+    return _mm512_cvtpd_ps(_mm512_sqrt_pd(_mm512_add_pd(_mm512_mul_pd(l, l), _mm512_mul_pd(z, z))));
+}
+__attribute__((target("avx512f,avx512vl,avx2")))
+static void ranges_avx512(float* out, const uint32_t* packed, size_t n, float tan_row, float znear, float span)
+{
+    const __m256 vspan = _mm256_set1_ps(span), vnear = _mm256_set1_ps(znear), vtan = _mm256_set1_ps(tan_row);
+    size_t k = 0;
+    for(; k + 8 <= n; k += 8) _mm256_storeu_ps(out + k, ranges8_avx512(packed + k, vspan, vnear, vtan));
+    for(; k < n; k++)
+    {
+        const float depth = (float)((double)(packed[k] >> 8) * (1.0/16777215.0));
+        const float len   = depth * span + znear;
+        const float zt    = tan_row * len;
+        out[k] = (float)__builtin_sqrt((double)len*(double)len + (double)zt*(double)zt);
+    }
+}
+__attribute__((target("avx512f,avx512vl,avx2")))
+static void word32_ranges_avx512(const uint32_t* w, float* rng, float tan_row, float znear, float span)
+{
+    const __m256 vspan = _mm256_set1_ps(span), vnear = _mm256_set1_ps(znear), vtan = _mm256_set1_ps(tan_row);
+    const int nt = ((uintptr_t)rng & 31u) == 0;
+    for(int k=0; k<32; k+=8)
+    {
+        const __m256 r = ranges8_avx512(w + k, vspan, vnear, vtan);
+        if(nt) _mm256_stream_ps(rng + k, r); else _mm256_storeu_ps(rng + k, r);
+    }
 }
 
 /* ---- depth -> range on the host ------------------------------------------------------------------------------
@@ -160,8 +199,63 @@ static void ranges_avx2(float* out, const uint32_t* packed, size_t n, float tan_
 void hz_ranges_from_packed(float* out, const uint32_t* packed, size_t n, float tan_row, float znear, float zfar)
 {
     const float span = zfar - znear;
+    if(cpu_avx512) { ranges_avx512(out, packed, n, tan_row, znear, span); return; }
     if(cpu_avx2) { ranges_avx2(out, packed, n, tan_row, znear, span); return; }
     for(size_t k=0; k<n; k++) out[k] = range_of_packed(packed[k], tan_row, znear, span);
+}
+
+/* 32 terrain pixels in a row - below the horizon that is nearly every mask word - straight from the blob's words into the
+ * caller's buffers: ranges 4 at a time through the double-precision square root, depths by a shift, the shades packed to
+ * bytes and spread to B,G,R.  Streaming stores where the destination is aligned (a 16000-wide image: always): the sky was
+ * written the same way, nothing of these lines is in any cache, and an ordinary store would first read the line it is
+ * about to overwrite. */
+__attribute__((target("avx2")))
+static void word32_avx2(const uint32_t* w, float* rng, uint32_t* z24, unsigned char* bgr, float tan_row, float znear, float span)
+{
+    if(rng)
+    {
+        const __m256d inv = _mm256_set1_pd(1.0/16777215.0);
+        const __m128  vspan = _mm_set1_ps(span), vnear = _mm_set1_ps(znear), vtan = _mm_set1_ps(tan_row);
+        const int nt = ((uintptr_t)rng & 15u) == 0;
+        for(int k=0; k<32; k+=4)
+        {
+            const __m128i zi    = _mm_srli_epi32(_mm_loadu_si128((const __m128i*)(w + k)), 8);
+            const __m128  depth = _mm256_cvtpd_ps(_mm256_mul_pd(_mm256_cvtepi32_pd(zi), inv));
+            const __m128  len   = _mm_add_ps(_mm_mul_ps(depth, vspan), vnear);
+            const __m128  zt    = _mm_mul_ps(vtan, len);
+            const __m256d l = _mm256_cvtps_pd(len), z = _mm256_cvtps_pd(zt);
+            const __m128  r = _mm256_cvtpd_ps(_mm256_sqrt_pd(_mm256_add_pd(_mm256_mul_pd(l, l), _mm256_mul_pd(z, z))));
+            if(nt) _mm_stream_ps(rng + k, r); else _mm_storeu_ps(rng + k, r);
+        }
+    }
+    if(z24)
+    {
+        const int nt = ((uintptr_t)z24 & 15u) == 0;
+        for(int k=0; k<32; k+=4)
+        {
+            const __m128i zi = _mm_srli_epi32(_mm_loadu_si128((const __m128i*)(w + k)), 8);
+            if(nt) _mm_stream_si128((__m128i*)(z24 + k), zi); else _mm_storeu_si128((__m128i*)(z24 + k), zi);
+        }
+    }
+    if(bgr)
+    {
+        const __m128i lo8 = _mm_set1_epi32(0xFF);
+        const __m128i m0 = _mm_setr_epi8(-128,-128,0, -128,-128,1, -128,-128,2, -128,-128,3, -128,-128,4, -128);
+        const __m128i m1 = _mm_setr_epi8(-128,5, -128,-128,6, -128,-128,7, -128,-128,8, -128,-128,9, -128,-128);
+        const __m128i m2 = _mm_setr_epi8(10, -128,-128,11, -128,-128,12, -128,-128,13, -128,-128,14, -128,-128,15);
+        const int nt = ((uintptr_t)bgr & 15u) == 0;
+        for(int k=0; k<32; k+=16)
+        {
+            /* 16 shades as bytes (reference fragment.glsl:15-16: colour = (red,0,0)), then 48 bytes B,G,R = 0,0,shade */
+            const __m128i a = _mm_and_si128(_mm_loadu_si128((const __m128i*)(w + k)),      lo8), b = _mm_and_si128(_mm_loadu_si128((const __m128i*)(w + k + 4)),  lo8);
+            const __m128i c = _mm_and_si128(_mm_loadu_si128((const __m128i*)(w + k + 8)),  lo8), d = _mm_and_si128(_mm_loadu_si128((const __m128i*)(w + k + 12)), lo8);
+            const __m128i r = _mm_packus_epi16(_mm_packus_epi32(a, b), _mm_packus_epi32(c, d));
+            const __m128i o0 = _mm_shuffle_epi8(r, m0), o1 = _mm_shuffle_epi8(r, m1), o2 = _mm_shuffle_epi8(r, m2);
+            unsigned char* q = bgr + 3*k;
+            if(nt) { _mm_stream_si128((__m128i*)q, o0); _mm_stream_si128((__m128i*)(q + 16), o1); _mm_stream_si128((__m128i*)(q + 32), o2); }
+            else   { _mm_storeu_si128((__m128i*)q, o0); _mm_storeu_si128((__m128i*)(q + 16), o1); _mm_storeu_si128((__m128i*)(q + 32), o2); }
+        }
+    }
 }
 
 /* one blob into the caller's buffers.  Returns 0, or -1 if the blob does not describe pixels of dst's image - decided
@@ -200,6 +294,8 @@ int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
     int32_t*       index  = src_idx ? dst->index : NULL;
     if(ranges && !dst->tanel) return -1;
 
+    const float span = dst->zfar - dst->znear;
+    int streamed = 0;
     size_t k = 0;                                   /* terrain pixels of the blob so far */
     for(int r=0; r<HZ_BLOB_ROWS; r++)
     {
@@ -207,19 +303,10 @@ int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
         const size_t T = blob[2 + r];
         if(T == 0) continue;
         const uint32_t* m = mask + (size_t)r*mw;
-        /* the row's terrain pixels, converted where they lie together: ranges, depths, shades */
-        float         rng[HZ_BLOB_COLS];
-        uint32_t      zz[HZ_BLOB_COLS];
-        unsigned char shade[HZ_BLOB_COLS + 16];
-        const unsigned char* red = src_red ? src_red + k : shade;
-        if(src_pk)
-        {
-            const uint32_t* w = src_pk + k;
-            if(ranges) hz_ranges_from_packed(rng, w, T, dst->tanel[H-1 - yo], dst->znear, dst->zfar);
-            if(z24) for(size_t q=0; q<T; q++) zz[q] = w[q] >> 8;
-            if(bgr) for(size_t q=0; q<T; q++) shade[q] = (unsigned char)w[q];     /* reference fragment.glsl:15-16: colour = (red,0,0) */
-        }
-        const int32_t* idx = src_idx ? src_idx + k : NULL;
+        const uint32_t*      pk  = src_pk  ? src_pk  + k : NULL;
+        const int32_t*       idx = src_idx ? src_idx + k : NULL;
+        const unsigned char* red = src_red ? src_red + k : NULL;
+        const float tan_row = ranges ? dst->tanel[H-1 - yo] : 0.f;
         const size_t row = (size_t)yo*W + x0;
         size_t q = 0;                               /* terrain pixels of the row so far */
         for(int w=0; w<mw; w++)
@@ -230,14 +317,28 @@ int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
             if(bits == 0xFFFFFFFFu)
             {
                 /* 32 terrain pixels in a row: below the horizon that is nearly every word */
-                if(ranges) memcpy(ranges + o, rng + q, 128);
-                if(index)  memcpy(index + o,  idx + q, 128);
-                if(z24)    memcpy(z24 + o,    zz + q,  128);
-                if(bgr)
+                if(pk && cpu_avx2)
+                {
+                    if(ranges && cpu_avx512) word32_ranges_avx512(pk + q, ranges + o, tan_row, dst->znear, span);
+                    word32_avx2(pk + q, ranges && !cpu_avx512 ? ranges + o : NULL, z24 ? z24 + o : NULL, bgr ? bgr + 3*o : NULL, tan_row, dst->znear, span);
+                    streamed = 1;
+                }
+                else if(pk)
+                {
+                    for(int c=0; c<32; c++)
+                    {
+                        const uint32_t v = pk[q + c];
+                        if(ranges) ranges[o + c] = range_of_packed(v, tan_row, dst->znear, span);
+                        if(z24)    z24[o + c]    = v >> 8;
+                        if(bgr)    { unsigned char* b3 = bgr + 3*(o + c); b3[0] = 0; b3[1] = 0; b3[2] = (unsigned char)v; }
+                    }
+                }
+                else if(bgr)
                 {
                     if(cpu_ssse3) { expand16_ssse3(bgr + 3*o, red + q); expand16_ssse3(bgr + 3*o + 48, red + q + 16); }
                     else expand_scalar(bgr + 3*o, red + q, 32);
                 }
+                if(index) memcpy(index + o, idx + q, 128);
                 q += 32;
                 continue;
             }
@@ -245,14 +346,20 @@ int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
             {
                 const int c = __builtin_ctz(bits);
                 bits &= bits - 1;
-                if(ranges) ranges[o + c] = rng[q];
-                if(index)  index[o + c]  = idx[q];
-                if(z24)    z24[o + c]    = zz[q];
-                if(bgr)    { unsigned char* b3 = bgr + 3*(o + c); b3[0] = 0; b3[1] = 0; b3[2] = red[q]; }
+                if(pk)
+                {
+                    const uint32_t v = pk[q];
+                    if(ranges) ranges[o + c] = range_of_packed(v, tan_row, dst->znear, span);
+                    if(z24)    z24[o + c]    = v >> 8;
+                    if(bgr)    { unsigned char* b3 = bgr + 3*(o + c); b3[0] = 0; b3[1] = 0; b3[2] = (unsigned char)v; }
+                }
+                else if(bgr) { unsigned char* b3 = bgr + 3*(o + c); b3[0] = 0; b3[1] = 0; b3[2] = red[q]; }
+                if(index) index[o + c] = idx[q];
                 q++;
             }
         }
         k += T;
     }
+    if(streamed) _mm_sfence();
     return 0;
 }

@@ -42,6 +42,7 @@ struct hz_params_t
 #ifdef HZ_EXPERIMENTS
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
 #endif
+    const hz_polar_t* vcache;          /* k_march<.., VCACHE>: the view-independent half of every vertex's transform, [N][N] (hz_num.h: hz_polar_t; hz_draw.cpp: the vertex cache) */
     const uint32_t* hiz;               /* mr_flush, k_big: coarse depth (hz_k_hiz.h: level 1, level 2 behind it; second rounds of zoomed views), or NULL.
                                         * (One pointer, the rest follows from SW and H: every scalar register k_march holds costs it lane spills in its loop.) */
     float z_guard;                     /* hz_tri_depth_floor(): 1/500 + max(W,H)*2^-22                          */

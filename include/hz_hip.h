@@ -101,7 +101,7 @@ int  hz_hip_set_profiling(hz_dev_t* d, int on);
  * defaults below, overridden - for debugging only - by environment variables read once when it is created
  * (HZ_SERIAL, HZ_TWO_PASS=0|1, HZ_NEAR_CELLS, HZ_HIZ, HZ_TILES, HZ_TILE_LIST, HZ_ADAPT, HZ_ADAPT_HI, HZ_PRETEST_MARCH,
  * HZ_NO_WORKLIST, HZ_NO_FAST_MATH, HZ_RESOLVE_CLEARS, HZ_QUEUE_CAPACITY, HZ_HOST_DENSE, HZ_HOST_SECTORS,
- * HZ_HOST_TIMES); hz_hip_set_options() replaces them (queued work is waited for first; `serial` and
+ * HZ_HOST_TIMES, HZ_VERTEX_CACHE); hz_hip_set_options() replaces them (queued work is waited for first; `serial` and
  * `queue_capacity` only take effect at creation). */
 typedef struct
 {
@@ -121,6 +121,8 @@ typedef struct
     int host_dense;       /* 0    1: results for host memory travel whole (every pixel) instead of without the sky */
     int host_sectors;     /* 0    azimuth sectors a call that delivers into host memory is drawn and shipped in (draw of sector s+1 beside the transfer of sector s); 0: by image size */
     int host_times;       /* 0    1: such a call says on stderr where its time went */
+    int vertex_cache;     /* 1    0: every draw computes every vertex's transform in full; 1: from the second draw from a viewpoint on, the half of it that
+                           *      depends on the viewer's position alone (two atan, two square roots) is kept in HBM, 16 bytes per vertex, and read back */
 } hz_options_t;
 int  hz_hip_get_options(hz_dev_t* d, hz_options_t* o);
 int  hz_hip_set_options(hz_dev_t* d, const hz_options_t* o);
@@ -280,7 +282,8 @@ int   hz_hip_wait_for(hz_dev_t* d, void* stream);
 
 /* What the last draw of the context was (bench.py records it with every timing; tests assert on it): out[0] rounds
  * (1 / 2), out[1] its second round kept coarse depth (zoomed views, draws of a series), out[2] the first round's
- * reach in cells, out[3] only the strips behind the drawn columns were launched */
+ * reach in cells, out[3] only the strips behind the drawn columns were launched, out[4] its vertices came from the
+ * vertex cache (hz_options_t::vertex_cache).  out: room for 5 ints. */
 int  hz_hip_last_plan(hz_dev_t* d, int* out);
 /* What the first round's reach of zoomed views goes by (hz_kernels.hip, adapt): the latest second round whose queue
  * counters have reached the host - out[0] the reach of that draw's first round in cells, out[1] / out[2] the records and

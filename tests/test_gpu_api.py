@@ -382,9 +382,9 @@ def test_which_draws_keep_coarse_depth(monkeypatch):
     dev = lib.horizonator_amd_device(C.byref(h._ctx))
 
     def plan():
-        out = (C.c_int * 4)()
+        out = (C.c_int * 5)()
         assert lib.hz_hip_last_plan(dev, out) == 0
-        return [int(x) for x in out]
+        return [int(x) for x in out][:4]
 
     try:
         img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0")
@@ -445,5 +445,36 @@ def test_the_reach_of_a_zoomed_view_follows_the_draws_before(monkeypatch):
         assert len(set(reaches[2:])) == 1, reaches      # ... and kept, or given up for good
         h.set_view(-12, 8, zfar=200000.0)               # another view: short again
         assert draw()[0] == 384
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("fast_math", [1, 0])
+def test_vertex_cache_draws_the_same_bytes(fast_math):
+    """hz_options_t::vertex_cache: the first draw from a viewpoint computes every vertex, the second fills the cache (16 bytes
+    per vertex: the view-independent half of the transform, reference vertex.glsl:133-134, 154, 156), the draws after it read
+    it - whatever the azimuths, the aspect, the depth and colour extents; a move starts over.  Every one of them against the oracle."""
+    import horizonator_amd
+    R, W, H = 300, 1600, 400
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    m = od.mosaic()
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+    try:
+        h.set_options(fast_math=fast_math, vertex_cache=1)
+        used = []
+        for lat, lon in ((LAT, LON), (LAT + 0.031, LON - 0.017), (LAT, LON)):
+            for az0, az1, kw in ((-180.0, 180.0, dict(zfar=90000.0)), (-180.0, 180.0, dict(zfar=90000.0)), (10.0, 75.0, dict(zfar=30000.0)),
+                                 (-180.0, 180.0, dict(znear=50.0, zfar=20000.0, znear_color=2000.0, zfar_color=9000.0)), (100.0, 330.0, dict(zfar=90000.0))):
+                want = oracle.render(m, od.view(lat, lon, W, H, az0, az1, **kw), W, H)
+                got = h.render_full(az0, az1, lat=lat, lon=lon, **kw)
+                hzutil.assert_same_render(dict(bgr=got[0], ranges=got[1], index=got[2], z24=got[3]), want, f"{lat} {lon} {az0} {az1} {kw}")
+                used.append(h.last_plan()["vertex_cache"])
+        # per viewpoint: cold, fill + cached, cached, cached, cached
+        assert used == [False, True, True, True, True] * 3, used
+        h.set_options(vertex_cache=0)
+        got = h.render_full(-180.0, 180.0, lat=LAT, lon=LON, zfar=90000.0)
+        assert not h.last_plan()["vertex_cache"]
+        assert np.array_equal(got[3], oracle.render(m, od.view(LAT, LON, W, H, -180.0, 180.0, zfar=90000.0), W, H)["z24"])
     finally:
         h.close()

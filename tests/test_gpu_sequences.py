@@ -2,7 +2,7 @@
 device memory, with and without the index map, sectors that change, picks (which read the
 framebuffer after the conversion has cleared it: the draw is repeated), draws that are never
 converted, packed and sparse strips - interleaved in random order, with one or two rounds per
-draw forced at random.  What the streams, events, three framebuffers and their flags have to
+draw forced at random; the viewer moves or only turns (draws from the vertex cache between cold ones), options change.  What the streams, events, three framebuffers and their flags have to
 get right is the ORDER of things; every result is compared with the oracle's render of the view
 that was current when it was asked for."""
 import numpy as np
@@ -50,11 +50,21 @@ def test_random_call_sequences_against_the_oracle(seed, monkeypatch):
         view, c0, c1 = new_view(), 0, W
         h.set_view(view["a0"], view["a1"], lat=view["lat"], lon=view["lon"], zfar=view["zfar"])
         for step in range(40):
-            op = rng.choice(["view", "sector", "host", "full", "device", "device_ranges_only", "pick", "draw_only", "packed", "sparse"])
+            op = rng.choice(["view", "turn", "turn", "options", "sector", "host", "full", "device", "device_ranges_only", "pick", "draw_only", "packed", "sparse"])
             what = f"seed {seed} step {step} {op} sector [{c0},{c1}) {view}"
             if op == "view":
                 view = new_view()
                 h.set_view(view["a0"], view["a1"], lat=view["lat"], lon=view["lon"], zfar=view["zfar"])
+            elif op == "turn":
+                # the viewer stays where it is and looks elsewhere (other azimuths, another far clip): from the second draw from
+                # a viewpoint on, the view-independent half of the transform comes from the vertex cache (hz_draw.cpp)
+                t = new_view()
+                view = dict(view, a0=t["a0"], a1=t["a1"], zfar=t["zfar"])
+                h.set_view(view["a0"], view["a1"], zfar=view["zfar"])
+            elif op == "options":
+                # none of them may change a byte: the vertex cache off / on (a cold draw between cached ones), host results in
+                # 1..3 sectors
+                h.set_options(vertex_cache=int(rng.integers(0, 2)), host_sectors=int(rng.integers(0, 4)))
             elif op == "sector":
                 c0 = int(rng.integers(0, W - 8)) if rng.integers(0, 3) else 0
                 c1 = int(rng.integers(c0 + 4, W + 1)) if rng.integers(0, 3) else W

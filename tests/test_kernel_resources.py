@@ -42,9 +42,12 @@ def _one(kernels, fragment):
 
 def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     k = _kernels()
-    march = _one(k, "k_marchILb0ELb0E")             # the production instance (no per-wave counters, no coarse depth)
-    assert march["private_segment_fixed_size"] == 0, "k_march<false, false> must not use scratch memory"
-    zoomed = _one(k, "k_marchILb0ELb1E")            # ... of zoomed views (coarse depth, hz_k_hiz.h)
+    march = _one(k, "k_marchILb0ELb0ELb0E")         # the production instance (no per-wave counters, no coarse depth, every vertex computed)
+    assert march["private_segment_fixed_size"] == 0, "k_march<false, false, false> must not use scratch memory"
+    zoomed = _one(k, "k_marchILb0ELb1ELb0E")        # ... of zoomed views and series (coarse depth, hz_k_hiz.h)
+    for name in ("k_marchILb0ELb0ELb1E", "k_marchILb0ELb1ELb1E"):      # ... and those that read the vertex cache (round 5)
+        cached = _one(k, name)
+        assert cached["private_segment_fixed_size"] == 0 and cached["vgpr_count"] <= 104 and cached["group_segment_fixed_size"] <= 7168, (name, cached)
     assert zoomed["private_segment_fixed_size"] == 0 and zoomed["vgpr_count"] <= 112 and zoomed["group_segment_fixed_size"] <= 7168, zoomed
     # round 4: 104 registers at most - four marching waves then leave 96 of a SIMD's 512, i.e. TWO waves of k_big or of the
     # conversion (48 each) instead of one: the first round's k_big beside a marching kernel 650 -> 450 us, a render of a
@@ -53,11 +56,11 @@ def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     assert march["group_segment_fixed_size"] <= 7168
     left_vgprs = 512 - 4*((march["vgpr_count"] + 7)//8*8)
     left_lds = 160*1024 - 16*march["group_segment_fixed_size"]
-    for name in ("k_bigPy", "k_resolve4ILb1E", "k_resolve4ILb0E", "k_clipPKs"):
+    for name in ("k_bigPy", "k_resolve4ILb1E", "k_resolve4ILb0E", "k_clipILb0E", "k_clipILb1E"):
         other = _one(k, name)
         assert other["private_segment_fixed_size"] == 0, name
         # two waves of each beside the marching waves (k_clip: one, when a marching wave has gone)
         assert 2*((other["vgpr_count"] + 7)//8*8) <= left_vgprs or name.startswith("k_clip"), (name, other, left_vgprs)
         assert other["group_segment_fixed_size"] <= 5120 and 2*other["group_segment_fixed_size"] <= left_lds, (name, other)
     # k_clip is a 64-thread workgroup that is placed when one marching wave has gone: 96 registers at most
-    assert _one(k, "k_clipPKs")["vgpr_count"] <= 96
+    assert _one(k, "k_clipILb0E")["vgpr_count"] <= 96 and _one(k, "k_clipILb1E")["vgpr_count"] <= 96
