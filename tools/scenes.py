@@ -6,7 +6,7 @@ viewpoints), configs[4] - each drawn a few times back to back on one MI355X, out
     python tools/scenes.py [--scenes a,b,...] [--steps K] [--counters] > line.json
 
 bench.py runs the same scenes (small step counts) and puts them into its line under "scenes";
-tools/gpu_scenes.sh sweeps the library's heuristics (first round's reach, one / two rounds) over
+tools/history/gpu_scenes.sh swept the library's heuristics (first round's reach, one / two rounds) over
 them for profiles/r3_scenes.json.
 
 Per scene: ms per render, picoseconds per triangle of the mosaic (2 (N-1)^2 of them: what the reference
