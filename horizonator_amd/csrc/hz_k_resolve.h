@@ -230,30 +230,37 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, int SW, i
     unsigned char* segflag = touched + (size_t)glrow*seg_stride + (x0 >> HZ_SEG_LOG2);
     const bool wide = (SW & 3) == 0;
 
-    unsigned long long key[8][4];
+    /* The words of the tile are read twice - once for the terrain bits, once more (out of L2: 64 KB a workgroup) when they
+     * are written out - instead of being kept in 64 registers in between (round 4): with 96 registers a wave of this kernel
+     * found room on a SIMD only when a marching wave had left it, and a call that draws its panorama in sectors converts sector
+     * s while the marching kernel of sector s+1 fills the chip (profiles/r5_host_inclusive.txt: the conversions of the first
+     * sectors waited for the last draw).  Now two of its waves fit beside four marching waves, like k_resolve4's. */
+    auto load4 = [&](int it, unsigned long long key[4])
+    {
+        const int c = (it << 8) + 4*lane;
+        key[0] = key[1] = key[2] = key[3] = HZ_FB_CLEAR;
+        if(c + 3 < n && wide)
+        {
+            const ulonglong2 a = *(const ulonglong2*)(row + c), b = *(const ulonglong2*)(row + c + 2);
+            key[0] = a.x; key[1] = a.y; key[2] = b.x; key[3] = b.y;
+        }
+        else
+        {
+            #pragma unroll
+            for(int k=0; k<4; k++) if(c + k < n) key[k] = row[c + k];
+        }
+    };
     uint32_t nibs = 0, flagged = 0;
     #pragma unroll
     for(int it=0; it<8; it++)
-    {
-        key[it][0] = key[it][1] = key[it][2] = key[it][3] = HZ_FB_CLEAR;
         if(it < nit && have && segflag[it])                 /* (the same byte for the whole wave) */
         {
             flagged |= 1u << it;
-            const int c = (it << 8) + 4*lane;
-            if(c + 3 < n && wide)
-            {
-                const ulonglong2 a = *(const ulonglong2*)(row + c), b = *(const ulonglong2*)(row + c + 2);
-                key[it][0] = a.x; key[it][1] = a.y; key[it][2] = b.x; key[it][3] = b.y;
-            }
-            else
-            {
-                #pragma unroll
-                for(int k=0; k<4; k++) if(c + k < n) key[it][k] = row[c + k];
-            }
+            unsigned long long key[4];
+            load4(it, key);
             #pragma unroll
-            for(int k=0; k<4; k++) nibs |= ((uint32_t)(key[it][k] >> 40) != HZ_Z24_MAX ? 1u : 0u) << (4*it + k);
+            for(int k=0; k<4; k++) nibs |= ((uint32_t)(key[k] >> 40) != HZ_Z24_MAX ? 1u : 0u) << (4*it + k);
         }
-    }
     uint32_t count = (uint32_t)__popc(nibs);
     #pragma unroll
     for(int m=32; m>=1; m>>=1) count += __shfl_xor(count, m);
@@ -315,6 +322,25 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, int SW, i
                 v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
                 if((lane & 7) == 0 && (it << 8) + 4*lane < n) mask[(it << 3) + (lane >> 3)] = v;
                 if(!((flagged >> it) & 1u)) continue;
+                unsigned long long key[4];
+                load4(it, key);
+                if(CLEAR)
+                {
+                    /* glClear behind the last reader (reference horizonator-lib.c:896), as k_resolve4<true> */
+                    const int c = (it << 8) + 4*lane;
+                    if(c + 3 < n && wide)
+                    {
+                        const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
+                        if((key[0] & key[1]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c)     = ones;
+                        if((key[2] & key[3]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c + 2) = ones;
+                    }
+                    else
+                    {
+                        #pragma unroll
+                        for(int k=0; k<4; k++) if(c + k < n && key[k] != HZ_FB_CLEAR) row[c + k] = HZ_FB_CLEAR;
+                    }
+                    if(lane == 0) segflag[it] = 0;
+                }
                 unsigned long long b[4];
                 #pragma unroll
                 for(int k=0; k<4; k++) b[k] = __ballot((nib >> k) & 1u);
@@ -323,7 +349,7 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, int SW, i
                 for(int k=0; k<4; k++)
                     if((nib >> k) & 1u)
                     {
-                        const unsigned long long kk = key[it][k];
+                        const unsigned long long kk = key[k];
                         if(d_pk)  d_pk[q]  = ((uint32_t)(kk >> 40) << 8) | (uint32_t)(kk & 0xFFu);     /* z24 << 8 | red8 */
                         if(d_idx) d_idx[q] = (int32_t)(uint32_t)(kk >> 8);
                         if(d_red) d_red[q] = (unsigned char)(kk & 0xFFu);       /* reference fragment.glsl:15-16: colour = (red,0,0) */
@@ -332,25 +358,17 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, int SW, i
                 at += (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
             }
     }
-    if(CLEAR && have)
+    if(CLEAR && have && start == HP_NONE)
     {
-        /* glClear behind the last reader (reference horizonator-lib.c:896), as k_resolve4<true> */
+        /* (nothing was sent - a stale flag, or no room in the stream, which the host reports: the framebuffer is left as
+         * glClear would leave it all the same) */
         #pragma unroll
         for(int it=0; it<8; it++)
             if((flagged >> it) & 1u)
             {
                 const int c = (it << 8) + 4*lane;
-                if(c + 3 < n && wide)
-                {
-                    const ulonglong2 ones = { HZ_FB_CLEAR, HZ_FB_CLEAR };
-                    if((key[it][0] & key[it][1]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c)     = ones;
-                    if((key[it][2] & key[it][3]) != HZ_FB_CLEAR) *(ulonglong2*)(row + c + 2) = ones;
-                }
-                else
-                {
-                    #pragma unroll
-                    for(int k=0; k<4; k++) if(c + k < n && key[it][k] != HZ_FB_CLEAR) row[c + k] = HZ_FB_CLEAR;
-                }
+                #pragma unroll
+                for(int k=0; k<4; k++) if(c + k < n && row[c + k] != HZ_FB_CLEAR) row[c + k] = HZ_FB_CLEAR;
                 if(lane == 0) segflag[it] = 0;
             }
     }
