@@ -300,8 +300,9 @@ def main():
         return S["ex"]
 
     c_loop = args.loop == "c"
-    if c_loop and not (multi and sparse and args.backend == "nccl"):
-        raise SystemExit("--loop c drives the RCCL exchange of sparse strips: N > 1 (or --exchange-anyway), --backend nccl, --wire sparse")
+    if c_loop and not (multi and sparse):
+        raise SystemExit("--loop c drives the exchange of sparse strips: N > 1 (or --exchange-anyway), --wire sparse")
+    c_transport = "rccl" if args.backend == "nccl" else "gloo"     # (gloo: diagnostics - ranks that share a GPU, through host memory)
 
     def c_series():
         """--loop c: the communicator, strip buffers and bins of horizonator_rccl_render_series for this layout and scene;
@@ -314,7 +315,7 @@ def main():
                 words += int(S["d_pk"][0][0].item())
             from horizonator_amd.sharding import RcclSeries
             cap = agree_on_capacity(words, S["HDR"], S["FULL"], cdev)
-            S["rs"] = RcclSeries(h, S["layout"], H, cap, d_img.data_ptr(), d_rng.data_ptr(), S["rotate"], dev, nslots=NBUF)
+            S["rs"] = RcclSeries(h, S["layout"], H, cap, d_img.data_ptr(), d_rng.data_ptr(), S["rotate"], dev, nslots=NBUF, transport=c_transport)
             state["wire_words"] = S["rs"].words
         return S["rs"]
 
@@ -330,7 +331,7 @@ def main():
             if not int(t.item()):
                 drop_series()
                 from horizonator_amd.sharding import RcclSeries
-                S["rs"] = RcclSeries(h, S["layout"], H, S["FULL"], d_img.data_ptr(), d_rng.data_ptr(), S["rotate"], dev, nslots=NBUF)
+                S["rs"] = RcclSeries(h, S["layout"], H, S["FULL"], d_img.data_ptr(), d_rng.data_ptr(), S["rotate"], dev, nslots=NBUF, transport=c_transport)
                 state["wire_words"] = S["rs"].words
                 S["rs"].run(n)
         state["converted"] += sum(1 for i in range(first, first + n) if (i % world if S["rotate"] else 0) == rank)

@@ -68,7 +68,7 @@ static int series_convert(const horizonator_context_t* ctx, const horizonator_rc
 int horizonator_rccl_render_series(const horizonator_context_t* ctx, void* comm, const horizonator_rccl_series_t* s,
                                    long first, int count, int check_fit)
 {
-    if(ctx == NULL || comm == NULL || s == NULL || s->world < 1 || s->rank < 0 || s->rank >= s->world || s->nslots < 1 || s->nslots > 4 ||
+    if(ctx == NULL || s == NULL || (comm == NULL && s->exchange == NULL) || s->world < 1 || s->rank < 0 || s->rank >= s->world || s->nslots < 1 || s->nslots > 4 ||
        s->d_strips == NULL || s->col0 == NULL || s->ncols == NULL || first < 0 || count < 0 || s->words < s->header_words + 1)
     {
         MSG("bad arguments");
@@ -102,8 +102,14 @@ int horizonator_rccl_render_series(const horizonator_context_t* ctx, void* comm,
         else if(!horizonator_amd_waits_for_stream(ctx, s->stream)) { rc = -1; break; }     /* whatever the caller's stream still does with the slot */
         if(draws && !horizonator_amd_render_sparse(ctx, s->d_strips[slot], s->mask_stride)) { rc = -1; break; }
         /* (queued behind the strip's conversion, and behind the conversion that last read this slot's bins) */
-        if(horizonator_rccl_gather_strips(ctx, comm, s->rank, s->world, series_root(s, i), s->d_strips[slot], s->words,
-                                          s->rank == series_root(s, i) ? s->d_bins + (size_t)slot*s->world : NULL, s->stream) != 0) { rc = -1; break; }
+        uint32_t* const* bins = s->rank == series_root(s, i) ? s->d_bins + (size_t)slot*s->world : NULL;
+        if(s->exchange != NULL)
+        {
+            /* the caller's transport: behind the strip's conversion, like the RCCL gather */
+            if(!horizonator_amd_stream_waits_for_outputs(ctx, s->stream)) { rc = -1; break; }
+            if(s->exchange(s->exchange_user, series_root(s, i), s->d_strips[slot], s->words, bins, s->stream) != 0) { MSG("the caller's exchange failed"); rc = -1; break; }
+        }
+        else if(horizonator_rccl_gather_strips(ctx, comm, s->rank, s->world, series_root(s, i), s->d_strips[slot], s->words, bins, s->stream) != 0) { rc = -1; break; }
         if(hipEventRecord(exchanged[slot], (hipStream_t)s->stream) != hipSuccess) { MSG("hipEventRecord failed"); rc = -1; break; }
         last_slot = slot;
     }

@@ -405,7 +405,11 @@ class _Series(C.Structure):
                 ("d_strips", C.POINTER(C.c_void_p)), ("d_bins", C.POINTER(C.c_void_p)),
                 ("words", C.c_size_t), ("header_words", C.c_size_t), ("mask_stride", C.c_int),
                 ("col0", C.POINTER(C.c_int)), ("ncols", C.POINTER(C.c_int)),
-                ("d_image", C.c_void_p), ("d_ranges", C.c_void_p), ("stream", C.c_void_p)]
+                ("d_image", C.c_void_p), ("d_ranges", C.c_void_p), ("stream", C.c_void_p),
+                ("exchange", C.c_void_p), ("exchange_user", C.c_void_p)]
+
+
+_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p)
 
 
 class RcclSeries:
@@ -419,11 +423,14 @@ class RcclSeries:
         rs.close()
     """
 
-    def __init__(self, h, layout, height, words, d_image, d_ranges, rotate, device, nslots=2, group=None):
+    def __init__(self, h, layout, height, words, d_image, d_ranges, rotate, device, nslots=2, group=None, transport="rccl"):
+        """transport "gloo": the strips travel through host memory over torch.distributed's process group instead of over
+        RCCL (horizonator_rccl_series_t::exchange) - slow, but ranks that SHARE a GPU can run it, which RCCL refuses: the
+        C loop's slot and rotation logic with world > 1 on a box with one GPU (tests/test_gpu_bench_multi.py)"""
         import os
         from . import _lib
         self.world, self.rank = _world_and_rank(group)
-        self.h, self.device = h, device
+        self.h, self.device, self.group = h, device, group
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         self._rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
         _lib.load()
@@ -432,17 +439,21 @@ class RcclSeries:
         self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
         self._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         self._hz.horizonator_rccl_render_series.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Series), C.c_long, C.c_int, C.c_int]
-        uid = _NcclUniqueId()
-        if self.rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId() failed")
-        if self.world > 1:
-            box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]      # (the raw 128 bytes: .internal as bytes would stop at a NUL)
-            dist.broadcast_object_list(box, src=0, group=group)
-            C.memmove(C.addressof(uid), box[0], 128)
         self.comm = C.c_void_p()
         torch.cuda.set_device(device)
-        if self._rccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank) != 0:
-            raise RuntimeError("ncclCommInitRank() failed")
+        if transport == "rccl":
+            uid = _NcclUniqueId()
+            if self.rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise RuntimeError("ncclGetUniqueId() failed")
+            if self.world > 1:
+                box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]      # (the raw 128 bytes: .internal as bytes would stop at a NUL)
+                dist.broadcast_object_list(box, src=0, group=group)
+                C.memmove(C.addressof(uid), box[0], 128)
+            if self._rccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank) != 0:
+                raise RuntimeError("ncclCommInitRank() failed")
+        elif transport != "gloo":
+            raise ValueError("transport: rccl or gloo")
+        self.transport = transport
         self.nslots, self.rotate = int(nslots), bool(rotate)
         widest = max(c1 - c0 for c0, c1 in layout)
         self.mask_stride = sparse_mask_stride(widest)
@@ -461,8 +472,32 @@ class RcclSeries:
         self._s = _Series(self.rank, self.world, int(self.rotate), self.nslots,
                           C.cast(self._strips, C.POINTER(C.c_void_p)), C.cast(self._bins, C.POINTER(C.c_void_p)) if gathers else None,
                           self.words, self.hdr, self.mask_stride, C.cast(self._col0, C.POINTER(C.c_int)), C.cast(self._ncols, C.POINTER(C.c_int)),
-                          int(d_image) if d_image else None, int(d_ranges) if d_ranges else None, self.stream.cuda_stream)
+                          int(d_image) if d_image else None, int(d_ranges) if d_ranges else None, self.stream.cuda_stream, None, None)
+        if transport == "gloo":
+            self._by_ptr = {t.data_ptr(): t for t in self.strips + self.bins}
+            self._cb = _EXCHANGE_FN(self._gloo_exchange)            # (kept alive with the object)
+            self._s.exchange = C.cast(self._cb, C.c_void_p)
         self.next = 0
+
+    def _gloo_exchange(self, user, root, d_send, words, d_recv, stream):
+        """horizonator_rccl_series_t::exchange over the torch.distributed group (gloo), through host memory: complete when it returns"""
+        try:
+            self.stream.synchronize()                               # the strip is complete (the C loop ordered the stream behind its conversion)
+            mine = self._by_ptr[d_send][:words].cpu()
+            if self.rank == root:
+                parts = [torch.empty(words, dtype=torch.int32) for _ in range(self.world)]
+                dist.gather(mine, parts, dst=root, group=self.group)
+                with torch.cuda.stream(self.stream):
+                    for r, p in enumerate(parts):
+                        self._by_ptr[d_recv[r]][:words].copy_(p.to(self.device))
+                self.stream.synchronize()
+            else:
+                dist.gather(mine, None, dst=root, group=self.group)
+            return 0
+        except Exception as e:                                      # (an exception must not unwind through the C frames)
+            import sys
+            print("RcclSeries gloo exchange:", repr(e), file=sys.stderr)
+            return -1
 
     def run(self, count, check_fit=False):
         """queue `count` more panoramas; with check_fit: wait for the last strip and return True if it fit the agreed words"""
@@ -481,6 +516,8 @@ class RcclSeries:
             self.sync()
             self._rccl.ncclCommDestroy(self.comm)
             self.comm = C.c_void_p()
+        elif self.transport == "gloo":
+            self.sync()
 
 
 # ---- a batch of viewpoints (BASELINE.json configs[3]) --------------------------

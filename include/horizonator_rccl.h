@@ -78,6 +78,14 @@ typedef struct
     void* d_image;
     float* d_ranges;
     void* stream;
+    /* NULL: the strips travel over RCCL (`comm`).  Otherwise the exchange of one panorama is the caller's: called once per
+     * panorama in place of horizonator_rccl_gather_strips() with the arguments that would have got (`comm` may then be NULL) -
+     * every rank sends `words` from d_send, rank `root` receives rank r's into d_recv[r] (NULL on the other ranks) - and must
+     * leave the transfer ordered on `stream` (queued on it, or complete when it returns).  0 on success.  What it is for: a
+     * transport other than RCCL - tests/test_gpu_rccl.py runs the series with two ranks that share one GPU (which RCCL
+     * refuses) over torch.distributed's gloo backend, so that the slot and rotation logic meets a second rank. */
+    int (*exchange)(void* user, int root, const uint32_t* d_send, size_t words, uint32_t* const* d_recv, void* stream);
+    void* exchange_user;
 } horizonator_rccl_series_t;
 int horizonator_rccl_render_series(const horizonator_context_t* ctx, void* comm, const horizonator_rccl_series_t* s,
                                    long first, int count, int check_fit);

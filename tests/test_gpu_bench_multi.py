@@ -55,3 +55,15 @@ def test_the_series_driven_from_c_with_one_rank():
     line = _bench("--gpus", "1", "--exchange-anyway", "--loop", "c")
     assert line["gathered_panorama_equals_single_gpu_render"] is True
     assert line["loop"]["host_us_per_panorama"] > 0
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_the_series_driven_from_c_with_ranks_sharing_one_gpu(ranks):
+    """horizonator_rccl_render_series with world > 1: RCCL refuses ranks that share a GPU, so the strips travel over gloo
+    (horizonator_rccl_series_t::exchange) - the C loop's slots, its rotation of the gathering rank and its ordering against
+    the contexts' streams meet a second and a third rank all the same; both gather modes against the single-GPU render"""
+    line = _bench("--gpus", str(ranks), "--backend", "gloo", "--same-gpu", "--loop", "c")
+    assert line["n_gpus"] == ranks
+    assert line["gathered_panorama_equals_single_gpu_render"] is True
+    assert line["gather_root0"]["gathered_panorama_equals_single_gpu_render"] is True
+    assert line["loop"]["driver"].startswith("horizonator_rccl_render_series")
