@@ -548,11 +548,12 @@ def main():
     same_viewpoint = None
     if world == 1 and not args.no_extra and not args.exchange_anyway and args.raster != 1:
         h.set_options(vertex_cache=1)
-        dt_c, _ = timed(args.zfar, args.steps, max(args.warmup, 3))
+        dt_c, kern_c = timed(args.zfar, args.steps, max(args.warmup, 3))
         plan_c = h.last_plan()
         img_c = d_img.cpu().numpy()
         same_viewpoint = {"ms_per_step": dt_c / args.steps * 1e3, "value": W * H * args.steps / dt_c / 1e6, "unit": "Mpix/s",
                           "from_vertex_cache": bool(plan_c.get("vertex_cache")),
+                          "kernel_ms": (kern_c[-1]["raster_ms"] if kern_c else None),
                           "equals_the_cold_render": bool(last is not None and np.array_equal(img_c, last["img"]) and np.array_equal(d_rng.cpu().numpy(), last["rng"])),
                           "what": "the same K renders with the library's default: the viewer has not moved, so from the second draw on the "
                                   "view-independent half of every vertex's transform (two atan, two square roots; 16 B per vertex, %.2f GB) "
