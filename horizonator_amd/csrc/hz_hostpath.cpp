@@ -238,17 +238,12 @@ struct hz_hostjob
     std::vector<float>* tanel;          /* the job's own copy: the scatter tasks read it */
     hz_copy_pool::batch_t filled;
     /* device side */
-    uint32_t*     d_hs;                 /* the streams of blobs of the job's sectors: in HBM (the copy engine fetches them) ... */
+    uint32_t*     d_hs;                 /* the streams of blobs of the job's sectors */
     size_t        hs_capacity;          /* words */
-    uint32_t*     h_hs;                 /* ... or in pinned host memory, written by k_pack_host itself over PCIe (zero_copy) */
-    uint32_t*     h_hs_dev;             /* (the device's pointer to it) */
-    size_t        h_capacity;
-    bool          zero_copy;
     unsigned int* d_cursor;             /* 4 words per sector: [0] words in use, [1] blobs, [2] nonzero: a blob did not fit */
     unsigned int* h_cursor;             /* the same in pinned memory */
     hipEvent_t    ev_known[HZ_HOST_MAX_SECTORS];    /* sector s's cursor words have reached h_cursor */
     std::chrono::steady_clock::time_point t_begin;
-    double t_sky_queued, t_queued[HZ_HOST_MAX_SECTORS];     /* host_times: ms since t_begin when the sky tasks / sector s's work had been queued */
 };
 
 struct hz_hoststate
@@ -307,7 +302,6 @@ void hz_hostpath_destroy(hz_dev_t* d)
     {
         hz_hostjob& jb = h->job[j];
         (void)hipFree(jb.d_hs); (void)hipFree(jb.d_cursor);
-        if(jb.h_hs) (void)hipHostFree(jb.h_hs);
         if(jb.h_cursor) (void)hipHostFree(jb.h_cursor);
         for(int s=0; s<HZ_HOST_MAX_SECTORS; s++) if(jb.ev_known[s]) (void)hipEventDestroy(jb.ev_known[s]);
         delete jb.band_left; delete jb.tanel;
@@ -380,23 +374,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         if(jb.cap[s] >= ((size_t)1 << 32)) return -2;              /* (a stream is addressed in 32 bits) */
         jb.off[s] = need; need += jb.cap[s];
     }
-    jb.zero_copy = getenv("HZ_HOST_ZERO_COPY") == NULL || atoi(getenv("HZ_HOST_ZERO_COPY")) != 0;
-    if(jb.zero_copy && need > jb.h_capacity)
-    {
-        HZ_CHECK(hz_sync_all(d));
-        if(jb.h_hs) (void)hipHostFree(jb.h_hs);
-        jb.h_hs = jb.h_hs_dev = NULL; jb.h_capacity = 0;
-        if(hipHostMalloc((void**)&jb.h_hs, need*sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-           hipHostGetDevicePointer((void**)&jb.h_hs_dev, jb.h_hs, 0) != hipSuccess)
-        {
-            (void)hipGetLastError();
-            if(jb.h_hs) (void)hipHostFree(jb.h_hs);
-            jb.h_hs = jb.h_hs_dev = NULL;
-            jb.zero_copy = false;                       /* (no pinned memory for it: through HBM and the copy engine) */
-        }
-        else jb.h_capacity = need;
-    }
-    if(!jb.zero_copy && need > jb.hs_capacity)
+    if(need > jb.hs_capacity)
     {
         HZ_CHECK(hz_sync_all(d));
         (void)hipFree(jb.d_hs); jb.d_hs = NULL; jb.hs_capacity = 0;
@@ -450,7 +428,6 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
             }
         }
     pool->push_tasks(&jb.filled, tasks);
-    jb.t_sky_queued = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
     jb.active = true;
     h->next_begin++;
     /* from here on the pool's tasks name the job and the caller's buffers: whatever fails below, hz_hip_host_end() (or
@@ -475,7 +452,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         if(hz_rstream_after_draw(d) != 0) { rc = -1; break; }
         const int SW = d->col1 - d->col0;
         if(prof && s == jb.nsec-1) HZ_TRY(hipEventRecord(d->ev[4], d->rstream));
-        hz_hostpack_t hp = { (jb.zero_copy ? jb.h_hs_dev : jb.d_hs) + jb.off[s], jb.d_cursor + 4*s, (unsigned int)jb.cap[s], (unsigned int)(HZ_STAGE_BYTES/4), flags };
+        hz_hostpack_t hp = { jb.d_hs + jb.off[s], jb.d_cursor + 4*s, (unsigned int)jb.cap[s], (unsigned int)(HZ_STAGE_BYTES/4), flags };
         const dim3 grid((unsigned)((SW + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), (unsigned)((H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS));
         unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];
         if(err == hipSuccess)
@@ -488,7 +465,6 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         if(prof && s == jb.nsec-1) { HZ_TRY(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
         HZ_TRY(hipMemcpyAsync(jb.h_cursor + 4*s, jb.d_cursor + 4*s, 4*sizeof(unsigned int), hipMemcpyDeviceToHost, d->rstream));
         HZ_TRY(hipEventRecord(jb.ev_known[s], d->rstream));
-        jb.t_queued[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
     }
     #undef HZ_TRY
     d->col0 = user_col0; d->col1 = user_col1;
@@ -570,7 +546,6 @@ static int host_end(hz_dev_t* d)
         if(k == chunks.size()) { if(known == jb.nsec || !learn(true)) break; }
         if(err != hipSuccess || rc != 0) break;
         /* keep the copy engines up to HZ_STAGE_SLOTS - 2 chunks ahead of the chunk the host threads get next */
-        if(jb.zero_copy) issued = chunks.size();            /* (every known chunk is in host memory already: k_pack_host put it there) */
         for(; issued < chunks.size() && issued < k + HZ_STAGE_SLOTS - 2 && err == hipSuccess; issued++)
         {
             const int slot = (int)(issued % HZ_STAGE_SLOTS);
@@ -582,17 +557,14 @@ static int host_end(hz_dev_t* d)
         }
         if(err != hipSuccess || k >= issued) continue;
         const int slot = (int)(k % HZ_STAGE_SLOTS);
-        const chunk_t c = chunks[k];
-        if(!jb.zero_copy)
-        {
-            const double t_w0 = since();
-            HZ_TRY(hipEventSynchronize(h->ev_stage[slot]));
-            if(err != hipSuccess) break;
-            t_waited += since() - t_w0;
-        }
+        const double t_w0 = since();
+        HZ_TRY(hipEventSynchronize(h->ev_stage[slot]));
+        if(err != hipSuccess) break;
+        t_waited += since() - t_w0;
         if(k == 0) t_first = since();
         t_arrived = since();
-        const uint32_t* chunk = jb.zero_copy ? jb.h_hs + jb.off[c.sector] + c.w0 : (const uint32_t*)h->h_stage[slot];
+        const chunk_t c = chunks[k];
+        const uint32_t* chunk = (const uint32_t*)h->h_stage[slot];
         size_t* const o = offs[c.sector].data() + noffs[c.sector];
         const size_t room = offs[c.sector].size() - noffs[c.sector];
         const size_t nb = hz_blob_walk(chunk, c.nw, first[c.sector], o, room, &first[c.sector]);
@@ -617,12 +589,9 @@ static int host_end(hz_dev_t* d)
     pool->wait(&jb.filled);
     if(d->env.host_times)
     {
-        fprintf(stderr, "hz_hip host path: %.1f MB of blobs (%zu) in %d sector(s) for %.1f MB of results%s; ms since the call began: sky tasks queued %.2f, sectors queued",
+        fprintf(stderr, "hz_hip host path: %.1f MB of blobs (%zu) in %d sector(s) for %.1f MB of results; ms since the call began: end() entered %.2f, sectors known",
                 4e-6*(double)total_words, total_blobs, jb.nsec,
-                1e-6*(double)jb.out_w*d->H*((jb.sc.dst.bgr ? 3 : 0) + (jb.sc.dst.ranges ? 4 : 0) + (jb.sc.dst.index ? 4 : 0) + (jb.sc.dst.z24 ? 4 : 0)),
-                jb.zero_copy ? ", written into host memory by the kernel" : ", through HBM and the copy engine", jb.t_sky_queued);
-        for(int s=0; s<jb.nsec; s++) fprintf(stderr, " %.2f", jb.t_queued[s]);
-        fprintf(stderr, ", end() entered %.2f, sectors known", t_enter);
+                1e-6*(double)jb.out_w*d->H*((jb.sc.dst.bgr ? 3 : 0) + (jb.sc.dst.ranges ? 4 : 0) + (jb.sc.dst.index ? 4 : 0) + (jb.sc.dst.z24 ? 4 : 0)), t_enter);
         for(int s=0; s<jb.nsec; s++) fprintf(stderr, " %.2f", t_known[s]);
         fprintf(stderr, ", first chunk here %.2f, last chunk here %.2f (%.2f spent waiting for chunks), blobs in place %.2f, sky and everything %.2f\n",
                 t_first, t_arrived, t_waited, t_scattered, since());
