@@ -244,12 +244,13 @@ struct hz_hostjob
     unsigned int* h_cursor;             /* the same in pinned memory */
     hipEvent_t    ev_known[HZ_HOST_MAX_SECTORS];    /* sector s's cursor words have reached h_cursor */
     std::chrono::steady_clock::time_point t_begin;
+    double t_sky_queued, t_queued[HZ_HOST_MAX_SECTORS];     /* host_times: ms since t_begin when the sky tasks / sector s's work had been queued */
 };
 
 struct hz_hoststate
 {
     hipStream_t    cstream[HZ_COPY_STREAMS];
-    unsigned char* h_stage[HZ_STAGE_SLOTS];
+    unsigned char* h_stage[HZ_STAGE_SLOTS];     /* slot k of ONE pinned allocation (h_stage[0]): a copy may span consecutive slots */
     hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
     hipEvent_t     ev_band[HZ_HOST_BANDS];
     hz_hostjob     job[HZ_HOST_JOBS];
@@ -267,11 +268,18 @@ static int ensure_host(hz_dev_t* d)
     hz_hoststate* h = new hz_hoststate();
     memset((void*)h, 0, sizeof(*h));
     d->host = h;
-    for(int k=0; k<HZ_COPY_STREAMS; k++) HZ_CHECK(hipStreamCreateWithFlags(&h->cstream[k], hipStreamNonBlocking));
+    /* The copies get streams of the highest priority: HIP deals its streams onto a handful of hardware queues, per
+     * priority level, and a queue is worked through in order - on a queue shared with one of the context's draw streams the
+     * copies of sector 0 sat behind the marching kernels of sectors 1 to 3, which had been queued before the copies could be
+     * (round 5: first chunk 0.75 ms after its sector was known, profiles/r5_host_inclusive.txt). */
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for(int k=0; k<HZ_COPY_STREAMS; k++) HZ_CHECK(hipStreamCreateWithPriority(&h->cstream[k], hipStreamNonBlocking, prio_hi));
     for(int k=0; k<HZ_HOST_BANDS; k++)   HZ_CHECK(hipEventCreateWithFlags(&h->ev_band[k], hipEventDisableTiming));
+    HZ_CHECK(hipHostMalloc((void**)&h->h_stage[0], (size_t)HZ_STAGE_SLOTS*HZ_STAGE_BYTES, hipHostMallocDefault));
     for(int k=0; k<HZ_STAGE_SLOTS; k++)
     {
-        HZ_CHECK(hipHostMalloc((void**)&h->h_stage[k], HZ_STAGE_BYTES, hipHostMallocDefault));
+        h->h_stage[k] = h->h_stage[0] + (size_t)k*HZ_STAGE_BYTES;
         HZ_CHECK(hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
     }
     for(int j=0; j<HZ_HOST_JOBS; j++)
@@ -291,11 +299,8 @@ void hz_hostpath_destroy(hz_dev_t* d)
     hz_hoststate* h = d->host;
     if(!h) return;
     for(int k=0; k<HZ_COPY_STREAMS; k++) if(h->cstream[k]) (void)hipStreamSynchronize(h->cstream[k]);
-    for(int k=0; k<HZ_STAGE_SLOTS; k++)
-    {
-        if(h->h_stage[k])  (void)hipHostFree(h->h_stage[k]);
-        if(h->ev_stage[k]) (void)hipEventDestroy(h->ev_stage[k]);
-    }
+    if(h->h_stage[0]) (void)hipHostFree(h->h_stage[0]);
+    for(int k=0; k<HZ_STAGE_SLOTS; k++) if(h->ev_stage[k]) (void)hipEventDestroy(h->ev_stage[k]);
     for(int k=0; k<HZ_HOST_BANDS; k++)   if(h->ev_band[k]) (void)hipEventDestroy(h->ev_band[k]);
     for(int k=0; k<HZ_COPY_STREAMS; k++) if(h->cstream[k]) (void)hipStreamDestroy(h->cstream[k]);
     for(int j=0; j<HZ_HOST_JOBS; j++)
@@ -428,6 +433,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
             }
         }
     pool->push_tasks(&jb.filled, tasks);
+    jb.t_sky_queued = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
     jb.active = true;
     h->next_begin++;
     /* from here on the pool's tasks name the job and the caller's buffers: whatever fails below, hz_hip_host_end() (or
@@ -465,6 +471,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         if(prof && s == jb.nsec-1) { HZ_TRY(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
         HZ_TRY(hipMemcpyAsync(jb.h_cursor + 4*s, jb.d_cursor + 4*s, 4*sizeof(unsigned int), hipMemcpyDeviceToHost, d->rstream));
         HZ_TRY(hipEventRecord(jb.ev_known[s], d->rstream));
+        jb.t_queued[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
     }
     #undef HZ_TRY
     d->col0 = user_col0; d->col1 = user_col1;
@@ -501,7 +508,9 @@ static int host_end(hz_dev_t* d)
     const double t_enter = since();
     double t_known[HZ_HOST_MAX_SECTORS] = { 0 }, t_first = 0, t_arrived = 0, t_waited = 0;
 
-    struct chunk_t { int sector; size_t w0, nw; };
+    struct chunk_t { int sector; size_t w0, nw; int ev; };          /* ev: the staging slot whose event says the chunk has arrived (the first slot of its copy) */
+    size_t ncopies = 0;
+    int run_of[HZ_HOST_MAX_SECTORS] = { 0 };                        /* copies issued for sector s so far */
     std::deque<chunk_t> chunks;                         /* (grows as the sectors' lengths become known) */
     std::deque<hz_copy_pool::batch_t> done;             /* one per chunk: its scatter tasks (references stay valid as it grows) */
     std::vector<std::vector<size_t>> offs(jb.nsec);     /* where the blobs of sector s start, chunk after chunk */
@@ -534,7 +543,7 @@ static int host_end(hz_dev_t* d)
         total_words += c[0]; total_blobs += c[1];
         for(size_t w0 = 0; w0 < c[0]; w0 += chunk_words)
         {
-            chunks.push_back({ s, w0, w0 + chunk_words < c[0] ? chunk_words : c[0] - w0 });
+            chunks.push_back({ s, w0, w0 + chunk_words < c[0] ? chunk_words : c[0] - w0, 0 });
             done.push_back({ 0 });
         }
         return true;
@@ -545,25 +554,39 @@ static int host_end(hz_dev_t* d)
         while(learn(false)) {}
         if(k == chunks.size()) { if(known == jb.nsec || !learn(true)) break; }
         if(err != hipSuccess || rc != 0) break;
-        /* keep the copy engines up to HZ_STAGE_SLOTS - 2 chunks ahead of the chunk the host threads get next */
-        for(; issued < chunks.size() && issued < k + HZ_STAGE_SLOTS - 2 && err == hipSuccess; issued++)
+        /* keep the copy engine up to HZ_STAGE_SLOTS - 4 chunks ahead of the chunk the host threads get next.  One copy moves
+         * up to four consecutive chunks of a sector (consecutive staging slots: the ring is one allocation): a copy costs the
+         * engine ~22 us on top of its bytes - 4 MB copies ran at 46 GB/s where 16 MB ones reach 57 (tools/zero_copy.hip) - ,
+         * but what a copy holds can only be scattered when all of it has arrived: a sector's first copy is one chunk, its
+         * second two, then four. */
+        while(issued < chunks.size() && issued < k + HZ_STAGE_SLOTS - 4 && err == hipSuccess)
         {
-            const int slot = (int)(issued % HZ_STAGE_SLOTS);
-            if(issued >= HZ_STAGE_SLOTS) pool->wait(&done[issued - HZ_STAGE_SLOTS]);        /* the slot's previous chunk has been scattered */
-            hipStream_t cs = h->cstream[issued % HZ_COPY_STREAMS];
+            const int slot = (int)(issued % HZ_STAGE_SLOTS), sector = chunks[issued].sector;
+            size_t g = run_of[sector] == 0 ? 1 : run_of[sector] == 1 ? 2 : 4;
+            if(g > (size_t)(HZ_STAGE_SLOTS - slot)) g = HZ_STAGE_SLOTS - slot;                      /* (no copy wraps round the ring) */
+            while(g > 1 && (issued + g > chunks.size() || issued + g > k + HZ_STAGE_SLOTS - 4 || chunks[issued + g-1].sector != sector)) g--;
+            size_t nw = 0;
+            for(size_t i=0; i<g; i++)
+            {
+                if(issued + i >= HZ_STAGE_SLOTS) pool->wait(&done[issued + i - HZ_STAGE_SLOTS]);     /* the slot's previous chunk has been scattered */
+                chunks[issued + i].ev = slot;
+                nw += chunks[issued + i].nw;
+            }
+            hipStream_t cs = h->cstream[ncopies % HZ_COPY_STREAMS];
             const chunk_t& c = chunks[issued];
-            HZ_TRY(hipMemcpyAsync(h->h_stage[slot], jb.d_hs + jb.off[c.sector] + c.w0, c.nw*sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+            HZ_TRY(hipMemcpyAsync(h->h_stage[slot], jb.d_hs + jb.off[sector] + c.w0, nw*sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
             HZ_TRY(hipEventRecord(h->ev_stage[slot], cs));
+            issued += g; ncopies++; run_of[sector]++;
         }
         if(err != hipSuccess || k >= issued) continue;
         const int slot = (int)(k % HZ_STAGE_SLOTS);
         const double t_w0 = since();
-        HZ_TRY(hipEventSynchronize(h->ev_stage[slot]));
+        const chunk_t c = chunks[k];
+        HZ_TRY(hipEventSynchronize(h->ev_stage[c.ev]));
         if(err != hipSuccess) break;
         t_waited += since() - t_w0;
         if(k == 0) t_first = since();
         t_arrived = since();
-        const chunk_t c = chunks[k];
         const uint32_t* chunk = (const uint32_t*)h->h_stage[slot];
         size_t* const o = offs[c.sector].data() + noffs[c.sector];
         const size_t room = offs[c.sector].size() - noffs[c.sector];
@@ -589,9 +612,11 @@ static int host_end(hz_dev_t* d)
     pool->wait(&jb.filled);
     if(d->env.host_times)
     {
-        fprintf(stderr, "hz_hip host path: %.1f MB of blobs (%zu) in %d sector(s) for %.1f MB of results; ms since the call began: end() entered %.2f, sectors known",
-                4e-6*(double)total_words, total_blobs, jb.nsec,
-                1e-6*(double)jb.out_w*d->H*((jb.sc.dst.bgr ? 3 : 0) + (jb.sc.dst.ranges ? 4 : 0) + (jb.sc.dst.index ? 4 : 0) + (jb.sc.dst.z24 ? 4 : 0)), t_enter);
+        fprintf(stderr, "hz_hip host path: %.1f MB of blobs (%zu) in %d sector(s), %zu copies, for %.1f MB of results; ms since the call began: sky tasks queued %.2f, sectors queued",
+                4e-6*(double)total_words, total_blobs, jb.nsec, ncopies,
+                1e-6*(double)jb.out_w*d->H*((jb.sc.dst.bgr ? 3 : 0) + (jb.sc.dst.ranges ? 4 : 0) + (jb.sc.dst.index ? 4 : 0) + (jb.sc.dst.z24 ? 4 : 0)), jb.t_sky_queued);
+        for(int s=0; s<jb.nsec; s++) fprintf(stderr, " %.2f", jb.t_queued[s]);
+        fprintf(stderr, ", end() entered %.2f, sectors known", t_enter);
         for(int s=0; s<jb.nsec; s++) fprintf(stderr, " %.2f", t_known[s]);
         fprintf(stderr, ", first chunk here %.2f, last chunk here %.2f (%.2f spent waiting for chunks), blobs in place %.2f, sky and everything %.2f\n",
                 t_first, t_arrived, t_waited, t_scattered, since());
