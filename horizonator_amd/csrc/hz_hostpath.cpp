@@ -26,6 +26,7 @@
  * 65535 rows and hz_options_t::host_dense. */
 #include "hz_dev.h"
 
+#include <sched.h>
 #include <sys/mman.h>
 
 #include <atomic>
@@ -84,7 +85,33 @@ struct hz_copy_pool
             if(madvise(probe, 4096, MADV_POPULATE_WRITE) != 0) populate_works = false;
             munmap(probe, 4096);
         }
-        for(int k=0; k<n; k++) threads.emplace_back([this] { run(); });
+        /* HZ_COPY_NODE=here (an experiment of round 5): the pool's threads stay on the NUMA node of the thread that made the
+         * pool - the caller's buffers were most likely first touched there */
+        cpu_set_t node_cpus; bool pin = false;
+        const char* where = getenv("HZ_COPY_NODE");
+        if(where && strcmp(where, "here") == 0)
+        {
+            const int cpu = sched_getcpu();
+            for(int node=0; node<16 && !pin; node++)
+            {
+                char path[96]; snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+                FILE* f = fopen(path, "r"); if(!f) break;
+                char buf[4096]; if(!fgets(buf, sizeof(buf), f)) { fclose(f); continue; } fclose(f);
+                CPU_ZERO(&node_cpus); bool mine = false;
+                for(char* tok = strtok(buf, ",\n"); tok; tok = strtok(NULL, ",\n"))
+                {
+                    int a, b;
+                    if(sscanf(tok, "%d-%d", &a, &b) != 2) { if(sscanf(tok, "%d", &a) != 1) continue; b = a; }
+                    for(int c=a; c<=b; c++) { CPU_SET(c, &node_cpus); if(c == cpu) mine = true; }
+                }
+                pin = mine;
+            }
+        }
+        for(int k=0; k<n; k++)
+        {
+            threads.emplace_back([this] { run(); });
+            if(pin) (void)pthread_setaffinity_np(threads.back().native_handle(), sizeof(node_cpus), &node_cpus);
+        }
     }
     ~hz_copy_pool()
     {
