@@ -115,6 +115,9 @@ static void expand_scalar(unsigned char* dst, const unsigned char* red, int n)
 /* what this machine's vector unit can do, found out once when the library is loaded (not lazily by whichever pool
  * thread comes first) */
 static int cpu_ssse3, cpu_avx2, cpu_avx512;
+/* streaming (non-temporal) stores for runs of 32 terrain pixels; 0: ordinary stores (tools/scatter_bench.c measures both) */
+static int scatter_streaming = 1;
+void hz_scatter_set_streaming(int on) { scatter_streaming = on; }
 __attribute__((constructor)) static void hz_scatter_probe_cpu(void)
 {
     __builtin_cpu_init();
@@ -153,7 +156,7 @@ __attribute__((target("avx512f,avx512vl,avx2")))
 static void word32_ranges_avx512(const uint32_t* w, float* rng, float tan_row, float znear, float span)
 {
     const __m256 vspan = _mm256_set1_ps(span), vnear = _mm256_set1_ps(znear), vtan = _mm256_set1_ps(tan_row);
-    const int nt = ((uintptr_t)rng & 31u) == 0;
+    const int nt = scatter_streaming && ((uintptr_t)rng & 31u) == 0;
     for(int k=0; k<32; k+=8)
     {
         const __m256 r = ranges8_avx512(w + k, vspan, vnear, vtan);
@@ -216,7 +219,7 @@ static void word32_avx2(const uint32_t* w, float* rng, uint32_t* z24, unsigned c
     {
         const __m256d inv = _mm256_set1_pd(1.0/16777215.0);
         const __m128  vspan = _mm_set1_ps(span), vnear = _mm_set1_ps(znear), vtan = _mm_set1_ps(tan_row);
-        const int nt = ((uintptr_t)rng & 15u) == 0;
+        const int nt = scatter_streaming && ((uintptr_t)rng & 15u) == 0;
         for(int k=0; k<32; k+=4)
         {
             const __m128i zi    = _mm_srli_epi32(_mm_loadu_si128((const __m128i*)(w + k)), 8);
@@ -230,7 +233,7 @@ static void word32_avx2(const uint32_t* w, float* rng, uint32_t* z24, unsigned c
     }
     if(z24)
     {
-        const int nt = ((uintptr_t)z24 & 15u) == 0;
+        const int nt = scatter_streaming && ((uintptr_t)z24 & 15u) == 0;
         for(int k=0; k<32; k+=4)
         {
             const __m128i zi = _mm_srli_epi32(_mm_loadu_si128((const __m128i*)(w + k)), 8);
@@ -243,7 +246,7 @@ static void word32_avx2(const uint32_t* w, float* rng, uint32_t* z24, unsigned c
         const __m128i m0 = _mm_setr_epi8(-128,-128,0, -128,-128,1, -128,-128,2, -128,-128,3, -128,-128,4, -128);
         const __m128i m1 = _mm_setr_epi8(-128,5, -128,-128,6, -128,-128,7, -128,-128,8, -128,-128,9, -128,-128);
         const __m128i m2 = _mm_setr_epi8(10, -128,-128,11, -128,-128,12, -128,-128,13, -128,-128,14, -128,-128,15);
-        const int nt = ((uintptr_t)bgr & 15u) == 0;
+        const int nt = scatter_streaming && ((uintptr_t)bgr & 15u) == 0;
         for(int k=0; k<32; k+=16)
         {
             /* 16 shades as bytes (reference fragment.glsl:15-16: colour = (red,0,0)), then 48 bytes B,G,R = 0,0,shade */

@@ -36,6 +36,7 @@ typedef struct
 } hz_scatter_dst_t;
 
 void   hz_sky_fill(unsigned char* buf, size_t lo, size_t hi, int kind);
+void   hz_scatter_set_streaming(int on);     /* diagnostics (tools/scatter_bench.c): 0 = ordinary instead of streaming stores */
 size_t hz_blob_walk(const uint32_t* chunk, size_t nwords, size_t first, size_t* offsets, size_t max, size_t* beyond);
 int    hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst);
 /* out[k] = range of packed[k] = z24<<8 | red8 in a row whose tan(elevation) is tan_row: reference
