@@ -264,7 +264,55 @@ static void word32_avx2(const uint32_t* w, float* rng, uint32_t* z24, unsigned c
 /* one blob into the caller's buffers.  Returns 0, or -1 if the blob does not describe pixels of dst's image - decided
  * BEFORE anything is written: the columns and rows lie inside the image, every row's mask has exactly the bits its count
  * says and none beyond the blob's columns, and the arrays those counts imply fit the size the blob declares. */
-int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
+/* npx (<= 32) sky pixels from pixel o on: the constants of hz_sky_fill() */
+static void sky_run(const hz_scatter_dst_t* d, int want_bgr, int want_rng, int want_idx, int want_z, size_t o, int npx, int stream_ok)
+{
+    if(npx == 32 && stream_ok && scatter_streaming)
+    {
+        if(want_rng && ((uintptr_t)(d->ranges + o) & 15u) == 0)
+        {
+            const __m128 v = _mm_set1_ps(-1.0f);
+            for(int k=0; k<32; k+=4) _mm_stream_ps(d->ranges + o + k, v);
+            want_rng = 0;
+        }
+        if(want_z && ((uintptr_t)(d->z24 + o) & 15u) == 0)
+        {
+            const __m128i v = _mm_set1_epi32(0x00FFFFFF);
+            for(int k=0; k<32; k+=4) _mm_stream_si128((__m128i*)(d->z24 + o + k), v);
+            want_z = 0;
+        }
+        if(want_idx && ((uintptr_t)(d->index + o) & 15u) == 0)
+        {
+            const __m128i v = _mm_set1_epi32(-1);
+            for(int k=0; k<32; k+=4) _mm_stream_si128((__m128i*)(d->index + o + k), v);
+            want_idx = 0;
+        }
+        if(want_bgr && ((uintptr_t)(d->bgr + 3*o) & 15u) == 0)
+        {
+            /* B,G,R = 255,0,0 (reference horizonator-lib.c:185): 96 bytes = two periods of the 48-byte pattern */
+            const __m128i v0 = _mm_setr_epi8(-1,0,0, -1,0,0, -1,0,0, -1,0,0, -1,0,0, -1), v1 = _mm_setr_epi8(0,0,-1, 0,0,-1, 0,0,-1, 0,0,-1, 0,0,-1, 0),
+                          v2 = _mm_setr_epi8(0,-1,0, 0,-1,0, 0,-1,0, 0,-1,0, 0,-1,0, 0);
+            __m128i* q = (__m128i*)(d->bgr + 3*o);
+            _mm_stream_si128(q, v0); _mm_stream_si128(q+1, v1); _mm_stream_si128(q+2, v2);
+            _mm_stream_si128(q+3, v0); _mm_stream_si128(q+4, v1); _mm_stream_si128(q+5, v2);
+            want_bgr = 0;
+        }
+    }
+    for(int c=0; c<npx; c++)
+    {
+        if(want_rng) d->ranges[o + c] = -1.0f;                                              /* reference horizonator-lib.c:1016 */
+        if(want_z)   d->z24[o + c] = 0x00FFFFFFu;
+        if(want_idx) d->index[o + c] = -1;
+        if(want_bgr) { unsigned char* b3 = d->bgr + 3*(o + c); b3[0] = 255; b3[1] = 0; b3[2] = 0; }
+    }
+}
+
+int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst) { return hz_blob_scatter_mode(blob, dst, 0); }
+
+/* full != 0: every pixel of the blob's tile (its rows inside the image x its columns) is written, the sky's constants where
+ * the mask says sky - for tiles the sky has NOT been filled into beforehand: each byte of the caller's buffers is then
+ * written once instead of twice */
+int hz_blob_scatter_mode(const uint32_t* blob, const hz_scatter_dst_t* dst, int full)
 {
     const int W = dst->W, H = dst->H;
     const uint32_t flags = blob[0] >> 16;
@@ -304,7 +352,7 @@ int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
     {
         const int yo = yo0 + r;
         const size_t T = blob[2 + r];
-        if(T == 0) continue;
+        if(yo >= H || (T == 0 && !full)) continue;
         const uint32_t* m = mask + (size_t)r*mw;
         const uint32_t*      pk  = src_pk  ? src_pk  + k : NULL;
         const int32_t*       idx = src_idx ? src_idx + k : NULL;
@@ -315,8 +363,15 @@ int hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst)
         for(int w=0; w<mw; w++)
         {
             uint32_t bits = m[w];
-            if(!bits) continue;
             const size_t o = row + 32u*(size_t)w;
+            if(full && bits != 0xFFFFFFFFu)
+            {
+                /* (the arrays the blob does not carry are not touched: what it carries is what the caller asked for) */
+                /* (a word with sky only: streaming stores; with both: ordinary ones - the terrain pixels that follow go into the same lines) */
+                sky_run(dst, bgr != NULL, ranges != NULL, index != NULL, z24 != NULL, o, w == mw-1 && (n & 31) ? (n & 31) : 32, bits == 0);
+                streamed = 1;
+            }
+            if(!bits) continue;
             if(bits == 0xFFFFFFFFu)
             {
                 /* 32 terrain pixels in a row: below the horizon that is nearly every word */

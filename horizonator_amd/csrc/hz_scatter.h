@@ -39,6 +39,7 @@ void   hz_sky_fill(unsigned char* buf, size_t lo, size_t hi, int kind);
 void   hz_scatter_set_streaming(int on);     /* diagnostics (tools/scatter_bench.c): 0 = ordinary instead of streaming stores */
 size_t hz_blob_walk(const uint32_t* chunk, size_t nwords, size_t first, size_t* offsets, size_t max, size_t* beyond);
 int    hz_blob_scatter(const uint32_t* blob, const hz_scatter_dst_t* dst);
+int    hz_blob_scatter_mode(const uint32_t* blob, const hz_scatter_dst_t* dst, int full);
 /* out[k] = range of packed[k] = z24<<8 | red8 in a row whose tan(elevation) is tan_row: reference
  * horizonator-lib.c:1013-1025, bit for bit what the device's conversions compute (hz_k_resolve.h: hz_range_from_z24) */
 void   hz_ranges_from_packed(float* out, const uint32_t* packed, size_t n, float tan_row, float znear, float zfar);

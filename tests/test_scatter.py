@@ -27,6 +27,8 @@ def _lib():
     lib.hz_blob_walk.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.hz_blob_scatter.restype = C.c_int
     lib.hz_blob_scatter.argtypes = [C.c_void_p, C.POINTER(Dst)]
+    lib.hz_blob_scatter_mode.restype = C.c_int
+    lib.hz_blob_scatter_mode.argtypes = [C.c_void_p, C.POINTER(Dst), C.c_int]
     lib.hz_ranges_from_packed.restype = None
     lib.hz_ranges_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float]
     return lib
@@ -104,10 +106,12 @@ def test_host_ranges_are_the_reference_conversion_bit_for_bit():
         assert (raw[n:] == 123.0).all()
 
 
+@pytest.mark.parametrize("full", [0, 1])
 @pytest.mark.parametrize("flags", [PACKED, PACKED | INDEX, RED, INDEX, RED | INDEX])
 @pytest.mark.parametrize("col0", [0, 1000])
-def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0):
-    """col0: the blobs are those of an azimuth sector that starts at image column col0 (their x0 carries the offset)"""
+def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0, full):
+    """col0: the blobs are those of an azimuth sector that starts at image column col0 (their x0 carries the offset);
+    full: the sky is NOT filled in beforehand where a blob lands - the blob writes the sky pixels of its tile itself"""
     lib = _lib()
     g = np.random.default_rng(flags)
     SW, H = 5000, 23                      # a last tile of 904 columns, a last blob of 3 rows
@@ -122,6 +126,7 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0):
     z24 = g.integers(0, 0xFFFFFF, (H, SW)).astype(np.uint32)
     red = g.integers(0, 256, (H, SW)).astype(np.uint8)
     rng = _ranges(z24, tanel[::-1][:, None], znear, zfar)
+    full_mode = full
     full = np.zeros((H, W), bool); full[:, col0:col0 + SW] = terrain
     def place(a, fill):
         out = np.full((H, W), fill, a.dtype); out[:, col0:col0 + SW] = a; return out
@@ -131,6 +136,13 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0):
     got = {"bgr": np.empty((H, W, 3), np.uint8), "ranges": np.empty((H, W), np.float32), "index": np.empty((H, W), np.int32), "z24": np.empty((H, W), np.uint32)}
     for kind, k in enumerate(("bgr", "ranges", "index", "z24")):
         lib.hz_sky_fill(got[k].ctypes.data, 0, got[k].nbytes, kind)
+    if full_mode:
+        # rubbish where blobs will land (every tile with terrain: all but rows 4..7 of the first 2048 columns), in the arrays they carry
+        for k, f in (("bgr", PACKED | RED), ("ranges", PACKED), ("z24", PACKED), ("index", INDEX)):
+            if flags & f:
+                keep = got[k][4:8, col0:col0 + 2048].copy()
+                got[k][:, col0:col0 + SW] = 0x55
+                got[k][4:8, col0:col0 + 2048] = keep
     blobs = []
     for yo0 in range(0, H, ROWS):
         for x0 in range(0, SW, COLS):
@@ -165,7 +177,7 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0):
         if k == 1:
             at += 8
         assert int(offs[k]) == at
-        assert lib.hz_blob_scatter(chunk[at:].ctypes.data, C.byref(dst)) == 0
+        assert lib.hz_blob_scatter_mode(chunk[at:].ctypes.data, C.byref(dst), full_mode) == 0
         at += len(b)
     carried = {"bgr": flags & (PACKED | RED), "ranges": flags & PACKED, "z24": flags & PACKED, "index": flags & INDEX}
     for k in ("bgr", "ranges", "index", "z24"):
