@@ -52,6 +52,7 @@ struct hz_copy_pool
     struct scatter_t
     {
         hz_scatter_dst_t dst;
+        int y_pre;                      /* rows [0, y_pre) get the sky beforehand (band by band); a blob below writes the sky pixels of its tile itself */
         int band_rows, nbands;
         std::atomic<int>* band_left;
         std::atomic<int> bad;
@@ -145,10 +146,12 @@ struct hz_copy_pool
                  * sector that hold its rows.  Sky tasks queue behind blobs (q_lo), so the ones this blob waits for may
                  * not have been taken by any thread yet: the waiting thread takes sky tasks itself. */
                 const int yo = (int)(blob[0] & 0xFFFFu);
-                for(int b = yo/t.sc->band_rows; b <= (yo + HZ_BLOB_ROWS-1)/t.sc->band_rows && b < t.sc->nbands; b++)
-                    while(t.sc->band_left[(size_t)t.sector*t.sc->nbands + b].load(std::memory_order_acquire) > 0)
-                        if(!run_one_low()) std::this_thread::yield();
-                if(hz_blob_scatter(blob, &t.sc->dst) != 0) t.sc->bad.store(1);
+                const bool prefilled = yo < t.sc->y_pre;
+                if(prefilled)
+                    for(int b = yo/t.sc->band_rows; b <= (yo + HZ_BLOB_ROWS-1)/t.sc->band_rows && b < t.sc->nbands; b++)
+                        while(t.sc->band_left[(size_t)t.sector*t.sc->nbands + b].load(std::memory_order_acquire) > 0)
+                            if(!run_one_low()) std::this_thread::yield();
+                if(hz_blob_scatter_mode(blob, &t.sc->dst, prefilled ? 0 : 1) != 0) t.sc->bad.store(1);
             }
             break;
         }
@@ -208,6 +211,18 @@ struct hz_copy_pool
         {
             std::lock_guard<std::mutex> lk(m);
             for(task_t& t : ts) { t.batch = b; (t.kind == FILL || t.kind == MAP ? q_lo : q_hi).push_back(t); }
+            b->pending += (int)ts.size();
+        }
+        cv_work.notify_all();
+        ts.clear();
+    }
+    /* ... sky tasks that are not ahead of anything: into the queue that is served first */
+    void push_tasks_hi(batch_t* b, std::vector<task_t>& ts)
+    {
+        if(ts.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for(task_t& t : ts) { t.batch = b; q_hi.push_back(t); }
             b->pending += (int)ts.size();
         }
         cv_work.notify_all();
@@ -436,10 +451,28 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         const uintptr_t huge = (uintptr_t)2 << 20, lo = ((uintptr_t)bufs[k].p + huge-1) & ~(huge-1), hi = ((uintptr_t)bufs[k].p + (size_t)jb.out_w*H*bufs[k].px_bytes) & ~(huge-1);
         if(hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
     }
+    /* How much of the image gets its sky beforehand.  Filling (448 MB in ~1.05 ms with this pool: tools/hostfill_bench.c) and
+     * scattering get in each other's way when they run at the same time - side by side they take 4 ms where one after the
+     * other they take 2.4 (tools/scatter_bench.c, profiles/r5_host_microbenchmarks.txt) - so only as much of the image is
+     * filled beforehand as there is time for until the first sector's blobs arrive: all of it for a call in one sector (the
+     * draw takes longer than the fill), the upper 85 / 60 / 45 % for 2 / 3 / 4 and more sectors - sky for the most part -, and
+     * nothing when another panorama is in flight (its blobs are arriving now).  Below that row a blob writes the sky
+     * pixels of its own tile (hz_blob_scatter_mode: every byte once), and the tiles that turn out to have no blob are filled
+     * when their sector has been walked.  HZ_HOST_PREFILL=percent overrides. */
+    {
+        int percent = jb.nsec <= 1 ? 100 : jb.nsec == 2 ? 85 : jb.nsec == 3 ? 60 : 45;
+        if(h->next_begin != h->next_end) percent = 0;
+        const char* e = getenv("HZ_HOST_PREFILL");
+        if(e && atoi(e) >= 0 && atoi(e) <= 100) percent = atoi(e);
+        sc.y_pre = (int)((long long)H*percent/100) / HZ_BLOB_ROWS * HZ_BLOB_ROWS;
+        if(percent >= 100) sc.y_pre = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
+    }
     const int widest = jb.col[1] - jb.col[0];
     sc.band_rows = (int)(((size_t)2 << 20)/((size_t)widest*4) + 1);
     if(sc.band_rows < HZ_BLOB_ROWS) sc.band_rows = HZ_BLOB_ROWS;
-    sc.nbands = (H + sc.band_rows-1)/sc.band_rows;
+    sc.band_rows = (sc.band_rows + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
+    const int pre_rows = sc.y_pre < H ? sc.y_pre : H;
+    sc.nbands = (pre_rows + sc.band_rows-1)/sc.band_rows;
     std::vector<std::atomic<int>>(static_cast<size_t>(jb.nsec)*sc.nbands).swap(*jb.band_left);
     sc.band_left = jb.band_left->data();
     jb.filled.pending = 0;
@@ -447,7 +480,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
     for(int s=0; s<jb.nsec; s++)
         for(int b=0; b<sc.nbands; b++)
         {
-            const int y0 = b*sc.band_rows, y1 = y0 + sc.band_rows < H ? y0 + sc.band_rows : H;
+            const int y0 = b*sc.band_rows, y1 = y0 + sc.band_rows < pre_rows ? y0 + sc.band_rows : pre_rows;
             sc.band_left[(size_t)s*sc.nbands + b].store(nbuf);
             for(int k=0; k<nbuf; k++)
             {
@@ -543,6 +576,48 @@ static int host_end(hz_dev_t* d)
     std::vector<std::vector<size_t>> offs(jb.nsec);     /* where the blobs of sector s start, chunk after chunk */
     size_t noffs[HZ_HOST_MAX_SECTORS] = { 0 }, first[HZ_HOST_MAX_SECTORS] = { 0 };
     size_t total_words = 0, total_blobs = 0;
+    /* below y_pre: which tiles of sector s (4 rows x <= 2048 columns, as k_pack_host cuts them) have sent a blob; the others
+     * get their sky when the sector's last chunk has been walked */
+    const int H = d->H, y_pre = jb.sc.y_pre, ty0 = y_pre/HZ_BLOB_ROWS, nty = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS;
+    std::vector<std::vector<unsigned char>> seen(jb.nsec);
+    size_t chunks_of[HZ_HOST_MAX_SECTORS] = { 0 }, walked_of[HZ_HOST_MAX_SECTORS] = { 0 };
+    bool absent_done[HZ_HOST_MAX_SECTORS] = { false };
+    hz_copy_pool::batch_t late_sky = { 0 };
+    struct { unsigned char* p; size_t px_bytes; int sky; } bufs[4];
+    int nbuf = 0;
+    if(jb.sc.dst.bgr)    bufs[nbuf++] = { jb.sc.dst.bgr, 3, HZ_SKY_BGR };
+    if(jb.sc.dst.ranges) bufs[nbuf++] = { (unsigned char*)jb.sc.dst.ranges, 4, HZ_SKY_RANGES };
+    if(jb.sc.dst.index)  bufs[nbuf++] = { (unsigned char*)jb.sc.dst.index, 4, HZ_SKY_INDEX };
+    if(jb.sc.dst.z24)    bufs[nbuf++] = { (unsigned char*)jb.sc.dst.z24, 4, HZ_SKY_Z24 };
+    /* the sky of sector s's tiles without a blob (rows from y_pre down): one task per run of such tiles in a column of tiles */
+    auto fill_absent = [&](int s)
+    {
+        if(absent_done[s] || ty0 >= nty) { absent_done[s] = true; return; }
+        absent_done[s] = true;
+        const int sw = jb.col[s+1] - jb.col[s], ntx = (sw + HZ_BLOB_COLS-1)/HZ_BLOB_COLS;
+        std::vector<hz_copy_pool::task_t> ts;
+        for(int tx=0; tx<ntx; tx++)
+        {
+            const size_t x0 = (size_t)(jb.col[s] - jb.out_col0) + (size_t)tx*HZ_BLOB_COLS;
+            const size_t w = (size_t)(sw - tx*HZ_BLOB_COLS < HZ_BLOB_COLS ? sw - tx*HZ_BLOB_COLS : HZ_BLOB_COLS);
+            for(int ty=ty0; ty<nty; )
+            {
+                if(!seen[s].empty() && seen[s][(size_t)(ty - ty0)*ntx + tx]) { ty++; continue; }
+                int t1 = ty + 1;
+                while(t1 < nty && t1 - ty < 64 && (seen[s].empty() || !seen[s][(size_t)(t1 - ty0)*ntx + tx])) t1++;
+                const int y0 = ty*HZ_BLOB_ROWS, y1 = t1*HZ_BLOB_ROWS < H ? t1*HZ_BLOB_ROWS : H;
+                for(int k=0; k<nbuf; k++)
+                {
+                    hz_copy_pool::task_t t = {};
+                    t.kind = hz_copy_pool::FILL; t.dst = bufs[k].p; t.sky = bufs[k].sky; t.left = NULL;
+                    t.lo = ((size_t)y0*jb.out_w + x0)*bufs[k].px_bytes; t.n = w*bufs[k].px_bytes; t.rows = y1 - y0; t.pitch = (size_t)jb.out_w*bufs[k].px_bytes;
+                    ts.push_back(t);
+                }
+                ty = t1;
+            }
+        }
+        pool->push_tasks_hi(&late_sky, ts);
+    };
     const size_t chunk_words = HZ_STAGE_BYTES/4;
     int rc = 0, known = 0;
     hipError_t err = hipSuccess;
@@ -568,6 +643,9 @@ static int host_end(hz_dev_t* d)
         if(c[2]) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: the stream of blobs overflowed (%zu words)", jb.cap[s]); rc = -1; return false; }
         offs[s].resize((size_t)c[1] + 1);
         total_words += c[0]; total_blobs += c[1];
+        if(ty0 < nty) seen[s].assign((size_t)(nty - ty0)*(size_t)((jb.col[s+1] - jb.col[s] + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), 0);
+        chunks_of[s] = ((size_t)c[0] + chunk_words-1)/chunk_words;
+        if(chunks_of[s] == 0) fill_absent(s);              /* (a sector without any terrain) */
         for(size_t w0 = 0; w0 < c[0]; w0 += chunk_words)
         {
             chunks.push_back({ s, w0, w0 + chunk_words < c[0] ? chunk_words : c[0] - w0, 0 });
@@ -620,6 +698,17 @@ static int host_end(hz_dev_t* d)
         const size_t nb = hz_blob_walk(chunk, c.nw, first[c.sector], o, room, &first[c.sector]);
         if(nb == (size_t)-1 || nb > room) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: chunk %zu of the stream is not a sequence of blobs", k); rc = -1; break; }
         noffs[c.sector] += nb;
+        if(!seen[c.sector].empty())
+        {
+            const int ntx = (jb.col[c.sector+1] - jb.col[c.sector] + HZ_BLOB_COLS-1)/HZ_BLOB_COLS;
+            for(size_t b=0; b<nb; b++)
+            {
+                const uint32_t* blob = chunk + o[b];
+                const int yo = (int)(blob[0] & 0xFFFFu), tx = ((int)blob[1] - (jb.col[c.sector] - jb.out_col0))/HZ_BLOB_COLS;
+                if(yo >= y_pre && yo/HZ_BLOB_ROWS < nty && tx >= 0 && tx < ntx) seen[c.sector][(size_t)(yo/HZ_BLOB_ROWS - ty0)*ntx + tx] = 1;
+            }
+        }
+        if(++walked_of[c.sector] == chunks_of[c.sector]) fill_absent(c.sector);
         /* tasks of ~256 KB of blobs */
         for(size_t b0=0; b0<nb; )
         {
@@ -634,8 +723,11 @@ static int host_end(hz_dev_t* d)
         k++;
     }
     #undef HZ_TRY
+    /* (whatever ended the loop early - an error: every sector still gets its sky, the tasks below name this frame's variables) */
+    if(err == hipSuccess && rc == 0) for(int s=0; s<jb.nsec; s++) if(s < known) fill_absent(s);
     for(size_t i=0; i<done.size(); i++) pool->wait(&done[i]);
     const double t_scattered = since();
+    pool->wait(&late_sky);
     pool->wait(&jb.filled);
     if(d->env.host_times)
     {

@@ -54,6 +54,30 @@ def test_any_number_of_sectors_delivers_the_oracles_bytes(scene, sectors):
         h.set_options(host_sectors=0)
 
 
+@pytest.mark.parametrize("prefill", [0, 37, 100])
+@pytest.mark.parametrize("sectors", [1, 3])
+def test_any_share_of_sky_filled_beforehand(scene, sectors, prefill, monkeypatch):
+    """HZ_HOST_PREFILL: the rows that get their sky before the blobs arrive (the others: a blob writes the sky pixels of its own
+    tile, tiles without a blob are filled when their sector has been walked) - every byte of every buffer is written either
+    way: the buffers start out as rubbish"""
+    h, od, W, H = scene
+    monkeypatch.setenv("HZ_HOST_PREFILL", str(prefill))
+    h.set_options(host_sectors=sectors)
+    try:
+        for az0, az1, zfar in ((-180.0, 180.0, 200000.0), (-100.0, -10.0, 3000.0)):      # (the second: a close far clip - sectors and tiles without any terrain)
+            want = _want(od, W, H, az0, az1, zfar)
+            h.set_view(az0, az1, zfar=zfar)
+            image = np.full((H, W, 3), 0x5A, np.uint8); ranges = np.full((H, W), 123.0, np.float32)
+            h.render_into(image, ranges)
+            assert np.array_equal(image, want["bgr"]) and np.array_equal(ranges, want["ranges"]), (sectors, prefill, az0)
+            image[:] = 0x5A
+            h.render_into(image, None)
+            assert np.array_equal(image, want["bgr"])
+    finally:
+        h.set_options(host_sectors=0)
+        h.set_view(-180.0, 180.0, zfar=40000.0)
+
+
 def test_two_panoramas_in_flight(scene):
     """begin k+1 before end k: different views, buffers of their own, ended in the order begun"""
     h, od, W, H = scene
