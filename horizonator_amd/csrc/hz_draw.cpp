@@ -1175,14 +1175,9 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
         const float ppr = p.halfW * p.u.az_ndc_per_rad;
         if(ppr/(float)HZ_NEAR_CELLS_MAX >= HZ_HIZ_MIN_PX) report = d->adapt.h_counts[next];        /* (a view whose reach has the choice) */
     }
-    /* (HZ_TILES2=1, an experiment of round 5: the second round's large triangles by screen tile too - round 4 measured +5..140 %
-     * over the suite's scenes; the views whose second round queues several hundred thousand records were not among them) */
-    bool by_tile_second = false;
-    {
-        const char* e = getenv("HZ_TILES2");
-        if(e && atoi(e) > 0 && zoomed_view && p.pass == 2 && d->raster != HZ_RASTER_SCATTER && tile_bins(d, next) == 0) by_tile_second = true;
-    }
-    if(queue_kernels(d, q, p, d->qstream, next, by_tile_second, zoomed_view, report) != 0) return -1;
+    /* (the second round's large triangles by screen tile too: round 4 measured +5..140 % over the suite's scenes; round 5 on the
+     * views whose second round queues the most - summit 1.69 -> 2.09 ms, the 10 degree view 1.54 -> 3.71, south 1.27 -> 1.36: no) */
+    if(queue_kernels(d, q, p, d->qstream, next, false, zoomed_view, report) != 0) return -1;
     if(prof) HZ_CHECK(hipEventRecord(d->ev[3], d->qstream));
     if(report)
     {

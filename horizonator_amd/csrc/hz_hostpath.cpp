@@ -455,12 +455,12 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
      * scattering get in each other's way when they run at the same time - side by side they take 4 ms where one after the
      * other they take 2.4 (tools/scatter_bench.c, profiles/r5_host_microbenchmarks.txt) - so only as much of the image is
      * filled beforehand as there is time for until the first sector's blobs arrive: all of it for a call in one sector (the
-     * draw takes longer than the fill), the upper 85 / 60 / 45 % for 2 / 3 / 4 and more sectors - sky for the most part -, and
+     * draw takes longer than the fill), the upper 60 % for 2 sectors, 30 % for more - sky for the most part -, and
      * nothing when another panorama is in flight (its blobs are arriving now).  Below that row a blob writes the sky
      * pixels of its own tile (hz_blob_scatter_mode: every byte once), and the tiles that turn out to have no blob are filled
      * when their sector has been walked.  HZ_HOST_PREFILL=percent overrides. */
     {
-        int percent = jb.nsec <= 1 ? 100 : jb.nsec == 2 ? 85 : jb.nsec == 3 ? 60 : 45;
+        int percent = jb.nsec <= 1 ? 100 : jb.nsec == 2 ? 60 : 30;     /* (4 sectors of 16000 x 4000: 3.36 ms with 45 %, 3.25 with 60, 3.15 with 30) */
         if(h->next_begin != h->next_end) percent = 0;
         const char* e = getenv("HZ_HOST_PREFILL");
         if(e && atoi(e) >= 0 && atoi(e) <= 100) percent = atoi(e);
@@ -668,6 +668,8 @@ static int host_end(hz_dev_t* d)
         {
             const int slot = (int)(issued % HZ_STAGE_SLOTS), sector = chunks[issued].sector;
             size_t g = run_of[sector] == 0 ? 1 : run_of[sector] == 1 ? 2 : 4;
+            /* ... and the last chunks of the last sector one by one again: what arrives last is scattered with nothing left to hide behind */
+            if(known == jb.nsec && sector == jb.nsec-1 && chunks.size() - issued <= 3) g = 1;
             if(g > (size_t)(HZ_STAGE_SLOTS - slot)) g = HZ_STAGE_SLOTS - slot;                      /* (no copy wraps round the ring) */
             while(g > 1 && (issued + g > chunks.size() || issued + g > k + HZ_STAGE_SLOTS - 4 || chunks[issued + g-1].sector != sector)) g--;
             size_t nw = 0;

@@ -97,7 +97,7 @@ struct mr_queue_t
 #ifndef HZ_NFB
 #define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
 #endif
-#define HZ_STAGE_SLOTS 16               /* pinned staging chunks in flight between device and caller memory */
+#define HZ_STAGE_SLOTS 32               /* pinned staging chunks in flight between device and caller memory (128 MB: a copy of four chunks must never wait for the scatter of an old one) */
 #define HZ_STAGE_BYTES ((size_t)4 << 20)    /* (16 MB until round 5: a chunk's blobs are scattered when all of it has arrived - 0.26 ms for 16 MB) */
 #define HZ_COPY_STREAMS 2               /* device -> host copies alternate between that many streams (copy engines) */
 #define HZ_HOST_BANDS  4                /* the conversion runs in that many bands of rows when its results go to the host */
