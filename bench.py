@@ -634,7 +634,7 @@ def main():
     # what actually bounds the dominant kernel: the SIMDs' vector issue slots.
     # Recorded counters of the same workload (profiles/), set against the duration measured now.
     valu = None
-    mix = next((m for m in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (4, 3, 2)) if os.path.exists(m)), "")
+    mix = next((m for m in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(m)), "")
     if args.config == "cfg3" and args.zfar == 600000.0 and world == 1 and args.raster in (0, 2) and os.path.exists(mix):
         try:
             rec = json.load(open(mix))

@@ -77,7 +77,8 @@ def classify(instr):
 
 def main():
     key = sys.argv[1] if len(sys.argv) > 1 else "k_march_coarse_depth"
-    mix = json.load(open(os.path.join(ROOT, "profiles", "pmc_r4_instruction_mix_cfg3.json")))
+    mix_path = next(p for p in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (5, 4)) if os.path.exists(p))
+    mix = json.load(open(mix_path))
     k = max((v for name, v in mix.items() if name.startswith(key + " grid")), key=lambda v: v["SQ_INSTS_VALU"])
     issue = {}
     for r in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["rows"]:
@@ -87,7 +88,7 @@ def main():
     two_waves = {r["instr"]: r["cycles_per_wave_instr_at_nominal_clock"] for r in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["rows"] if r.get("waves_per_simd_asked") == 2}
 
     # the listing's vector instructions by class (static: what kinds of instruction the kernel is made of)
-    frag = "k_marchILb0ELb1E" if key.endswith("coarse_depth") else "k_marchILb0ELb0E"
+    frag = "k_marchILb0ELb1ELb0E" if key.endswith("coarse_depth") else "k_marchILb0ELb0ELb0E"     # (k_march<COUNTERS, HIZ, VCACHE>)
     static = collections.Counter()
     meta = {}
     for ins in listing(frag):
