@@ -257,7 +257,8 @@ static int create_impl(hz_dev_t* d)
     for(int k=0; k<HZ_NFB; k++)
     {
         HZ_CHECK(hipHostMalloc((void**)&d->adapt.h_counts[k], 6*sizeof(unsigned int), hipHostMallocDefault));
-        HZ_CHECK(hipEventCreateWithFlags(&d->adapt.ev[k], hipEventDisableTiming));
+        /* (release to system scope: k_big's report lies in pinned HOST memory, and the host reads it when it finds this event complete) */
+        HZ_CHECK(hipEventCreateWithFlags(&d->adapt.ev[k], hipEventDisableTiming | hipEventReleaseToSystem));
     }
     return 0;
 }

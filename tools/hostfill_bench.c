@@ -53,6 +53,28 @@ int main(int argc, char** argv)
             double t4 = now();
             printf("node %2d threads %2d: populate %.2f ms, fill %.2f ms (%.0f GB/s), again %.2f ms (%.0f GB/s), memset %.2f ms\n", node, T, t1-t0, t2-t1, n/(t2-t1)*1e-6, t3-t2, n/(t3-t2)*1e-6, t4-t3);
             munmap(p, n);
+            /* the same with transparent huge pages asked for (where the system offers them on request: madvise mode) */
+            p = mmap(NULL, n + (2 << 20), PROT_READ|PROT_WRITE, MAP_PRIVATE|MAP_ANONYMOUS, -1, 0);
+            unsigned char* q = (unsigned char*)(((unsigned long)p + (2 << 20) - 1) & ~(unsigned long)((2 << 20) - 1));
+            madvise(q, n, 14 /* MADV_HUGEPAGE */);
+            double h0 = now();
+            #pragma omp parallel for schedule(static)
+            for(int k=0; k<64; k++) madvise(q + n/64*k, n/64, MADV_POPULATE_WRITE);
+            double h1 = now();
+            #pragma omp parallel for schedule(dynamic)
+            for(int k=0; k<128; k++) hz_sky_fill(q, n/128*k, n/128*(k+1), k & 1);
+            double h2 = now();
+            munmap(p, n + (2 << 20));
+            /* ... and filled without populating first (the first touch of every page is a streaming store) */
+            p = mmap(NULL, n + (2 << 20), PROT_READ|PROT_WRITE, MAP_PRIVATE|MAP_ANONYMOUS, -1, 0);
+            q = (unsigned char*)(((unsigned long)p + (2 << 20) - 1) & ~(unsigned long)((2 << 20) - 1));
+            madvise(q, n, 14);
+            double g0 = now();
+            #pragma omp parallel for schedule(dynamic)
+            for(int k=0; k<128; k++) hz_sky_fill(q, n/128*k, n/128*(k+1), k & 1);
+            double g1 = now();
+            munmap(p, n + (2 << 20));
+            printf("node %2d threads %2d: with MADV_HUGEPAGE: populate %.2f ms, then fill %.2f ms; fill of untouched pages %.2f ms\n", node, T, h1-h0, h2-h1, g1-g0);
         }
     }
     return 0;
