@@ -3,24 +3,34 @@
  * Plain C++ over the HIP runtime API (compiled by g++); kernels through hz_launch.h.
  *
  * What lies between the framebuffer and the caller's buffers is PCIe (a 16000 x 4000 panorama is 448 MB of results;
- * the link moves ~62 GB/s), so a call is organised around the link:
+ * the link moves ~50 GB/s in copies of 4 MB, ~56 in copies of 16), so a call is organised around the link:
  *
- *   - Only the terrain pixels travel, 4 bytes each (k_pack_host: blobs of z24<<8 | red8 with a mask, hz_scatter.h).
- *     62 % of the benchmark image is sky - BGR (255,0,0), range -1 (reference horizonator-lib.c:185, :1016) - which a
- *     pool of host threads writes into the caller's buffers with streaming stores while the device draws; the same
- *     threads make BGR bytes, depth and range of each blob as it arrives (hz_scatter.c: the readback conversion,
- *     reference :1013-1025, in the host's vector unit - bit for bit what k_resolve4 computes).  102 MB instead of 448.
+ *   - Only the terrain pixels travel, 4 bytes each (k_pack_host: blobs of z24<<8 | red8 with a mask, hz_scatter.h);
+ *     a pool of host threads makes BGR bytes, depth and range of each blob as it arrives (hz_scatter.c: the readback
+ *     conversion, reference :1013-1025, in the host's vector unit - bit for bit what k_resolve4 computes).  103 MB
+ *     instead of 448.
  *   - The panorama is drawn and shipped in azimuth SECTORS (hz_options_t::host_sectors; whole images of 12 Mpix and
  *     more: 2, from 32 Mpix: 4): sector s+1 is drawn while the blobs of sector s cross the link - the draw is hidden
  *     behind the transfer except for the first sector's.  A sector's pixels are bit-identical to the same pixels of
  *     a whole draw (hz_hip_set_sector), so the bytes the caller gets do not depend on the number of sectors.
- *   - The stream of a sector travels in chunks of HZ_STAGE_BYTES through a ring of pinned staging buffers (two copy
- *     streams in turn); a chunk's blobs are scattered while the next chunks are in flight.
+ *   - The stream of a sector travels through a ring of HZ_STAGE_SLOTS pinned chunks of HZ_STAGE_BYTES; one copy moves
+ *     up to four consecutive chunks (a copy costs the engine ~22 us beyond its bytes), a sector's first copy one, the
+ *     panorama's last ones too (they are scattered with nothing left to hide behind).  Two copy streams in turn, of
+ *     the HIGHEST priority: HIP deals streams onto a few hardware queues, and on a queue shared with a draw stream the
+ *     first sector's copies waited behind the marching kernels of the sectors queued after it.
+ *   - 62 % of the benchmark image is sky - BGR (255,0,0), range -1 (reference horizonator-lib.c:185, :1016).  The pool
+ *     writes it with streaming stores, but only the rows [0, y_pre) beforehand: as much as there is time for until
+ *     the first blobs arrive (one sector: everything, behind the draw; four: the upper 30 %).  Below y_pre a blob
+ *     writes the sky pixels of its own tile (hz_blob_scatter_mode), and the tiles without a blob are filled when
+ *     their sector has been walked (fill_absent).  Filling and scattering side by side cost the host 3.8-4.3 ms where
+ *     one after the other they cost 2.4 (profiles/r5_host_microbenchmarks.txt): every byte is written once.
  *   - hz_hip_host_begin() / hz_hip_host_end() split a call in two: a caller that begins panorama k+1 before it ends
  *     panorama k (two sets of buffers) has the device draw k+1 while k crosses the link, and pays the link only.
  *
- * Round 4 (one sector, 5 bytes per pixel, draw and transfer strictly in series): 4.3 ms per call; the timeline of a
- * call of this version: profiles/r5_host_inclusive.txt.
+ * Round 4 (one sector, 5 bytes per pixel, draw and transfer strictly in series): 4.3 ms per call; this version:
+ * 3.2-3.5 ms, its timeline in profiles/r5_host_inclusive.txt (HZ_HOST_TIMES=1 prints one per call).  Tried and dropped:
+ * k_pack_host storing straight into pinned host memory (38 GB/s from its compacted stores, and the host reads that
+ * memory slowly: 3.9-6.0 ms).
  *
  * The dense path at the end of the file (every pixel travels: 448 MB) serves textured colour, images taller than
  * 65535 rows and hz_options_t::host_dense. */
