@@ -24,10 +24,29 @@ def _check(what, seed=0, n=0):
 
 
 def test_reciprocal_every_float_in_range():
+    """v_rcp_f32 + one Newton step is the correctly rounded reciprocal of every float with 2^-62 <= |b| <= 2^62 (round 5:
+    tools/exact_seq.hip found it so on the MI355X; hipcc's own sequence has two more steps)"""
     _check(0)
 
 
+def test_quotient_by_two_pi_every_numerator():
+    """... and one correction step the correctly rounded a/(2 pi) of every numerator that is zero or in 2^-100 .. 2^30"""
+    _check(6)
+
+
+def test_min_over_max_with_one_is_the_number_or_its_reciprocal():
+    """the arc tangent's min(t,1)/max(t,1): every t that is zero or in 2^-62 .. 2^62"""
+    _check(7)
+
+
+@pytest.mark.parametrize("what,seed", [(8, 21), (8, 22), (9, 23), (9, 24)])
+def test_abridged_arc_tangent_seeded_pairs(what, seed):
+    """hzf_atan2 (reciprocal given or not, the sign taken from the operands' sign bits) against hz_atan2: 2^30 pairs per seed"""
+    _check(what, seed=seed * 0x3000000000, n=1 << 30)
+
+
 def test_square_root_every_float_from_2_pow_minus_96():
+    """round 5: v_rsq_f32 and one Newton step (five instructions instead of nine)"""
     _check(1)
 
 
