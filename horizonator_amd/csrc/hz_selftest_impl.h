@@ -93,6 +93,20 @@ void k_check_fastmath(int what, unsigned long long seed, unsigned long long n, u
             in_range = __float_as_uint(a) == 0u || (a >= 2.16840434e-19f && a <= 4.61168602e18f);
             if(in_range) { want = hz_min(a, 1.0f) / hz_max(a, 1.0f); got = hzf_fold_to_unit(a); }
         }
+        else if(what == 8 || what == 9)     /* the abridged arc tangent against hz_atan2: seeded (y, x), y zero or 2^-30 .. 2^30 of either
+                                             * sign, x likewise but never zero; 9: x > 0 (the elevation angle's: a distance, up to 2^30.5) */
+        {
+            const unsigned long long r1 = hz_mix64(seed + 2*k), r2 = hz_mix64(seed + 2*k + 1);
+            a = hz_seeded_float(r1, 127-30, 127+29);
+            b = hz_seeded_float(r2, 127-30, 127+29);
+            if((r1 >> 60) == 0 && what == 9) a = 0.0f;     /* (the azimuth's y is an east offset in range: never zero) */
+            if((r1 >> 60) == 1) a = __uint_as_float((__float_as_uint(a) & 0x80000000u) | (__float_as_uint(b) & 0x7FFFFFFFu));    /* |y| = |x| */
+            if((r1 >> 60) == 2) a = __uint_as_float(__float_as_uint(a) & 0xFFFFFF00u);                                          /* short mantissas */
+            if((r2 >> 60) == 2) b = __uint_as_float(__float_as_uint(b) & 0xFFFFFF00u);
+            if(what == 9) b = hz_abs(b) * (((r2 >> 59) & 1) ? 1.41421354f : 1.0f);
+            want = hz_atan2(a, b);
+            got  = what == 9 ? hzf_atan2<true>(a, b) : hzf_atan2<false>(a, b);
+        }
         else                                /* division by a per-draw constant through hzf_div_by: k = numerator pattern */
         {
             b = __uint_as_float((uint32_t)seed);
@@ -116,7 +130,7 @@ extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long se
 {
     hz_device_guard device_guard_(device);
     if(!device_guard_.ok) return -1;
-    if(what < 0 || what > 7) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
+    if(what < 0 || what > 9) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
     if(what == 0 || what == 1 || what == 3 || what == 6 || what == 7) n = 1ull << 32;
     if(what == 4) n = (1ull << 31) - 1;
     unsigned long long* d_bad = NULL; float* d_first = NULL;
