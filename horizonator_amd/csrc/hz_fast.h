@@ -37,9 +37,25 @@
  * With a divisor that is a per-draw constant the reciprocal refinement is done
  * once per wave (hzf_setup) and a division costs five instructions.
  *
+ * Round 5: where the operand is ONE float - a reciprocal, a square root, a
+ * quotient by 2 pi - "the same bits as `/` and sqrtf" can be had for every
+ * operand by trying them all, and tools/exact_seq.hip did, on the MI355X, for
+ * shorter sequences than hipcc's (profiles/r5_exact_sequences.txt):
+ *     1/b         v_rcp + one Newton step (3 instructions, not 7): the correctly
+ *                 rounded reciprocal of every float with 2^-62 <= |b| <= 2^62
+ *     sqrt(x)     v_rsq, s = x*y, h = y/2, s + (x - s*s)*h (5, not 9): the
+ *                 correctly rounded root of every float from 2^-96 on
+ *     a/(2 pi)    one correction step (3, not 5): every numerator that is zero or
+ *                 has 2^-62 <= |a| <= 2^30
+ * and the transform's remaining general division, min(t,1)/max(t,1), is t itself
+ * or the reciprocal of t.  These are statements about gfx950's v_rcp_f32 and
+ * v_rsq_f32, not about IEEE arithmetic: tests/test_gpu_fastmath.py tries every
+ * operand again on whatever device the library runs on.
+ *
  * tests/test_gpu_fastmath.py runs the abridged sequences against `/` and
- * sqrtf on the device: every float32 bit pattern for the reciprocal and the
- * square root, 2^32 seeded pairs for the division.
+ * sqrtf on the device: every float32 bit pattern for the reciprocal, the
+ * square root and the quotients by a draw's constants, 2^32 seeded pairs for
+ * the general division (hzf_div: no longer part of the transform).
  */
 #pragma once
 
@@ -71,19 +87,26 @@ __device__ static inline float hzf_div_by(float a, float c, float rr)
     return __builtin_fmaf(e, rr, q);
 }
 __device__ static inline float hzf_div(float a, float b) { return hzf_div_by(a, b, hzf_refined_rcp(b)); }
-__device__ static inline float hzf_rcp(float b)          { return hzf_div_by(1.0f, b, hzf_refined_rcp(b)); }
+/* 1.0f/b for 2^-62 <= |b| <= 2^62: the refined reciprocal IS the correctly rounded one (every such b tried) */
+__device__ static inline float hzf_rcp(float b)          { return hzf_refined_rcp(b); }
+/* a/c for c = 2 pi, rr = hzf_refined_rcp(c), a zero or 2^-62 <= |a| <= 2^30: one correction step (every such a tried) */
+__device__ static inline float hzf_div_by_two_pi(float a, float rr)
+{
+    const float q = a*rr;
+    const float e = __builtin_fmaf(-HZ_TWO_PI, q, a);
+    return __builtin_fmaf(e, rr, q);
+}
+/* min(t,1)/max(t,1) for t = 0 or 2^-62 <= t <= 2^62: t/1 or 1/t */
+__device__ static inline float hzf_fold_to_unit(float t) { return (1.0f < t) ? hzf_rcp(t) : t; }
 
-/* sqrtf(x), 2^-96 <= x < inf */
+/* sqrtf(x), 2^-96 <= x < inf (every such x tried): Newton's step from x*rsq(x) with rsq(x)/2 for 1/(2 sqrt x) */
 __device__ static inline float hzf_sqrt(float x)
 {
-    const float s    = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __int_as_float(__float_as_int(s) - 1);
-    const float s_up = __int_as_float(__float_as_int(s) + 1);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x);
-    const float r_up = __builtin_fmaf(-s_up, s, x);
-    float r = (r_dn <= 0.0f) ? s_dn : s;
-    r = (r_up > 0.0f) ? s_up : r;
-    return r;
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x*y;
+    const float h = 0.5f*y;
+    const float r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, h, s);
 }
 
 /* per-wave constants of a draw */
@@ -110,18 +133,18 @@ __device__ static inline hzf_const_t hzf_setup(const hz_xform_t* u)
  * in that range too: the 1/4 scaling of huge denominators (>= 1e18) never acts,
  * t*1 = t and s*1 = s exactly.  XPOS: x > 0 is known (the elevation angle, whose
  * x is a distance). */
+/* (rcp: 1.0f/t of the denominator t the function picks - x's magnitude, or y where x <= 0 -, which the marching wave
+ * has ahead of time for the azimuth: its y is the same for every row of a strip, its x the same for every lane of a row) */
 template<bool XPOS>
-__device__ static inline float hzf_atan2(float y, float x)
+__device__ static inline float hzf_atan2_r(float y, float x, float rcp)
 {
     const bool  flip = XPOS ? false : (0.f >= x);
     const float ax   = hz_abs(x);
     const float s    = flip ? ax : y;
-    const float t    = flip ? y  : ax;
-    const float rcp  = hzf_rcp(t);
     const float sot  = s * rcp;
     const float tn   = (ax == hz_abs(y)) ? 1.0f : hz_abs(sot);
 
-    const float u  = hzf_div(hz_min(tn, 1.0f), hz_max(tn, 1.0f));
+    const float u  = hzf_fold_to_unit(tn);
     const float u2 = u*u;
     const float u3 = u2*u;
     const float u5 = u3*u2;
@@ -134,28 +157,42 @@ __device__ static inline float hzf_atan2(float y, float x)
     p = p + (u9*-0.0121323213173444f)*u2;
     const float a   = (1.0f < tn) ? ((p*-2.0f + HZ_HALF_PI) + p) : p;
     const float arc = flip ? (HZ_HALF_PI + a) : a;
-    return (hz_min(y, rcp) < 0.f) ? -arc : arc;
+    /* (min(y, rcp) < 0 ? -arc : arc) - arc is +0 or positive (p >= 0 on [0, 1]), y is not -0 (see above) and rcp is a
+     * number other than zero: the result's sign bit is the OR of theirs */
+    const uint32_t sign = ((uint32_t)__float_as_int(y) | (uint32_t)__float_as_int(rcp)) & 0x80000000u;
+    return __int_as_float((int)((uint32_t)__float_as_int(arc) | sign));
+}
+template<bool XPOS>
+__device__ static inline float hzf_atan2(float y, float x)
+{
+    const float t = (XPOS ? false : (0.f >= x)) ? y : hz_abs(x);
+    return hzf_atan2_r<XPOS>(y, x, hzf_rcp(t));
 }
 
 /* hz_transform_en() under the range conditions: e, n in [2^-30, 2^30] in
  * magnitude (not zero), h = fz - viewer_z zero or in that range, the depth and
  * colour extents and their spans in that range (hzf_draw_ok) */
 /* (in two halves, as hz_num.h's: hzf_polar_en() is what depends on the viewer's position alone, hzf_finish() the rest) */
-__device__ static inline hz_polar_t hzf_polar_en(const hz_xform_t* u, float e, float n, float fz)
+/* (rcp_az: 1.0f/e where n <= 0, 1.0f/|n| elsewhere - hzf_rcp() of it) */
+__device__ static inline hz_polar_t hzf_polar_en_r(const hz_xform_t* u, float e, float n, float fz, float rcp_az)
 {
     hz_polar_t q;
     const float h = fz - u->viewer_z;
     const float nn = n*n, ee = e*e;
     q.d_ne  = hzf_sqrt(nn + ee);
-    q.az    = hzf_atan2<false>(e, n);
+    q.az    = hzf_atan2_r<false>(e, n, rcp_az);
     q.el    = hzf_atan2<true>(h, q.d_ne);
     q.d_enh = hzf_sqrt(h*h + nn + ee);
     return q;
 }
+__device__ static inline hz_polar_t hzf_polar_en(const hz_xform_t* u, float e, float n, float fz)
+{
+    return hzf_polar_en_r(u, e, n, fz, hzf_rcp((0.f >= n) ? e : hz_abs(n)));
+}
 __device__ static inline hz_vertex_t hzf_finish(const hz_xform_t* u, const hzf_const_t* c, hz_polar_t q)
 {
     hz_vertex_t v;
-    const float d = hzf_div_by(q.az + -u->az_center, HZ_TWO_PI, c->rr_two_pi);
+    const float d = hzf_div_by_two_pi(q.az + -u->az_center, c->rr_two_pi);
     v.x = (HZ_TWO_PI*(d - hz_roundeven(d))) * u->az_ndc_per_rad;
     v.y = q.el * u->aspect * u->az_ndc_per_rad;
     v.z = hzf_div_by(q.d_enh - u->znear, c->zrange, c->rr_zrange) * 2.0f + -1.0f;
@@ -167,6 +204,10 @@ __device__ static inline hz_vertex_t hzf_finish(const hz_xform_t* u, const hzf_c
 __device__ static inline hz_vertex_t hzf_transform_en(const hz_xform_t* u, const hzf_const_t* c, float e, float n, float fz)
 {
     return hzf_finish(u, c, hzf_polar_en(u, e, n, fz));
+}
+__device__ static inline hz_vertex_t hzf_transform_en_r(const hz_xform_t* u, const hzf_const_t* c, float e, float n, float fz, float rcp_az)
+{
+    return hzf_finish(u, c, hzf_polar_en_r(u, e, n, fz, rcp_az));
 }
 
 #endif /* __HIPCC__ */

@@ -644,6 +644,13 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     const hzf_const_t fc = hzf_setup(&p.u);
     const bool fast_strip = p.fast_ok && __all(hzf_in_range(e));
     const unsigned long long fast_rows = __ballot(hzf_in_range(n_tab));
+    /* the reciprocal the azimuth's arc tangent begins with (hzf_atan2_r) is that of |n| north of the viewer - one value
+     * per row - and that of e elsewhere - one per lane, the same in every row: ahead of time, like n itself, in ONE
+     * register (a strip lies north or south of the viewer; the few that hold the viewer's row compute it row by row) */
+    const int  tab_rows   = min(jend - jbeg, 63);
+    const bool rcp_south  = __all(lane > tab_rows || 0.f >= n_tab);
+    const bool rcp_north  = __all(lane > tab_rows || !(0.f >= n_tab));
+    const float rcp_tab   = VCACHE ? 0.f : hzf_rcp(rcp_south ? e : hz_abs(n_tab));
 
     /* pending-triangle ring, wave-uniform state */
     unsigned int head = 0, count = 0;
@@ -685,8 +692,17 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         if(skip_row) continue;
 
         const bool fast = fast_strip && (rel >= 64 ? hzf_in_range(n) : (int)((fast_rows >> rel) & 1ull));
-        const hz_vertex_t vtx = VCACHE ? (fast ? hzf_finish(&p.u, &fc, q_cur) : hz_finish(&p.u, q_cur))
-                                       : (fast ? hzf_transform_en(&p.u, &fc, e, n, z) : hz_transform_en(&p.u, e, n, z));
+        hz_vertex_t vtx;
+        if(VCACHE) vtx = fast ? hzf_finish(&p.u, &fc, q_cur) : hz_finish(&p.u, q_cur);
+        else if(fast)
+        {
+            float rcp_az;
+            if(rel >= 64 || !(rcp_south || rcp_north)) rcp_az = hzf_rcp((0.f >= n) ? e : hz_abs(n));
+            else if(rcp_south) rcp_az = rcp_tab;
+            else rcp_az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rcp_tab), rel));
+            vtx = hzf_transform_en_r(&p.u, &fc, e, n, z, rcp_az);
+        }
+        else vtx = hz_transform_en(&p.u, e, n, z);
 
         bool in_volume, in_guard;
         hz_wvert_t cur = mr_window(vtx, p, &in_volume, &in_guard);

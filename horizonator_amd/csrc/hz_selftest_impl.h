@@ -32,7 +32,7 @@ void k_check_fastmath(int what, unsigned long long seed, unsigned long long n, u
         if(what == 0)                       /* reciprocal: every bit pattern (k = the pattern), those in range checked */
         {
             b = __uint_as_float((uint32_t)k);
-            in_range = hzf_in_range(b);
+            in_range = hz_abs(b) >= 2.16840434e-19f && hz_abs(b) <= 4.61168602e18f;        /* 2^-62 .. 2^62 */
             if(in_range) { want = 1.0f / b; got = hzf_rcp(b); }
         }
         else if(what == 1)                  /* square root: every bit pattern from 2^-96 up to the largest finite float */
@@ -77,13 +77,43 @@ void k_check_fastmath(int what, unsigned long long seed, unsigned long long n, u
             const bool ok = (q > 1073741824ll) ? f >= 1073741824 : (q < -1073741824ll) ? f <= -1073741824 : (int64_t)f == q;
             want = 0.f; got = ok ? 0.f : 1.f;
         }
+        else if(what == 6)                  /* the quotient by 2 pi in one correction step: k = numerator pattern, zero or 2^-100 .. 2^30 */
+        {
+            float two_pi = HZ_TWO_PI;
+            asm volatile("" : "+v"(two_pi));
+            b = two_pi;
+            a = __uint_as_float((uint32_t)k);
+            const float aa = hz_abs(a);
+            in_range = __float_as_uint(a) == 0u || (aa >= 7.88860905e-31f && aa <= 1073741824.0f);
+            if(in_range) { want = a / b; got = hzf_div_by_two_pi(a, hzf_refined_rcp(two_pi)); }
+        }
+        else if(what == 7)                  /* min(t,1)/max(t,1) as t or 1/t: k = the pattern of t, zero or 2^-62 .. 2^62 */
+        {
+            a = __uint_as_float((uint32_t)k);
+            in_range = __float_as_uint(a) == 0u || (a >= 2.16840434e-19f && a <= 4.61168602e18f);
+            if(in_range) { want = hz_min(a, 1.0f) / hz_max(a, 1.0f); got = hzf_fold_to_unit(a); }
+        }
+        else if(what == 8 || what == 9)     /* the abridged arc tangent against hz_atan2: seeded (y, x), y zero or 2^-30 .. 2^30 of either
+                                             * sign, x likewise but never zero; 9: x > 0 (the elevation angle's: a distance, up to 2^30.5) */
+        {
+            const unsigned long long r1 = hz_mix64(seed + 2*k), r2 = hz_mix64(seed + 2*k + 1);
+            a = hz_seeded_float(r1, 127-30, 127+29);
+            b = hz_seeded_float(r2, 127-30, 127+29);
+            if((r1 >> 60) == 0 && what == 9) a = 0.0f;     /* (the azimuth's y is an east offset in range: never zero) */
+            if((r1 >> 60) == 1) a = __uint_as_float((__float_as_uint(a) & 0x80000000u) | (__float_as_uint(b) & 0x7FFFFFFFu));    /* |y| = |x| */
+            if((r1 >> 60) == 2) a = __uint_as_float(__float_as_uint(a) & 0xFFFFFF00u);                                          /* short mantissas */
+            if((r2 >> 60) == 2) b = __uint_as_float(__float_as_uint(b) & 0xFFFFFF00u);
+            if(what == 9) b = hz_abs(b) * (((r2 >> 59) & 1) ? 1.41421354f : 1.0f);
+            want = hz_atan2(a, b);
+            got  = what == 9 ? hzf_atan2<true>(a, b) : hzf_atan2<false>(a, b);
+        }
         else                                /* division by a per-draw constant through hzf_div_by: k = numerator pattern */
         {
             b = __uint_as_float((uint32_t)seed);
             a = __uint_as_float((uint32_t)k);
             const float aa = hz_abs(a);
             /* (+0 only: a negative zero would come out positive - see hz_fast.h on why none gets here) */
-            in_range = __float_as_uint(a) == 0u || (aa >= 8.67361738e-19f && aa <= 1.15292150e18f);
+            in_range = __float_as_uint(a) == 0u || (aa >= 7.88860905e-31f && aa <= 1.15292150e18f);     /* 2^-100 .. 2^60 */
             if(in_range) { want = a / b; got = hzf_div_by(a, b, hzf_refined_rcp(b)); }
         }
         if(in_range && __float_as_uint(want) != __float_as_uint(got))
@@ -100,8 +130,8 @@ extern "C" int hz_hip_check_fastmath(int device, int what, unsigned long long se
 {
     hz_device_guard device_guard_(device);
     if(!device_guard_.ok) return -1;
-    if(what < 0 || what > 5) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
-    if(what == 0 || what == 1 || what == 3) n = 1ull << 32;
+    if(what < 0 || what > 9) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_check_fastmath: what = %d", what); return -1; }
+    if(what == 0 || what == 1 || what == 3 || what == 6 || what == 7) n = 1ull << 32;
     if(what == 4) n = (1ull << 31) - 1;
     unsigned long long* d_bad = NULL; float* d_first = NULL;
     HZ_CHECK(hipMalloc(&d_bad, 2*sizeof(unsigned long long)));

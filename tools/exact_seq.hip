@@ -14,8 +14,10 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if(e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while(0)
 
-#define LO 9.31322575e-10f      /* 2^-30 */
-#define HI 1073741824.0f        /* 2^30 */
+/* operands: hz_fast.h admits e, n, h in [2^-30, 2^30]; a tangent of two of them and its reciprocal lie in [2^-61, 2^61],
+ * an angle may be as small as 2^-61 */
+#define LO 2.168404345e-19f     /* 2^-62 */
+#define HI 4.611686018e18f      /* 2^62 */
 
 #define NCAND 8
 struct res_t { unsigned long long tried, bad[NCAND]; unsigned int first[NCAND]; };
@@ -108,7 +110,7 @@ __global__ void k_sqrt(res_t* out)
     for(int k=0; k<NCAND; k++) if(bad[k]) atomicAdd(&out->bad[k], bad[k]);
 }
 
-/* ---- quotient by a constant: every numerator that is zero or in [2^-30, 2^30] ---- */
+/* ---- quotient by a constant: every numerator that is zero or in [2^-62, 2^30] ---- */
 __global__ void k_divc(res_t* out, float c)
 {
     const unsigned long long gid = (unsigned long long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -121,7 +123,7 @@ __global__ void k_divc(res_t* out, float c)
     {
         const float a = __uint_as_float((unsigned int)b);
         const float m = fabsf(a);
-        if(!(m == 0.0f || (m >= LO && m <= HI))) continue;
+        if(!(m == 0.0f || (m >= LO && m <= 1073741824.0f))) continue;
         if(a == 0.0f && (b >> 31)) continue;            /* -0: not a numerator of the transform (hz_fast.h) */
         tried++;
         const float want = a / cc;
@@ -159,7 +161,7 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(k_rcp, dim3(grid), dim3(block), 0, 0, d);
     CHECK(hipDeviceSynchronize()); CHECK(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
     { const char* n[] = { "v_rcp_f32 alone", "A: rcp + one Newton step (3 instructions)", "B: rcp + two Newton steps (5)", "C: hzf_rcp of round 4 (7)", "D: rcp, one step, residual of that corrected with rcp (5)" };
-      report("reciprocal, every float with 2^-30 <= |x| <= 2^30", &h, n, 5); }
+      report("reciprocal, every float with 2^-62 <= |x| <= 2^62", &h, n, 5); }
 
     CHECK(hipMemset(d, 0, sizeof(res_t)));
     hipLaunchKernelGGL(k_sqrt, dim3(grid), dim3(block), 0, 0, d);
