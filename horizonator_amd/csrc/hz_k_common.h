@@ -11,9 +11,6 @@
  * (HZ_EXP_FB_MARCH / HZ_EXP_FB_BIG, experiments with WRONG pictures - profiles/r3_experiments.json):
  * 1 = the fragment is dropped here, 2 = a plain store instead of the atomic minimum: what the atomics
  * cost, i.e. what a rasteriser that owned its pixels could gain; p.debug (HZ_MARCH_DEBUG): timing splits */
-#define HZ_WHO_MARCH 0
-#define HZ_WHO_BIG   1
-#define HZ_WHO_OTHER 2                  /* (k_clip's own fragments: never part of an experiment) */
 #ifdef HZ_EXPERIMENTS
 #define HZ_DEBUG(p) ((p).debug)
 #else

@@ -701,6 +701,16 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
             else if(rcp_south) rcp_az = rcp_tab;
             else rcp_az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rcp_tab), rel));
             vtx = hzf_transform_en_r(&p.u, &fc, e, n, z, rcp_az);
+#ifdef HZ_EXP_TRANSFORM_TWICE
+            /* (tools/march_bounds.py: what does one more transform per vertex cost the kernel?  The same picture: the second
+             * result replaces the first where they differ, which is nowhere - but the compiler cannot know) */
+            {
+                float n2 = n; asm volatile("" : "+v"(n2));
+                const hz_vertex_t v2 = hzf_transform_en_r(&p.u, &fc, e, n2, z, rcp_az);
+                vtx.x = (v2.x == vtx.x) ? vtx.x : v2.y; vtx.y = (v2.y == vtx.y) ? vtx.y : v2.z;
+                vtx.z = (v2.z == vtx.z) ? vtx.z : v2.x; vtx.red = (v2.red == vtx.red) ? vtx.red : v2.x;
+            }
+#endif
         }
         else vtx = hz_transform_en(&p.u, e, n, z);
 

@@ -17,6 +17,11 @@
  * w1 / w2 tiles per row; l1 == NULL: the draw has none */
 struct hz_hiz_t { uint32_t* l1; uint32_t* l2; int w1, w2; };
 
+/* whose fragments an experiment of the -DHZ_EXPERIMENTS build acts on (hz_params_t::exp_fb) */
+#define HZ_WHO_MARCH 0
+#define HZ_WHO_BIG   1
+#define HZ_WHO_OTHER 2                  /* (k_clip's own fragments: never part of an experiment) */
+
 struct hz_params_t
 {
     hz_xform_t u;
