@@ -48,7 +48,7 @@ def variant(name, flags):
     dst = os.path.join("/tmp", "hz_variant_" + name)
     shutil.rmtree(dst, ignore_errors=True)
     shutil.copytree(ROOT, dst, ignore=shutil.ignore_patterns("gpurun_out", ".git", "build", "*.so", "__pycache__", "profiles"))
-    r = subprocess.run(["make", "-s", "-C", os.path.join(dst, "horizonator_amd", "csrc"), "HIPFLAGS_EXTRA=" + flags], capture_output=True, text=True)
+    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(dst, "horizonator_amd", "csrc"), "HIPFLAGS_EXTRA=" + flags], capture_output=True, text=True)
     if r.returncode != 0:
         return None, r.stderr[-400:]
     subprocess.run(["make", "-s", "-C", os.path.join(dst, "oracle")], capture_output=True, text=True)
