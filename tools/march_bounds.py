@@ -35,13 +35,14 @@ def run(root, env):
 
 
 def main():
-    builds = [("experiments", "-DHZ_EXPERIMENTS"), ("twice", "-DHZ_EXPERIMENTS -DHZ_EXP_TRANSFORM_TWICE")]
-    for name, flags in builds:
+    builds = [("experiments", "-DHZ_EXPERIMENTS", 3), ("twice", "-DHZ_EXPERIMENTS -DHZ_EXP_TRANSFORM_TWICE", 3),
+              ("waves5", "-DMR_WAVES_PER_EU=5", 1), ("shipped", "", 1)]
+    for name, flags, nenv in builds:
         root, err = ex.variant(name, flags)
         if root is None:
             print(name, "build failed:", err)
             continue
-        for env in ({}, {"HZ_MARCH_DEBUG": "2"}, {"HZ_MARCH_DEBUG": "1"}):
+        for env in ({}, {"HZ_MARCH_DEBUG": "2"}, {"HZ_MARCH_DEBUG": "1"})[:nenv]:
             print(f"{flags:48s} {' '.join(f'{k}={v}' for k, v in env.items()) or '-':18s}", run(root, env), flush=True)
 
 
