@@ -19,8 +19,11 @@ def main():
     assert after and before, (err, err2)
     diff = os.path.join(ex.ROOT, "tools", "patches", "r5_short_sequences.diff")
     subprocess.run(["git", "apply", "-R", diff], cwd=before, check=True)
-    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(before, "horizonator_amd", "csrc")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-400:]
+    # (-k: the self-test library of today does not compile against yesterday's hz_fast.h; the library itself does)
+    lib = os.path.join(before, "horizonator_amd", "libhorizonator.so")
+    os.remove(lib)
+    r = subprocess.run(["make", "-s", "-k", "-j8", "-C", os.path.join(before, "horizonator_amd", "csrc")], capture_output=True, text=True)
+    assert os.path.exists(lib), r.stderr[-400:]
     for k in range(3):
         print("before", mb.run(before, {}), flush=True)
         print("after ", mb.run(after, {}), flush=True)
