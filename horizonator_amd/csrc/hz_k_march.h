@@ -21,18 +21,18 @@
  * Workgroup = one wave, so nothing ever waits for another wave.
  */
 
-#define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
+#define MR_CAP    256               /* pending-triangle ids, ring (power of two): up to 63 waiting + the 126 of a row */
 #define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the
  * triangles waiting for set-up.  id = (cell row - first row of the segment)<<7
- * | lane<<1 | t.  Only 6 + 2 LDS stores per row of 126 triangles. */
+ * | lane<<1 | t (13 bits).  Only 6 + 2 LDS stores per row of 126 triangles. */
 struct mr_lds_t
 {
     uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
-    uint32_t ids[MR_CAP];
+    uint16_t ids[MR_CAP];
     uint32_t clip[64];              /* ids on their way to k_clip's queue (mr_clip_note) */
     uint32_t nclip;                 /* ... how many: kept here, not in a register (one scalar less to carry through the marching loop) */
 };
@@ -353,7 +353,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
      * none is used - `valid` / `live` guard everything that leaves the wave -
      * and the wave saves the ~50 instructions that gave those lanes zeros
      * (3.5 % of k_march's instructions went there). */
-    const uint32_t id_own = L.ids[(head + lane) & (MR_CAP-1)];
+    const uint32_t id_own = (uint32_t)L.ids[(head + lane) & (MR_CAP-1)];
     const uint32_t id = valid ? id_own : (uint32_t)__builtin_amdgcn_readlane((int)id_own, 0);
     const int t = id & 1, l = (id >> 1) & 63, rowoff = id >> 7;
     const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
@@ -673,9 +673,25 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     float n_cur = north_of(0);
     bool far_prev = true;
     bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
-    for(int j = jbeg; j <= jend; j++)
+    for(int j = jbeg; ; j++)
     {
         const int rel = j - jbeg;
+        /* THE place where waiting triangles are set up and drawn (round 5: one copy of mr_flush in the kernel instead
+         * of four - a third of the code, and what the compiler hoisted out of each copy no longer spills the loop's
+         * scalars): whenever 64 wait, before a row is stored over one they still need (vertex row rel replaces row
+         * rel - MR_RSLOTS in LDS: happens where survivors are sparse), and behind the last row */
+        const bool last = j > jend;
+        while(count >= 64u || (count && (last || first_row <= rel - MR_RSLOTS)))
+        {
+            const unsigned int nf = count < 64u ? count : 64u;
+            __syncthreads();            /* one wave: orders the LDS writes before the reads */
+            mr_flush<HIZ>(L, head, nf, lane, jbeg, i0, fb, q, p, dbg);
+            __syncthreads();
+            head = (head + nf) & (MR_CAP-1);
+            count -= nf;
+            if(count) first_row = (int)((uint32_t)L.ids[head] >> 7);
+        }
+        if(last) break;
         const float z = (float)z_next;
         const hz_polar_t q_cur = q_next;
         if(j < jend)
@@ -719,16 +735,6 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         const bool cur_simple = __all(in_guard && in_volume);
         if(!cur_simple) mr_window_flags(cur, vtx, in_guard);
 
-        /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
-         * still need it are set up now (happens where survivors are sparse) */
-        if(count && first_row <= rel - MR_RSLOTS)
-        {
-            __syncthreads();
-            mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
-            __syncthreads();
-            head = (head + count) & (MR_CAP-1);
-            count = 0;
-        }
         mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
 
         const mr_rowstate_t now = mr_rowstate_of(cur, p);
@@ -774,27 +780,13 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                     if(keep)
                     {
                         const unsigned int at = (head + count + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & (MR_CAP-1);
-                        L.ids[at] = ((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t;
+                        L.ids[at] = (uint16_t)(((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t);
                     }
                     count += (unsigned int)__popcll(m);
-                    if(count >= 64)
-                    {
-                        __syncthreads();        /* one wave: orders the LDS writes before the reads */
-                        mr_flush<HIZ>(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
-                        head = (head + 64) & (MR_CAP-1);
-                        count -= 64;
-                        if(count) first_row = (int)(L.ids[head] >> 7);
-                        __syncthreads();
-                    }
                 }
             }
         }
         prev = now; prev_simple = cur_simple;
-    }
-    if(count)
-    {
-        __syncthreads();
-        mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
     }
     mr_clip_flush(L, q, lane);
     if(COUNTERS && p.wave_cycles && lane == 0)
