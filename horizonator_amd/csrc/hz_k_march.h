@@ -557,6 +557,14 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     unsigned int dbgv[6] = {0,0,0,0,0,0};
     unsigned int* dbg = COUNTERS ? dbgv : nullptr;
 
+#ifndef MR_FIVE_WAVES
+    /* The kernel needs 96 registers since round 5 (one copy of mr_flush), which would let FIVE waves share a SIMD - and
+     * leave 32 of its 512 registers, room for no wave of any neighbouring kernel: alone on the chip the kernel gains
+     * 2 % (0.637 -> 0.625 ms), a series of renders loses 15 % (0.85 -> 0.98: profiles/r5_ab_march_waves.txt).  Naming
+     * v103 makes the kernel's register count 104 without changing an instruction: four waves and, beside them, two
+     * waves of k_big or of the conversion (tests/test_kernel_resources.py). */
+    asm volatile("" ::: "v103");
+#endif
     const int lane = threadIdx.x;
     /* which strip: from the launch grid (whole panoramas: every strip has work),
      * or from the draw's work list (azimuth sectors and views of less than 360
