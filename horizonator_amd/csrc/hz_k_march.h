@@ -684,20 +684,27 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     for(int j = jbeg; ; j++)
     {
         const int rel = j - jbeg;
-        /* THE place where waiting triangles are set up and drawn (round 5: one copy of mr_flush in the kernel instead
-         * of four - a third of the code, and what the compiler hoisted out of each copy no longer spills the loop's
+        /* THE place where waiting triangles are set up and drawn (round 5: two copies of mr_flush in the kernel instead
+         * of four - half the code, and what the compiler hoisted out of each copy no longer spills the loop's
          * scalars): whenever 64 wait, before a row is stored over one they still need (vertex row rel replaces row
          * rel - MR_RSLOTS in LDS: happens where survivors are sparse), and behind the last row */
         const bool last = j > jend;
-        while(count >= 64u || (count && (last || first_row <= rel - MR_RSLOTS)))
+        while(count >= 64u)
         {
-            const unsigned int nf = count < 64u ? count : 64u;
             __syncthreads();            /* one wave: orders the LDS writes before the reads */
-            mr_flush<HIZ>(L, head, nf, lane, jbeg, i0, fb, q, p, dbg);
+            mr_flush<HIZ>(L, head, 64u, lane, jbeg, i0, fb, q, p, dbg);     /* (a copy of its own: with all 64 lanes at work a dozen instructions go) */
             __syncthreads();
-            head = (head + nf) & (MR_CAP-1);
-            count -= nf;
+            head = (head + 64u) & (MR_CAP-1);
+            count -= 64u;
             if(count) first_row = (int)((uint32_t)L.ids[head] >> 7);
+        }
+        if(count && (last || first_row <= rel - MR_RSLOTS))
+        {
+            __syncthreads();
+            mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+            __syncthreads();
+            head = (head + count) & (MR_CAP-1);
+            count = 0;
         }
         if(last) break;
         const float z = (float)z_next;
