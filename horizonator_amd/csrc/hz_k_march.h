@@ -21,18 +21,18 @@
  * Workgroup = one wave, so nothing ever waits for another wave.
  */
 
-#define MR_CAP    256               /* pending-triangle ids, ring (power of two): up to 63 waiting + the 126 of a row */
+#define MR_CAP    128               /* pending-triangle ids, ring (power of two)    */
 #define MR_RSLOTS 4                 /* vertex rows kept in LDS (power of two)       */
 #define MR_FIELDS 6                 /* wx wy zw red xs ys                            */
 
 /* LDS of one wave: the last MR_RSLOTS vertex rows (structure of arrays: one
  * conflict-free 256-byte store per field and row) and a ring of ids of the
  * triangles waiting for set-up.  id = (cell row - first row of the segment)<<7
- * | lane<<1 | t (13 bits).  Only 6 + 2 LDS stores per row of 126 triangles. */
+ * | lane<<1 | t.  Only 6 + 2 LDS stores per row of 126 triangles. */
 struct mr_lds_t
 {
     uint32_t rows[MR_RSLOTS][MR_FIELDS][64];
-    uint16_t ids[MR_CAP];
+    uint32_t ids[MR_CAP];
     uint32_t clip[64];              /* ids on their way to k_clip's queue (mr_clip_note) */
     uint32_t nclip;                 /* ... how many: kept here, not in a register (one scalar less to carry through the marching loop) */
 };
@@ -353,7 +353,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
      * none is used - `valid` / `live` guard everything that leaves the wave -
      * and the wave saves the ~50 instructions that gave those lanes zeros
      * (3.5 % of k_march's instructions went there). */
-    const uint32_t id_own = (uint32_t)L.ids[(head + lane) & (MR_CAP-1)];
+    const uint32_t id_own = L.ids[(head + lane) & (MR_CAP-1)];
     const uint32_t id = valid ? id_own : (uint32_t)__builtin_amdgcn_readlane((int)id_own, 0);
     const int t = id & 1, l = (id >> 1) & 63, rowoff = id >> 7;
     const int s0 = rowoff & (MR_RSLOTS-1), s1 = (rowoff+1) & (MR_RSLOTS-1);
@@ -384,6 +384,18 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             const uint32_t rowbytes = (uint32_t)p.SW*8u;
             const uint32_t o0 = (uint32_t)box.py0*rowbytes, o1 = box.py1 > box.py0 ? o0 + rowbytes : o0;
             const int c0 = box.px0 - p.col0, cl = box.px1 - p.col0;
+#ifdef MR_EARLYZ_PAIRS
+            /* (an experiment of round 5, profiles/r5_ab_march_loop.txt) two neighbouring pixels to a load (12 bytes from
+             * the first one's upper half: its depth, the second one's lower half, the second one's depth): the box's first
+             * two columns and its last two - four loads instead of eight.  A box one column wide takes a neighbour's depth
+             * along (a larger zs: fewer triangles found hidden, never one too many); the pair stays inside the row. */
+            typedef uint32_t u3_t __attribute__((ext_vector_type(3)));
+            const int ca = max(min(c0, p.SW - 2), 0), cb = max(min(max(cl - 1, c0), p.SW - 2), 0);
+            const uint32_t ba = 8u*(uint32_t)ca, bb = 8u*(uint32_t)cb;
+            const u3_t a0 = *(const u3_t*)(hi + (o0 + ba)), b0 = *(const u3_t*)(hi + (o0 + bb));
+            const u3_t a1 = *(const u3_t*)(hi + (o1 + ba)), b1 = *(const u3_t*)(hi + (o1 + bb));
+            const uint32_t zs = max(max(max(a0.x, a0.z), max(b0.x, b0.z)), max(max(a1.x, a1.z), max(b1.x, b1.z))) >> 8;
+#else
             const int c1 = min(c0+1, cl), c2 = min(c0+2, cl);
             const uint32_t b0 = 8u*(uint32_t)c0, b1 = 8u*(uint32_t)c1, b2 = 8u*(uint32_t)c2, bl = 8u*(uint32_t)cl;
             uint32_t z[8];
@@ -392,6 +404,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             z[4] = *(const uint32_t*)(hi + (o1 + b0)); z[5] = *(const uint32_t*)(hi + (o1 + b1));
             z[6] = *(const uint32_t*)(hi + (o1 + b2)); z[7] = *(const uint32_t*)(hi + (o1 + bl));
             const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
+#endif
             if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }
         else if(HIZ && valid && p.hiz)
@@ -557,14 +570,6 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     unsigned int dbgv[6] = {0,0,0,0,0,0};
     unsigned int* dbg = COUNTERS ? dbgv : nullptr;
 
-#ifndef MR_FIVE_WAVES
-    /* The kernel needs 96 registers since round 5 (one copy of mr_flush), which would let FIVE waves share a SIMD - and
-     * leave 32 of its 512 registers, room for no wave of any neighbouring kernel: alone on the chip the kernel gains
-     * 2 % (0.637 -> 0.625 ms), a series of renders loses 15 % (0.85 -> 0.98: profiles/r5_ab_march_waves.txt).  Naming
-     * v103 makes the kernel's register count 104 without changing an instruction: four waves and, beside them, two
-     * waves of k_big or of the conversion (tests/test_kernel_resources.py). */
-    asm volatile("" ::: "v103");
-#endif
     const int lane = threadIdx.x;
     /* which strip: from the launch grid (whole panoramas: every strip has work),
      * or from the draw's work list (azimuth sectors and views of less than 360
@@ -681,32 +686,9 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     float n_cur = north_of(0);
     bool far_prev = true;
     bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
-    for(int j = jbeg; ; j++)
+    for(int j = jbeg; j <= jend; j++)
     {
         const int rel = j - jbeg;
-        /* THE place where waiting triangles are set up and drawn (round 5: two copies of mr_flush in the kernel instead
-         * of four - half the code, and what the compiler hoisted out of each copy no longer spills the loop's
-         * scalars): whenever 64 wait, before a row is stored over one they still need (vertex row rel replaces row
-         * rel - MR_RSLOTS in LDS: happens where survivors are sparse), and behind the last row */
-        const bool last = j > jend;
-        while(count >= 64u)
-        {
-            __syncthreads();            /* one wave: orders the LDS writes before the reads */
-            mr_flush<HIZ>(L, head, 64u, lane, jbeg, i0, fb, q, p, dbg);     /* (a copy of its own: with all 64 lanes at work a dozen instructions go) */
-            __syncthreads();
-            head = (head + 64u) & (MR_CAP-1);
-            count -= 64u;
-            if(count) first_row = (int)((uint32_t)L.ids[head] >> 7);
-        }
-        if(count && (last || first_row <= rel - MR_RSLOTS))
-        {
-            __syncthreads();
-            mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
-            __syncthreads();
-            head = (head + count) & (MR_CAP-1);
-            count = 0;
-        }
-        if(last) break;
         const float z = (float)z_next;
         const hz_polar_t q_cur = q_next;
         if(j < jend)
@@ -750,6 +732,16 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         const bool cur_simple = __all(in_guard && in_volume);
         if(!cur_simple) mr_window_flags(cur, vtx, in_guard);
 
+        /* this row replaces vertex row rel-MR_RSLOTS in LDS: triangles that
+         * still need it are set up now (happens where survivors are sparse) */
+        if(count && first_row <= rel - MR_RSLOTS)
+        {
+            __syncthreads();
+            mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+            __syncthreads();
+            head = (head + count) & (MR_CAP-1);
+            count = 0;
+        }
         mr_store_row(L, rel & (MR_RSLOTS-1), lane, cur);
 
         const mr_rowstate_t now = mr_rowstate_of(cur, p);
@@ -795,14 +787,34 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                     if(keep)
                     {
                         const unsigned int at = (head + count + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) & (MR_CAP-1);
-                        L.ids[at] = (uint16_t)(((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t);
+                        L.ids[at] = ((uint32_t)(rel-1) << 7) | ((uint32_t)lane << 1) | (uint32_t)t;
                     }
                     count += (unsigned int)__popcll(m);
+                    if(count >= 64)
+                    {
+                        __syncthreads();        /* one wave: orders the LDS writes before the reads */
+                        mr_flush<HIZ>(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
+                        head = (head + 64) & (MR_CAP-1);
+                        count -= 64;
+                        if(count) first_row = (int)(L.ids[head] >> 7);
+                        __syncthreads();
+                    }
                 }
             }
         }
         prev = now; prev_simple = cur_simple;
     }
+    if(count)
+    {
+        __syncthreads();
+        mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+    }
+    /* (Four inlined copies of mr_flush - this one, the one before a row is stored, two in the unrolled loop over a cell's
+     * triangles - and 104 registers.  Round 5 tried ONE place at the top of the row loop instead (tools/patches/
+     * r5_one_flush_copy.diff): 96 registers, scalar spills 24 -> 9, a third of the code - and with four waves per SIMD
+     * the kernel takes 0.675 instead of 0.640 ms, a render of a series 0.885 instead of 0.836; with the five waves 96
+     * registers allow 0.625 alone and 0.98 in a series, whose other kernels then find no registers beside the marching
+     * waves; two copies: 0.670 / 0.873.  profiles/r5_ab_march_loop.txt.) */
     mr_clip_flush(L, q, lane);
     if(COUNTERS && p.wave_cycles && lane == 0)
     {

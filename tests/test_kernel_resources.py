@@ -54,7 +54,7 @@ def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     # series 0.93 -> 0.85 ms (profiles/r4_ab_kbig_addr32.txt)
     assert march["vgpr_count"] <= 104 and zoomed["vgpr_count"] <= 104, (march, zoomed)
     # round 5: ... and more than 96 - FOUR waves per SIMD, not five, which would leave their neighbours no room at all (a series
-    # of renders 0.85 -> 0.98 ms: profiles/r5_ab_march_waves.txt; hz_k_march.h names v103 for that)
+    # of renders 0.85 -> 0.98 ms with a 96-register build of the kernel: profiles/r5_ab_march_loop.txt)
     for name in ("k_marchILb0ELb0ELb0E", "k_marchILb0ELb1ELb0E", "k_marchILb0ELb0ELb1E", "k_marchILb0ELb1ELb1E"):
         assert 96 < _one(k, name)["vgpr_count"] <= 104, (name, _one(k, name))
     assert march["group_segment_fixed_size"] <= 7168
