@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B on ONE box: the marching loop with four inlined copies of mr_flush (until round 5), with one, with two
-(tools/patches/r5_*_flush_cop*.diff applied to copies of the tree), all at four waves per SIMD (104 registers):
+(tools/patches/r5_*_flush_cop*.diff applied to copies of the tree; the patched kernels name v103 to stay at four waves per
+SIMD, 104 registers, like the four copies):
 k_march alone and a render of a series of 20, three times each, alternating.
 
     python tools/ab_flush_copies.py > gpurun_out/r5_ab_flush_copies.txt"""
@@ -24,8 +25,8 @@ def patched(name, diff):
 
 
 def main():
-    trees = [("four copies", patched("four", "r5_four_flush_copies.diff")), ("one copy   ", patched("one", "r5_one_flush_copy.diff")),
-             ("two copies ", patched("two", None))]
+    trees = [("four copies", patched("four", None)), ("one copy   ", patched("one", "r5_one_flush_copy.diff")),
+             ("two copies ", patched("two", "r5_two_flush_copies.diff"))]
     for k in range(3):
         for name, root in trees:
             print(name, mb.run(root, {}), flush=True)
