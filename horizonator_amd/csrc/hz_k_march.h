@@ -685,7 +685,12 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
      * With the default zfar = 40 km this is most of a large mosaic. */
     float n_cur = north_of(0);
     bool far_prev = true;
+#ifdef MR_FAR_GATE
+    /* (a draw none of whose vertices lies beyond zfar - p.far_strips, from the mosaic's corners - asks no row) */
+    bool far_cur  = p.far_strips && __all(n_cur*n_cur + e*e > p.far_dd);
+#else
     bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
+#endif
     for(int j = jbeg; j <= jend; j++)
     {
         const int rel = j - jbeg;
@@ -697,7 +702,11 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
             else z_next = mosaic[(size_t)(j+1)*p.N + ic];
         }
         const float n_next   = (j == jend) ? 0.f : north_of(rel+1);
+#ifdef MR_FAR_GATE
+        const bool  far_next = (j == jend) || (p.far_strips && __all(n_next*n_next + e*e > p.far_dd));
+#else
         const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
+#endif
         const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
         const bool  skip_cells = far_prev && far_cur;               /* cell row j-1 entirely clipped */
         const float n = n_cur;
