@@ -1097,7 +1097,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
              * first (with tables it would have to wait: 1.26 -> 1.40 ms).  One sweep: more of them beside the second
              * round, one in front of k_big (which tests its chunks of rows against the same tables), one between a
              * nearer and a farther band of the second round - each was measured, none paid. */
-            const bool early_z = true;        /* (the early depth test addresses the framebuffer with 32-bit byte offsets: every framebuffer is below 4 GB, hz_hip_create) */
+            const bool early_z = p.SW >= 2;   /* (the early depth test addresses the framebuffer with 32-bit byte offsets - every framebuffer is below 4 GB, hz_hip_create - and reads pixels in pairs) */
             hz_hiz_t hz = {};
             {
                 const bool zoomed = zoomed_view;

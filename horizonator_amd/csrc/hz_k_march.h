@@ -384,27 +384,17 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
             const uint32_t rowbytes = (uint32_t)p.SW*8u;
             const uint32_t o0 = (uint32_t)box.py0*rowbytes, o1 = box.py1 > box.py0 ? o0 + rowbytes : o0;
             const int c0 = box.px0 - p.col0, cl = box.px1 - p.col0;
-#ifdef MR_EARLYZ_PAIRS
-            /* (an experiment of round 5, profiles/r5_ab_march_loop.txt) two neighbouring pixels to a load (12 bytes from
-             * the first one's upper half: its depth, the second one's lower half, the second one's depth): the box's first
-             * two columns and its last two - four loads instead of eight.  A box one column wide takes a neighbour's depth
-             * along (a larger zs: fewer triangles found hidden, never one too many); the pair stays inside the row. */
+            /* two neighbouring pixels to a load (12 bytes from the first one's upper half: its depth, the second one's
+             * lower half, the second one's depth): the box's first two columns and its last two - four loads where round 4
+             * had eight, one per pixel (k_march alone 0.635 -> 0.627 ms, a render of a series -1.6 %: profiles/
+             * r5_ab_march_loop.txt).  A box one column wide takes a neighbour's depth along (a larger zs: fewer triangles
+             * found hidden, never one too many); the pair stays inside the row (SW >= 2: draw_impl). */
             typedef uint32_t u3_t __attribute__((ext_vector_type(3)));
-            const int ca = max(min(c0, p.SW - 2), 0), cb = max(min(max(cl - 1, c0), p.SW - 2), 0);
+            const int ca = min(c0, p.SW - 2), cb = min(max(cl - 1, c0), p.SW - 2);
             const uint32_t ba = 8u*(uint32_t)ca, bb = 8u*(uint32_t)cb;
             const u3_t a0 = *(const u3_t*)(hi + (o0 + ba)), b0 = *(const u3_t*)(hi + (o0 + bb));
             const u3_t a1 = *(const u3_t*)(hi + (o1 + ba)), b1 = *(const u3_t*)(hi + (o1 + bb));
             const uint32_t zs = max(max(max(a0.x, a0.z), max(b0.x, b0.z)), max(max(a1.x, a1.z), max(b1.x, b1.z))) >> 8;
-#else
-            const int c1 = min(c0+1, cl), c2 = min(c0+2, cl);
-            const uint32_t b0 = 8u*(uint32_t)c0, b1 = 8u*(uint32_t)c1, b2 = 8u*(uint32_t)c2, bl = 8u*(uint32_t)cl;
-            uint32_t z[8];
-            z[0] = *(const uint32_t*)(hi + (o0 + b0)); z[1] = *(const uint32_t*)(hi + (o0 + b1));
-            z[2] = *(const uint32_t*)(hi + (o0 + b2)); z[3] = *(const uint32_t*)(hi + (o0 + bl));
-            z[4] = *(const uint32_t*)(hi + (o1 + b0)); z[5] = *(const uint32_t*)(hi + (o1 + b1));
-            z[6] = *(const uint32_t*)(hi + (o1 + b2)); z[7] = *(const uint32_t*)(hi + (o1 + bl));
-            const uint32_t zs = max(max(max(z[0], z[1]), max(z[2], z[3])), max(max(z[4], z[5]), max(z[6], z[7]))) >> 8;
-#endif
             if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }
         else if(HIZ && valid && p.hiz)
@@ -685,12 +675,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
      * With the default zfar = 40 km this is most of a large mosaic. */
     float n_cur = north_of(0);
     bool far_prev = true;
-#ifdef MR_FAR_GATE
-    /* (a draw none of whose vertices lies beyond zfar - p.far_strips, from the mosaic's corners - asks no row) */
-    bool far_cur  = p.far_strips && __all(n_cur*n_cur + e*e > p.far_dd);
-#else
     bool far_cur  = __all(n_cur*n_cur + e*e > p.far_dd);
-#endif
     for(int j = jbeg; j <= jend; j++)
     {
         const int rel = j - jbeg;
@@ -702,11 +687,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
             else z_next = mosaic[(size_t)(j+1)*p.N + ic];
         }
         const float n_next   = (j == jend) ? 0.f : north_of(rel+1);
-#ifdef MR_FAR_GATE
-        const bool  far_next = (j == jend) || (p.far_strips && __all(n_next*n_next + e*e > p.far_dd));
-#else
         const bool  far_next = (j == jend) || __all(n_next*n_next + e*e > p.far_dd);
-#endif
         const bool  skip_row   = far_prev && far_cur && far_next;   /* vertex row j not needed       */
         const bool  skip_cells = far_prev && far_cur;               /* cell row j-1 entirely clipped */
         const float n = n_cur;

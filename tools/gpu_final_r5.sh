@@ -32,6 +32,7 @@ timeout 900 python tools/hiz_ab.py cfg3_zoom45 cfg3_zoom45_east cfg3_zoom45_sout
 timeout 600 python bench.py --gpus 4 --backend gloo --same-gpu --steps 8 --warmup 2 --no-cpu-baseline --no-host --no-extra --loop c 2>>$O/multi.err | grep "^{" > $O/multi_4ranks_one_gpu_c_loop.json
 BENCH_HOST_TIMES=1 timeout 300 python bench.py --gpus 1 --exchange-anyway --steps 20 --warmup 4 --no-cpu-baseline --no-host --no-extra 2>>$O/multi.err | grep "^{" > $O/exchange_anyway.json
 python tools/sector_timing.py > $O/sector_timing.txt 2>&1
+bash tools/gpu_scene_kernels.sh cfg3_zoom45_summit > $O/summit_kernels.txt 2>&1
 bash tools/gpu_modes.sh > $O/modes.txt 2>&1
 fi
 ls $O
