@@ -81,6 +81,11 @@ def test_any_share_of_sky_filled_beforehand(scene, sectors, prefill, monkeypatch
 def test_two_panoramas_in_flight(scene):
     """begin k+1 before end k: different views, buffers of their own, ended in the order begun"""
     h, od, W, H = scene
+    if h.options()["host_dense"]:
+        # (tools/gpu_modes.sh runs the suite with HZ_HOST_DENSE=1 too: such a context delivers with the synchronous call only, and says so)
+        with pytest.raises(RuntimeError):
+            h.render_begin(np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32))
+        return
     views = [(-180.0, 180.0, 200000.0, LAT, LON), (-100.0, 100.0, 60000.0, LAT + 0.02, LON - 0.03), (-180.0, 180.0, 9000.0, LAT - 0.01, LON)]
     for sectors in (0, 3):
         h.set_options(host_sectors=sectors)
