@@ -1135,6 +1135,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
                 if(cells_to_zfar <= 0.25f*ppr) p.inline_max = 32;
+                { const char* e_ = getenv("HZ_EXP_INLINE_MAX"); if(e_ && atoi(e_) > 0 && zoomed_view) p.inline_max = (unsigned int)atoi(e_); }   /* TEMPORARY: experiment */
             }
             p.hiz = hz.l1;
             /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment
