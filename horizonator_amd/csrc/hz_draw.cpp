@@ -827,6 +827,7 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
         grid = dim3(nlist, 1);
     }
 #ifdef HZ_SELFTEST
+    if(getenv("HZ_WT_DEBUG")) fprintf(stderr, "launch_march: pass %d d_cycles %p grid %u x %u list %p n %u\n", pm.pass, (void*)d->wave_timing.d_cycles, grid.x, grid.y, (const void*)d_list, nlist);
     /* diagnostics (hz_hip_debug_wave_timing, libhorizonator_selftest.so only): the instance with per-wave counters */
     if(d->wave_timing.d_cycles && pm.pass != 1)
     {
