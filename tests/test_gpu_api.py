@@ -470,8 +470,12 @@ def test_vertex_cache_draws_the_same_bytes(fast_math):
                 got = h.render_full(az0, az1, lat=lat, lon=lon, **kw)
                 hzutil.assert_same_render(dict(bgr=got[0], ranges=got[1], index=got[2], z24=got[3]), want, f"{lat} {lon} {az0} {az1} {kw}")
                 used.append(h.last_plan()["vertex_cache"])
-        # per viewpoint: cold, fill + cached, cached, cached, cached
-        assert used == [False, True, True, True, True] * 3, used
+        # per viewpoint: cold, fill + cached, cached, cached, cached (a call that is drawn in several sectors - HZ_HOST_SECTORS of
+        # tools/gpu_modes.sh; this image is one by default - draws from the viewpoint several times itself)
+        if h.options()["host_sectors"] in (0, 1):
+            assert used == [False, True, True, True, True] * 3, used
+        else:
+            assert all(used[1:5]) and all(used[6:10]) and all(used[11:15]), used
         h.set_options(vertex_cache=0)
         got = h.render_full(-180.0, 180.0, lat=LAT, lon=LON, zfar=90000.0)
         assert not h.last_plan()["vertex_cache"]
