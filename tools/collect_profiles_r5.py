@@ -62,6 +62,6 @@ with open(os.path.join(P, "r5_multi_rank_loops_on_one_gpu.jsonl"), "w") as f:
         if os.path.exists(os.path.join(O, name)):
             f.write(open(os.path.join(O, name)).read().strip() + "\n")
 if os.path.exists(os.path.join(O, "pytest_full.txt")):
-    lines = open(os.path.join(O, "pytest_full.txt")).read().strip().splitlines()
+    lines = [l for l in open(os.path.join(O, "pytest_full.txt")).read().strip().splitlines() if " passed" in l or " failed" in l or " error" in l]
     open(os.path.join(P, "r5_gpu_suite.txt"), "w").write("python -m pytest tests -x -q -m gpu on the MI355X box (tools/gpu_final_r5.sh):\n" + "\n".join(lines[-3:]) + "\n")
     print("r5_gpu_suite.txt")
