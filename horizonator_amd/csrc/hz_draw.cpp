@@ -827,7 +827,6 @@ static int launch_march(hz_dev_t* d, hipStream_t st, const mr_queue_t& q, const 
         grid = dim3(nlist, 1);
     }
 #ifdef HZ_SELFTEST
-    if(getenv("HZ_WT_DEBUG")) fprintf(stderr, "launch_march: pass %d d_cycles %p grid %u x %u list %p n %u\n", pm.pass, (void*)d->wave_timing.d_cycles, grid.x, grid.y, (const void*)d_list, nlist);
     /* diagnostics (hz_hip_debug_wave_timing, libhorizonator_selftest.so only): the instance with per-wave counters */
     if(d->wave_timing.d_cycles && pm.pass != 1)
     {
@@ -1136,7 +1135,8 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
                 if(cells_to_zfar <= 0.25f*ppr) p.inline_max = 32;
-                { const char* e_ = getenv("HZ_EXP_INLINE_MAX"); if(e_ && atoi(e_) > 0 && zoomed_view) p.inline_max = (unsigned int)atoi(e_); }   /* TEMPORARY: experiment */
+                /* (zoomed views keep 64 as well: with 32 the seven views of profiles/r5_zoomed_views.txt take 10.0 instead of 8.8 ms
+                 * in sum, with 16 10.8 - their medium triangles are most of their pixels, and k_mid draws them no faster) */
             }
             p.hiz = hz.l1;
             /* ... and its waves read a framebuffer word before the atomic and leave the atomic out where the fragment

@@ -485,7 +485,6 @@ extern "C" int hz_hip_debug_wave_timing(hz_dev_t* d, const hz_view_t* view, unsi
     d->wave_timing.d_cycles = d_cycles; d->wave_timing.capacity = capacity_words;
     d->wave_timing.grid_x = d->wave_timing.grid_y = 0;
     int rc = hz_draw_impl(d, view);
-    if(getenv("HZ_WT_DEBUG")) fprintf(stderr, "hz_hip_debug_wave_timing: rc %d grid %u %u plan %d %d %d %d %d\n", rc, d->wave_timing.grid_x, d->wave_timing.grid_y, d->last_plan[0], d->last_plan[1], d->last_plan[2], d->last_plan[3], d->last_plan[4]);
     d->wave_timing.d_cycles = NULL; d->wave_timing.capacity = 0;
     if(rc == 0 && hz_sync_all(d) != hipSuccess) rc = -1;
     grid[0] = d->wave_timing.grid_x; grid[1] = d->wave_timing.grid_y;
