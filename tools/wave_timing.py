@@ -37,6 +37,8 @@ flushes = (a[:, :, 1] >> 32).astype(np.int64); tris = (a[:, :, 1] & 0xFFFFFFFF).
 big = (a[:, :, 2] >> 32).astype(np.int64); mid = (a[:, :, 2] & 0xFFFFFFFF).astype(np.int64)
 items = (a[:, :, 3] & 0xFFFFFFFF).astype(np.int64); hidden = (a[:, :, 3] >> 32).astype(np.int64)
 print("zfar", ZFAR, "grid", gx, gy, "waves", gx*gy)
+if os.environ.get("HZ_WT_SAVE"):                    # the raw counters, for tools/wave_schedule.py
+    np.save(os.environ["HZ_WT_SAVE"], a)
 busy = t > 3.0
 print("waves longer than 3 us: %d, their sum %.1f ms; the others: sum %.1f ms, median %.2f us" % (busy.sum(), t[busy].sum()/1e3, t[~busy].sum()/1e3, np.median(t[~busy]) if (~busy).any() else 0))
 q = np.percentile(t, [50, 90, 99, 99.9, 100])
