@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5b28; mkdir -p $O
+timeout 2400 python tools/ab_flags.py -DMR_EARLYZ_LAZY > $O/ab_flags.txt 2>&1
+cat $O/ab_flags.txt
