@@ -388,27 +388,14 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
              * lower half, the second one's depth): the box's first two columns and its last two - four loads where round 4
              * had eight, one per pixel (k_march alone 0.635 -> 0.627 ms, a render of a series -1.6 %: profiles/
              * r5_ab_march_loop.txt).  A box one column wide takes a neighbour's depth along (a larger zs: fewer triangles
-             * found hidden, never one too many); the pair stays inside the row (SW >= 2: draw_impl). */
+             * found hidden, never one too many); the pair stays inside the row (SW >= 2: draw_impl).  (The second pair and the second
+             * row only in the lanes whose box has them - fewer addresses, two branches - is slower: 0.648 against 0.628 ms.) */
             typedef uint32_t u3_t __attribute__((ext_vector_type(3)));
             const int ca = min(c0, p.SW - 2), cb = min(max(cl - 1, c0), p.SW - 2);
             const uint32_t ba = 8u*(uint32_t)ca, bb = 8u*(uint32_t)cb;
-#ifdef MR_EARLYZ_LAZY
-            /* (experiment) the second pair and the second row only in the lanes whose box has them */
-            const u3_t a0 = *(const u3_t*)(hi + (o0 + ba));
-            uint32_t zm = max(a0.x, a0.z);
-            if(bb != ba) { const u3_t b0 = *(const u3_t*)(hi + (o0 + bb)); zm = max(zm, max(b0.x, b0.z)); }
-            if(o1 != o0)
-            {
-                const u3_t a1 = *(const u3_t*)(hi + (o1 + ba));
-                zm = max(zm, max(a1.x, a1.z));
-                if(bb != ba) { const u3_t b1 = *(const u3_t*)(hi + (o1 + bb)); zm = max(zm, max(b1.x, b1.z)); }
-            }
-            const uint32_t zs = zm >> 8;
-#else
             const u3_t a0 = *(const u3_t*)(hi + (o0 + ba)), b0 = *(const u3_t*)(hi + (o0 + bb));
             const u3_t a1 = *(const u3_t*)(hi + (o1 + ba)), b1 = *(const u3_t*)(hi + (o1 + bb));
             const uint32_t zs = max(max(max(a0.x, a0.z), max(b0.x, b0.z)), max(max(a1.x, a1.z), max(b1.x, b1.z))) >> 8;
-#endif
             if(hz_tri_hidden(&a, &b, &c, p.z_hide_k, zs)) live = false;
         }
         else if(HIZ && valid && p.hiz)
