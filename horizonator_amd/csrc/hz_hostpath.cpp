@@ -62,7 +62,7 @@ struct hz_copy_pool
     struct scatter_t
     {
         hz_scatter_dst_t dst;
-        int y_pre[8];                   /* per sector (HZ_HOST_MAX_SECTORS): rows [0, y_pre) get the sky beforehand (band by band); a blob below writes the sky pixels of its tile itself */
+        int y_pre;                      /* rows [0, y_pre) get the sky beforehand (band by band); a blob below writes the sky pixels of its tile itself */
         int band_rows, nbands;
         std::atomic<int>* band_left;
         std::atomic<int> bad;
@@ -156,7 +156,7 @@ struct hz_copy_pool
                  * sector that hold its rows.  Sky tasks queue behind blobs (q_lo), so the ones this blob waits for may
                  * not have been taken by any thread yet: the waiting thread takes sky tasks itself. */
                 const int yo = (int)(blob[0] & 0xFFFFu);
-                const bool prefilled = yo < t.sc->y_pre[t.sector];
+                const bool prefilled = yo < t.sc->y_pre;
                 if(prefilled)
                     for(int b = yo/t.sc->band_rows; b <= (yo + HZ_BLOB_ROWS-1)/t.sc->band_rows && b < t.sc->nbands; b++)
                         while(t.sc->band_left[(size_t)t.sector*t.sc->nbands + b].load(std::memory_order_acquire) > 0)
@@ -474,26 +474,15 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         if(h->next_begin != h->next_end) percent = 0;
         const char* e = getenv("HZ_HOST_PREFILL");
         if(e && atoi(e) >= 0 && atoi(e) <= 100) percent = atoi(e);
-        /* ... and all of the LAST sector where there are three or more: what is left to do when the last chunk has arrived is
-         * what the call's caller waits for, and the sky of the last sector's tiles without a blob was a quarter of a millisecond
-         * of that (its sky is written while the first sectors travel, when the pool has time) */
-        int percent_last = (jb.nsec >= 3 && h->next_begin == h->next_end && !(e && atoi(e) >= 0 && atoi(e) <= 100)) ? 100 : percent;
-        const char* el = getenv("HZ_HOST_PREFILL_LAST");
-        if(el && atoi(el) >= 0 && atoi(el) <= 100) percent_last = atoi(el);
-        for(int s=0; s<jb.nsec; s++)
-        {
-            const int pc = s == jb.nsec-1 ? percent_last : percent;
-            sc.y_pre[s] = (int)((long long)H*pc/100) / HZ_BLOB_ROWS * HZ_BLOB_ROWS;
-            if(pc >= 100) sc.y_pre[s] = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
-        }
+        sc.y_pre = (int)((long long)H*percent/100) / HZ_BLOB_ROWS * HZ_BLOB_ROWS;
+        if(percent >= 100) sc.y_pre = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
     }
     const int widest = jb.col[1] - jb.col[0];
     sc.band_rows = (int)(((size_t)2 << 20)/((size_t)widest*4) + 1);
     if(sc.band_rows < HZ_BLOB_ROWS) sc.band_rows = HZ_BLOB_ROWS;
     sc.band_rows = (sc.band_rows + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
-    int pre_rows_max = 0;
-    for(int s=0; s<jb.nsec; s++) { const int r = sc.y_pre[s] < H ? sc.y_pre[s] : H; if(r > pre_rows_max) pre_rows_max = r; }
-    sc.nbands = (pre_rows_max + sc.band_rows-1)/sc.band_rows;
+    const int pre_rows = sc.y_pre < H ? sc.y_pre : H;
+    sc.nbands = (pre_rows + sc.band_rows-1)/sc.band_rows;
     std::vector<std::atomic<int>>(static_cast<size_t>(jb.nsec)*sc.nbands).swap(*jb.band_left);
     sc.band_left = jb.band_left->data();
     jb.filled.pending = 0;
@@ -501,9 +490,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
     for(int s=0; s<jb.nsec; s++)
         for(int b=0; b<sc.nbands; b++)
         {
-            const int pre_rows = sc.y_pre[s] < H ? sc.y_pre[s] : H;
             const int y0 = b*sc.band_rows, y1 = y0 + sc.band_rows < pre_rows ? y0 + sc.band_rows : pre_rows;
-            if(y0 >= pre_rows) { sc.band_left[(size_t)s*sc.nbands + b].store(0); continue; }
             sc.band_left[(size_t)s*sc.nbands + b].store(nbuf);
             for(int k=0; k<nbuf; k++)
             {
@@ -601,8 +588,7 @@ static int host_end(hz_dev_t* d)
     size_t total_words = 0, total_blobs = 0;
     /* below y_pre: which tiles of sector s (4 rows x <= 2048 columns, as k_pack_host cuts them) have sent a blob; the others
      * get their sky when the sector's last chunk has been walked */
-    const int H = d->H, nty = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS;
-    auto ty0_of = [&](int s) { return jb.sc.y_pre[s]/HZ_BLOB_ROWS; };
+    const int H = d->H, y_pre = jb.sc.y_pre, ty0 = y_pre/HZ_BLOB_ROWS, nty = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS;
     std::vector<std::vector<unsigned char>> seen(jb.nsec);
     size_t chunks_of[HZ_HOST_MAX_SECTORS] = { 0 }, walked_of[HZ_HOST_MAX_SECTORS] = { 0 };
     bool absent_done[HZ_HOST_MAX_SECTORS] = { false };
@@ -616,7 +602,6 @@ static int host_end(hz_dev_t* d)
     /* the sky of sector s's tiles without a blob (rows from y_pre down): one task per run of such tiles in a column of tiles */
     auto fill_absent = [&](int s)
     {
-        const int ty0 = ty0_of(s);
         if(absent_done[s] || ty0 >= nty) { absent_done[s] = true; return; }
         absent_done[s] = true;
         const int sw = jb.col[s+1] - jb.col[s], ntx = (sw + HZ_BLOB_COLS-1)/HZ_BLOB_COLS;
@@ -668,7 +653,7 @@ static int host_end(hz_dev_t* d)
         if(c[2]) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: the stream of blobs overflowed (%zu words)", jb.cap[s]); rc = -1; return false; }
         offs[s].resize((size_t)c[1] + 1);
         total_words += c[0]; total_blobs += c[1];
-        if(ty0_of(s) < nty) seen[s].assign((size_t)(nty - ty0_of(s))*(size_t)((jb.col[s+1] - jb.col[s] + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), 0);
+        if(ty0 < nty) seen[s].assign((size_t)(nty - ty0)*(size_t)((jb.col[s+1] - jb.col[s] + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), 0);
         chunks_of[s] = ((size_t)c[0] + chunk_words-1)/chunk_words;
         if(chunks_of[s] == 0) fill_absent(s);              /* (a sector without any terrain) */
         for(size_t w0 = 0; w0 < c[0]; w0 += chunk_words)
@@ -732,7 +717,7 @@ static int host_end(hz_dev_t* d)
             {
                 const uint32_t* blob = chunk + o[b];
                 const int yo = (int)(blob[0] & 0xFFFFu), tx = ((int)blob[1] - (jb.col[c.sector] - jb.out_col0))/HZ_BLOB_COLS;
-                if(yo >= jb.sc.y_pre[c.sector] && yo/HZ_BLOB_ROWS < nty && tx >= 0 && tx < ntx) seen[c.sector][(size_t)(yo/HZ_BLOB_ROWS - ty0_of(c.sector))*ntx + tx] = 1;
+                if(yo >= y_pre && yo/HZ_BLOB_ROWS < nty && tx >= 0 && tx < ntx) seen[c.sector][(size_t)(yo/HZ_BLOB_ROWS - ty0)*ntx + tx] = 1;
             }
         }
         if(++walked_of[c.sector] == chunks_of[c.sector]) fill_absent(c.sector);
