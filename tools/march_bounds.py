@@ -13,7 +13,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import experiments as ex
 
-BENCH = ["bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host", "--no-extra"]
+BENCH = ["bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-host", "--no-scenes", "--zfar", "600000"]
 
 
 def run(root, env):
@@ -31,6 +31,8 @@ def run(root, env):
             out["k_march alone, ms"] = round(d["roofline"]["kernel_ms"], 4)
         else:
             out["render of a series, ms"] = round(d["ms_per_step"], 4)
+            if "same_viewpoint" in d:
+                out["the same view again, ms"] = round(d["same_viewpoint"]["ms_per_step"], 4)
     return out
 
 
