@@ -257,47 +257,6 @@ __device__ static void mr_distribute(const hz_rec_t& r, uint32_t npix, int lane,
      * at least half the lanes still have a pixel left (boxes of similar size,
      * the common case inside one flush) */
     uint32_t done = 0;
-#ifdef MR_PIPE_PRETEST
-    /* (experiment) where the fragments are read before their atomics (p.pretest_march), the read of one round is in flight
-     * while the next round's fragment is made: the compare and the atomic of a fragment come one round late */
-    if(p.pretest_march)
-    {
-        bool pend = false;
-        unsigned long long pkey = 0, pval = 0;
-        int ppx = 0, ppy = 0;
-        for(;;)
-        {
-            const bool more = npix > done;
-            if(__popcll(__ballot(more)) < 32) break;
-            bool have = false;
-            unsigned long long key = 0, val = 0;
-            int px = 0, py = 0;
-            if(more)
-            {
-                const int ry = (int)(((float)done + 0.5f) * r.inv_bw);
-                const int rx = (int)done - ry*r.bw;
-                px = r.px0 + rx; py = r.py0 + ry;
-                done++;
-                if(hz_edges_cover(&r.e, px, py))
-                {
-                    hz_tri_t t;
-                    hz_planes_from_rec(t, r);
-                    uint32_t zi, r8;
-                    if(hz_tri_fragment(&t, px, py, &zi, &r8))
-                    {
-                        key = hz_pack(zi, r.prim, r8);
-                        have = true;
-                        val = __hip_atomic_load(hz_fb_word(fb, p, px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            if(pend && pkey < pval) hz_fb_min<HZ_WHO_MARCH>(fb, p, ppx, ppy, pkey);
-            pend = have; pkey = key; pval = val; ppx = px; ppy = py;
-        }
-        if(pend && pkey < pval) hz_fb_min<HZ_WHO_MARCH>(fb, p, ppx, ppy, pkey);
-    }
-    else
-#endif
     for(;;)
     {
         const bool more = npix > done;
