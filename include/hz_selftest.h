@@ -48,7 +48,7 @@ int  hz_hip_check_fastmath(int device, int what, unsigned long long seed, unsign
 int  hz_hip_check_exactness(int device, int what, unsigned long long seed, unsigned long long n,
                             int W, int H, int col0, int col1, unsigned long long* out);
 
-/* diagnostics (tools/bigqueue_stats.py): the queue of large triangles the last
+/* diagnostics (tools/history/bigqueue_stats.py): the queue of large triangles the last
  * draw left behind - set 0: its only or second round, 1: the first round of a
  * two-round draw.  counters: 6 words (mr_queue_t); recs: 10 int32 per record
  * (px0 py0 bw bh, the three edge vectors' dx, then dy, in 1/256 pixel), at most max_rec */
