@@ -4,9 +4,12 @@
  * sequence that only exist for operands near the ends of the float32 range.
  *
  * Why: k_march is bound by the SIMDs' vector issue rate (profiles/valu_issue.json:
- * v_fma/v_mul/v_add_f32 2 cycles per wave64 instruction, most others 4,
- * v_rcp/v_sqrt 8), and of the ~860 cycles its transform takes per row of 64
- * vertices, 430 are seven divisions (46 cycles each) and two square roots (53).
+ * v_fma/v_mul/v_add_f32 2.7-2.9 cycles per wave64 instruction, most others 4.2-4.6,
+ * v_rcp/v_rsq/v_sqrt 8), and with hipcc's own sequences seven divisions (46 cycles
+ * each) and two square roots (56) were half of what its transform cost per row of
+ * 64 vertices.  Round 3: those sequences without their range handling (below).
+ * Round 5: shorter sequences still, each proved by trying every operand (further
+ * below) - 164 -> 127 instructions per vertex, profiles/r5_ab_short_sequences.txt.
  *
  * hipcc's float32 division (default, correctly rounded) is
  *     ds = v_div_scale(b,b,a)   as = v_div_scale(a,b,a)      [pre-scaling by 2^+-64]
