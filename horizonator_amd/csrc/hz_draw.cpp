@@ -459,10 +459,12 @@ mr_zones_t hz_make_zones(const hz_params_t& p, bool near_first)
     /* a narrow azimuth sector keeps only a fraction of the waves alive: shorter
      * segments far from the viewer then restore the parallelism (at the price
      * of one extra vertex row per segment) */
+    /* (32 rows at most since round 5: the far zones are dispatched last in draws with the early depth test, and with 64 rows
+     * their waves - 100 us each - were the kernel's tail: whole panorama, k_march alone 0.623 -> 0.613 ms, a render of a
+     * series 0.844 -> 0.837, two alternating runs; 16 rows: 0.616 / 0.842) */
     int far_rows = 64*p.SW/p.W;
     if(far_rows < 16) far_rows = 16;
-    if(far_rows > 64) far_rows = 64;
-    { const char* e_ = getenv("HZ_EXP_FAR_ROWS"); if(e_ && atoi(e_) >= 8 && atoi(e_) <= 64 && p.SW == p.W) far_rows = atoi(e_); }   /* TEMPORARY: experiment */
+    if(far_rows > 32) far_rows = 32;
     /* ... and nearer in (cells of 1 to 4 pixels) a narrow sector's kernel was as long as its longest waves: 16 rows of
      * 63 cells with a visible triangle in nearly every lane and a flush per row take 100-170 us (tools/wave_timing.py,
      * HZ_WT_SECTOR=8,0), the whole sector's waves 92 us of the chip - the kernel took 174.  Sectors of less than a sixth
