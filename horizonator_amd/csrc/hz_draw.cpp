@@ -471,8 +471,7 @@ mr_zones_t hz_make_zones(const hz_params_t& p, bool near_first)
      * of the image cut that zone into 8-row segments: an eighth's strips back to back 0.198 -> 0.169 ms (the widest),
      * 0.156 -> 0.153 (the narrowest); a quarter's and the whole image's waves are many enough to hide their longest
      * (0.273 -> 0.275; profiles/r4_sector_rules.txt). */
-    int z16 = 6*p.SW < p.W ? 8 : 16;
-    { const char* e_ = getenv("HZ_EXP_Z16"); if(e_ && atoi(e_) >= 4 && atoi(e_) <= 32) z16 = atoi(e_); }   /* TEMPORARY: experiment */
+    const int z16 = 6*p.SW < p.W ? 8 : 16;          /* (a whole panorama with 8: the kernel +3 %; with 32: -1 % alone, the same in a series - profiles/r5_ab_march_loop.txt (8)) */
     const int rows[MR_NZONES] = { far_rows, z16, 4, 2, 4, z16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
