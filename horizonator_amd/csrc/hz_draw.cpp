@@ -761,8 +761,13 @@ static int next_framebuffer(hz_dev_t* d, hz_params_t& p)
         HZ_CHECK(hipMemsetAsync(d->d_fbs[prev], 0xFF, d->fb_used[prev]*sizeof(unsigned long long), d->rstream));
         HZ_CHECK(hipMemsetAsync(d->d_touched[prev], 0, (size_t)d->seg_stride*d->H, d->rstream));
         /* ... and its queue sets with it (the clearing conversions do that themselves) */
-        HZ_CHECK(hipMemsetAsync(d->d_big_counters_s[prev], 0, 6*sizeof(unsigned int), d->rstream));
-        HZ_CHECK(hipMemsetAsync(d->d_big_counters_s[HZ_NFB + prev], 0, 6*sizeof(unsigned int), d->rstream));
+        /* (the counters of the mid and clip queues, [3..5], and the shards of the big triangles' behind HZ_CNT_LAST's copy: two pieces each) */
+        for(int w=0; w<2; w++)
+        {
+            unsigned int* c = d->d_big_counters_s[(w ? HZ_NFB : 0) + prev];
+            HZ_CHECK(hipMemsetAsync(c, 0, 6*sizeof(unsigned int), d->rstream));
+            HZ_CHECK(hipMemsetAsync(c + HZ_QSHARD0, 0, (size_t)HZ_QSHARDS*HZ_QSHARD_STRIDE*sizeof(unsigned int), d->rstream));
+        }
     }
     if(prof) HZ_CHECK(hipEventRecord(d->ev[1], d->rstream));
     d->fb_used[prev] = 0;

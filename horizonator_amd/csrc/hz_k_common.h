@@ -65,10 +65,62 @@ __device__ static inline void hz_queue_clip(const mr_queue_t& q, bool want, uint
  * launch of its own in front of every marching kernel (on that stream it was
  * 40-90 us between consecutive panoramas), and no arrival counter in k_big
  * (4096 atomics on one address: + 40 us per launch, measured). */
+__device__ static inline unsigned int* hz_qshard(unsigned int* counters, int s) { return counters + HZ_QSHARD0 + s*HZ_QSHARD_STRIDE; }
+__device__ static inline const unsigned int* hz_qshard(const unsigned int* counters, int s) { return counters + HZ_QSHARD0 + s*HZ_QSHARD_STRIDE; }
+/* the items shard s holds (those at and beyond its first overflow were drawn by their producer) */
+__device__ static inline unsigned int hz_queue_nitems_of(const unsigned int* counters, int s)
+{
+    const unsigned int* c = hz_qshard(counters, s);
+    return min(c[1], ~c[2]);
+}
+/* is item slot g in use? */
+__device__ static inline bool hz_queue_item_valid(const unsigned int* counters, unsigned int g)
+{
+    return (g / HZ_QSHARDS) < hz_queue_nitems_of(counters, (int)(g % HZ_QSHARDS));
+}
+/* the item slots a consumer has to look at: [0, that) */
+__device__ static inline unsigned int hz_queue_span(const unsigned int* counters)
+{
+    unsigned int m = 0;
+    #pragma unroll
+    for(int s=0; s<HZ_QSHARDS; s++) m = max(m, hz_queue_nitems_of(counters, s));
+    return m*HZ_QSHARDS;
+}
+__device__ static inline void hz_queue_totals(const unsigned int* counters, unsigned int* records, unsigned int* items)
+{
+    unsigned int r = 0, n = 0;
+    #pragma unroll
+    for(int s=0; s<HZ_QSHARDS; s++) { r += hz_qshard(counters, s)[0]; n += hz_qshard(counters, s)[1]; }
+    *records = r; *items = n;
+}
+/* room for nrec records and nitems items from shard `shard`: the SLOTS of the first record and of the first item (the
+ * next ones: + HZ_QSHARDS each); false: they do not fit - the caller draws them itself, and the shard's items from
+ * here on are not valid */
+__device__ static inline bool hz_queue_reserve(const mr_queue_t& q, int shard, uint32_t nrec, uint32_t nitems, uint32_t* rec_slot, uint32_t* item_slot)
+{
+    unsigned int* c = hz_qshard(q.counters, shard);
+    const unsigned long long both = atomicAdd((unsigned long long*)c, (unsigned long long)nrec | ((unsigned long long)nitems << 32));
+    const uint32_t rl = (uint32_t)both, il = (uint32_t)(both >> 32);
+    *rec_slot = rl*HZ_QSHARDS + (uint32_t)shard; *item_slot = il*HZ_QSHARDS + (uint32_t)shard;
+    if((unsigned long long)rl + nrec <= q.bigrec_capacity/HZ_QSHARDS && (unsigned long long)il + nitems <= q.bigitem_capacity/HZ_QSHARDS) return true;
+    atomicMax(c + 2, ~il);
+    return false;
+}
 __device__ static inline void hz_counters_consume(unsigned int* a, unsigned int* b)
 {
+    unsigned int* const both[2] = { a, b };
     #pragma unroll
-    for(int k=0; k<6; k++) { a[HZ_CNT_LAST + k] = a[k]; a[k] = 0u; b[HZ_CNT_LAST + k] = b[k]; b[k] = 0u; }
+    for(int w=0; w<2; w++)
+    {
+        unsigned int* c = both[w];
+        unsigned int records, items;
+        hz_queue_totals(c, &records, &items);
+        c[HZ_CNT_LAST + 0] = records; c[HZ_CNT_LAST + 1] = items; c[HZ_CNT_LAST + 2] = 0u;
+        #pragma unroll
+        for(int k=3; k<6; k++) { c[HZ_CNT_LAST + k] = c[k]; c[k] = 0u; }
+        #pragma unroll
+        for(int s=0; s<HZ_QSHARDS; s++) { unsigned int* q = hz_qshard(c, s); q[0] = 0u; q[1] = 0u; q[2] = 0u; }
+    }
 }
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
  * larger ones up to HZ_INLINE_MAX_PIX go to k_mid, the rest to k_big */
@@ -228,14 +280,8 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
         nchunks += hz_big_chunks(box.px1 - box.px0 + 1, box.py1 - box.py0 + 1);
     }
     if(npieces == 0) return;
-    bool queued = false;
-    uint32_t ri = atomicAdd(&q.counters[0], npieces), ii = 0;
-    if(ri + npieces <= q.bigrec_capacity)
-    {
-        ii = atomicAdd(&q.counters[1], nchunks);
-        if(ii + nchunks <= q.bigitem_capacity) queued = true;
-        else atomicMax(&q.counters[2], ~ii);
-    }
+    uint32_t ri = 0, ii = 0;            /* slots: the next record / item of this reservation is HZ_QSHARDS further on */
+    const bool queued = hz_queue_reserve(q, (int)(blockIdx.x % HZ_QSHARDS), npieces, nchunks, &ri, &ii);
     if(!queued && !inline_ok) return;
     for(int k=2; k<n; k++)
     {
@@ -260,8 +306,8 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
         const uint32_t chunks = hz_big_chunks(br.r.bw, br.bh);
         q.bigrec[ri] = br;
         if(jobs && chunks > HZ_CLIP_JOB_MIN) { uint32_t* job = jobs[*njobs]; job[0] = ii; job[1] = ri; job[2] = chunks; (*njobs)++; }
-        else for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
-        ri++; ii += chunks;
+        else for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii + c2*HZ_QSHARDS].rec = ri; q.bigitem[ii + c2*HZ_QSHARDS].chunk = c2; }
+        ri += HZ_QSHARDS; ii += chunks*HZ_QSHARDS;
     }
 }
 
@@ -323,7 +369,7 @@ void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__
                 for(int jb=0; jb<s_njobs[c]; jb++)
                 {
                     const uint32_t ii = s_job[c][jb][0], ri = s_job[c][jb][1], chunks = s_job[c][jb][2];
-                    for(uint32_t c2 = threadIdx.x; c2 < chunks; c2 += 64u) { q.bigitem[ii+c2].rec = ri; q.bigitem[ii+c2].chunk = c2; }
+                    for(uint32_t c2 = threadIdx.x; c2 < chunks; c2 += 64u) { q.bigitem[ii + c2*HZ_QSHARDS].rec = ri; q.bigitem[ii + c2*HZ_QSHARDS].chunk = c2; }
                 }
             __syncthreads();
         }

@@ -149,18 +149,14 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
             {
                 /* large: hand over to k_big, 64 tiles per work item */
                 const unsigned int chunks = hz_big_chunks(r.bw, bh);
-                unsigned int ri = atomicAdd(&big_counters[0], 1u), ii = 0;
-                bool queued = false;
-                if(ri < bigrec_capacity)
-                {
-                    ii = atomicAdd(&big_counters[1], chunks);
-                    if(ii + chunks <= bigitem_capacity) queued = true;
-                    else atomicMax(&big_counters[2], ~ii);     /* items from here on are not valid */
-                }
+                uint32_t ri = 0, ii = 0;
+                mr_queue_t qq = {};
+                qq.counters = big_counters; qq.bigrec_capacity = bigrec_capacity; qq.bigitem_capacity = bigitem_capacity;
+                const bool queued = hz_queue_reserve(qq, (int)(blockIdx.x % HZ_QSHARDS), 1u, chunks, &ri, &ii);
                 if(queued)
                 {
                     bigrec[ri].r = r; bigrec[ri].bh = bh;
-                    for(unsigned int c2=0; c2<chunks; c2++) { bigitem[ii+c2].rec = ri; bigitem[ii+c2].chunk = c2; }
+                    for(unsigned int c2=0; c2<chunks; c2++) { bigitem[ii + c2*HZ_QSHARDS].rec = ri; bigitem[ii + c2*HZ_QSHARDS].chunk = c2; }
                 }
                 else
                 {
@@ -310,14 +306,15 @@ void k_big(unsigned long long* __restrict__ fb,
     __shared__ uint32_t s_start[256/64][64];
     __shared__ int32_t  s_delta[256/64][64];
     /* (report: pinned host memory - what this round queued, for the host's choice of the next first round's reach: hz_kernels.hip, adapt) */
-    if(report && blockIdx.x == 0 && threadIdx.x == 0) { report[0] = big_counters[0]; report[1] = big_counters[1]; }
+    if(report && blockIdx.x == 0 && threadIdx.x == 0) { unsigned int records, items; hz_queue_totals(big_counters, &records, &items); report[0] = records; report[1] = items; }
     const int wv = threadIdx.x >> 6;
     s_start[wv][threadIdx.x & 63] = 0u;
     KB_LDS_ORDER();
     /* (tile_state: the round's triangles were binned and drawn by screen tile - hz_k_tile.h - unless there were too many) */
     if(tile_state && tile_state[0] == 0) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
-    const unsigned int nitems = min(big_counters[1], ~big_counters[2]);
+    /* (item slots [0, nitems): slot g belongs to shard g % HZ_QSHARDS and is in use if that shard got that far - hz_types.h) */
+    const unsigned int nitems = hz_queue_span(big_counters);
     (void)bigrec_capacity; (void)bigitem_capacity;
     const int lane = threadIdx.x & 63;
     const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
@@ -327,12 +324,16 @@ void k_big(unsigned long long* __restrict__ fb,
      * their latency hides behind the pixel work */
     hz_bigitem_t item_next = {};
     hz_bigrec_t  rec_next  = {};
-    if(wave_global < nitems) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
+    bool valid_next = wave_global < nitems && hz_queue_item_valid(big_counters, wave_global);
+    if(valid_next) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
     for(unsigned int it = wave_global; it < nitems; it += nwaves)
     {
         const hz_bigitem_t item = item_next;
         const hz_bigrec_t  br   = rec_next;
-        if(it + nwaves < nitems) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
+        const bool valid = valid_next;
+        valid_next = it + nwaves < nitems && hz_queue_item_valid(big_counters, it + nwaves);
+        if(valid_next) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
+        if(!valid) continue;
         hz_tri_t tri;
         hz_planes_from_rec(tri, br.r);
         const int px0 = br.r.px0, py0 = br.r.py0, bw = br.r.bw, bh = br.bh;

@@ -418,20 +418,39 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     HZ_ON_DEVICE(d);
     if(hz_hip_sync(d) != 0) return -1;
     const int k = (set ? HZ_NFB : 0) + d->fbi;
-    /* (a conversion that cleared the framebuffer emptied the queues too and left a copy of the counters) */
-    HZ_CHECK(hipMemcpy(counters, d->d_big_counters_s[k] + (d->fb_consumed ? HZ_CNT_LAST : 0), 6*sizeof(unsigned int), hipMemcpyDeviceToHost));
-    counters[2] = ~counters[2]; counters[5] = ~counters[5];     /* as documented: the first invalid index */
-    unsigned int n = counters[0] < d->bigrec_capacity ? counters[0] : d->bigrec_capacity;
-    if((int)n > max_rec) n = (unsigned int)max_rec;
-    if(n == 0 || recs == NULL) return 0;
-    hz_bigrec_t* h = (hz_bigrec_t*)malloc((size_t)n*sizeof(hz_bigrec_t));
-    if(!h) return -1;
-    HZ_CHECK(hipMemcpy(h, d->d_bigrec_s[k], (size_t)n*sizeof(hz_bigrec_t), hipMemcpyDeviceToHost));
-    for(unsigned int r=0; r<n; r++)
+    /* (a conversion that cleared the framebuffer emptied the queues too and left a copy of the counters - of the big
+     * triangles' shards their sums: the records themselves can then no longer be told from the slots in between) */
+    std::vector<unsigned int> all(HZ_NCOUNTERS);
+    HZ_CHECK(hipMemcpy(all.data(), d->d_big_counters_s[k], HZ_NCOUNTERS*sizeof(unsigned int), hipMemcpyDeviceToHost));
+    unsigned int per_shard[HZ_QSHARDS], longest = 0;
+    if(d->fb_consumed) { for(int c=0; c<6; c++) counters[c] = all[HZ_CNT_LAST + c]; for(int s=0; s<HZ_QSHARDS; s++) per_shard[s] = 0; }
+    else
     {
-        int32_t* o = recs + (size_t)r*10;
-        o[0] = h[r].r.px0; o[1] = h[r].r.py0; o[2] = h[r].r.bw; o[3] = h[r].bh;
-        for(int m=0; m<3; m++) { o[4+m] = h[r].r.e.dx[m]; o[7+m] = -h[r].r.e.ndy[m]; }
+        counters[0] = counters[1] = 0; counters[2] = 0;
+        for(int s=0; s<HZ_QSHARDS; s++)
+        {
+            const unsigned int* c = all.data() + HZ_QSHARD0 + s*HZ_QSHARD_STRIDE;
+            per_shard[s] = c[0] < d->bigrec_capacity/HZ_QSHARDS ? c[0] : d->bigrec_capacity/HZ_QSHARDS;
+            counters[0] += c[0]; counters[1] += c[1]; if(c[2]) counters[2] = c[2];
+            if(per_shard[s] > longest) longest = per_shard[s];
+        }
+        for(int c=3; c<6; c++) counters[c] = all[c];
+    }
+    counters[2] = ~counters[2]; counters[5] = ~counters[5];     /* as documented: the first invalid index (of one of the shards) */
+    if(longest == 0 || recs == NULL || max_rec <= 0) return 0;
+    /* record slot g belongs to shard g % HZ_QSHARDS and is its (g / HZ_QSHARDS)-th */
+    const size_t slots = (size_t)longest*HZ_QSHARDS;
+    hz_bigrec_t* h = (hz_bigrec_t*)malloc(slots*sizeof(hz_bigrec_t));
+    if(!h) return -1;
+    HZ_CHECK(hipMemcpy(h, d->d_bigrec_s[k], slots*sizeof(hz_bigrec_t), hipMemcpyDeviceToHost));
+    int n = 0;
+    for(size_t g=0; g<slots && n<max_rec; g++)
+    {
+        if(g/HZ_QSHARDS >= per_shard[g % HZ_QSHARDS]) continue;
+        int32_t* o = recs + (size_t)n*10;
+        o[0] = h[g].r.px0; o[1] = h[g].r.py0; o[2] = h[g].r.bw; o[3] = h[g].bh;
+        for(int m=0; m<3; m++) { o[4+m] = h[g].r.e.dx[m]; o[7+m] = -h[g].r.e.ndy[m]; }
+        n++;
     }
     free(h);
     return 0;

@@ -92,13 +92,23 @@ struct mr_queue_t
     hz_bigitem_t* bigitem;          /* ... and their work items                                  */
     hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
     uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
-    unsigned int* counters;         /* [0] big records [1] big items [2] ~(first invalid big item)
-                                     * [3] mid records [4] clip ids [5] ~(first invalid mid record) */
+    unsigned int* counters;         /* [3] mid records [4] clip ids [5] ~(first invalid mid record); the big triangles' counters:
+                                     * HZ_QSHARDS of them from [HZ_QSHARD0] on (below); [0] [1] [2]: their sums as the last draw left them */
     unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
 };
 
-#define HZ_NCOUNTERS 16
-#define HZ_CNT_LAST  8                  /* [8..14): the counters as the last draw left them (diagnostics) */
+/* The queue of big triangles has HZ_QSHARDS counters (round 5).  Every append is one RETURNING atomic - the appender needs
+ * the index it got -, and one address takes 83 M of those a second from the whole chip, 12 ns each, whoever asks
+ * (tools/atomic_one_address.hip; 16 addresses: 16 times that): the 10 degree view's second round has 36.6 K flushes that
+ * append - 0.44 ms of atomics on ONE word for a kernel of 0.42 ms -, a first round's marching kernel 3.5 K in its 44 us.
+ * A wave appends through the counter of its shard (its block's number); shard s hands out the records s, s + S, s + 2 S, ...
+ * and the items likewise: slot g of either array belongs to shard g % S and is the (g / S)-th of it, so the arrays stay
+ * dense up to S times the longest shard - the consumers walk that far and skip the slots beyond a shard's own count. */
+#define HZ_QSHARDS       16             /* (a power of two) */
+#define HZ_QSHARD_STRIDE 32             /* words between two shards' counters: 128 bytes */
+#define HZ_QSHARD0       16             /* shard s: counters[HZ_QSHARD0 + s*HZ_QSHARD_STRIDE + {0 records, 1 items (one 64-bit word), 2 ~(first invalid item)}] */
+#define HZ_NCOUNTERS (HZ_QSHARD0 + HZ_QSHARDS*HZ_QSHARD_STRIDE)
+#define HZ_CNT_LAST  8                  /* [8..14): the counters as the last draw left them (diagnostics; the big triangles': sums over the shards) */
 #ifndef HZ_NFB
 #define HZ_NFB 3                        /* framebuffers (and queue sets per round) a context cycles through */
 #endif
