@@ -460,22 +460,23 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t nb    = (uint32_t)__popcll(bigmask);
         uint32_t rbase = 0, ibase = 0, ok = 0;
+        const int shard = (int)((blockIdx.x + 5u*blockIdx.y) % HZ_QSHARDS);
         if(lane == 0)
         {
             /* records and items in one step (the two counters of a shard are the halves of one 64-bit word), through the
              * counter of this wave's shard: atomics on one address are served one after the other, 12 ns apiece
              * (hz_types.h: HZ_QSHARDS) */
-            ok = hz_queue_reserve(q, (int)((blockIdx.x + 5u*blockIdx.y) % HZ_QSHARDS), nb, total, &rbase, &ibase) ? 1u : 0u;
+            ok = hz_queue_reserve(q, shard, nb, total, &rbase, &ibase) ? 1u : 0u;
         }
         rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase); ibase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ibase); ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
         if(is_big)
         {
             if(ok)
             {
-                const uint32_t ri = rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull))*HZ_QSHARDS;
-                const uint32_t ii = ibase + (incl - chunks)*HZ_QSHARDS;
+                const uint32_t ri = HZ_QSLOT(rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull)), shard);
+                const uint32_t ii = ibase + (incl - chunks);
                 q.bigrec[ri].r = r; q.bigrec[ri].bh = bh;
-                for(uint32_t c2=0; c2<chunks; c2++) { q.bigitem[ii + c2*HZ_QSHARDS].rec = ri; q.bigitem[ii + c2*HZ_QSHARDS].chunk = c2; }
+                for(uint32_t c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard); q.bigitem[g].rec = ri; q.bigitem[g].chunk = c2; }
             }
             else
             {

@@ -152,11 +152,13 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
                 uint32_t ri = 0, ii = 0;
                 mr_queue_t qq = {};
                 qq.counters = big_counters; qq.bigrec_capacity = bigrec_capacity; qq.bigitem_capacity = bigitem_capacity;
-                const bool queued = hz_queue_reserve(qq, (int)(blockIdx.x % HZ_QSHARDS), 1u, chunks, &ri, &ii);
+                const int shard = (int)(blockIdx.x % HZ_QSHARDS);
+                const bool queued = hz_queue_reserve(qq, shard, 1u, chunks, &ri, &ii);
                 if(queued)
                 {
-                    bigrec[ri].r = r; bigrec[ri].bh = bh;
-                    for(unsigned int c2=0; c2<chunks; c2++) { bigitem[ii + c2*HZ_QSHARDS].rec = ri; bigitem[ii + c2*HZ_QSHARDS].chunk = c2; }
+                    const uint32_t rslot = HZ_QSLOT(ri, shard);
+                    bigrec[rslot].r = r; bigrec[rslot].bh = bh;
+                    for(unsigned int c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard); bigitem[g].rec = rslot; bigitem[g].chunk = c2; }
                 }
                 else
                 {
@@ -313,7 +315,7 @@ void k_big(unsigned long long* __restrict__ fb,
     /* (tile_state: the round's triangles were binned and drawn by screen tile - hz_k_tile.h - unless there were too many) */
     if(tile_state && tile_state[0] == 0) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
-    /* (item slots [0, nitems): slot g belongs to shard g % HZ_QSHARDS and is in use if that shard got that far - hz_types.h) */
+    /* (item slots [0, nitems): a slot is in use if the shard it belongs to got that far - hz_types.h, HZ_QSLOT) */
     const unsigned int nitems = hz_queue_span(big_counters);
     (void)bigrec_capacity; (void)bigitem_capacity;
     const int lane = threadIdx.x & 63;

@@ -101,10 +101,16 @@ struct mr_queue_t
  * the index it got -, and one address takes 83 M of those a second from the whole chip, 12 ns each, whoever asks
  * (tools/atomic_one_address.hip; 16 addresses: 16 times that): the 10 degree view's second round has 36.6 K flushes that
  * append - 0.44 ms of atomics on ONE word for a kernel of 0.42 ms -, a first round's marching kernel 3.5 K in its 44 us.
- * A wave appends through the counter of its shard (its block's number); shard s hands out the records s, s + S, s + 2 S, ...
- * and the items likewise: slot g of either array belongs to shard g % S and is the (g / S)-th of it, so the arrays stay
- * dense up to S times the longest shard - the consumers walk that far and skip the slots beyond a shard's own count. */
+ * A wave appends through the counter of its shard (its block's number); the shards own the arrays of records and of items
+ * in turns, HZ_QBLOCK slots at a time (16 items are one cache line: handed out one slot at a time the items cost a line
+ * each to write and to read, and a render of a series 3 % - profiles/r5_ab_queue_shards.txt): the l-th record or item of
+ * shard s lies in slot HZ_QSLOT(l, s), so the arrays stay dense up to S times the longest shard - the consumers walk that
+ * far and skip the slots beyond a shard's own count. */
 #define HZ_QSHARDS       16             /* (a power of two) */
+#define HZ_QBLOCK_LOG2   4
+#define HZ_QBLOCK        (1 << HZ_QBLOCK_LOG2)
+#define HZ_QSHARD_ROOM(capacity) (((capacity)/(HZ_QSHARDS*HZ_QBLOCK))*HZ_QBLOCK)      /* records or items a shard may hold of an array of `capacity` */
+#define HZ_QSLOT(l, s)   ((((((uint32_t)(l)) >> HZ_QBLOCK_LOG2)*HZ_QSHARDS + (uint32_t)(s)) << HZ_QBLOCK_LOG2) | (((uint32_t)(l)) & (HZ_QBLOCK-1)))
 #define HZ_QSHARD_STRIDE 32             /* words between two shards' counters: 128 bytes */
 #define HZ_QSHARD0       16             /* shard s: counters[HZ_QSHARD0 + s*HZ_QSHARD_STRIDE + {0 records, 1 items (one 64-bit word), 2 ~(first invalid item)}] */
 #define HZ_NCOUNTERS (HZ_QSHARD0 + HZ_QSHARDS*HZ_QSHARD_STRIDE)
