@@ -1068,6 +1068,15 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
             /* round 1, on its own stream */
             const mr_queue_t qn = queue_set(d, HZ_NFB + next);
             HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_free[next], 0));
+            {
+                /* zoomed: a cell at the first round's reach is still HZ_HIZ_MIN_PX pixels wide.  Such a view's waves append to
+                 * the queue of big triangles with nearly every flush: through sixteen counters instead of one (hz_types.h,
+                 * HZ_QSHARDS: the seven views of profiles/r5_zoomed_views.txt 8.8 -> 7.4 ms in sum, the slowest 1.69 -> 1.49) */
+                const float ppr = p.halfW * p.u.az_ndc_per_rad;
+                const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
+                zoomed_view = reach > 0.f && ppr/reach >= HZ_HIZ_MIN_PX;
+                p.qshards_log2 = zoomed_view ? HZ_QSHARDS_LOG2 : 0;
+            }
             hz_params_t p1 = p;
             p1.pass = 1; p1.early_z = 0;
             if(fresh_lists)
@@ -1082,7 +1091,6 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                  * degree view of 16000 columns: 40; a 90 degree view, 26, is better off with k_big: 0.92 against 1.08 ms) */
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
-                zoomed_view = reach > 0.f && ppr/reach >= HZ_HIZ_MIN_PX;
                 if(d->env.tiles < 0 && d->raster != HZ_RASTER_SCATTER && reach > 0.f && ppr/reach >= HZ_TILES_MIN_PX) by_tile_first = true;
                 if(by_tile_first && tile_bins(d, HZ_NFB + next) != 0) by_tile_first = false;       /* (no memory for the bins: k_big) */
             }
@@ -1196,6 +1204,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
         d->adapt.pending[next] = 1; d->adapt.reach_of[next] = (p.near_j1 - p.near_j0)/2;
         d->adapt.long_of[next] = d->adapt.reach_of[next] > HZ_NEAR_CELLS_WIDE ? 1 : 0; d->adapt.serial_of[next] = d->adapt.serial;
     }
+    d->last_qshards_log2 = p.qshards_log2;
     d->last_plan[0] = p.pass == 2 ? 2 : 1; d->last_plan[1] = use_hiz ? 1 : 0;
     d->last_plan[2] = p.pass == 2 ? (p.near_j1 - p.near_j0)/2 : 0; d->last_plan[3] = p.cull_strips ? 1 : 0;
     d->last_plan[4] = p.vcache ? 1 : 0;

@@ -73,20 +73,20 @@ __device__ static inline unsigned int hz_queue_nitems_of(const unsigned int* cou
     const unsigned int* c = hz_qshard(counters, s);
     return min(c[1], ~c[2]);
 }
-/* is item slot g in use?  (g = HZ_QSLOT(l, s) taken apart) */
-__device__ static inline bool hz_queue_item_valid(const unsigned int* counters, unsigned int g)
+/* is item slot g in use?  (g = HZ_QSLOT(l, s, sl) taken apart) */
+__device__ static inline bool hz_queue_item_valid(const unsigned int* counters, unsigned int g, int sl)
 {
     const unsigned int block = g >> HZ_QBLOCK_LOG2;
-    const unsigned int l = ((block / HZ_QSHARDS) << HZ_QBLOCK_LOG2) | (g & (HZ_QBLOCK-1));
-    return l < hz_queue_nitems_of(counters, (int)(block % HZ_QSHARDS));
+    const unsigned int l = ((block >> sl) << HZ_QBLOCK_LOG2) | (g & (HZ_QBLOCK-1));
+    return l < hz_queue_nitems_of(counters, (int)(block & ((1u << sl) - 1u)));
 }
 /* the item slots a consumer has to look at: [0, that) */
-__device__ static inline unsigned int hz_queue_span(const unsigned int* counters)
+__device__ static inline unsigned int hz_queue_span(const unsigned int* counters, int sl)
 {
     unsigned int m = 0;
     #pragma unroll
-    for(int s=0; s<HZ_QSHARDS; s++) m = max(m, hz_queue_nitems_of(counters, s));
-    return ((m + HZ_QBLOCK-1) & ~(unsigned int)(HZ_QBLOCK-1))*HZ_QSHARDS;
+    for(int s=0; s<HZ_QSHARDS; s++) m = max(m, hz_queue_nitems_of(counters, s));        /* (shards a draw does not use stay at zero) */
+    return ((m + HZ_QBLOCK-1) & ~(unsigned int)(HZ_QBLOCK-1)) << sl;
 }
 __device__ static inline void hz_queue_totals(const unsigned int* counters, unsigned int* records, unsigned int* items)
 {
@@ -96,16 +96,16 @@ __device__ static inline void hz_queue_totals(const unsigned int* counters, unsi
     *records = r; *items = n;
 }
 /* room for nrec records and nitems items from shard `shard`: the shard's own numbers of the first record and of the first
- * item (their slots: HZ_QSLOT(number, shard)); false: they do not fit - the caller draws them itself, and the shard's
+ * item (their slots: HZ_QSLOT(number, shard, sl)); false: they do not fit - the caller draws them itself, and the shard's
  * items from here on are not valid */
-__device__ static inline bool hz_queue_reserve(const mr_queue_t& q, int shard, uint32_t nrec, uint32_t nitems, uint32_t* rec0, uint32_t* item0)
+__device__ static inline bool hz_queue_reserve(const mr_queue_t& q, int shard, int sl, uint32_t nrec, uint32_t nitems, uint32_t* rec0, uint32_t* item0)
 {
     unsigned int* c = hz_qshard(q.counters, shard);
     const unsigned long long both = atomicAdd((unsigned long long*)c, (unsigned long long)nrec | ((unsigned long long)nitems << 32));
     const uint32_t rl = (uint32_t)both, il = (uint32_t)(both >> 32);
     *rec0 = rl; *item0 = il;
     /* (a shard's room: whole blocks, so that its last slot lies inside the array) */
-    if((unsigned long long)rl + nrec <= HZ_QSHARD_ROOM(q.bigrec_capacity) && (unsigned long long)il + nitems <= HZ_QSHARD_ROOM(q.bigitem_capacity)) return true;
+    if((unsigned long long)rl + nrec <= HZ_QSHARD_ROOM(q.bigrec_capacity, sl) && (unsigned long long)il + nitems <= HZ_QSHARD_ROOM(q.bigitem_capacity, sl)) return true;
     atomicMax(c + 2, ~il);
     return false;
 }
@@ -284,8 +284,8 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
     }
     if(npieces == 0) return;
     uint32_t ri = 0, ii = 0;            /* the shard's own numbers of the next record / item of this reservation */
-    const int shard = (int)(blockIdx.x % HZ_QSHARDS);
-    const bool queued = hz_queue_reserve(q, shard, npieces, nchunks, &ri, &ii);
+    const int sl = p.qshards_log2, shard = (int)(blockIdx.x & ((1u << sl) - 1u));
+    const bool queued = hz_queue_reserve(q, shard, sl, npieces, nchunks, &ri, &ii);
     if(!queued && !inline_ok) return;
     for(int k=2; k<n; k++)
     {
@@ -308,10 +308,10 @@ __device__ static void hz_clip_and_draw(const int16_t* mosaic, unsigned long lon
         br.r.prim = prim;
         br.bh = box.py1 - box.py0 + 1;
         const uint32_t chunks = hz_big_chunks(br.r.bw, br.bh);
-        const uint32_t rslot = HZ_QSLOT(ri, shard);
+        const uint32_t rslot = HZ_QSLOT(ri, shard, sl);
         q.bigrec[rslot] = br;
         if(jobs && chunks > HZ_CLIP_JOB_MIN) { uint32_t* job = jobs[*njobs]; job[0] = ii; job[1] = rslot; job[2] = chunks | ((uint32_t)shard << 24); (*njobs)++; }     /* (chunks: at most 65535, an image's rows) */
-        else for(uint32_t c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard); q.bigitem[g].rec = rslot; q.bigitem[g].chunk = c2; }
+        else for(uint32_t c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard, sl); q.bigitem[g].rec = rslot; q.bigitem[g].chunk = c2; }
         ri++; ii += chunks;
     }
 }
@@ -374,7 +374,7 @@ void k_clip(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__
                 for(int jb=0; jb<s_njobs[c]; jb++)
                 {
                     const uint32_t ii = s_job[c][jb][0], rslot = s_job[c][jb][1], chunks = s_job[c][jb][2] & 0xFFFFFFu, shard = s_job[c][jb][2] >> 24;
-                    for(uint32_t c2 = threadIdx.x; c2 < chunks; c2 += 64u) { const uint32_t g = HZ_QSLOT(ii + c2, shard); q.bigitem[g].rec = rslot; q.bigitem[g].chunk = c2; }
+                    for(uint32_t c2 = threadIdx.x; c2 < chunks; c2 += 64u) { const uint32_t g = HZ_QSLOT(ii + c2, shard, p.qshards_log2); q.bigitem[g].rec = rslot; q.bigitem[g].chunk = c2; }
                 }
             __syncthreads();
         }

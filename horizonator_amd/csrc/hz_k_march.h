@@ -460,23 +460,23 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t nb    = (uint32_t)__popcll(bigmask);
         uint32_t rbase = 0, ibase = 0, ok = 0;
-        const int shard = (int)((blockIdx.x + 5u*blockIdx.y) % HZ_QSHARDS);
+        const int sl = p.qshards_log2, shard = (int)((blockIdx.x + 5u*blockIdx.y) & ((1u << sl) - 1u));
         if(lane == 0)
         {
             /* records and items in one step (the two counters of a shard are the halves of one 64-bit word), through the
              * counter of this wave's shard: atomics on one address are served one after the other, 12 ns apiece
-             * (hz_types.h: HZ_QSHARDS) */
-            ok = hz_queue_reserve(q, shard, nb, total, &rbase, &ibase) ? 1u : 0u;
+             * (hz_types.h: HZ_QSHARDS; whole panoramas: one shard) */
+            ok = hz_queue_reserve(q, shard, sl, nb, total, &rbase, &ibase) ? 1u : 0u;
         }
         rbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase); ibase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ibase); ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
         if(is_big)
         {
             if(ok)
             {
-                const uint32_t ri = HZ_QSLOT(rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull)), shard);
+                const uint32_t ri = HZ_QSLOT(rbase + (uint32_t)__popcll(bigmask & ((1ull << lane) - 1ull)), shard, sl);
                 const uint32_t ii = ibase + (incl - chunks);
                 q.bigrec[ri].r = r; q.bigrec[ri].bh = bh;
-                for(uint32_t c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard); q.bigitem[g].rec = ri; q.bigitem[g].chunk = c2; }
+                for(uint32_t c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard, sl); q.bigitem[g].rec = ri; q.bigitem[g].chunk = c2; }
             }
             else
             {

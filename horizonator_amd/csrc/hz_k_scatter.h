@@ -152,13 +152,13 @@ void k_scatter(const int16_t* __restrict__ mosaic, unsigned long long* __restric
                 uint32_t ri = 0, ii = 0;
                 mr_queue_t qq = {};
                 qq.counters = big_counters; qq.bigrec_capacity = bigrec_capacity; qq.bigitem_capacity = bigitem_capacity;
-                const int shard = (int)(blockIdx.x % HZ_QSHARDS);
-                const bool queued = hz_queue_reserve(qq, shard, 1u, chunks, &ri, &ii);
+                const int sl = p.qshards_log2, shard = (int)(blockIdx.x & ((1u << sl) - 1u));
+                const bool queued = hz_queue_reserve(qq, shard, sl, 1u, chunks, &ri, &ii);
                 if(queued)
                 {
-                    const uint32_t rslot = HZ_QSLOT(ri, shard);
+                    const uint32_t rslot = HZ_QSLOT(ri, shard, sl);
                     bigrec[rslot].r = r; bigrec[rslot].bh = bh;
-                    for(unsigned int c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard); bigitem[g].rec = rslot; bigitem[g].chunk = c2; }
+                    for(unsigned int c2=0; c2<chunks; c2++) { const uint32_t g = HZ_QSLOT(ii + c2, shard, sl); bigitem[g].rec = rslot; bigitem[g].chunk = c2; }
                 }
                 else
                 {
@@ -316,7 +316,7 @@ void k_big(unsigned long long* __restrict__ fb,
     if(tile_state && tile_state[0] == 0) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
     /* (item slots [0, nitems): a slot is in use if the shard it belongs to got that far - hz_types.h, HZ_QSLOT) */
-    const unsigned int nitems = hz_queue_span(big_counters);
+    const unsigned int nitems = hz_queue_span(big_counters, p.qshards_log2);
     (void)bigrec_capacity; (void)bigitem_capacity;
     const int lane = threadIdx.x & 63;
     const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
@@ -326,14 +326,14 @@ void k_big(unsigned long long* __restrict__ fb,
      * their latency hides behind the pixel work */
     hz_bigitem_t item_next = {};
     hz_bigrec_t  rec_next  = {};
-    bool valid_next = wave_global < nitems && hz_queue_item_valid(big_counters, wave_global);
+    bool valid_next = wave_global < nitems && hz_queue_item_valid(big_counters, wave_global, p.qshards_log2);
     if(valid_next) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
     for(unsigned int it = wave_global; it < nitems; it += nwaves)
     {
         const hz_bigitem_t item = item_next;
         const hz_bigrec_t  br   = rec_next;
         const bool valid = valid_next;
-        valid_next = it + nwaves < nitems && hz_queue_item_valid(big_counters, it + nwaves);
+        valid_next = it + nwaves < nitems && hz_queue_item_valid(big_counters, it + nwaves, p.qshards_log2);
         if(valid_next) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
         if(!valid) continue;
         hz_tri_t tri;

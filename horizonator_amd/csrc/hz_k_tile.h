@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256)
 void k_tile_bin(const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
                 const unsigned int* __restrict__ big_counters, unsigned int bigrec_capacity, tl_bins_t tb, hz_params_t p)
 {
-    const unsigned int nitems = hz_queue_span(big_counters);        /* item slots, not all of them in use: hz_types.h, HZ_QSHARDS */
+    const unsigned int nitems = hz_queue_span(big_counters, p.qshards_log2);        /* item slots, not all of them in use: hz_types.h, HZ_QSHARDS */
     const int lane = threadIdx.x & 63;
     (void)bigrec_capacity;
     for(unsigned int base = (blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6))*64u; base < nitems; base += gridDim.x*(blockDim.x/64)*64u)
@@ -85,7 +85,7 @@ void k_tile_bin(const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __re
         bool mine = false;
         unsigned int rec = 0;
         int tx0 = 0, ty0 = 0, ntx = 1, nt = 0;
-        if(it < nitems && hz_queue_item_valid(big_counters, it))
+        if(it < nitems && hz_queue_item_valid(big_counters, it, p.qshards_log2))
         {
             const hz_bigitem_t item = bigitem[it];
             if(item.chunk == 0)

@@ -423,6 +423,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     std::vector<unsigned int> all(HZ_NCOUNTERS);
     HZ_CHECK(hipMemcpy(all.data(), d->d_big_counters_s[k], HZ_NCOUNTERS*sizeof(unsigned int), hipMemcpyDeviceToHost));
     unsigned int per_shard[HZ_QSHARDS], longest = 0;
+    const int sl = d->last_qshards_log2;          /* (of the last draw: hz_draw_impl) */
     if(d->fb_consumed) { for(int c=0; c<6; c++) counters[c] = all[HZ_CNT_LAST + c]; for(int s=0; s<HZ_QSHARDS; s++) per_shard[s] = 0; }
     else
     {
@@ -430,7 +431,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
         for(int s=0; s<HZ_QSHARDS; s++)
         {
             const unsigned int* c = all.data() + HZ_QSHARD0 + s*HZ_QSHARD_STRIDE;
-            per_shard[s] = c[0] < HZ_QSHARD_ROOM(d->bigrec_capacity) ? c[0] : HZ_QSHARD_ROOM(d->bigrec_capacity);
+            per_shard[s] = c[0] < HZ_QSHARD_ROOM(d->bigrec_capacity, sl) ? c[0] : HZ_QSHARD_ROOM(d->bigrec_capacity, sl);
             counters[0] += c[0]; counters[1] += c[1]; if(c[2]) counters[2] = c[2];
             if(per_shard[s] > longest) longest = per_shard[s];
         }
@@ -439,7 +440,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     counters[2] = ~counters[2]; counters[5] = ~counters[5];     /* as documented: the first invalid index (of one of the shards) */
     if(longest == 0 || recs == NULL || max_rec <= 0) return 0;
     /* which record of which shard a slot holds: HZ_QSLOT (hz_types.h) taken apart */
-    const size_t slots = (size_t)((longest + HZ_QBLOCK-1)/HZ_QBLOCK*HZ_QBLOCK)*HZ_QSHARDS;
+    const size_t slots = (size_t)((longest + HZ_QBLOCK-1)/HZ_QBLOCK*HZ_QBLOCK) << sl;
     hz_bigrec_t* h = (hz_bigrec_t*)malloc(slots*sizeof(hz_bigrec_t));
     if(!h) return -1;
     HZ_CHECK(hipMemcpy(h, d->d_bigrec_s[k], slots*sizeof(hz_bigrec_t), hipMemcpyDeviceToHost));
@@ -447,7 +448,7 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     for(size_t g=0; g<slots && n<max_rec; g++)
     {
         const size_t block = g >> HZ_QBLOCK_LOG2;
-        if((((block / HZ_QSHARDS) << HZ_QBLOCK_LOG2) | (g & (HZ_QBLOCK-1))) >= per_shard[block % HZ_QSHARDS]) continue;
+        if((((block >> sl) << HZ_QBLOCK_LOG2) | (g & (HZ_QBLOCK-1))) >= per_shard[block & (((size_t)1 << sl) - 1)]) continue;
         int32_t* o = recs + (size_t)n*10;
         o[0] = h[g].r.px0; o[1] = h[g].r.py0; o[2] = h[g].r.bw; o[3] = h[g].bh;
         for(int m=0; m<3; m++) { o[4+m] = h[g].r.e.dx[m]; o[7+m] = -h[g].r.e.ndy[m]; }

@@ -44,6 +44,7 @@ struct hz_params_t
     int   near_j0, near_j1;            /* cell rows [j0,j1) that make up "next to the viewer"                   */
     int   early_z;                     /* mr_flush: skip triangles whose box is already covered by nearer depth */
     int   pretest_march;               /* the marching waves read a word before the atomic (draw_impl decides) */
+    int   qshards_log2;                /* the counters the queue of big triangles is appended through: 1 << that (HZ_QSHARDS, below) */
 #ifdef HZ_EXPERIMENTS
     int   exp_fb[2];                   /* experiments (wrong pictures), see hz_fb_min: [0] the marching waves' fragments, [1] k_big's */
 #endif
@@ -104,13 +105,17 @@ struct mr_queue_t
  * A wave appends through the counter of its shard (its block's number); the shards own the arrays of records and of items
  * in turns, HZ_QBLOCK slots at a time (16 items are one cache line: handed out one slot at a time the items cost a line
  * each to write and to read, and a render of a series 3 % - profiles/r5_ab_queue_shards.txt): the l-th record or item of
- * shard s lies in slot HZ_QSLOT(l, s), so the arrays stay dense up to S times the longest shard - the consumers walk that
+ * shard s lies in slot HZ_QSLOT(l, s, sl), so the arrays stay dense up to S times the longest shard - the consumers walk that
  * far and skip the slots beyond a shard's own count. */
-#define HZ_QSHARDS       16             /* (a power of two) */
+#define HZ_QSHARDS_LOG2  4
+#define HZ_QSHARDS       (1 << HZ_QSHARDS_LOG2)
 #define HZ_QBLOCK_LOG2   4
 #define HZ_QBLOCK        (1 << HZ_QBLOCK_LOG2)
-#define HZ_QSHARD_ROOM(capacity) (((capacity)/(HZ_QSHARDS*HZ_QBLOCK))*HZ_QBLOCK)      /* records or items a shard may hold of an array of `capacity` */
-#define HZ_QSLOT(l, s)   ((((((uint32_t)(l)) >> HZ_QBLOCK_LOG2)*HZ_QSHARDS + (uint32_t)(s)) << HZ_QBLOCK_LOG2) | (((uint32_t)(l)) & (HZ_QBLOCK-1)))
+/* (sl: log2 of the shards a draw uses - hz_params_t::qshards_log2: HZ_QSHARDS_LOG2 for zoomed views, whose waves append with nearly
+ * every flush; 0 = one counter and the arrays in plain order for whole panoramas, whose appends are few: with sixteen shards a
+ * render of a series took 1-3 % longer, profiles/r5_ab_queue_shards.txt) */
+#define HZ_QSHARD_ROOM(capacity, sl) ((((capacity) >> ((sl) + HZ_QBLOCK_LOG2))) << HZ_QBLOCK_LOG2)      /* records or items a shard may hold of an array of `capacity` */
+#define HZ_QSLOT(l, s, sl) (((((((uint32_t)(l)) >> HZ_QBLOCK_LOG2) << (sl)) + (uint32_t)(s)) << HZ_QBLOCK_LOG2) | (((uint32_t)(l)) & (HZ_QBLOCK-1)))
 #define HZ_QSHARD_STRIDE 32             /* words between two shards' counters: 128 bytes */
 #define HZ_QSHARD0       16             /* shard s: counters[HZ_QSHARD0 + s*HZ_QSHARD_STRIDE + {0 records, 1 items (one 64-bit word), 2 ~(first invalid item)}] */
 #define HZ_NCOUNTERS (HZ_QSHARD0 + HZ_QSHARDS*HZ_QSHARD_STRIDE)
