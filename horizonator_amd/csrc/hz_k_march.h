@@ -335,7 +335,7 @@ void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ mid
 }
 
 /* set up and rasterise the `n` (<= 64) oldest pending triangles */
-template<bool HIZ>
+template<bool HIZ, bool SHARDS>
 __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned int n, int lane,
                                 int jbeg, int i0,
                                 unsigned long long* fb, const mr_queue_t& q, const hz_params_t& p,
@@ -460,7 +460,9 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t nb    = (uint32_t)__popcll(bigmask);
         uint32_t rbase = 0, ibase = 0, ok = 0;
-        const int sl = p.qshards_log2, shard = (int)((blockIdx.x + 5u*blockIdx.y) & ((1u << sl) - 1u));
+        /* (SHARDS: p.qshards_log2 = HZ_QSHARDS_LOG2, zoomed views; else 0 - as a constant: whole panoramas append with the code they
+         * had before there were shards, which as a variable shift cost their marching kernel 1.5 %) */
+        const int sl = SHARDS ? HZ_QSHARDS_LOG2 : 0, shard = (int)((blockIdx.x + 5u*blockIdx.y) & ((1u << sl) - 1u));
         if(lane == 0)
         {
             /* records and items in one step (the two counters of a shard are the halves of one 64-bit word), through the
@@ -548,7 +550,7 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
  * a context keeps its four numbers per vertex (p.vcache, 16 bytes each, written by k_polar_fill when a viewpoint is drawn
  * a second time) and this instance reads them instead of the elevation: a 16-byte load and the ~30 instructions of
  * hz_finish() per vertex where the cold instance spends ~155.  Same operations on the same numbers: same bits. */
-template<bool COUNTERS, bool HIZ, bool VCACHE>
+template<bool COUNTERS, bool HIZ, bool VCACHE, bool SHARDS>
 __global__ __launch_bounds__(64) MR_OCCUPANCY
 void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict__ fb,
              mr_queue_t q, mr_zones_t zn, hz_params_t p)
@@ -725,7 +727,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
         if(count && first_row <= rel - MR_RSLOTS)
         {
             __syncthreads();
-            mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+            mr_flush<HIZ, SHARDS>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
             __syncthreads();
             head = (head + count) & (MR_CAP-1);
             count = 0;
@@ -781,7 +783,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
                     if(count >= 64)
                     {
                         __syncthreads();        /* one wave: orders the LDS writes before the reads */
-                        mr_flush<HIZ>(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
+                        mr_flush<HIZ, SHARDS>(L, head, 64, lane, jbeg, i0, fb, q, p, dbg);
                         head = (head + 64) & (MR_CAP-1);
                         count -= 64;
                         if(count) first_row = (int)(L.ids[head] >> 7);
@@ -795,7 +797,7 @@ void k_march(const int16_t* __restrict__ mosaic, unsigned long long* __restrict_
     if(count)
     {
         __syncthreads();
-        mr_flush<HIZ>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
+        mr_flush<HIZ, SHARDS>(L, head, count, lane, jbeg, i0, fb, q, p, dbg);
     }
     /* (Four inlined copies of mr_flush - this one, the one before a row is stored, two in the unrolled loop over a cell's
      * triangles - and 104 registers.  Round 5 tried ONE place at the top of the row loop instead (tools/patches/

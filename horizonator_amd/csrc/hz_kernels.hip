@@ -198,18 +198,29 @@ void hzk_mid(dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, 
 
 void hzk_march(bool counters, bool hiz, bool vcache, dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, unsigned long long* fb, mr_queue_t q, mr_zones_t zn, hz_params_t p)
 {
+    /* (the instance appends through as many queue counters as the draw's other kernels expect: hz_types.h, HZ_QSHARDS) */
+    const bool shards = p.qshards_log2 != 0;
 #ifdef HZ_SELFTEST
-    if(counters) { hipLaunchKernelGGL((k_march<true, true, false>), grid, block, 0, stream, mosaic, fb, q, zn, p); return; }
-#endif
-    (void)counters;
-    if(vcache)
+    if(counters)
     {
-        if(hiz) hipLaunchKernelGGL((k_march<false, true, true>), grid, block, 0, stream, mosaic, fb, q, zn, p);
-        else hipLaunchKernelGGL((k_march<false, false, true>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+        if(shards) hipLaunchKernelGGL((k_march<true, true, false, true>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+        else hipLaunchKernelGGL((k_march<true, true, false, false>), grid, block, 0, stream, mosaic, fb, q, zn, p);
         return;
     }
-    if(hiz) hipLaunchKernelGGL((k_march<false, true, false>), grid, block, 0, stream, mosaic, fb, q, zn, p);
-    else hipLaunchKernelGGL((k_march<false, false, false>), grid, block, 0, stream, mosaic, fb, q, zn, p);
+#endif
+    (void)counters;
+    #define HZK_MARCH(H, V, S) hipLaunchKernelGGL((k_march<false, H, V, S>), grid, block, 0, stream, mosaic, fb, q, zn, p)
+    if(shards)
+    {
+        if(vcache) { if(hiz) HZK_MARCH(true, true, true); else HZK_MARCH(false, true, true); }
+        else       { if(hiz) HZK_MARCH(true, false, true); else HZK_MARCH(false, false, true); }
+    }
+    else
+    {
+        if(vcache) { if(hiz) HZK_MARCH(true, true, false); else HZK_MARCH(false, true, false); }
+        else       { if(hiz) HZK_MARCH(true, false, false); else HZK_MARCH(false, false, false); }
+    }
+    #undef HZK_MARCH
 }
 
 void hzk_polar_fill(dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosaic, hz_polar_t* q, int N, hz_xform_t u)

@@ -42,10 +42,11 @@ def _one(kernels, fragment):
 
 def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     k = _kernels()
-    march = _one(k, "k_marchILb0ELb0ELb0E")         # the production instance (no per-wave counters, no coarse depth, every vertex computed)
-    assert march["private_segment_fixed_size"] == 0, "k_march<false, false, false> must not use scratch memory"
-    zoomed = _one(k, "k_marchILb0ELb1ELb0E")        # ... of zoomed views and series (coarse depth, hz_k_hiz.h)
-    for name in ("k_marchILb0ELb0ELb1E", "k_marchILb0ELb1ELb1E"):      # ... and those that read the vertex cache (round 5)
+    march = _one(k, "k_marchILb0ELb0ELb0ELb0E")     # the production instance (no per-wave counters, no coarse depth, every vertex computed, one queue counter)
+    assert march["private_segment_fixed_size"] == 0, "k_march<false, false, false, false> must not use scratch memory"
+    zoomed = _one(k, "k_marchILb0ELb1ELb0ELb0E")    # ... of series (coarse depth, hz_k_hiz.h)
+    # ... those that read the vertex cache (round 5), and those of zoomed views (sixteen queue counters: hz_types.h, HZ_QSHARDS)
+    for name in ("k_marchILb0ELb0ELb1ELb0E", "k_marchILb0ELb1ELb1ELb0E", "k_marchILb0ELb0ELb0ELb1E", "k_marchILb0ELb1ELb0ELb1E", "k_marchILb0ELb0ELb1ELb1E", "k_marchILb0ELb1ELb1ELb1E"):
         cached = _one(k, name)
         assert cached["private_segment_fixed_size"] == 0 and cached["vgpr_count"] <= 104 and cached["group_segment_fixed_size"] <= 7168, (name, cached)
     assert zoomed["private_segment_fixed_size"] == 0 and zoomed["vgpr_count"] <= 112 and zoomed["group_segment_fixed_size"] <= 7168, zoomed
@@ -55,7 +56,7 @@ def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     assert march["vgpr_count"] <= 104 and zoomed["vgpr_count"] <= 104, (march, zoomed)
     # round 5: ... and more than 96 - FOUR waves per SIMD, not five, which would leave their neighbours no room at all (a series
     # of renders 0.85 -> 0.98 ms with a 96-register build of the kernel: profiles/r5_ab_march_loop.txt)
-    for name in ("k_marchILb0ELb0ELb0E", "k_marchILb0ELb1ELb0E", "k_marchILb0ELb0ELb1E", "k_marchILb0ELb1ELb1E"):
+    for name in [f"k_marchILb0ELb{h}ELb{v}ELb{q}E" for h in (0, 1) for v in (0, 1) for q in (0, 1)]:
         assert 96 < _one(k, name)["vgpr_count"] <= 104, (name, _one(k, name))
     assert march["group_segment_fixed_size"] <= 7168
     left_vgprs = 512 - 4*((march["vgpr_count"] + 7)//8*8)

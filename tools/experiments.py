@@ -135,7 +135,7 @@ def main():
                 tk.ROOT = root
                 k = tk._kernels()
                 tk.ROOT = save
-                rec["k_march_resources"] = {"k_march<false,false>": tk._one(k, "k_marchILb0ELb0E"), "k_march<false,true> (coarse depth)": tk._one(k, "k_marchILb0ELb1E")}
+                rec["k_march_resources"] = {"k_march<false,false>": tk._one(k, "k_marchILb0ELb0ELb0ELb0E"), "k_march<false,true> (coarse depth)": tk._one(k, "k_marchILb0ELb1ELb0ELb0E")}
             except Exception as e:
                 rec["k_march_resources"] = repr(e)
         doc["rows"].append(rec)

@@ -88,7 +88,7 @@ def main():
     two_waves = {r["instr"]: r["cycles_per_wave_instr_at_nominal_clock"] for r in json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["rows"] if r.get("waves_per_simd_asked") == 2}
 
     # the listing's vector instructions by class (static: what kinds of instruction the kernel is made of)
-    frag = "k_marchILb0ELb1ELb0E" if key.endswith("coarse_depth") else "k_marchILb0ELb0ELb0E"     # (k_march<COUNTERS, HIZ, VCACHE>)
+    frag = "k_marchILb0ELb1ELb0ELb0E" if key.endswith("coarse_depth") else "k_marchILb0ELb0ELb0ELb0E"     # (k_march<COUNTERS, HIZ, VCACHE, SHARDS>)
     static = collections.Counter()
     meta = {}
     for ins in listing(frag):
