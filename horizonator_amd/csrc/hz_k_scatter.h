@@ -292,6 +292,9 @@ __device__ static inline uint32_t hz_row_span(const hz_edges_t& e, int row, int3
  * the shape of the triangle - the long thin slivers next to the viewer cover a
  * quarter of their boxes. */
 #define KB_LDS_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while(0)
+/* SHARDS: the queue was filled through HZ_QSHARDS counters (zoomed views: p.qshards_log2, hz_types.h); else through one, and
+ * this is the loop it had before there were shards (the general one cost a render of a series 1 %) */
+template<bool SHARDS>
 __global__ __launch_bounds__(256)
 void k_big(unsigned long long* __restrict__ fb,
            const hz_bigrec_t* __restrict__ bigrec, const hz_bigitem_t* __restrict__ bigitem,
@@ -316,7 +319,8 @@ void k_big(unsigned long long* __restrict__ fb,
     if(tile_state && tile_state[0] == 0) return;
     /* items at and beyond the first overflow were rasterised inline by their producer */
     /* (item slots [0, nitems): a slot is in use if the shard it belongs to got that far - hz_types.h, HZ_QSLOT) */
-    const unsigned int nitems = hz_queue_span(big_counters, p.qshards_log2);
+    const int sl = SHARDS ? HZ_QSHARDS_LOG2 : 0;
+    const unsigned int nitems = SHARDS ? hz_queue_span(big_counters, sl) : hz_queue_nitems_of(big_counters, 0);
     (void)bigrec_capacity; (void)bigitem_capacity;
     const int lane = threadIdx.x & 63;
     const unsigned int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6));
@@ -326,14 +330,14 @@ void k_big(unsigned long long* __restrict__ fb,
      * their latency hides behind the pixel work */
     hz_bigitem_t item_next = {};
     hz_bigrec_t  rec_next  = {};
-    bool valid_next = wave_global < nitems && hz_queue_item_valid(big_counters, wave_global, p.qshards_log2);
+    bool valid_next = wave_global < nitems && (!SHARDS || hz_queue_item_valid(big_counters, wave_global, sl));
     if(valid_next) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
     for(unsigned int it = wave_global; it < nitems; it += nwaves)
     {
         const hz_bigitem_t item = item_next;
         const hz_bigrec_t  br   = rec_next;
         const bool valid = valid_next;
-        valid_next = it + nwaves < nitems && hz_queue_item_valid(big_counters, it + nwaves, p.qshards_log2);
+        valid_next = it + nwaves < nitems && (!SHARDS || hz_queue_item_valid(big_counters, it + nwaves, sl));
         if(valid_next) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
         if(!valid) continue;
         hz_tri_t tri;

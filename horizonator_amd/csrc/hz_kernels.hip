@@ -275,7 +275,8 @@ void hzk_scatter(dim3 grid, dim3 block, hipStream_t stream, const int16_t* mosai
 
 void hzk_big(dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, const hz_bigrec_t* bigrec, const hz_bigitem_t* bigitem, const unsigned int* big_counters, unsigned int bigrec_capacity, unsigned int bigitem_capacity, hz_params_t p, const unsigned int* tile_state, unsigned int* report)
 {
-    hipLaunchKernelGGL(k_big, grid, block, 0, stream, fb, bigrec, bigitem, big_counters, bigrec_capacity, bigitem_capacity, p, tile_state, report);
+    if(p.qshards_log2 != 0) hipLaunchKernelGGL(k_big<true>, grid, block, 0, stream, fb, bigrec, bigitem, big_counters, bigrec_capacity, bigitem_capacity, p, tile_state, report);
+    else hipLaunchKernelGGL(k_big<false>, grid, block, 0, stream, fb, bigrec, bigitem, big_counters, bigrec_capacity, bigitem_capacity, p, tile_state, report);
 }
 
 void hzk_shade_tex(dim3 grid, dim3 block, hipStream_t stream, const unsigned long long* fb, const int16_t* mosaic, const uint32_t* texels, hz_texparams_t tp, unsigned char* bgr, hz_params_t p)

@@ -62,7 +62,7 @@ def test_what_runs_beside_the_marching_kernel_fits_beside_it():
     left_vgprs = 512 - 4*((march["vgpr_count"] + 7)//8*8)
     left_lds = 160*1024 - 16*march["group_segment_fixed_size"]
     # (k_pack_host: a call that delivers into host memory converts sector s while the marching kernel of sector s+1 runs - round 5)
-    for name in ("k_bigPy", "k_resolve4ILb1E", "k_resolve4ILb0E", "k_pack_hostILb1E", "k_pack_hostILb0E", "k_clipILb0E", "k_clipILb1E"):
+    for name in ("k_bigILb0E", "k_bigILb1E", "k_resolve4ILb1E", "k_resolve4ILb0E", "k_pack_hostILb1E", "k_pack_hostILb0E", "k_clipILb0E", "k_clipILb1E"):
         other = _one(k, name)
         assert other["private_segment_fixed_size"] == 0, name
         # two waves of each beside the marching waves (k_clip: one, when a marching wave has gone)

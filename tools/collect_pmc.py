@@ -21,6 +21,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(indir + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name.startswith("k_big<"): name = "k_big"          # (k_big<SHARDS>: whole panoramas run <false>)
         if name.startswith("k_march<"):          # k_march<COUNTERS, HIZ>: false, false = the plain production instance;
             args = [a.strip() for a in name[name.index("<")+1:name.rindex(">")].split(",")]
             name = "k_march_coarse_depth" if len(args) > 1 and args[1] == "true" else "k_march"    # (second rounds of a series / of zoomed views)

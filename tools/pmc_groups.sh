@@ -20,6 +20,7 @@ for f in glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"):
         # a kernel launched with different grids in one render (k_march: the strips next to the viewer,
         # then all the others) is kept apart by its grid size
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name.startswith("k_big<"): name = "k_big"
         if name.startswith("k_march<"):          # k_march<COUNTERS, HIZ>: the second rounds of a series of renders run the instance with coarse depth
             args = [a.strip() for a in name[name.index("<")+1:name.rindex(">")].split(",")]
             name = "k_march_coarse_depth" if len(args) > 1 and args[1] == "true" else "k_march"
