@@ -472,7 +472,9 @@ mr_zones_t hz_make_zones(const hz_params_t& p, bool near_first)
      * 0.156 -> 0.153 (the narrowest); a quarter's and the whole image's waves are many enough to hide their longest
      * (0.273 -> 0.275; profiles/r4_sector_rules.txt). */
     const int z16 = 6*p.SW < p.W ? 8 : 16;          /* (a whole panorama with 8: the kernel +3 %; with 32: -1 % alone, the same in a series - profiles/r5_ab_march_loop.txt (8)) */
-    const int rows[MR_NZONES] = { far_rows, z16, 4, 2, 4, z16, far_rows };
+    int z4 = 4;
+    { const char* e_ = getenv("HZ_EXP_Z4"); if(e_ && atoi(e_) >= 1 && atoi(e_) <= 8) z4 = atoi(e_); }   /* TEMPORARY: experiment */
+    const int rows[MR_NZONES] = { far_rows, z16, z4, 2, z4, z16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
      * early and the kernel ends on short ones.  With the early depth test
