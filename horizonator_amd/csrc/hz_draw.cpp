@@ -472,8 +472,13 @@ mr_zones_t hz_make_zones(const hz_params_t& p, bool near_first)
      * 0.156 -> 0.153 (the narrowest); a quarter's and the whole image's waves are many enough to hide their longest
      * (0.273 -> 0.275; profiles/r4_sector_rules.txt). */
     const int z16 = 6*p.SW < p.W ? 8 : 16;          /* (a whole panorama with 8: the kernel +3 %; with 32: -1 % alone, the same in a series - profiles/r5_ab_march_loop.txt (8)) */
-    int z4 = 4;
-    { const char* e_ = getenv("HZ_EXP_Z4"); if(e_ && atoi(e_) >= 1 && atoi(e_) <= 8) z4 = atoi(e_); }   /* TEMPORARY: experiment */
+    /* A far clip so close that even the farthest cell is four pixels wide (the API's default 40 km at 16000 columns) leaves a
+     * second round fewer waves than the chip has slots for, and the kernel is as long as the longest of them (tools/wave_timing.py,
+     * HZ_WT_ZFAR=40000: 3.8 K waves, 106 us of work per slot, the longest wave 379 us): two rows to a wave there instead of four -
+     * the kernel 0.141 -> 0.105 ms, a render that is waited for 0.896 -> 0.861, a render of a series 0.589 -> 0.583 (its first
+     * round is what a series at 40 km waits for); the whole panorama at 600 km with 2: 0.829 -> 0.850. */
+    const float cells_to_zfar = sqrtf(p.far_dd)/(p.u.deg_per_cell*111194.9f);
+    const int z4 = cells_to_zfar <= 0.25f*ppr ? 2 : 4;
     const int rows[MR_NZONES] = { far_rows, z16, z4, 2, z4, z16, far_rows };
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
