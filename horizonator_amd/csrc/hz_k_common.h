@@ -119,10 +119,12 @@ __device__ static inline void hz_counters_consume(unsigned int* a, unsigned int*
         unsigned int records, items;
         hz_queue_totals(c, &records, &items);
         c[HZ_CNT_LAST + 0] = records; c[HZ_CNT_LAST + 1] = items; c[HZ_CNT_LAST + 2] = 0u;
+        unsigned int mids = 0;
         #pragma unroll
-        for(int k=3; k<6; k++) { c[HZ_CNT_LAST + k] = c[k]; c[k] = 0u; }
+        for(int s=0; s<HZ_QSHARDS; s++) mids += hz_qshard(c, s)[4];
+        c[HZ_CNT_LAST + 3] = mids; c[HZ_CNT_LAST + 4] = c[4]; c[HZ_CNT_LAST + 5] = 0u; c[4] = 0u;
         #pragma unroll
-        for(int s=0; s<HZ_QSHARDS; s++) { unsigned int* q = hz_qshard(c, s); q[0] = 0u; q[1] = 0u; q[2] = 0u; }
+        for(int s=0; s<HZ_QSHARDS; s++) { unsigned int* q = hz_qshard(c, s); q[0] = 0u; q[1] = 0u; q[2] = 0u; q[4] = 0u; q[5] = 0u; }
     }
 }
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;

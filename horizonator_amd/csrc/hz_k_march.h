@@ -315,16 +315,23 @@ void k_mid(unsigned long long* __restrict__ fb, const hz_rec_t* __restrict__ mid
            const unsigned int* __restrict__ counters, unsigned int midrec_capacity, hz_params_t p)
 {
     const int lane = threadIdx.x;
-    /* records from the first reservation that did not fit were not written
+    /* record slots [0, n): slot g holds a record if the shard it belongs to got that far (hz_types.h, HZ_QSLOT; one shard:
+     * every slot below its count).  Records from a shard's first reservation that did not fit were not written
      * (their triangles were rasterised by the marching wave instead) */
-    const unsigned int n = min(min(counters[3], ~counters[5]), midrec_capacity);
+    const int sl = p.qshards_log2;
+    unsigned int longest = 0;
+    #pragma unroll
+    for(int s=0; s<HZ_QSHARDS; s++) { const unsigned int* c = hz_qshard(counters, s) + 4; longest = max(longest, min(min(c[0], ~c[1]), HZ_QSHARD_ROOM(midrec_capacity, sl))); }
+    const unsigned int n = ((longest + HZ_QBLOCK-1) & ~(unsigned int)(HZ_QBLOCK-1)) << sl;
     for(unsigned int base = blockIdx.x*64u; base < n; base += gridDim.x*64u)
     {
         hz_rec_t r = {};
         uint32_t npix = 0;
-        if(base + lane < n)
+        const unsigned int g = base + lane, block = g >> HZ_QBLOCK_LOG2;
+        const unsigned int* c = hz_qshard(counters, (int)(block & ((1u << sl) - 1u))) + 4;
+        if(g < n && (((block >> sl) << HZ_QBLOCK_LOG2) | (g & (HZ_QBLOCK-1))) < min(min(c[0], ~c[1]), HZ_QSHARD_ROOM(midrec_capacity, sl)))
         {
-            r = midrec[base + lane];
+            r = midrec[g];
             /* queued records carry the pixel count of the box in the inv_bw
              * slot (the reciprocal is cheaper to redo than to store) */
             npix = __float_as_uint(r.inv_bw);
@@ -498,22 +505,25 @@ __device__ static void mr_flush(const mr_lds_t& L, unsigned int head, unsigned i
     if(dbg) { dbg[3] += (unsigned int)__popcll(midmask); }
     if(midmask)
     {
+        /* (through the counter of this wave's shard, like the big triangles: hz_types.h, HZ_QSHARDS) */
+        const int slm = SHARDS ? HZ_QSHARDS_LOG2 : 0, mshard = (int)((blockIdx.x + 5u*blockIdx.y) & ((1u << slm) - 1u));
+        unsigned int* const mc = hz_qshard(q.counters, mshard) + 4;     /* [0] the shard's records, [1] ~(its first invalid one) */
         uint32_t mbase = 0;
-        if(lane == 0) mbase = atomicAdd(&q.counters[3], (uint32_t)__popcll(midmask));
+        if(lane == 0) mbase = atomicAdd(mc, (uint32_t)__popcll(midmask));
         mbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)mbase);
-        if(mbase + (uint32_t)__popcll(midmask) <= q.midrec_capacity)
+        if(mbase + (uint32_t)__popcll(midmask) <= HZ_QSHARD_ROOM(q.midrec_capacity, slm))
         {
             if(is_mid)
             {
                 hz_rec_t m = r;
                 m.inv_bw = __uint_as_float(npix);       /* see k_mid */
-                q.midrec[mbase + (uint32_t)__popcll(midmask & ((1ull << lane) - 1ull))] = m;
+                q.midrec[HZ_QSLOT(mbase + (uint32_t)__popcll(midmask & ((1ull << lane) - 1ull)), mshard, slm)] = m;
                 npix = 0;
             }
         }
-        /* else: queue full, they stay here; the slots from mbase on hold nothing
+        /* else: queue full, they stay here; the shard's slots from mbase on hold nothing
          * of this draw and k_mid must not read them */
-        else if(lane == 0) atomicMax(&q.counters[5], ~mbase);
+        else if(lane == 0) atomicMax(mc + 1, ~mbase);
     }
 
     if(dbg && HZ_DEBUG(p) == 4)

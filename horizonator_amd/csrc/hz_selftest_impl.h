@@ -427,15 +427,16 @@ extern "C" int hz_hip_debug_bigqueue(hz_dev_t* d, int set, unsigned int* counter
     if(d->fb_consumed) { for(int c=0; c<6; c++) counters[c] = all[HZ_CNT_LAST + c]; for(int s=0; s<HZ_QSHARDS; s++) per_shard[s] = 0; }
     else
     {
-        counters[0] = counters[1] = 0; counters[2] = 0;
+        counters[0] = counters[1] = 0; counters[2] = 0; counters[3] = 0; counters[5] = 0;
         for(int s=0; s<HZ_QSHARDS; s++)
         {
             const unsigned int* c = all.data() + HZ_QSHARD0 + s*HZ_QSHARD_STRIDE;
             per_shard[s] = c[0] < HZ_QSHARD_ROOM(d->bigrec_capacity, sl) ? c[0] : HZ_QSHARD_ROOM(d->bigrec_capacity, sl);
             counters[0] += c[0]; counters[1] += c[1]; if(c[2]) counters[2] = c[2];
+            counters[3] += c[4]; if(c[5]) counters[5] = c[5];
             if(per_shard[s] > longest) longest = per_shard[s];
         }
-        for(int c=3; c<6; c++) counters[c] = all[c];
+        counters[4] = all[4];
     }
     counters[2] = ~counters[2]; counters[5] = ~counters[5];     /* as documented: the first invalid index (of one of the shards) */
     if(longest == 0 || recs == NULL || max_rec <= 0) return 0;

@@ -93,7 +93,7 @@ struct mr_queue_t
     hz_bigitem_t* bigitem;          /* ... and their work items                                  */
     hz_rec_t*     midrec;           /* set-up triangles for k_mid                                */
     uint32_t*     clip;             /* ids of triangles that have to go through the clipper      */
-    unsigned int* counters;         /* [3] mid records [4] clip ids [5] ~(first invalid mid record); the big triangles' counters:
+    unsigned int* counters;         /* [4] clip ids; the big and the medium triangles' counters:
                                      * HZ_QSHARDS of them from [HZ_QSHARD0] on (below); [0] [1] [2]: their sums as the last draw left them */
     unsigned int  bigrec_capacity, bigitem_capacity, midrec_capacity, clip_capacity;
 };
@@ -117,7 +117,7 @@ struct mr_queue_t
 #define HZ_QSHARD_ROOM(capacity, sl) ((((capacity) >> ((sl) + HZ_QBLOCK_LOG2))) << HZ_QBLOCK_LOG2)      /* records or items a shard may hold of an array of `capacity` */
 #define HZ_QSLOT(l, s, sl) (((((((uint32_t)(l)) >> HZ_QBLOCK_LOG2) << (sl)) + (uint32_t)(s)) << HZ_QBLOCK_LOG2) | (((uint32_t)(l)) & (HZ_QBLOCK-1)))
 #define HZ_QSHARD_STRIDE 32             /* words between two shards' counters: 128 bytes */
-#define HZ_QSHARD0       16             /* shard s: counters[HZ_QSHARD0 + s*HZ_QSHARD_STRIDE + {0 records, 1 items (one 64-bit word), 2 ~(first invalid item)}] */
+#define HZ_QSHARD0       16             /* shard s: counters[HZ_QSHARD0 + s*HZ_QSHARD_STRIDE + {0 records, 1 items (one 64-bit word), 2 ~(first invalid item); 4 records for k_mid, 5 ~(first invalid one)}] */
 #define HZ_NCOUNTERS (HZ_QSHARD0 + HZ_QSHARDS*HZ_QSHARD_STRIDE)
 #define HZ_CNT_LAST  8                  /* [8..14): the counters as the last draw left them (diagnostics; the big triangles': sums over the shards) */
 #ifndef HZ_NFB
