@@ -111,20 +111,23 @@ __device__ static inline bool hz_queue_reserve(const mr_queue_t& q, int shard, i
 }
 __device__ static inline void hz_counters_consume(unsigned int* a, unsigned int* b)
 {
-    unsigned int* const both[2] = { a, b };
-    #pragma unroll
+    /* (one thread of a conversion runs this: loops that stay loops - unrolled they cost k_resolve4 ten registers, and with them
+     * its second wave beside the marching kernel's) */
+    #pragma unroll 1
     for(int w=0; w<2; w++)
     {
-        unsigned int* c = both[w];
-        unsigned int records, items;
-        hz_queue_totals(c, &records, &items);
+        unsigned int* c = w ? b : a;
+        unsigned int records = 0, items = 0, mids = 0;
+        #pragma unroll 1
+        for(int s=0; s<HZ_QSHARDS; s++)
+        {
+            unsigned int* q = hz_qshard(c, s);
+            records += q[0]; items += q[1]; mids += q[4];
+            q[0] = 0u; q[1] = 0u; q[2] = 0u; q[4] = 0u; q[5] = 0u;
+        }
         c[HZ_CNT_LAST + 0] = records; c[HZ_CNT_LAST + 1] = items; c[HZ_CNT_LAST + 2] = 0u;
-        unsigned int mids = 0;
-        #pragma unroll
-        for(int s=0; s<HZ_QSHARDS; s++) mids += hz_qshard(c, s)[4];
-        c[HZ_CNT_LAST + 3] = mids; c[HZ_CNT_LAST + 4] = c[4]; c[HZ_CNT_LAST + 5] = 0u; c[4] = 0u;
-        #pragma unroll
-        for(int s=0; s<HZ_QSHARDS; s++) { unsigned int* q = hz_qshard(c, s); q[0] = 0u; q[1] = 0u; q[2] = 0u; q[4] = 0u; q[5] = 0u; }
+        c[HZ_CNT_LAST + 3] = mids; c[HZ_CNT_LAST + 4] = c[4]; c[HZ_CNT_LAST + 5] = 0u;
+        c[4] = 0u;
     }
 }
 /* k_march: boxes up to p.inline_max pixels are rasterised by the marching wave;
