@@ -1072,7 +1072,6 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
              * waves like a whole image does; k_mid was the remedy for one-round sector draws.
              * Gathering rank, 2 / 4 / 8 sectors: 1.19 -> 1.03, 0.82 -> 0.75, 0.69 -> 0.64 ms) */
             p.inline_max = HZ_INLINE_MAX_PIX;
-            { const char* e_ = getenv("HZ_EXP_SECTOR_INLINE"); if(e_ && atoi(e_) > 0 && p.SW != p.W) p.inline_max = (unsigned int)atoi(e_); }   /* TEMPORARY: experiment */
             /* round 1, on its own stream */
             const mr_queue_t qn = queue_set(d, HZ_NFB + next);
             HZ_CHECK(hipStreamWaitEvent(d->nstream, d->ev_free[next], 0));
@@ -1083,8 +1082,11 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                 const float ppr = p.halfW * p.u.az_ndc_per_rad;
                 const float reach = 0.5f*(float)(p.near_j1 - p.near_j0);
                 zoomed_view = reach > 0.f && ppr/reach >= HZ_HIZ_MIN_PX;
-                p.qshards_log2 = zoomed_view ? HZ_QSHARDS_LOG2 : 0;
-                { const char* e_ = getenv("HZ_EXP_SHARDS"); if(e_) p.qshards_log2 = atoi(e_) ? HZ_QSHARDS_LOG2 : 0; }   /* TEMPORARY: experiment */
+                /* ... and so do the waves of a draw whose far clip is close (the API's default 40 km: every wave is next to the viewer):
+                 * a render of a series at 40 km 0.593 -> 0.571 ms.  Sectors of a whole panorama: no difference (0.166 ms a strip of an
+                 * eighth either way), whole panoramas: 1 % slower - one counter (profiles/r5_ab_queue_shards.txt) */
+                const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
+                p.qshards_log2 = (zoomed_view || cells_to_zfar <= 0.25f*ppr) ? HZ_QSHARDS_LOG2 : 0;
             }
             hz_params_t p1 = p;
             p1.pass = 1; p1.early_z = 0;
