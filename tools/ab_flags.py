@@ -11,7 +11,19 @@ import experiments as ex
 import march_bounds as mb
 
 
+def host_call(root):
+    """tools/host_inclusive.py cfg3 in that tree: ms per call into kept buffers"""
+    import re
+    import subprocess
+    r = subprocess.run([sys.executable, "tools/host_inclusive.py", "cfg3"], cwd=root, capture_output=True, text=True)
+    m = re.search(r"kept buffers ([0-9.]+) ms/call", r.stdout + r.stderr)
+    return float(m.group(1)) if m else None
+
+
 def main():
+    host = "--host" in sys.argv
+    if host:
+        sys.argv.remove("--host")
     trees = [("as shipped", ex.variant("shipped", "")[0])]
     for k, flags in enumerate(sys.argv[1:]):
         root, err = ex.variant(f"flags{k}", flags)
@@ -19,7 +31,7 @@ def main():
         trees.append((flags, root))
     for k in range(3):
         for name, root in trees:
-            print(f"{name:40s}", mb.run(root, {}), flush=True)
+            print(f"{name:40s}", mb.run(root, {}), *(["host call", host_call(root)] if host else []), flush=True)
 
 
 if __name__ == "__main__":
