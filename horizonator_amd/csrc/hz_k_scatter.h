@@ -330,14 +330,24 @@ void k_big(unsigned long long* __restrict__ fb,
      * their latency hides behind the pixel work */
     hz_bigitem_t item_next = {};
     hz_bigrec_t  rec_next  = {};
-    bool valid_next = wave_global < nitems && (!SHARDS || hz_queue_item_valid(big_counters, wave_global, sl));
+    /* (how far each shard got: lane s holds shard s's count, an item's validity is one v_readlane - no memory access in the loop) */
+    unsigned int shard_items = 0;
+    if(SHARDS) shard_items = hz_queue_nitems_of(big_counters, lane & (HZ_QSHARDS-1));
+    auto slot_in_use = [&](unsigned int g) -> bool
+    {
+        if(!SHARDS) return true;
+        const unsigned int block = g >> HZ_QBLOCK_LOG2;
+        const unsigned int l = ((block >> sl) << HZ_QBLOCK_LOG2) | (g & (HZ_QBLOCK-1));
+        return l < (unsigned int)__builtin_amdgcn_readlane((int)shard_items, (int)(block & ((1u << sl) - 1u)));
+    };
+    bool valid_next = wave_global < nitems && slot_in_use(wave_global);
     if(valid_next) { item_next = bigitem[wave_global]; rec_next = bigrec[item_next.rec]; }
     for(unsigned int it = wave_global; it < nitems; it += nwaves)
     {
         const hz_bigitem_t item = item_next;
         const hz_bigrec_t  br   = rec_next;
         const bool valid = valid_next;
-        valid_next = it + nwaves < nitems && (!SHARDS || hz_queue_item_valid(big_counters, it + nwaves, sl));
+        valid_next = it + nwaves < nitems && slot_in_use(it + nwaves);
         if(valid_next) { item_next = bigitem[it + nwaves]; rec_next = bigrec[item_next.rec]; }
         if(!valid) continue;
         hz_tri_t tri;
