@@ -1090,9 +1090,6 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
             }
             hz_params_t p1 = p;
             p1.pass = 1; p1.early_z = 0;
-#ifdef HZ_QSHARDS_SECOND_ROUNDS
-            p.qshards_log2 = HZ_QSHARDS_LOG2;           /* (an experiment's build: the second round of every two-round draw) */
-#endif
             if(fresh_lists)
             {
                 hz_list_items(p1, zn, a0, a1, *d->list_scratch);
