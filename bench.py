@@ -545,6 +545,24 @@ def main():
 
     last = keep_last(args.zfar)
 
+    # What ONE panorama costs (N = 1): the series above is K panoramas queued back to back, whose rounds and conversions
+    # overlap; a caller that waits for each render sees this instead.  Outputs left in HBM, like `value`.
+    single_latency = None
+    if world == 1 and not args.exchange_anyway:
+        ts1 = []
+        for k in range(8):
+            drain()
+            fence()
+            t1 = time.perf_counter()
+            step()
+            drain()
+            h.sync()
+            fence()
+            ts1.append(time.perf_counter() - t1)
+        single_latency = {"value": float(np.median(ts1[2:])) * 1e3, "samples_ms": [round(x * 1e3, 4) for x in ts1],
+                          "what": "one render waited for, nothing queued before or behind it, outputs left in HBM (cold draw: vertex "
+                                  "cache off); median of 6 after 2 warm-ups"}
+
     same_viewpoint = None
     if world == 1 and not args.no_extra and not args.exchange_anyway and args.raster != 1:
         h.set_options(vertex_cache=1)
@@ -634,7 +652,7 @@ def main():
     # what actually bounds the dominant kernel: the SIMDs' vector issue slots.
     # Recorded counters of the same workload (profiles/), set against the duration measured now.
     valu = None
-    mix = next((m for m in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(m)), "")
+    mix = next((m for m in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(m)), "")
     if args.config == "cfg3" and args.zfar == 600000.0 and world == 1 and args.raster in (0, 2) and os.path.exists(mix):
         try:
             rec = json.load(open(mix))
@@ -647,6 +665,19 @@ def main():
                     "issue_busy_ms": busy_ms, "frac_of_kernel_ms": busy_ms / raster_ms,
                     "source": "counters RECORDED in profiles/" + os.path.basename(mix) + " (a rocprofv3 --pmc run of this workload), set against the "
                               "kernel duration measured live in this run; issue rates per instruction kind: profiles/valu_issue.json"}
+            # ... and the roof that binds the RENDER, not one kernel: the vector-issue cycles of every kernel of one panorama of a
+            # series (recorded, the same file) against the period measured now - all 1024 SIMDs busy for that share of the time
+            per_render = {"k_march_coarse_depth grid": 1, "k_march grid 2": 1, "k_big grid": 2, "k_clip": 2, "k_hiz grid": 1, "k_resolve4": 1}
+            quad = 0.0
+            for key, v in rec.items():
+                for prefix, launches in per_render.items():
+                    if key.startswith(prefix) and isinstance(v, dict) and "SQ_ACTIVE_INST_VALU" in v:
+                        quad += launches * v["SQ_ACTIVE_INST_VALU"]
+            valu["whole_render"] = {"active_quad_cycles": quad, "issue_busy_ms": quad * 4.0 / (1024 * 2.4e9) * 1e3,
+                                    "frac_of_ms_per_step": quad * 4.0 / (1024 * 2.4e9) * 1e3 / (dt / args.steps * 1e3),
+                                    "what": "sum over the kernels of one panorama of a series (second-round k_march, the first round's, "
+                                            "2 x k_big, 2 x k_clip, k_hiz, k_resolve4) of the recorded SQ_ACTIVE_INST_VALU, as time on "
+                                            "1024 SIMDs at 2.4 GHz, over ms_per_step: the share of the chip's vector issue the render uses"}
         except Exception:
             valu = None
 
@@ -684,6 +715,18 @@ def main():
             ts.append(time.perf_counter() - t0)
         t = float(np.median(ts[2:]))
         same = bool(np.array_equal(himg, want_img) and np.array_equal(hrng, want_rng))
+        # a viewer that MOVES between calls, with the library's defaults (vertex cache on): every call is a first draw from
+        # its viewpoint - no call may pay for a cache fill (the sectors of one call are one draw)
+        h.set_options(vertex_cache=1)
+        ts_move = []
+        for k in range(8):
+            h.set_view(-180.0, 180.0, lat=LAT + 1e-4 * (k + 1), lon=LON, znear=ZNEAR, zfar=args.zfar)
+            t0 = time.perf_counter()
+            h.render_into(himg, hrng)
+            ts_move.append(time.perf_counter() - t0)
+        moved_fill = bool(h.last_plan().get("vertex_cache"))
+        h.set_options(vertex_cache=0)
+        h.set_view(-180.0, 180.0, lat=LAT, lon=LON, znear=ZNEAR, zfar=args.zfar)
         ts_fresh = []
         for k in range(8):          # the reference's Python wrapper: new arrays (untouched pages) on every call
             t0 = time.perf_counter()
@@ -717,6 +760,12 @@ def main():
                              "pixels only travel, 4 B each (the sky, 62 % of this image, is constants the host threads fill in while the "
                              "device draws; ranges are made of the depths on the host)",
                      "ms_all_calls": [round(x * 1e3, 3) for x in ts],
+                     "first_call_ms": ts[0] * 1e3,
+                     "first_call": "the first horizonator_render_offscreen() of this context into host memory (buffers from np.zeros: "
+                                   "untouched pages; the pool, the transfer stream and the pinned landing were made by horizonator_init)",
+                     "moving_viewer_ms": float(np.median(ts_move[2:])) * 1e3, "moving_viewer_used_vertex_cache": moved_fill,
+                     "moving_viewer": "the same call with the library's default options from a viewpoint that moves by 1e-4 degrees of "
+                                      "latitude between calls (median of 6 after 2)",
                      "ms_with_fresh_arrays_per_call": t_fresh * 1e3,
                      "ms_per_panorama_two_in_flight": t_series * 1e3,
                      "two_in_flight": "horizonator_amd_render_begin / _end with two sets of buffers: begin k+1, then end k - the device draws one "
@@ -818,6 +867,8 @@ def main():
             "cpu_baseline": cpu,
             "reference_llvmpipe_recorded": ref_rec,
         }
+        if single_latency is not None:
+            line["single_panorama_latency_ms"] = single_latency
         if same_viewpoint is not None:
             line["same_viewpoint"] = same_viewpoint
         if host_incl is not None:

@@ -204,6 +204,7 @@ def _open(path, selftest):
     sig("hz_hip_render_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_host_begin", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_host_end", i, vp)
+    sig("hz_hip_host_prepare", i, vp, i, i, i, i)
     sig("hz_hip_read_depth", i, vp, i, i, P(C.c_uint32))
     sig("hz_hip_link_cells", i, vp, P(View), vp, vp, vp, vp, d, d, d, i, i, i, i, vp, vp)
     sig("hz_hip_poi_visibility", i, vp, P(View), vp, i, vp, i, vp, vp, vp)
@@ -251,7 +252,7 @@ DECLARED_SYMBOLS = [
     # include/hz_hip.h
     "hz_hip_device_count", "hz_hip_create", "hz_hip_destroy", "hz_hip_upload_mosaic",
     "hz_hip_download_mosaic", "hz_hip_ingest_tiles", "hz_hip_set_sector", "hz_hip_set_raster",
-    "hz_hip_set_profiling", "hz_hip_get_options", "hz_hip_set_options", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host", "hz_hip_render_to_host", "hz_hip_host_begin", "hz_hip_host_end",
+    "hz_hip_set_profiling", "hz_hip_get_options", "hz_hip_set_options", "hz_hip_set_texture", "hz_hip_pack", "hz_hip_resolve_packed", "hz_hip_pack_sparse", "hz_hip_resolve_sparse", "hz_hip_resolve_sparse_strips", "hz_hip_draw", "hz_hip_resolve", "hz_hip_resolve_to_host", "hz_hip_render_to_host", "hz_hip_host_begin", "hz_hip_host_end", "hz_hip_host_prepare",
     "hz_hip_read_depth", "hz_hip_link_cells", "hz_hip_poi_visibility", "hz_hip_sync", "hz_hip_last_times", "hz_hip_stream", "hz_hip_wait_outputs", "hz_hip_wait_for", "hz_hip_last_plan", "hz_hip_last_queue_counts", "hz_hip_last_error",
 ]
 # include/hz_selftest.h: what libhorizonator_selftest.so exports on top of those (and libhorizonator.so must not)

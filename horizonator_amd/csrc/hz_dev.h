@@ -156,7 +156,8 @@ struct hz_dev
         int           seen_reach; unsigned int seen_records, seen_items;   /* the last observation (hz_hip_last_queue_counts) */
     } adapt;
     /* the vertex cache (hz_draw.cpp: vertex_cache): the view-independent half of every vertex's transform for the viewpoint `key` */
-    struct { hz_polar_t* d_polar; hz_xform_t key; int state /* 0 nothing, 1 the viewpoint has been drawn once, 2 filled */; int unavailable; hipEvent_t ev_filled; } vc;
+    struct { hz_polar_t* d_polar; hz_xform_t key; int state /* 0 nothing, 1 the viewpoint has been drawn once, 2 filled */; int unavailable; hipEvent_t ev_filled;
+             int same_draw;     /* this draw is another sector of the call that made the draw before (hz_hostpath.cpp): not another draw from the viewpoint */ } vc;
     int                 last_qshards_log2;      /* hz_params_t::qshards_log2 of the last draw (diagnostics: hz_hip_debug_bigqueue) */
     int                 last_plan[5];           /* the last draw (hz_hip_last_plan): rounds, coarse depth kept, the first round's reach in cells, launched from a work list */
     int                 stream_reads_fb;       /* a reader of the framebuffer (pick, annotator passes) was queued on `stream` since the last draw */

@@ -11,6 +11,8 @@
 #include "hz_dev.h"
 #include "hz_fast.h"
 
+#include <time.h>
+
 thread_local char hz_g_last_error[512];
 extern "C" const char* hz_hip_last_error(void) { return g_last_error; }
 
@@ -173,9 +175,25 @@ static int tile_bins(hz_dev_t* d, int set)
     return 0;
 }
 
+/* HZ_INIT_TIMES=1: what a context's set-up is made of, on stderr (tools/init_times.py) */
+struct hz_stopwatch
+{
+    bool on; timespec t0;
+    explicit hz_stopwatch(const char* var) : on(getenv(var) && atoi(getenv(var)) != 0) { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    void lap(const char* what)
+    {
+        if(!on) return;
+        timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "hz_hip init: %-34s %8.2f ms\n", what, 1e3*(double)(t1.tv_sec - t0.tv_sec) + 1e-6*(double)(t1.tv_nsec - t0.tv_nsec));
+        t0 = t1;
+    }
+};
+
 static int create_impl(hz_dev_t* d)
 {
+    hz_stopwatch sw("HZ_INIT_TIMES");
     HZ_ON_DEVICE(d);
+    sw.lap("first HIP call (runtime, device)");
     d->env = hz_options_from_env();
 #ifdef HZ_EXPERIMENTS
     d->exp = experiments_from_env();
@@ -190,6 +208,7 @@ static int create_impl(hz_dev_t* d)
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_readers, hipEventDisableTiming));
     HZ_CHECK(hipEventCreateWithFlags(&d->ev_tanel,   hipEventDisableTiming));
     HZ_CHECK(hipMalloc(&d->d_mosaic, (size_t)d->N*d->N*sizeof(int16_t)));
+    sw.lap("streams, events, mosaic");
     d->seg_stride = (d->W + HZ_SEG-1) / HZ_SEG;
     for(int i=0; i<HZ_NFB; i++)
     {
@@ -202,6 +221,7 @@ static int create_impl(hz_dev_t* d)
         d->fb_used[i] = 0;
     }
     d->fbi = HZ_NFB-1; d->d_fb = d->d_fbs[HZ_NFB-1];
+    sw.lap("framebuffers");
     /* queues of triangles too large for the marching wave (k_scatter: for the in-block
      * pass).  The benchmark panorama (16000x4000) produces ~0.3 M records and ~0.4 M work
      * items, a 45 degree view of the same size 1.5 M records (every triangle covers 64
@@ -249,6 +269,7 @@ static int create_impl(hz_dev_t* d)
          * by default they are made when a zoomed view first asks for them: tile_bins()) */
         if(d->env.tiles > 0 && i >= HZ_NFB && tile_bins(d, i) != 0) return -1;
     }
+    sw.lap("queue sets");
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     HZ_CHECK(hipMalloc(&d->d_tanel, (size_t)d->H*sizeof(float)));
     d->h_tanel = (float*)malloc((size_t)d->H*sizeof(float));
@@ -260,6 +281,7 @@ static int create_impl(hz_dev_t* d)
         /* (release to system scope: k_big's report lies in pinned HOST memory, and the host reads it when it finds this event complete) */
         HZ_CHECK(hipEventCreateWithFlags(&d->adapt.ev[k], hipEventDisableTiming | hipEventReleaseToSystem));
     }
+    sw.lap("the rest");
     return 0;
 }
 
@@ -332,6 +354,8 @@ extern "C" int hz_hip_ingest_tiles(hz_dev_t* d, const unsigned char* const* tile
         hzk_ingest(grid, dim3(256), d->stream, (const unsigned char* const*)d_ptrs, d->d_mosaic, d->N, ntx, nty, cpd, oc_x, oc_y);
         if(hipGetLastError() != hipSuccess) break;
         if(hipStreamSynchronize(d->stream) != hipSuccess) break;
+        d->adapt.have_view = 0;         /* (as hz_hip_upload_mosaic: what was observed, and cached, was the old terrain's) */
+        d->vc.state = 0;
         rc = 0;
     } while(0);
     (void)hipStreamSynchronize(d->stream);
@@ -953,6 +977,9 @@ static int vertex_cache(hz_dev_t* d, hz_params_t& p)
         d->vc.key = p.u; d->vc.state = 1;           /* seen once: this draw computes everything, as always */
         return 0;
     }
+    /* (a call that delivers into host memory draws its panorama in sectors, hz_hostpath.cpp: the later sectors are the SAME
+     * draw from this viewpoint, not the second - a viewer that moves between such calls never pays for a fill) */
+    if(d->vc.state == 1 && d->vc.same_draw) return 0;
     if(d->vc.state == 1)
     {
         /* the second draw from here: fill.  On the first round's stream, behind everything that may still read the cache of

@@ -14,6 +14,8 @@
 #include <string.h>
 #include <unistd.h>
 #include <pthread.h>
+#include <stdio.h>
+#include <time.h>
 
 #include "horizonator.h"
 #include "horizonator_amd.h"
@@ -45,6 +47,17 @@ typedef struct
     bool         tanel_valid;   /* ... computed for these azimuth extents: */
     float        tanel_az0, tanel_az1;
 } hz_state_t;
+
+/* HZ_INIT_TIMES=1: what horizonator_init() is made of, on stderr (the device side's share: hz_draw.cpp) */
+static double init_lap(double* since, const char* what)
+{
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    const double now = 1e3*(double)t.tv_sec + 1e-6*(double)t.tv_nsec;
+    const char* e = getenv("HZ_INIT_TIMES");
+    if(what != NULL && e != NULL && atoi(e) != 0) fprintf(stderr, "horizonator_init: %-29s %8.2f ms\n", what, now - *since);
+    *since = now;
+    return now;
+}
 
 #define HZ_MAX_CONTEXTS 64
 static hz_state_t g_state[HZ_MAX_CONTEXTS];
@@ -259,7 +272,9 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
         MSG("No HIP device is visible; this library has no CPU or OpenGL fallback");
         goto done;
     }
+    double lap; init_lap(&lap, NULL);
     s->dev = hz_hip_create(device, N, offscreen_width, offscreen_height);
+    init_lap(&lap, "device state");
     if(s->dev == NULL)
     {
         MSG("Couldn't create the device state: %s", hz_hip_last_error());
@@ -294,6 +309,7 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
         mosaic = malloc((size_t)N*N*sizeof(int16_t));
         if(mosaic == NULL) { MSG("out of memory for a %dx%d mosaic", N, N); goto done; }
         hz_tileset_build_mosaic(&s->tiles, mosaic);
+        init_lap(&lap, "mosaic built on the host");
         if(0 != hz_hip_upload_mosaic(s->dev, mosaic))
         {
             MSG("Mosaic upload failed: %s", hz_hip_last_error());
@@ -301,8 +317,15 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
         }
     }
 
+    init_lap(&lap, "DEM in HBM");
     s->tanel = malloc((size_t)offscreen_height*sizeof(float));
     if(s->tanel == NULL) goto done;
+
+    /* what horizonator_render_offscreen() needs beyond the draw - host threads, the transfer stream, pinned memory for a
+     * panorama's terrain pixels - is made here, not inside the first call: the reference's CLI makes exactly one
+     * (reference standalone.c:433-460).  A failure is not fatal: the call then makes them itself, or takes the dense path. */
+    (void)hz_hip_host_prepare(s->dev, 1, 1, 0, 0);
+    init_lap(&lap, "host path prepared");
 
     /* reference horizonator-lib.c:203; the count overflows int for 11x11
      * SRTM1 mosaics, which the reference cannot load anyway: saturate */
@@ -346,6 +369,7 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
     ctx->offscreen.height = offscreen_height;
 
     if(!horizonator_pan_zoom(ctx, -45.f, 45.f)) goto done;                  /* reference :670 */
+    init_lap(&lap, "texture, first view");
     result = true;
 
  done:
@@ -411,7 +435,10 @@ bool horizonator_init(horizonator_context_t* ctx,
     memset(s, 0, sizeof(*s));
 
     bool result = false;
-    if(!load_tiles(s, ctx, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, dir_dems, SRTM1))
+    double lap; init_lap(&lap, NULL);
+    const bool loaded = load_tiles(s, ctx, viewer_lat, viewer_lon, render_radius_cells, render_radius_m, dir_dems, SRTM1);
+    init_lap(&lap, "tiles mapped");
+    if(!loaded)
         MSG("Couldn't init DEMs. Giving up");
     else
         result = init_device_side(ctx, s, slot, viewer_lat, viewer_lon, viewer_z, offscreen_width, offscreen_height,

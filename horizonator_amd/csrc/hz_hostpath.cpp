@@ -3,270 +3,41 @@
  * Plain C++ over the HIP runtime API (compiled by g++); kernels through hz_launch.h.
  *
  * What lies between the framebuffer and the caller's buffers is PCIe (a 16000 x 4000 panorama is 448 MB of results;
- * the link moves ~50 GB/s in copies of 4 MB, ~56 in copies of 16), so a call is organised around the link:
+ * the link moves ~55 GB/s), so a call is organised around the link:
  *
  *   - Only the terrain pixels travel, 4 bytes each (k_pack_host: blobs of z24<<8 | red8 with a mask, hz_scatter.h);
- *     a pool of host threads makes BGR bytes, depth and range of each blob as it arrives (hz_scatter.c: the readback
- *     conversion, reference :1013-1025, in the host's vector unit - bit for bit what k_resolve4 computes).  103 MB
- *     instead of 448.
- *   - The panorama is drawn and shipped in azimuth SECTORS (hz_options_t::host_sectors; whole images of 12 Mpix and
- *     more: 2, from 32 Mpix: 4): sector s+1 is drawn while the blobs of sector s cross the link - the draw is hidden
- *     behind the transfer except for the first sector's.  A sector's pixels are bit-identical to the same pixels of
- *     a whole draw (hz_hip_set_sector), so the bytes the caller gets do not depend on the number of sectors.
- *   - The stream of a sector travels through a ring of HZ_STAGE_SLOTS pinned chunks of HZ_STAGE_BYTES; one copy moves
- *     up to four consecutive chunks (a copy costs the engine ~22 us beyond its bytes), a sector's first copy one, the
- *     panorama's last ones too (they are scattered with nothing left to hide behind).  Two copy streams in turn, of
- *     the HIGHEST priority: HIP deals streams onto a few hardware queues, and on a queue shared with a draw stream the
- *     first sector's copies waited behind the marching kernels of the sectors queued after it.
- *   - 62 % of the benchmark image is sky - BGR (255,0,0), range -1 (reference horizonator-lib.c:185, :1016).  The pool
- *     writes it with streaming stores, but only the rows [0, y_pre) beforehand: as much as there is time for until
- *     the first blobs arrive (one sector: everything, behind the draw; four: the upper 30 %).  Below y_pre a blob
- *     writes the sky pixels of its own tile (hz_blob_scatter_mode), and the tiles without a blob are filled when
- *     their sector has been walked (fill_absent).  Filling and scattering side by side cost the host 3.8-4.3 ms where
- *     one after the other they cost 2.4 (profiles/r5_host_microbenchmarks.txt): every byte is written once.
+ *     a pool of host threads (hz_pool.h) makes BGR bytes, depth and range of each blob as it arrives (hz_scatter.c:
+ *     the readback conversion, reference :1013-1025, in the host's vector unit - bit for bit what k_resolve4
+ *     computes).  103 MB instead of 448.
+ *   - Each panorama in flight has a pinned LANDING area of its own, and the copy engine moves a sector's stream there
+ *     in a few copies (4, 8, then 16 MB) as soon as the host knows the stream's length - which the device tells it
+ *     (k_tell, hz_k_tell.h: a few words into pinned memory behind each k_pack_host, polled) instead of being asked.
+ *     Round 5 moved the streams through one ring of chunks shared by everything: a copy could only be issued when its
+ *     slot had been scattered, and a panorama's copies only from its own hz_hip_host_end().  Now whoever waits - for a
+ *     sector, for a chunk - issues whatever copy has become possible meanwhile, the NEXT panorama's included: the copy
+ *     engine goes from one panorama's last blob to the next one's first without the host in between.
+ *     (Why the copy engine and not a kernel: a kernel storing the stream into host memory reaches the link's 55 GB/s
+ *     too, but the kernels beside it then take 1.5 to 100 times their time; beside the copy engine, 1.00 -
+ *     tools/pcie_beside.hip, profiles/r6_pcie_beside.txt.)
+ *   - A single call draws and ships its panorama in azimuth SECTORS (hz_options_t::host_sectors; whole images of
+ *     12 Mpix and more: 2, from 32 Mpix: 4): sector s+1 is drawn while the blobs of sector s cross the link - the draw
+ *     is hidden behind the transfer except for the first sector's.  A sector's pixels are bit-identical to the same
+ *     pixels of a whole draw (hz_hip_set_sector), so the bytes the caller gets do not depend on the number.
  *   - hz_hip_host_begin() / hz_hip_host_end() split a call in two: a caller that begins panorama k+1 before it ends
- *     panorama k (two sets of buffers) has the device draw k+1 while k crosses the link, and pays the link only.
+ *     panorama k (two sets of buffers) has the device draw k+1 while k crosses the link, and k+1's blobs follow k's
+ *     without a gap.
+ *   - 62 % of the benchmark image is sky - BGR (255,0,0), range -1 (reference horizonator-lib.c:185, :1016).  The pool
+ *     writes it with streaming stores: the rows [0, y_pre) beforehand (as much as there is time for until the first
+ *     blobs arrive); below y_pre a blob writes the sky pixels of its own tile (hz_blob_scatter_mode: every byte
+ *     once), and the tiles without a blob - k_pack_host leaves a bitmap of the tiles it sent, k_tell hands it over -
+ *     are filled as soon as their sector is known, while the host waits for chunks.
  *
- * Round 4 (one sector, 5 bytes per pixel, draw and transfer strictly in series): 4.3 ms per call; this version:
- * 3.2-3.5 ms, its timeline in profiles/r5_host_inclusive.txt (HZ_HOST_TIMES=1 prints one per call).  Tried and dropped:
- * k_pack_host storing straight into pinned host memory (38 GB/s from its compacted stores, and the host reads that
- * memory slowly: 3.9-6.0 ms).
- *
- * The dense path at the end of the file (every pixel travels: 448 MB) serves textured colour, images taller than
- * 65535 rows and hz_options_t::host_dense. */
+ * The dense path at the end of the file (every pixel travels: 448 MB, through a ring of pinned chunks) serves textured colour, images taller than 65535 rows and hz_options_t::host_dense. */
 #include "hz_dev.h"
+#include "hz_pool.h"
 
-#include <sched.h>
-#include <sys/mman.h>
-
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
-#include <thread>
-
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23
-#endif
-
-/* ------------------------------------------------------------------------ */
-/* the pool of host threads                                                  */
-
-struct hz_copy_pool
-{
-    struct batch_t { int pending; };
-    /* what the blobs of a panorama are scattered into (hz_scatter.c), and how far the sky is: the buffers are filled
-     * sector by sector, band of rows by band of rows; band_left[sector*nbands + b] = fill tasks of that piece not yet
-     * finished */
-    struct scatter_t
-    {
-        hz_scatter_dst_t dst;
-        int y_pre;                      /* rows [0, y_pre) get the sky beforehand (band by band); a blob below writes the sky pixels of its tile itself */
-        int band_rows, nbands;
-        std::atomic<int>* band_left;
-        std::atomic<int> bad;
-    };
-    enum { COPY = 0, MAP, FILL, SCATTER };
-    struct task_t
-    {
-        int kind;
-        unsigned char* dst; const unsigned char* src; size_t n;     /* COPY: dst[0..n) = src[0..n); MAP: the pages of dst[0..n) */
-        /* FILL: `rows` runs of n bytes, the first at byte lo of dst, `pitch` bytes apart; which constants (HZ_SKY_*); the piece's counter */
-        size_t lo, pitch; int rows, sky; std::atomic<int>* left;
-        scatter_t* sc; int sector; const uint32_t* chunk; const size_t* offs; size_t nblobs;     /* SCATTER: blobs chunk + offs[0..nblobs) of `sector` */
-        batch_t* batch;
-    };
-    std::mutex m, busy;                 /* busy: one call's transfer at a time (contexts on several threads share the pool and nothing else) */
-    std::condition_variable cv_work, cv_done;
-    std::vector<std::thread> threads;
-    /* two queues: blobs (and copies) before sky - a caller with two panoramas in flight has the sky of the second queued
-     * while the blobs of the first arrive, and those are what its hz_hip_host_end() waits for */
-    std::deque<task_t> q_hi, q_lo;
-    bool stop = false;
-    std::atomic<bool> populate_works{true};     /* does this kernel know MADV_POPULATE_WRITE?  Probed once, on a page of our own */
-
-    explicit hz_copy_pool(int n)
-    {
-        /* (EINVAL on a private anonymous page = the flag is unknown to this kernel; any later failure is about
-         * the caller's buffer - a pinned or device mapping, an unmapped range - and only skips that buffer) */
-        void* probe = mmap(NULL, 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if(probe != MAP_FAILED)
-        {
-            if(madvise(probe, 4096, MADV_POPULATE_WRITE) != 0) populate_works = false;
-            munmap(probe, 4096);
-        }
-        /* HZ_COPY_NODE=here (an experiment of round 5): the pool's threads stay on the NUMA node of the thread that made the
-         * pool - the caller's buffers were most likely first touched there */
-        cpu_set_t node_cpus; bool pin = false;
-        const char* where = getenv("HZ_COPY_NODE");
-        if(where && strcmp(where, "here") == 0)
-        {
-            const int cpu = sched_getcpu();
-            for(int node=0; node<16 && !pin; node++)
-            {
-                char path[96]; snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
-                FILE* f = fopen(path, "r"); if(!f) break;
-                char buf[4096]; if(!fgets(buf, sizeof(buf), f)) { fclose(f); continue; } fclose(f);
-                CPU_ZERO(&node_cpus); bool mine = false;
-                for(char* tok = strtok(buf, ",\n"); tok; tok = strtok(NULL, ",\n"))
-                {
-                    int a, b;
-                    if(sscanf(tok, "%d-%d", &a, &b) != 2) { if(sscanf(tok, "%d", &a) != 1) continue; b = a; }
-                    for(int c=a; c<=b; c++) { CPU_SET(c, &node_cpus); if(c == cpu) mine = true; }
-                }
-                pin = mine;
-            }
-        }
-        for(int k=0; k<n; k++)
-        {
-            threads.emplace_back([this] { run(); });
-            if(pin) (void)pthread_setaffinity_np(threads.back().native_handle(), sizeof(node_cpus), &node_cpus);
-        }
-    }
-    ~hz_copy_pool()
-    {
-        { std::lock_guard<std::mutex> g(m); stop = true; }
-        cv_work.notify_all();
-        for(auto& t : threads) t.join();
-    }
-    void map_pages(unsigned char* p, size_t n)
-    {
-        const uintptr_t page = 4096, lo = ((uintptr_t)p + page-1) & ~(page-1), hi = ((uintptr_t)p + n) & ~(page-1);
-        if(hi <= lo) return;
-        if(populate_works) { (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE); return; }     /* (a failure: the copies fault the pages in themselves) */
-        /* an older kernel: a write that changes nothing, one per page (atomic: a copy into the same page may be running) */
-        for(uintptr_t a = lo; a < hi; a += page) (void)__atomic_fetch_add((unsigned char*)a, 0, __ATOMIC_RELAXED);
-    }
-    void execute(const task_t& t)
-    {
-        switch(t.kind)
-        {
-        case COPY: memcpy(t.dst, t.src, t.n); break;
-        case MAP:  map_pages(t.dst, t.n); break;
-        case FILL:
-            for(int r=0; r<t.rows; r++) hz_sky_fill(t.dst, t.lo + (size_t)r*t.pitch, t.lo + (size_t)r*t.pitch + t.n, t.sky);
-            if(t.left) t.left->fetch_sub(1, std::memory_order_release);
-            break;
-        case SCATTER:
-            for(size_t k=0; k<t.nblobs; k++)
-            {
-                const uint32_t* blob = t.chunk + t.offs[k];
-                /* The terrain goes on top of the sky, which has to be there first: a blob waits for the piece(s) of its
-                 * sector that hold its rows.  Sky tasks queue behind blobs (q_lo), so the ones this blob waits for may
-                 * not have been taken by any thread yet: the waiting thread takes sky tasks itself. */
-                const int yo = (int)(blob[0] & 0xFFFFu);
-                const bool prefilled = yo < t.sc->y_pre;
-                if(prefilled)
-                    for(int b = yo/t.sc->band_rows; b <= (yo + HZ_BLOB_ROWS-1)/t.sc->band_rows && b < t.sc->nbands; b++)
-                        while(t.sc->band_left[(size_t)t.sector*t.sc->nbands + b].load(std::memory_order_acquire) > 0)
-                            if(!run_one_low()) std::this_thread::yield();
-                if(hz_blob_scatter_mode(blob, &t.sc->dst, prefilled ? 0 : 1) != 0) t.sc->bad.store(1);
-            }
-            break;
-        }
-    }
-    void finished(const task_t& t)      /* m held */
-    {
-        if(--t.batch->pending == 0) cv_done.notify_all();
-    }
-    /* a thread that waits for sky takes one sky task; false: none queued (others are working on them) */
-    bool run_one_low()
-    {
-        task_t t;
-        {
-            std::lock_guard<std::mutex> lk(m);
-            if(q_lo.empty()) return false;
-            t = q_lo.front(); q_lo.pop_front();
-        }
-        execute(t);
-        std::lock_guard<std::mutex> lk(m);
-        finished(t);
-        return true;
-    }
-    void run()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        for(;;)
-        {
-            cv_work.wait(lk, [this] { return stop || !q_hi.empty() || !q_lo.empty(); });
-            if(stop) return;
-            std::deque<task_t>& q = !q_hi.empty() ? q_hi : q_lo;
-            const task_t t = q.front(); q.pop_front();
-            lk.unlock();
-            execute(t);
-            lk.lock();
-            finished(t);
-        }
-    }
-    /* the tasks of one job: [dst, dst+n) in parts of at least `grain` bytes, at most one per thread */
-    void push(batch_t* b, unsigned char* d, const unsigned char* s, size_t n, size_t grain)
-    {
-        size_t nparts = threads.size(); if(nparts > n/grain + 1) nparts = n/grain + 1;
-        std::lock_guard<std::mutex> lk(m);
-        for(size_t k=0; k<nparts; k++)
-        {
-            const size_t lo = n*k/nparts, hi = n*(k+1)/nparts;
-            task_t t = {};
-            t.kind = s ? COPY : MAP; t.dst = d + lo; t.src = s ? s + lo : NULL; t.n = hi - lo; t.batch = b;
-            (s ? q_hi : q_lo).push_back(t);
-            b->pending++;
-        }
-        cv_work.notify_all();
-    }
-    /* several tasks of one batch at once (one trip through the lock) */
-    void push_tasks(batch_t* b, std::vector<task_t>& ts)
-    {
-        if(ts.empty()) return;
-        {
-            std::lock_guard<std::mutex> lk(m);
-            for(task_t& t : ts) { t.batch = b; (t.kind == FILL || t.kind == MAP ? q_lo : q_hi).push_back(t); }
-            b->pending += (int)ts.size();
-        }
-        cv_work.notify_all();
-        ts.clear();
-    }
-    /* ... sky tasks that are not ahead of anything: into the queue that is served first */
-    void push_tasks_hi(batch_t* b, std::vector<task_t>& ts)
-    {
-        if(ts.empty()) return;
-        {
-            std::lock_guard<std::mutex> lk(m);
-            for(task_t& t : ts) { t.batch = b; q_hi.push_back(t); }
-            b->pending += (int)ts.size();
-        }
-        cv_work.notify_all();
-        ts.clear();
-    }
-    void wait(batch_t* b)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [b] { return b->pending == 0; });
-    }
-};
-
-static hz_copy_pool* copy_pool()
-{
-    /* one pool per process, created on first use, never torn down (its threads
-     * sleep on a condition variable) */
-    static hz_copy_pool* pool = nullptr;
-    static std::mutex m;
-    std::lock_guard<std::mutex> g(m);
-    if(!pool)
-    {
-        /* 24: a 16000x4000 panorama into kept buffers takes 5.6 / 4.9 / 4.2 ms with 8 / 12 / 24 threads on the 2 x 64-core
-         * host of an 8-GPU node (round 4, profiles/r4_host_inclusive.txt); at most an eighth of the machine's hardware
-         * threads, so that eight processes, one per GPU, do not get in each other's way.  HZ_COPY_THREADS: the one switch
-         * that belongs to the process, not to a context. */
-        const unsigned hw = std::thread::hardware_concurrency();
-        int n = hw >= 32 ? (int)(hw/8 < 24 ? hw/8 : 24) : 4;
-        const char* e = getenv("HZ_COPY_THREADS");
-        if(e && atoi(e) > 0) n = atoi(e);
-        if(hw && (unsigned)n > hw) n = (int)hw;
-        pool = new hz_copy_pool(n);
-    }
-    return pool;
-}
+#include <immintrin.h>
 
 /* ------------------------------------------------------------------------ */
 /* the state of a context's host path                                        */
@@ -274,45 +45,86 @@ static hz_copy_pool* copy_pool()
 #define HZ_HOST_MAX_SECTORS 8
 #define HZ_HOST_JOBS        2           /* panoramas between hz_hip_host_begin() and hz_hip_host_end() */
 
+/* the control words of a panorama in flight, in HBM (d_ctl) and mirrored in pinned host memory (h_ctl):
+ *   [4*s .. 4*s+3]          sector s: k_pack_host's cursor words / k_tell's info words
+ *   [HZ_CTL_PRESENT + ..]   the sectors' tile bitmaps (sector s's: pres0[s], npres[s] words) */
+#define HZ_CTL_PRESENT (4*HZ_HOST_MAX_SECTORS)
+
 struct hz_hostjob
 {
     bool      active;
     bool      clears;                   /* its conversions cleared the framebuffers behind themselves */
     hz_view_t view;
     uint32_t  flags;                    /* HZ_BLOB_*: what its blobs carry */
+    unsigned int epoch;                 /* what k_tell writes into this job's info words */
     int       nsec;
     int       col[HZ_HOST_MAX_SECTORS+1];   /* image columns: sector s = [col[s], col[s+1]) */
     int       out_col0, out_w;          /* the caller's buffers are [H][out_w] and start at image column out_col0 */
-    size_t    off[HZ_HOST_MAX_SECTORS];     /* where sector s's stream starts in d_hs (words; a multiple of the chunk size) */
+    size_t    off[HZ_HOST_MAX_SECTORS];     /* where sector s's stream starts in d_hs / h_land (words; a multiple of the chunk size) */
     size_t    cap[HZ_HOST_MAX_SECTORS];     /* ... and the room it has */
+    size_t    chunk0[HZ_HOST_MAX_SECTORS], pres0[HZ_HOST_MAX_SECTORS], npres[HZ_HOST_MAX_SECTORS];
     hz_copy_pool::scatter_t sc;
     std::vector<std::atomic<int>>* band_left;
     std::vector<float>* tanel;          /* the job's own copy: the scatter tasks read it */
-    hz_copy_pool::batch_t filled;
+    hz_copy_pool::batch_t filled;       /* the sky tasks queued by begin */
     /* device side */
     uint32_t*     d_hs;                 /* the streams of blobs of the job's sectors */
     size_t        hs_capacity;          /* words */
-    unsigned int* d_cursor;             /* 4 words per sector: [0] words in use, [1] blobs, [2] nonzero: a blob did not fit */
-    unsigned int* h_cursor;             /* the same in pinned memory */
-    hipEvent_t    ev_known[HZ_HOST_MAX_SECTORS];    /* sector s's cursor words have reached h_cursor */
+    unsigned int* d_ctl;
+    size_t        ctl_capacity;         /* words (of d_ctl and of h_ctl) */
+    /* pinned host memory */
+    uint32_t*     h_land;               /* where the copy engine puts the streams: the same offsets as in d_hs */
+    size_t        land_capacity;        /* words */
+    unsigned int* h_ctl;
+    hipEvent_t    ev_told;              /* rstream: every k_tell of this job has run */
+    /* the transfer as far as the host has driven it (advance()) */
+    int           known;                /* sectors whose info words have arrived - and whose copies have been issued */
+    size_t        nwords[HZ_HOST_MAX_SECTORS], nblobs[HZ_HOST_MAX_SECTORS], nchunks[HZ_HOST_MAX_SECTORS];
+    bool          overflowed;
+    std::vector<hipEvent_t>* ev_copy;   /* [chunk number]: behind the copy that begins with that chunk */
+    std::vector<size_t>*     ev_of;     /* [chunk number]: the chunk number whose event says this one has landed */
+    double        t_known[HZ_HOST_MAX_SECTORS];
     std::chrono::steady_clock::time_point t_begin;
     double t_sky_queued, t_queued[HZ_HOST_MAX_SECTORS];     /* host_times: ms since t_begin when the sky tasks / sector s's work had been queued */
 };
 
 struct hz_hoststate
 {
-    hipStream_t    cstream[HZ_COPY_STREAMS];
-    unsigned char* h_stage[HZ_STAGE_SLOTS];     /* slot k of ONE pinned allocation (h_stage[0]): a copy may span consecutive slots */
-    hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
-    hipEvent_t     ev_band[HZ_HOST_BANDS];
+    hipStream_t    cstream[HZ_COPY_STREAMS];    /* the copies, taken in turn */
     hz_hostjob     job[HZ_HOST_JOBS];
     int            next_begin, next_end;    /* jobs are ended in the order they were begun */
-    /* internal output buffers of the dense path */
+    unsigned int   epoch;
+    size_t         ncopies;
+    /* the dense path: a ring of pinned chunks (made when that path is first taken) and internal output buffers */
+    unsigned char* h_stage[HZ_STAGE_SLOTS];     /* slot k of ONE pinned allocation (h_stage[0]) */
+    hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
+    hipEvent_t     ev_band[HZ_HOST_BANDS];
     unsigned char* d_bgr;
     float*         d_ranges;
     int32_t*       d_index;
     uint32_t*      d_z24;
 };
+
+static int make_hoststate(hz_hoststate* h)
+{
+    /* The copies get streams of the highest priority: HIP deals its streams onto a handful of hardware queues, per
+     * priority level, and a queue is worked through in order - on a queue shared with one of the context's draw streams
+     * the copies of sector 0 sat behind the marching kernels of sectors 1 to 3 (round 5: first chunk 0.75 ms after its
+     * sector was known, profiles/r5_host_inclusive.txt). */
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for(int k=0; k<HZ_COPY_STREAMS; k++) HZ_CHECK(hipStreamCreateWithPriority(&h->cstream[k], hipStreamNonBlocking, prio_hi));
+    for(int j=0; j<HZ_HOST_JOBS; j++)
+    {
+        hz_hostjob& jb = h->job[j];
+        jb.band_left = new std::vector<std::atomic<int>>();
+        jb.tanel = new std::vector<float>();
+        jb.ev_copy = new std::vector<hipEvent_t>();
+        jb.ev_of = new std::vector<size_t>();
+        HZ_CHECK(hipEventCreateWithFlags(&jb.ev_told, hipEventDisableTiming));
+    }
+    return 0;
+}
 
 static int ensure_host(hz_dev_t* d)
 {
@@ -320,36 +132,31 @@ static int ensure_host(hz_dev_t* d)
     hz_hoststate* h = new hz_hoststate();
     memset((void*)h, 0, sizeof(*h));
     d->host = h;
-    /* The copies get streams of the highest priority: HIP deals its streams onto a handful of hardware queues, per
-     * priority level, and a queue is worked through in order - on a queue shared with one of the context's draw streams the
-     * copies of sector 0 sat behind the marching kernels of sectors 1 to 3, which had been queued before the copies could be
-     * (round 5: first chunk 0.75 ms after its sector was known, profiles/r5_host_inclusive.txt). */
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    for(int k=0; k<HZ_COPY_STREAMS; k++) HZ_CHECK(hipStreamCreateWithPriority(&h->cstream[k], hipStreamNonBlocking, prio_hi));
-    for(int k=0; k<HZ_HOST_BANDS; k++)   HZ_CHECK(hipEventCreateWithFlags(&h->ev_band[k], hipEventDisableTiming));
-    HZ_CHECK(hipHostMalloc((void**)&h->h_stage[0], (size_t)HZ_STAGE_SLOTS*HZ_STAGE_BYTES, hipHostMallocDefault));
-    for(int k=0; k<HZ_STAGE_SLOTS; k++)
-    {
-        h->h_stage[k] = h->h_stage[0] + (size_t)k*HZ_STAGE_BYTES;
-        HZ_CHECK(hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
-    }
-    for(int j=0; j<HZ_HOST_JOBS; j++)
-    {
-        hz_hostjob& jb = h->job[j];
-        jb.band_left = new std::vector<std::atomic<int>>();
-        jb.tanel = new std::vector<float>();
-        HZ_CHECK(hipMalloc(&jb.d_cursor, 4*HZ_HOST_MAX_SECTORS*sizeof(unsigned int)));
-        HZ_CHECK(hipHostMalloc((void**)&jb.h_cursor, 4*HZ_HOST_MAX_SECTORS*sizeof(unsigned int), hipHostMallocDefault));
-        for(int s=0; s<HZ_HOST_MAX_SECTORS; s++) HZ_CHECK(hipEventCreateWithFlags(&jb.ev_known[s], hipEventDisableTiming));
-    }
+    if(make_hoststate(h) != 0) { hz_hostpath_destroy(d); return -1; }     /* (half made: nothing of it stays) */
     return 0;
 }
+
+/* the dense path's ring and band events */
+static int ensure_ring(hz_dev_t* d)
+{
+    hz_hoststate* h = d->host;
+    if(h->h_stage[0]) return 0;
+    unsigned char* ring = NULL;
+    HZ_CHECK(hipHostMalloc((void**)&ring, (size_t)HZ_STAGE_SLOTS*HZ_STAGE_BYTES, hipHostMallocDefault));
+    for(int k=0; k<HZ_HOST_BANDS; k++)  if(!h->ev_band[k])  HZ_CHECK(hipEventCreateWithFlags(&h->ev_band[k], hipEventDisableTiming));
+    for(int k=0; k<HZ_STAGE_SLOTS; k++) if(!h->ev_stage[k]) HZ_CHECK(hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
+    for(int k=0; k<HZ_STAGE_SLOTS; k++) h->h_stage[k] = ring + (size_t)k*HZ_STAGE_BYTES;
+    return 0;
+}
+
+static int host_end(hz_dev_t* d);
 
 void hz_hostpath_destroy(hz_dev_t* d)
 {
     hz_hoststate* h = d->host;
     if(!h) return;
+    /* panoramas begun and never ended: the pool's tasks name their buffers and counters, copies write their landing */
+    while(h->next_end != h->next_begin) (void)host_end(d);
     for(int k=0; k<HZ_COPY_STREAMS; k++) if(h->cstream[k]) (void)hipStreamSynchronize(h->cstream[k]);
     if(h->h_stage[0]) (void)hipHostFree(h->h_stage[0]);
     for(int k=0; k<HZ_STAGE_SLOTS; k++) if(h->ev_stage[k]) (void)hipEventDestroy(h->ev_stage[k]);
@@ -358,10 +165,12 @@ void hz_hostpath_destroy(hz_dev_t* d)
     for(int j=0; j<HZ_HOST_JOBS; j++)
     {
         hz_hostjob& jb = h->job[j];
-        (void)hipFree(jb.d_hs); (void)hipFree(jb.d_cursor);
-        if(jb.h_cursor) (void)hipHostFree(jb.h_cursor);
-        for(int s=0; s<HZ_HOST_MAX_SECTORS; s++) if(jb.ev_known[s]) (void)hipEventDestroy(jb.ev_known[s]);
-        delete jb.band_left; delete jb.tanel;
+        (void)hipFree(jb.d_hs); (void)hipFree(jb.d_ctl);
+        if(jb.h_land) (void)hipHostFree(jb.h_land);
+        if(jb.h_ctl)  (void)hipHostFree(jb.h_ctl);
+        if(jb.ev_told) (void)hipEventDestroy(jb.ev_told);
+        if(jb.ev_copy) for(hipEvent_t e : *jb.ev_copy) (void)hipEventDestroy(e);
+        delete jb.band_left; delete jb.tanel; delete jb.ev_copy; delete jb.ev_of;
     }
     (void)hipFree(h->d_bgr); (void)hipFree(h->d_ranges); (void)hipFree(h->d_index); (void)hipFree(h->d_z24);
     delete h;
@@ -369,7 +178,7 @@ void hz_hostpath_destroy(hz_dev_t* d)
 }
 
 /* ------------------------------------------------------------------------ */
-/* without the sky: begin (queue the draws and conversions, start the sky)   */
+/* without the sky: begin (queue the draws, conversions and shipments, start the sky) */
 
 /* words a sector's stream may need: every pixel terrain - its words, a byte of shade where that is what travels -,
  * per blob header + masks + padding, and per chunk one blob's worth of skipped room; a multiple of the chunk size */
@@ -386,12 +195,16 @@ static size_t hs_words_needed(int SW, int H, uint32_t flags)
 }
 
 /* how many sectors a call draws and ships its panorama in */
-static int sectors_for(const hz_dev_t* d, const hz_view_t* view, bool draws)
+static int sectors_for(const hz_dev_t* d, const hz_view_t* view, bool draws, bool another_in_flight)
 {
     if(!draws || d->col0 != 0 || d->col1 != d->W) return 1;        /* (a context that is itself one sector of a panorama; a conversion of a draw already made) */
     int n = d->env.host_sectors;
     if(n <= 0)
     {
+        /* (a series - the panorama before is crossing the link now - keeps the sectors: this one's first blobs are ready
+         * for the copy engine half a millisecond after the call, not a whole draw later, and a draw beside the copy engine
+         * costs what it costs alone.  HZ_HOST_SERIES_WHOLE=1: one draw, an experiment of round 6) */
+        if(another_in_flight && getenv("HZ_HOST_SERIES_WHOLE") && atoi(getenv("HZ_HOST_SERIES_WHOLE")) != 0) return 1;
         const double npix = (double)d->W*(double)d->H;
         n = npix >= 32.0e6 ? 4 : npix >= 12.0e6 ? 2 : 1;
         if(n > 1)
@@ -409,6 +222,66 @@ static int sectors_for(const hz_dev_t* d, const hz_view_t* view, bool draws)
     return n < 1 ? 1 : n;
 }
 
+/* the layout of a job: sectors, their streams, control words.  Returns the words of stream the job needs; *ctl_words: of control */
+static size_t lay_out(hz_hostjob& jb, const hz_dev_t* d, int nsec, uint32_t flags, size_t* ctl_words)
+{
+    const size_t chunk = HZ_STAGE_BYTES/4;
+    jb.nsec = nsec;
+    jb.out_col0 = d->col0; jb.out_w = d->col1 - d->col0;
+    for(int s=0; s<=nsec; s++) jb.col[s] = s == nsec ? d->col1 : d->col0 + (int)((long long)jb.out_w*s/nsec) / 64 * 64;
+    size_t need = 0, nchunks = 0, npres = 0;
+    for(int s=0; s<nsec; s++)
+    {
+        const int sw = jb.col[s+1] - jb.col[s];
+        jb.cap[s] = hs_words_needed(sw, d->H, flags);
+        jb.off[s] = need; need += jb.cap[s];
+        jb.chunk0[s] = nchunks; nchunks += jb.cap[s]/chunk;
+        jb.npres[s] = ((size_t)((sw + HZ_BLOB_COLS-1)/HZ_BLOB_COLS)*(size_t)((d->H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS) + 31)/32;
+        jb.pres0[s] = npres; npres += jb.npres[s];
+    }
+    for(int s=0; s<nsec; s++) jb.pres0[s] += HZ_CTL_PRESENT;
+    *ctl_words = HZ_CTL_PRESENT + npres;
+    jb.ev_of->assign(nchunks, 0);
+    return need;
+}
+
+/* the job's memory: streams in HBM, the landing and both sets of control words; -2: none to be had (the dense path) */
+static int job_memory(hz_dev_t* d, hz_hostjob& jb, size_t need, size_t ctl_words)
+{
+    if(need > jb.hs_capacity || need > jb.land_capacity || ctl_words > jb.ctl_capacity)
+        HZ_CHECK(hz_sync_all(d));       /* (nothing of this job is in flight - it is not active -, but frees serialise with the device anyway) */
+    if(need > jb.hs_capacity)
+    {
+        (void)hipFree(jb.d_hs); jb.d_hs = NULL; jb.hs_capacity = 0;
+        if(hipMalloc(&jb.d_hs, need*sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        jb.hs_capacity = need;
+    }
+    if(need > jb.land_capacity)
+    {
+        if(jb.h_land) (void)hipHostFree(jb.h_land);
+        jb.h_land = NULL; jb.land_capacity = 0;
+        if(hipHostMalloc((void**)&jb.h_land, need*sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        jb.land_capacity = need;
+    }
+    if(ctl_words > jb.ctl_capacity)
+    {
+        (void)hipFree(jb.d_ctl); jb.d_ctl = NULL;
+        if(jb.h_ctl) (void)hipHostFree(jb.h_ctl);
+        jb.h_ctl = NULL; jb.ctl_capacity = 0;
+        const size_t cap = ctl_words + ctl_words/4 + 256;
+        if(hipMalloc(&jb.d_ctl, cap*sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        if(hipHostMalloc((void**)&jb.h_ctl, cap*sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        memset(jb.h_ctl, 0, cap*sizeof(unsigned int));      /* (no epoch is 0) */
+        jb.ctl_capacity = cap;
+    }
+    return 0;
+}
+
+static uint32_t blob_flags(const void* bgr, const void* ranges, const void* index, const void* z24)
+{
+    return ((ranges || z24) ? HZ_BLOB_PACKED : bgr ? HZ_BLOB_RED : 0u) | (index ? HZ_BLOB_INDEX : 0u);
+}
+
 /* Queues everything the device has to do for one panorama into host memory and starts the sky.  draws: the panorama is
  * drawn here, sector by sector (else: the conversion of the draw already queued, or made again if it was consumed).
  * Returns the job's number, -1 on an error, -2 if this panorama has to take the dense path (no room for the stream). */
@@ -419,26 +292,26 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
     hz_hostjob& jb = h->job[h->next_begin % HZ_HOST_JOBS];
     if(jb.active) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_begin: %d panoramas are in flight already: end one first", HZ_HOST_JOBS); return -1; }
     const int H = d->H;
-    const uint32_t flags = ((ranges || z24) ? HZ_BLOB_PACKED : bgr ? HZ_BLOB_RED : 0u) | (index ? HZ_BLOB_INDEX : 0u);
+    const uint32_t flags = blob_flags(bgr, ranges, index, z24);
     if(ranges && !tanel) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: ranges requested without a tanel table"); return -1; }
-    jb.nsec = sectors_for(d, view, draws);
-    jb.out_col0 = d->col0; jb.out_w = d->col1 - d->col0;
-    for(int s=0; s<=jb.nsec; s++) jb.col[s] = s == jb.nsec ? d->col1 : d->col0 + (int)((long long)jb.out_w*s/jb.nsec) / 64 * 64;
-    size_t need = 0;
-    for(int s=0; s<jb.nsec; s++)
+    const bool another = h->next_begin != h->next_end;
+    size_t ctl_words = 0;
+    const size_t need = lay_out(jb, d, sectors_for(d, view, draws, another), flags, &ctl_words);
+    for(int s=0; s<jb.nsec; s++) if(jb.cap[s] >= ((size_t)1 << 32)) return -2;      /* (a stream is addressed in 32 bits) */
     {
-        jb.cap[s] = hs_words_needed(jb.col[s+1] - jb.col[s], H, flags);
-        if(jb.cap[s] >= ((size_t)1 << 32)) return -2;              /* (a stream is addressed in 32 bits) */
-        jb.off[s] = need; need += jb.cap[s];
-    }
-    if(need > jb.hs_capacity)
-    {
-        HZ_CHECK(hz_sync_all(d));
-        (void)hipFree(jb.d_hs); jb.d_hs = NULL; jb.hs_capacity = 0;
-        if(hipMalloc(&jb.d_hs, need*sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return -2; }
-        jb.hs_capacity = need;
+        const int rc = job_memory(d, jb, need, ctl_words);
+        if(rc != 0) return rc;
     }
     jb.view = *view; jb.flags = flags;
+    if(++h->epoch == 0) h->epoch = 1;
+    jb.epoch = h->epoch;
+    jb.known = 0; jb.overflowed = false;
+    while(jb.ev_copy->size() < jb.ev_of->size())
+    {
+        hipEvent_t e = NULL;
+        HZ_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        jb.ev_copy->push_back(e);
+    }
     jb.t_begin = std::chrono::steady_clock::now();
     if(ranges) jb.tanel->assign(tanel, tanel + H); else jb.tanel->clear();
 
@@ -467,11 +340,11 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
      * filled beforehand as there is time for until the first sector's blobs arrive: all of it for a call in one sector (the
      * draw takes longer than the fill), the upper 60 % for 2 sectors, 30 % for more - sky for the most part -, and
      * nothing when another panorama is in flight (its blobs are arriving now).  Below that row a blob writes the sky
-     * pixels of its own tile (hz_blob_scatter_mode: every byte once), and the tiles that turn out to have no blob are filled
-     * when their sector has been walked.  HZ_HOST_PREFILL=percent overrides. */
+     * pixels of its own tile (hz_blob_scatter_mode: every byte once), and the tiles without a blob are filled as soon as
+     * their sector's bitmap has arrived.  HZ_HOST_PREFILL=percent overrides. */
     {
         int percent = jb.nsec <= 1 ? 100 : jb.nsec == 2 ? 60 : 30;     /* (4 sectors of 16000 x 4000: 3.36 ms with 45 %, 3.25 with 60, 3.15 with 30) */
-        if(h->next_begin != h->next_end) percent = 0;
+        if(another) percent = 0;
         const char* e = getenv("HZ_HOST_PREFILL");
         if(e && atoi(e) >= 0 && atoi(e) <= 100) percent = atoi(e);
         sc.y_pre = (int)((long long)H*percent/100) / HZ_BLOB_ROWS * HZ_BLOB_ROWS;
@@ -515,20 +388,23 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
     hipError_t err = hipSuccess;
     const char* what = "";
     #define HZ_TRY(call) do { if(err == hipSuccess && rc == 0) { err = (call); if(err != hipSuccess) what = #call; } } while(0)
-    HZ_TRY(hipMemsetAsync(jb.d_cursor, 0, 4*HZ_HOST_MAX_SECTORS*sizeof(unsigned int), d->rstream));
+    HZ_TRY(hipMemsetAsync(jb.d_ctl, 0, ctl_words*sizeof(unsigned int), d->rstream));
     jb.clears = d->env.resolve_clears != 0;
     for(int s=0; s<jb.nsec && rc == 0 && err == hipSuccess; s++)
     {
         if(draws)
         {
             d->col0 = jb.col[s]; d->col1 = jb.col[s+1];
-            if(hz_draw_impl(d, view) != 0) { rc = -1; break; }
+            d->vc.same_draw = s > 0;            /* (the sectors of a call are ONE draw from its viewpoint: hz_draw.cpp, vertex_cache) */
+            const int drawn = hz_draw_impl(d, view);
+            d->vc.same_draw = 0;
+            if(drawn != 0) { rc = -1; break; }
         }
         else if(hz_fb_refill(d) != 0) { rc = -1; break; }
         if(hz_rstream_after_draw(d) != 0) { rc = -1; break; }
         const int SW = d->col1 - d->col0;
         if(prof && s == jb.nsec-1) HZ_TRY(hipEventRecord(d->ev[4], d->rstream));
-        hz_hostpack_t hp = { jb.d_hs + jb.off[s], jb.d_cursor + 4*s, (unsigned int)jb.cap[s], (unsigned int)(HZ_STAGE_BYTES/4), flags };
+        hz_hostpack_t hp = { jb.d_hs + jb.off[s], jb.d_ctl + 4*s, (unsigned int)jb.cap[s], (unsigned int)(HZ_STAGE_BYTES/4), flags, jb.d_ctl + jb.pres0[s] };
         const dim3 grid((unsigned)((SW + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), (unsigned)((H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS));
         unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];
         if(err == hipSuccess)
@@ -539,10 +415,19 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         }
         if(err == hipSuccess && jb.clears && hz_fb_mark_consumed(d) != 0) rc = -1;
         if(prof && s == jb.nsec-1) { HZ_TRY(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
-        HZ_TRY(hipMemcpyAsync(jb.h_cursor + 4*s, jb.d_cursor + 4*s, 4*sizeof(unsigned int), hipMemcpyDeviceToHost, d->rstream));
-        HZ_TRY(hipEventRecord(jb.ev_known[s], d->rstream));
+        /* ... and the host is told: the stream's length, the tiles it holds blobs for */
+        if(err == hipSuccess && rc == 0)
+        {
+            hz_tell_t tl;
+            tl.cursor = jb.d_ctl + 4*s; tl.present = jb.d_ctl + jb.pres0[s];
+            tl.h_info = jb.h_ctl + 4*s; tl.h_present = jb.h_ctl + jb.pres0[s];
+            tl.capacity = (unsigned int)jb.cap[s]; tl.npresent = (unsigned int)jb.npres[s]; tl.epoch = jb.epoch;
+            hzk_tell(d->rstream, tl);
+            HZ_TRY(hipGetLastError());
+        }
         jb.t_queued[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
     }
+    HZ_TRY(hipEventRecord(jb.ev_told, d->rstream));
     #undef HZ_TRY
     d->col0 = user_col0; d->col1 = user_col1;
     /* (a reader of the framebuffer after this call - pick, the annotator passes - wants the whole view: the last sector's
@@ -556,6 +441,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
     }
     if(rc != 0)
     {
+        (void)hipStreamSynchronize(d->rstream);     /* (k_tell's already queued write this job's control words) */
         pool->wait(&jb.filled);
         jb.active = false;
         h->next_begin--;
@@ -565,181 +451,193 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
 }
 
 /* ------------------------------------------------------------------------ */
-/* ... end: the streams through the staging ring, the blobs into their places */
+/* ... end: the blobs into their places as their chunks land                 */
+
+/* Whatever of panorama jb's transfer has become possible: the sectors whose info words have arrived (in order) are
+ * learned, and the copies of their streams issued - the first copy of a sector one chunk (its blobs can be scattered
+ * when it has landed), the second two, then four; a copy costs the engine ~20 us beyond its bytes (4 MB copies ran at
+ * 46 GB/s, 16 MB ones at 55: tools/zero_copy.hip); the last chunks of the last sector one by one again (what arrives
+ * last is scattered with nothing left to hide behind).  Returns -1 on a HIP error. */
+static int advance(hz_dev_t* d, hz_hostjob& jb)
+{
+    hz_hoststate* h = d->host;
+    const size_t chunk_words = HZ_STAGE_BYTES/4;
+    while(jb.known < jb.nsec)
+    {
+        const int s = jb.known;
+        const unsigned int* info = jb.h_ctl + 4*s;
+        if(__atomic_load_n(info + 3, __ATOMIC_ACQUIRE) != jb.epoch) break;
+        jb.t_known[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
+        jb.nwords[s] = info[0]; jb.nblobs[s] = info[1];
+        if(info[2] || jb.nwords[s] > jb.cap[s]) { jb.overflowed = true; jb.nwords[s] = 0; jb.nblobs[s] = 0; }
+        jb.nchunks[s] = (jb.nwords[s] + chunk_words-1)/chunk_words;
+        for(size_t c = 0, run = 0; c < jb.nchunks[s]; run++)
+        {
+            size_t g = run == 0 ? 1 : run == 1 ? 2 : 4;
+            if(s == jb.nsec-1 && jb.nchunks[s] - c <= 3) g = 1;
+            if(g > jb.nchunks[s] - c) g = jb.nchunks[s] - c;
+            const size_t w0 = c*chunk_words, w1 = (c + g)*chunk_words < jb.nwords[s] ? (c + g)*chunk_words : jb.nwords[s];
+            hipStream_t cs = h->cstream[h->ncopies++ % HZ_COPY_STREAMS];
+            HZ_CHECK(hipMemcpyAsync(jb.h_land + jb.off[s] + w0, jb.d_hs + jb.off[s] + w0, (w1 - w0)*sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+            HZ_CHECK(hipEventRecord((*jb.ev_copy)[jb.chunk0[s] + c], cs));
+            for(size_t i=0; i<g; i++) (*jb.ev_of)[jb.chunk0[s] + c + i] = jb.chunk0[s] + c;
+            c += g;
+        }
+        jb.known++;
+    }
+    return 0;
+}
 
 static int host_end(hz_dev_t* d)
 {
     hz_hoststate* h = d->host;
     hz_hostjob& jb = h->job[h->next_end % HZ_HOST_JOBS];
     if(!jb.active) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_end: no panorama is in flight"); return -1; }
+    /* the panorama begun after this one, if there is one: its copies are issued from here as they become possible */
+    hz_hostjob* next = h->next_begin - h->next_end > 1 ? &h->job[(h->next_end + 1) % HZ_HOST_JOBS] : NULL;
     hz_copy_pool* pool = copy_pool();
-    std::lock_guard<std::mutex> one(pool->busy);
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count(); };
     const double t_enter = since();
-    double t_known[HZ_HOST_MAX_SECTORS] = { 0 }, t_first = 0, t_arrived = 0, t_waited = 0;
+    double t_first = 0, t_arrived = 0, t_waited = 0;
 
-    struct chunk_t { int sector; size_t w0, nw; int ev; };          /* ev: the staging slot whose event says the chunk has arrived (the first slot of its copy) */
-    size_t ncopies = 0;
-    int run_of[HZ_HOST_MAX_SECTORS] = { 0 };                        /* copies issued for sector s so far */
-    std::deque<chunk_t> chunks;                         /* (grows as the sectors' lengths become known) */
-    std::deque<hz_copy_pool::batch_t> done;             /* one per chunk: its scatter tasks (references stay valid as it grows) */
-    std::vector<std::vector<size_t>> offs(jb.nsec);     /* where the blobs of sector s start, chunk after chunk */
-    size_t noffs[HZ_HOST_MAX_SECTORS] = { 0 }, first[HZ_HOST_MAX_SECTORS] = { 0 };
-    size_t total_words = 0, total_blobs = 0;
-    /* below y_pre: which tiles of sector s (4 rows x <= 2048 columns, as k_pack_host cuts them) have sent a blob; the others
-     * get their sky when the sector's last chunk has been walked */
     const int H = d->H, y_pre = jb.sc.y_pre, ty0 = y_pre/HZ_BLOB_ROWS, nty = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS;
-    std::vector<std::vector<unsigned char>> seen(jb.nsec);
-    size_t chunks_of[HZ_HOST_MAX_SECTORS] = { 0 }, walked_of[HZ_HOST_MAX_SECTORS] = { 0 };
-    bool absent_done[HZ_HOST_MAX_SECTORS] = { false };
-    hz_copy_pool::batch_t late_sky = { 0 };
+    const size_t chunk_words = HZ_STAGE_BYTES/4;
+    std::vector<std::vector<size_t>> offs(jb.nsec);     /* where the blobs of sector s start, chunk after chunk */
+    hz_copy_pool::batch_t placed = { 0 };               /* the job's scatter tasks and late sky */
     struct { unsigned char* p; size_t px_bytes; int sky; } bufs[4];
     int nbuf = 0;
     if(jb.sc.dst.bgr)    bufs[nbuf++] = { jb.sc.dst.bgr, 3, HZ_SKY_BGR };
     if(jb.sc.dst.ranges) bufs[nbuf++] = { (unsigned char*)jb.sc.dst.ranges, 4, HZ_SKY_RANGES };
     if(jb.sc.dst.index)  bufs[nbuf++] = { (unsigned char*)jb.sc.dst.index, 4, HZ_SKY_INDEX };
     if(jb.sc.dst.z24)    bufs[nbuf++] = { (unsigned char*)jb.sc.dst.z24, 4, HZ_SKY_Z24 };
-    /* the sky of sector s's tiles without a blob (rows from y_pre down): one task per run of such tiles in a column of tiles */
-    auto fill_absent = [&](int s)
+    std::vector<hz_copy_pool::task_t> tasks;
+    /* the sky of sector s's tiles without a blob (rows from y_pre down; `present`: k_pack_host's bitmap of the tiles it
+     * sent, NULL: none): one task per run of such tiles in a column of tiles */
+    auto fill_absent = [&](int s, const unsigned int* present)
     {
-        if(absent_done[s] || ty0 >= nty) { absent_done[s] = true; return; }
-        absent_done[s] = true;
+        if(ty0 >= nty) return;
         const int sw = jb.col[s+1] - jb.col[s], ntx = (sw + HZ_BLOB_COLS-1)/HZ_BLOB_COLS;
-        std::vector<hz_copy_pool::task_t> ts;
+        auto sent = [&](int tx, int ty) { const size_t t = (size_t)ty*ntx + tx; return present && ((present[t >> 5] >> (t & 31)) & 1u); };
         for(int tx=0; tx<ntx; tx++)
         {
             const size_t x0 = (size_t)(jb.col[s] - jb.out_col0) + (size_t)tx*HZ_BLOB_COLS;
             const size_t w = (size_t)(sw - tx*HZ_BLOB_COLS < HZ_BLOB_COLS ? sw - tx*HZ_BLOB_COLS : HZ_BLOB_COLS);
             for(int ty=ty0; ty<nty; )
             {
-                if(!seen[s].empty() && seen[s][(size_t)(ty - ty0)*ntx + tx]) { ty++; continue; }
+                if(sent(tx, ty)) { ty++; continue; }
                 int t1 = ty + 1;
-                while(t1 < nty && t1 - ty < 64 && (seen[s].empty() || !seen[s][(size_t)(t1 - ty0)*ntx + tx])) t1++;
+                while(t1 < nty && t1 - ty < 64 && !sent(tx, t1)) t1++;
                 const int y0 = ty*HZ_BLOB_ROWS, y1 = t1*HZ_BLOB_ROWS < H ? t1*HZ_BLOB_ROWS : H;
                 for(int k=0; k<nbuf; k++)
                 {
                     hz_copy_pool::task_t t = {};
                     t.kind = hz_copy_pool::FILL; t.dst = bufs[k].p; t.sky = bufs[k].sky; t.left = NULL;
                     t.lo = ((size_t)y0*jb.out_w + x0)*bufs[k].px_bytes; t.n = w*bufs[k].px_bytes; t.rows = y1 - y0; t.pitch = (size_t)jb.out_w*bufs[k].px_bytes;
-                    ts.push_back(t);
+                    tasks.push_back(t);
                 }
                 ty = t1;
             }
         }
-        pool->push_tasks_hi(&late_sky, ts);
+        pool->push_tasks(&placed, tasks);       /* (behind the blobs already queued: they are what the call waits for) */
     };
-    const size_t chunk_words = HZ_STAGE_BYTES/4;
-    int rc = 0, known = 0;
-    hipError_t err = hipSuccess;
-    const char* what = "";
-    #define HZ_TRY(call) do { if(err == hipSuccess) { err = (call); if(err != hipSuccess) what = #call; } } while(0)
-    std::vector<hz_copy_pool::task_t> tasks;
-    size_t issued = 0, k = 0;
-    /* one more sector's length: wait == false only looks */
-    auto learn = [&](bool wait) -> bool
+    int rc = 0, s_done = 0;
+    size_t total_words = 0, total_blobs = 0, nchunks_all = 0, ncopies = 0;
+    /* one turn of every wait below: copies that have become possible are issued - this panorama's later sectors, and, once
+     * all of this one's are on their way, the next panorama's */
+    auto turn = [&]() -> int
     {
-        if(known >= jb.nsec || err != hipSuccess || rc != 0) return false;
-        if(wait) HZ_TRY(hipEventSynchronize(jb.ev_known[known]));
-        else
-        {
-            const hipError_t q = hipEventQuery(jb.ev_known[known]);
-            if(q == hipErrorNotReady) { (void)hipGetLastError(); return false; }
-            if(q != hipSuccess) { err = q; what = "hipEventQuery(ev_known)"; }
-        }
-        if(err != hipSuccess) return false;
-        const int s = known++;
-        t_known[s] = since();
-        const unsigned int* c = jb.h_cursor + 4*s;
-        if(c[2]) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: the stream of blobs overflowed (%zu words)", jb.cap[s]); rc = -1; return false; }
-        offs[s].resize((size_t)c[1] + 1);
-        total_words += c[0]; total_blobs += c[1];
-        if(ty0 < nty) seen[s].assign((size_t)(nty - ty0)*(size_t)((jb.col[s+1] - jb.col[s] + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), 0);
-        chunks_of[s] = ((size_t)c[0] + chunk_words-1)/chunk_words;
-        if(chunks_of[s] == 0) fill_absent(s);              /* (a sector without any terrain) */
-        for(size_t w0 = 0; w0 < c[0]; w0 += chunk_words)
-        {
-            chunks.push_back({ s, w0, w0 + chunk_words < c[0] ? chunk_words : c[0] - w0, 0 });
-            done.push_back({ 0 });
-        }
-        return true;
+        if(advance(d, jb) != 0) return -1;
+        if(next && jb.known == jb.nsec && advance(d, *next) != 0) return -1;
+        _mm_pause();
+        return 0;
     };
-    for(;;)
+    for(int s=0; s<jb.nsec && rc == 0; s++, s_done++)
     {
-        /* whatever has become known; if there is nothing else to do, wait for the next sector */
-        while(learn(false)) {}
-        if(k == chunks.size()) { if(known == jb.nsec || !learn(true)) break; }
-        if(err != hipSuccess || rc != 0) break;
-        /* keep the copy engine up to HZ_STAGE_SLOTS - 4 chunks ahead of the chunk the host threads get next.  One copy moves
-         * up to four consecutive chunks of a sector (consecutive staging slots: the ring is one allocation): a copy costs the
-         * engine ~22 us on top of its bytes - 4 MB copies ran at 46 GB/s where 16 MB ones reach 57 (tools/zero_copy.hip) - ,
-         * but what a copy holds can only be scattered when all of it has arrived: a sector's first copy is one chunk, its
-         * second two, then four. */
-        while(issued < chunks.size() && issued < k + HZ_STAGE_SLOTS - 4 && err == hipSuccess)
+        for(unsigned int spins = 1; jb.known <= s && rc == 0; spins++)
         {
-            const int slot = (int)(issued % HZ_STAGE_SLOTS), sector = chunks[issued].sector;
-            size_t g = run_of[sector] == 0 ? 1 : run_of[sector] == 1 ? 2 : 4;
-            /* ... and the last chunks of the last sector one by one again: what arrives last is scattered with nothing left to hide behind */
-            if(known == jb.nsec && sector == jb.nsec-1 && chunks.size() - issued <= 3) g = 1;
-            if(g > (size_t)(HZ_STAGE_SLOTS - slot)) g = HZ_STAGE_SLOTS - slot;                      /* (no copy wraps round the ring) */
-            while(g > 1 && (issued + g > chunks.size() || issued + g > k + HZ_STAGE_SLOTS - 4 || chunks[issued + g-1].sector != sector)) g--;
-            size_t nw = 0;
-            for(size_t i=0; i<g; i++)
+            if(turn() != 0) { rc = -1; break; }
+            /* (the words come from k_tell: should its stream have run dry without them - a launch that failed, a device
+             * error - say so instead of spinning for ever) */
+            if((spins & 0xFFFu) == 0 && jb.known <= s)
             {
-                if(issued + i >= HZ_STAGE_SLOTS) pool->wait(&done[issued + i - HZ_STAGE_SLOTS]);     /* the slot's previous chunk has been scattered */
-                chunks[issued + i].ev = slot;
-                nw += chunks[issued + i].nw;
-            }
-            hipStream_t cs = h->cstream[ncopies % HZ_COPY_STREAMS];
-            const chunk_t& c = chunks[issued];
-            HZ_TRY(hipMemcpyAsync(h->h_stage[slot], jb.d_hs + jb.off[sector] + c.w0, nw*sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
-            HZ_TRY(hipEventRecord(h->ev_stage[slot], cs));
-            issued += g; ncopies++; run_of[sector]++;
-        }
-        if(err != hipSuccess || k >= issued) continue;
-        const int slot = (int)(k % HZ_STAGE_SLOTS);
-        const double t_w0 = since();
-        const chunk_t c = chunks[k];
-        HZ_TRY(hipEventSynchronize(h->ev_stage[c.ev]));
-        if(err != hipSuccess) break;
-        t_waited += since() - t_w0;
-        if(k == 0) t_first = since();
-        t_arrived = since();
-        const uint32_t* chunk = (const uint32_t*)h->h_stage[slot];
-        size_t* const o = offs[c.sector].data() + noffs[c.sector];
-        const size_t room = offs[c.sector].size() - noffs[c.sector];
-        const size_t nb = hz_blob_walk(chunk, c.nw, first[c.sector], o, room, &first[c.sector]);
-        if(nb == (size_t)-1 || nb > room) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: chunk %zu of the stream is not a sequence of blobs", k); rc = -1; break; }
-        noffs[c.sector] += nb;
-        if(!seen[c.sector].empty())
-        {
-            const int ntx = (jb.col[c.sector+1] - jb.col[c.sector] + HZ_BLOB_COLS-1)/HZ_BLOB_COLS;
-            for(size_t b=0; b<nb; b++)
-            {
-                const uint32_t* blob = chunk + o[b];
-                const int yo = (int)(blob[0] & 0xFFFFu), tx = ((int)blob[1] - (jb.col[c.sector] - jb.out_col0))/HZ_BLOB_COLS;
-                if(yo >= y_pre && yo/HZ_BLOB_ROWS < nty && tx >= 0 && tx < ntx) seen[c.sector][(size_t)(yo/HZ_BLOB_ROWS - ty0)*ntx + tx] = 1;
+                const hipError_t q = hipEventQuery(jb.ev_told);
+                (void)hipGetLastError();
+                if(q != hipErrorNotReady && (advance(d, jb) != 0 || jb.known <= s))
+                {
+                    snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_end: sector %d never reported%s%s", s, q != hipSuccess ? ": " : "", q != hipSuccess ? hipGetErrorString(q) : "");
+                    rc = -1;
+                }
             }
         }
-        if(++walked_of[c.sector] == chunks_of[c.sector]) fill_absent(c.sector);
-        /* tasks of ~256 KB of blobs */
-        for(size_t b0=0; b0<nb; )
+        if(rc != 0) break;
+        if(jb.overflowed) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: the stream of blobs overflowed (%zu words)", jb.cap[s]); rc = -1; break; }
+        const size_t nwords = jb.nwords[s], nblobs = jb.nblobs[s];
+        total_words += nwords; total_blobs += nblobs;
+        fill_absent(s, jb.h_ctl + jb.pres0[s]);
+        offs[s].resize(nblobs + 1);
+        size_t noffs = 0, first = 0;
+        const uint32_t* land = jb.h_land + jb.off[s];
+        for(size_t w0 = 0, c = 0; w0 < nwords && rc == 0; w0 += chunk_words, c++, nchunks_all++)
         {
-            size_t b1 = b0 + 1;
-            while(b1 < nb && o[b1] - o[b0] < 65536) b1++;
-            hz_copy_pool::task_t t = {};
-            t.kind = hz_copy_pool::SCATTER; t.sc = &jb.sc; t.sector = c.sector; t.chunk = chunk; t.offs = o + b0; t.nblobs = b1 - b0;
-            tasks.push_back(t);
-            b0 = b1;
+            const size_t nw = w0 + chunk_words < nwords ? chunk_words : nwords - w0;
+            const double t_w0 = since();
+            const size_t carrier = (*jb.ev_of)[jb.chunk0[s] + c];
+            if(carrier == jb.chunk0[s] + c) ncopies++;
+            for(;;)
+            {
+                const hipError_t q = hipEventQuery((*jb.ev_copy)[carrier]);
+                if(q == hipSuccess) break;
+                (void)hipGetLastError();
+                if(q != hipErrorNotReady || turn() != 0)
+                {
+                    if(q != hipErrorNotReady) snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_end: chunk %zu of sector %d: %s", c, s, hipGetErrorString(q));
+                    rc = -1; break;
+                }
+            }
+            if(rc != 0) break;
+            t_arrived = since(); t_waited += t_arrived - t_w0;
+            if(nchunks_all == 0) t_first = t_arrived;
+            const uint32_t* chunk = land + w0;
+            size_t* const o = offs[s].data() + noffs;
+            const size_t room = offs[s].size() - noffs;
+            const size_t nb = hz_blob_walk(chunk, nw, first, o, room, &first);
+            if(nb == (size_t)-1 || nb > room) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: chunk %zu of sector %d is not a sequence of blobs", c, s); rc = -1; break; }
+            noffs += nb;
+            /* tasks of ~256 KB of blobs */
+            for(size_t b0=0; b0<nb; )
+            {
+                size_t b1 = b0 + 1;
+                while(b1 < nb && o[b1] - o[b0] < 65536) b1++;
+                hz_copy_pool::task_t t = {};
+                t.kind = hz_copy_pool::SCATTER; t.sc = &jb.sc; t.sector = s; t.chunk = chunk; t.offs = o + b0; t.nblobs = b1 - b0;
+                tasks.push_back(t);
+                b0 = b1;
+            }
+            pool->push_tasks(&placed, tasks);
         }
-        pool->push_tasks(&done[k], tasks);
-        k++;
     }
-    #undef HZ_TRY
-    /* (whatever ended the loop early - an error: every sector still gets its sky, the tasks below name this frame's variables) */
-    if(err == hipSuccess && rc == 0) for(int s=0; s<jb.nsec; s++) if(s < known) fill_absent(s);
-    for(size_t i=0; i<done.size(); i++) pool->wait(&done[i]);
+    /* whatever ended the loop early: the sectors not reached keep the caller's buffers defined (sky), and nothing of the
+     * job may still be on its way when its memory is handed to the next */
+    if(rc != 0)
+    {
+        for(int s=s_done; s<jb.nsec; s++) fill_absent(s, NULL);
+        (void)hipEventSynchronize(jb.ev_told);
+        (void)advance(d, jb);                   /* (whatever it still learns is issued, and waited for here) */
+        for(int k=0; k<HZ_COPY_STREAMS; k++) (void)hipStreamSynchronize(h->cstream[k]);
+        (void)hipGetLastError();
+    }
+    /* the last blobs are being placed: the next panorama's copies keep being issued meanwhile */
+    {
+        std::unique_lock<std::mutex> lk(pool->m);
+        while(placed.pending != 0)
+        {
+            lk.unlock();
+            if(next && rc == 0 && advance(d, *next) != 0) rc = -1;
+            lk.lock();
+            if(placed.pending != 0) pool->cv_done.wait_for(lk, std::chrono::microseconds(next ? 20 : 1000));
+        }
+    }
     const double t_scattered = since();
-    pool->wait(&late_sky);
     pool->wait(&jb.filled);
     if(d->env.host_times)
     {
@@ -748,22 +646,37 @@ static int host_end(hz_dev_t* d)
                 1e-6*(double)jb.out_w*d->H*((jb.sc.dst.bgr ? 3 : 0) + (jb.sc.dst.ranges ? 4 : 0) + (jb.sc.dst.index ? 4 : 0) + (jb.sc.dst.z24 ? 4 : 0)), jb.t_sky_queued);
         for(int s=0; s<jb.nsec; s++) fprintf(stderr, " %.2f", jb.t_queued[s]);
         fprintf(stderr, ", end() entered %.2f, sectors known", t_enter);
-        for(int s=0; s<jb.nsec; s++) fprintf(stderr, " %.2f", t_known[s]);
+        for(int s=0; s<jb.known; s++) fprintf(stderr, " %.2f", jb.t_known[s]);
         fprintf(stderr, ", first chunk here %.2f, last chunk here %.2f (%.2f spent waiting for chunks), blobs in place %.2f, sky and everything %.2f\n",
                 t_first, t_arrived, t_waited, t_scattered, since());
     }
     jb.active = false;
     h->next_end++;
-    if(err != hipSuccess)
-    {
-        for(int i=0; i<HZ_COPY_STREAMS; i++) (void)hipStreamSynchronize(h->cstream[i]);
-        (void)hipStreamSynchronize(d->rstream);
-        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_end: %s -> %s", what, hipGetErrorString(err));
-        fprintf(stderr, "hz_hip: %s\n", g_last_error);
-        return -1;
-    }
+    if(rc != 0) fprintf(stderr, "hz_hip: %s\n", g_last_error);
     if(rc == 0 && jb.sc.bad.load()) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_resolve_to_host: a blob does not describe pixels of this image"); rc = -1; }
     return rc;
+}
+
+/* the pool, this context's streams and the memory of one panorama of the given outputs, ahead of the first call (the
+ * library's horizonator_init does this: the reference's CLI makes ONE call per process, standalone.c:433-460) */
+extern "C" int hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, int want_index, int want_z24)
+{
+    HZ_ON_DEVICE(d);
+    if(ensure_host(d) != 0) return -1;
+    (void)copy_pool();
+    hz_hostjob& jb = d->host->job[d->host->next_begin % HZ_HOST_JOBS];
+    if(jb.active || d->env.host_dense || d->H > 65535) return 0;
+    const uint32_t flags = blob_flags(want_bgr ? d : NULL, want_ranges ? d : NULL, want_index ? d : NULL, want_z24 ? d : NULL);
+    if(!flags) return 0;
+    /* (the layout with the most sectors the automatic rule may choose: it needs the most room) */
+    const double npix = (double)d->W*(double)d->H;
+    int nsec = d->env.host_sectors > 0 ? d->env.host_sectors : npix >= 32.0e6 ? 4 : npix >= 12.0e6 ? 2 : 1;
+    if(nsec > HZ_HOST_MAX_SECTORS) nsec = HZ_HOST_MAX_SECTORS;
+    while(nsec > 1 && d->W/nsec < 256) nsec--;
+    size_t ctl_words = 0;
+    const size_t need = lay_out(jb, d, nsec, flags, &ctl_words);
+    for(int s=0; s<jb.nsec; s++) if(jb.cap[s] >= ((size_t)1 << 32)) return 0;
+    return job_memory(d, jb, need, ctl_words) == -1 ? -1 : 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -855,7 +768,7 @@ static int resolve_to_host_dense(hz_dev_t* d, const hz_view_t* view, const float
                                  unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
     hz_hoststate* h = d->host;
-    if(ensure_out_buffers(d, bgr != NULL, ranges != NULL, index != NULL, z24 != NULL) != 0) return -1;
+    if(ensure_ring(d) != 0 || ensure_out_buffers(d, bgr != NULL, ranges != NULL, index != NULL, z24 != NULL) != 0) return -1;
     const int SW = d->col1 - d->col0;
     const size_t npix = (size_t)SW*d->H;
     unsigned char* dst[4]; const unsigned char* src[4]; size_t row_bytes[4];

@@ -289,6 +289,7 @@ void k_pack_host(unsigned long long* __restrict__ fb, hz_hostpack_t o, int SW, i
             if(start != HP_NONE) atomicAdd(&o.cursor[1], 1u);
             if(start != HP_NONE)
             {
+                if(o.present) { const uint32_t tile = blockIdx.y*gridDim.x + blockIdx.x; atomicOr(&o.present[tile >> 5], 1u << (tile & 31u)); }
                 uint32_t* b = o.out + start;
                 b[0] = (uint32_t)yo0 | (o.flags << 16); b[1] = (uint32_t)(x0 + col_off);
                 b[2] = s_count[0]; b[3] = s_count[1]; b[4] = s_count[2]; b[5] = s_count[3];

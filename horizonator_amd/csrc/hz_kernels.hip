@@ -39,6 +39,7 @@
 #include "hz_k_tile.h"
 #include "hz_k_march.h"
 #include "hz_k_resolve.h"
+#include "hz_k_tell.h"
 #include "hz_k_tex.h"
 
 /* ------------------------------------------------------------------------ */
@@ -244,6 +245,11 @@ void hzk_pack_host(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsign
 {
     if(clear) hipLaunchKernelGGL(k_pack_host<true>, grid, block, 0, stream, fb, o, SW, H, col_off, touched, seg_stride, qa, qb);
     else hipLaunchKernelGGL(k_pack_host<false>, grid, block, 0, stream, fb, o, SW, H, col_off, touched, seg_stride, qa, qb);
+}
+
+void hzk_tell(hipStream_t stream, hz_tell_t s)
+{
+    hipLaunchKernelGGL(k_tell, dim3(1), dim3(TELL_THREADS), 0, stream, s);
 }
 
 void hzk_pack(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, uint32_t* packed, int SW, int H, unsigned int* qa, unsigned int* qb)

@@ -15,6 +15,7 @@ void hzk_march(bool counters, bool hiz, bool vcache, dim3 grid, dim3 block, hipS
 void hzk_resolve(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, const float* tanel, unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24, int SW, int H, float znear, float zfar, unsigned int* qa, unsigned int* qb);
 void hzk_resolve4(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, const float* tanel, unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24, int SW, int H, float znear, float zfar, unsigned char* touched, int seg_stride, unsigned int* qa, unsigned int* qb, int yo0, int yo1, int nt);
 void hzk_pack_host(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, hz_hostpack_t o, int SW, int H, int col_off, unsigned char* touched, int seg_stride, unsigned int* qa, unsigned int* qb);
+void hzk_tell(hipStream_t stream, hz_tell_t s);
 void hzk_pack(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, uint32_t* packed, int SW, int H, unsigned int* qa, unsigned int* qb);
 void hzk_resolve_packed(dim3 grid, dim3 block, hipStream_t stream, const uint32_t* packed, int stride, int ncols, const float* tanel, unsigned char* bgr, float* ranges, int out_W, int out_col0, int H, float znear, float zfar);
 void hzk_pack_sparse(bool clear, dim3 grid, dim3 block, hipStream_t stream, unsigned long long* fb, uint32_t* out, int SW, int H, int mask_stride, unsigned char* touched, int seg_stride, unsigned int* qa, unsigned int* qb);

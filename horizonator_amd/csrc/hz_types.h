@@ -243,8 +243,22 @@ struct hz_hostpack_t
     unsigned int  capacity;         /* words                                                                   */
     unsigned int  chunk_words;      /* no blob straddles a multiple of this                                    */
     uint32_t      flags;            /* HZ_BLOB_*: the arrays a blob carries                                    */
+    unsigned int* present;          /* one bit per tile of the grid (tile = blockIdx.y*gridDim.x + blockIdx.x): a blob was sent for it; may be NULL */
 };
 #define HP_NONE 0xFFFFFFFFu
+
+/* ... and what k_tell (hz_k_tell.h) tells the host about that stream, in pinned host memory */
+struct hz_tell_t
+{
+    const unsigned int* cursor;         /* k_pack_host's cursor words: [0] words in use, [1] blobs, [2] overflow      */
+    const unsigned int* present;        /* the sector's tile bitmap in HBM, npresent words                            */
+    unsigned int*       h_info;         /* pinned: 4 words                                                            */
+    unsigned int*       h_present;      /* pinned: npresent words                                                     */
+    unsigned int        capacity;       /* words of the stream                                                        */
+    unsigned int        npresent;
+    unsigned int        epoch;          /* never 0                                                                    */
+};
+
 
 #define SP_WAVES  4                     /* rows per workgroup                            */
 #define SP_STEPS  8                     /* steps whose words stay in registers           */

@@ -3,7 +3,8 @@ including PCIe, next to the device-resident number bench.py reports.  Three call
 (standalone.c), one that gets fresh arrays from every call (the reference's Python wrapper, horizonator-pywrap.c:234-250:
 PyArray_SimpleNew per render - untouched pages), one that renders a series with two sets of buffers
 (horizonator_amd_render_begin / _end).  HZ_HOST_TIMES=1 adds each call's timeline on stderr; argv: configs, then
-sectors=N[,N...] for a sweep of hz_options_t::host_sectors."""
+sectors=N[,N...] for a sweep of hz_options_t::host_sectors, and any number of env=NAME=VALUE[,NAME=VALUE...]: the whole
+measurement once more in a context made with those variables set (the switches a context reads when it is made)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,10 +12,16 @@ import numpy as np
 import hzutil, horizonator_amd
 LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
 CONFIGS = (("cfg2", 1800, 8000, 2000), ("cfg3", 4200, 16000, 4000))
-names = [a for a in sys.argv[1:] if not a.startswith("sectors=")]
+names = [a for a in sys.argv[1:] if not a.startswith(("sectors=", "env="))]
 sweep = [int(x) for a in sys.argv[1:] if a.startswith("sectors=") for x in a[8:].split(",")] or [0]
-for name, R, W, H in [c for c in CONFIGS if not names or c[0] in names]:
-    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
+variants = [{}] + [dict(kv.split("=", 1) for kv in a[4:].split(",")) for a in sys.argv[1:] if a.startswith("env=")]
+for name, R, W, H, env in [c + (e,) for c in CONFIGS if not names or c[0] in names for e in variants]:
+    for k in set(k for e in variants for k in e): os.environ.pop(k, None)
+    os.environ.update(env)
+    dems = hzutil.dem_dir_for(LAT, LON, R)
+    t0 = time.perf_counter()
+    h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=dems, render_radius_cells=R)
+    print(f"{name} {env or ''}: horizonator_init {time.perf_counter() - t0:.3f} s", flush=True)
     h.set_view(-180, 180, zfar=600000.0)
     import torch
     d_img = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda:0"); d_rng = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
@@ -44,6 +51,7 @@ for name, R, W, H in [c for c in CONFIGS if not names or c[0] in names]:
         t3 = float(np.median(np.diff(marks[2:])))
         same = same and bool(np.array_equal(img, want_img) and np.array_equal(rng2, want_rng) and np.array_equal(img2, want_img) and np.array_equal(rng, want_rng))
         print(f"{name} [host_sectors={sectors or 'auto'} HZ_COPY_THREADS={os.environ.get('HZ_COPY_THREADS', 'default')} HZ_HOST_DENSE={os.environ.get('HZ_HOST_DENSE', '0')}] equals the device render: {same}")
+        print(f"{name}: calls in order, ms: " + " ".join(f"{x*1e3:.2f}" for x in ts))
         print(f"{name}: kept buffers {t*1e3:.2f} ms/call (min {min(ts[2:])*1e3:.2f}, max {max(ts[2:])*1e3:.2f}; {7*W*H/t/1e9:.1f} GB/s of results); fresh numpy arrays per call {t2*1e3:.2f} ms/call; "
               f"two in flight {t3*1e3:.2f} ms per panorama", flush=True)
         del img, rng, img2, rng2
