@@ -106,16 +106,25 @@ def test_host_ranges_are_the_reference_conversion_bit_for_bit():
         assert (raw[n:] == 123.0).all()
 
 
+def _aligned(shape, dtype):
+    """an array whose first byte lies on a 64-byte boundary (whole cache lines can be streamed into it)"""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.empty(n + 64, np.uint8)
+    off = (-raw.ctypes.data) % 64
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
 @pytest.mark.parametrize("full", [0, 1])
 @pytest.mark.parametrize("flags", [PACKED, PACKED | INDEX, RED, INDEX, RED | INDEX])
-@pytest.mark.parametrize("col0", [0, 1000])
+@pytest.mark.parametrize("col0", [0, 1000, 1024])
 def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0, full):
-    """col0: the blobs are those of an azimuth sector that starts at image column col0 (their x0 carries the offset);
+    """col0: the blobs are those of an azimuth sector that starts at image column col0 (their x0 carries the offset; 1024:
+    an image whose rows and tiles start on cache lines, as the benchmark's do - whole lines are streamed);
     full: the sky is NOT filled in beforehand where a blob lands - the blob writes the sky pixels of its tile itself"""
     lib = _lib()
     g = np.random.default_rng(flags)
     SW, H = 5000, 23                      # a last tile of 904 columns, a last blob of 3 rows
-    W = SW + col0 + 37
+    W = SW + col0 + 37 if col0 != 1024 else 6080
     znear, zfar = 100.0, 40000.0
     tanel = np.tan(np.linspace(-0.5, 0.5, H)).astype(np.float32)           # per GL row (row 0 = bottom)
     terrain = g.random((H, SW)) < 0.6
@@ -133,7 +142,7 @@ def test_blobs_land_where_the_dense_copy_would_put_them(flags, col0, full):
     want = {"bgr": np.zeros((H, W, 3), np.uint8), "ranges": np.where(full, place(rng, 0), np.float32(-1)).astype(np.float32),
             "index": np.where(full, place(idx, 0), -1).astype(np.int32), "z24": np.where(full, place(z24, 0), 0xFFFFFF).astype(np.uint32)}
     want["bgr"][..., 0] = np.where(full, 0, 255); want["bgr"][..., 2] = np.where(full, place(red, 0), 0)
-    got = {"bgr": np.empty((H, W, 3), np.uint8), "ranges": np.empty((H, W), np.float32), "index": np.empty((H, W), np.int32), "z24": np.empty((H, W), np.uint32)}
+    got = {"bgr": _aligned((H, W, 3), np.uint8), "ranges": _aligned((H, W), np.float32), "index": _aligned((H, W), np.int32), "z24": _aligned((H, W), np.uint32)}
     for kind, k in enumerate(("bgr", "ranges", "index", "z24")):
         lib.hz_sky_fill(got[k].ctypes.data, 0, got[k].nbytes, kind)
     if full_mode:
