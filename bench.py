@@ -771,7 +771,7 @@ def main():
                      "two_in_flight": "horizonator_amd_render_begin / _end with two sets of buffers: begin k+1, then end k - the device draws one "
                                       "panorama while the other crosses PCIe; median interval between ends over a series of %d" % nser,
                      "host_sectors": opts.get("host_sectors", 0) or ("auto: 4" if W * H >= 32e6 else "auto: 2" if W * H >= 12e6 else "auto: 1"),
-                     "copy_threads": int(os.environ.get("HZ_COPY_THREADS", 0)) or (min(24, (os.cpu_count() or 8) // 8) if (os.cpu_count() or 8) >= 32 else 4),
+                     "copy_threads": int(os.environ.get("HZ_COPY_THREADS", 0)) or (min(32, (os.cpu_count() or 8) // 8) if (os.cpu_count() or 8) >= 32 else 4),
                      "equals_device_render": same, "two_in_flight_equals_device_render": same_series}
         del himg2, hrng2, want_img, want_rng
         del himg, hrng

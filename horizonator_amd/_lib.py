@@ -204,7 +204,7 @@ def _open(path, selftest):
     sig("hz_hip_render_to_host", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_host_begin", i, vp, P(View), vp, vp, vp, vp, vp)
     sig("hz_hip_host_end", i, vp)
-    sig("hz_hip_host_prepare", i, vp, i, i, i, i)
+    sig("hz_hip_host_prepare", i, vp, i, i, i, i, vp)
     sig("hz_hip_read_depth", i, vp, i, i, P(C.c_uint32))
     sig("hz_hip_link_cells", i, vp, P(View), vp, vp, vp, vp, d, d, d, i, i, i, i, vp, vp)
     sig("hz_hip_poi_visibility", i, vp, P(View), vp, i, vp, i, vp, vp, vp)

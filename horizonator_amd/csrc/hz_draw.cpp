@@ -1010,6 +1010,7 @@ static int vertex_cache(hz_dev_t* d, hz_params_t& p)
 
 int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
 {
+    hz_stopwatch sw("HZ_DRAW_TIMES");
     hz_params_t p = hz_make_params(d, view);
     const bool prof = d->profiling != 0;
     d->last_view = *view; d->have_view = 1; d->fb_consumed = 0;
@@ -1041,7 +1042,9 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
             }
         }
     (void)hipGetLastError();                /* (hipErrorNotReady from a query is not an error) */
+    sw.lap("draw: params, adapt");
     if(next_framebuffer(d, p) != 0) return -1;
+    sw.lap("draw: next framebuffer");
     const int next = d->fbi;
     if(d->raster != HZ_RASTER_SCATTER && vertex_cache(d, p) != 0) return -1;
 
@@ -1122,8 +1125,10 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                 hz_list_items(p1, zn, a0, a1, *d->list_scratch);
                 if(upload_list(d, 0, d->nstream, *d->list_scratch) != 0) return -1;
             }
+            sw.lap("draw: first list");
             if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
             if(launch_march(d, d->nstream, qn, zn, p1, listed ? d->lists->d_items[0] : NULL, d->lists->n[0]) != 0) return -1;
+            sw.lap("draw: first march launched");
             {
                 /* (zoomed further than coarse depth asks for: a cell at the first round's reach still HZ_TILES_MIN_PX = 35 pixels wide - a 45
                  * degree view of 16000 columns: 40; a 90 degree view, 26, is better off with k_big: 0.92 against 1.08 ms) */
@@ -1133,6 +1138,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                 if(by_tile_first && tile_bins(d, HZ_NFB + next) != 0) by_tile_first = false;       /* (no memory for the bins: k_big) */
             }
             if(queue_kernels(d, qn, p1, d->nstream, HZ_NFB + next, by_tile_first, zoomed_view) != 0) return -1;
+            sw.lap("draw: first queue kernels");
             if(prof) HZ_CHECK(hipEventRecord(d->ev[6], d->nstream));
             /* The second round waits for the first - unless the chip is idle: a draw that
              * finds the marching kernel of the draw before it finished (a single render, or
@@ -1168,6 +1174,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                  * it: 0.91 -> 1.00 ms per render.  It stays here.) */
                 if(use_hiz && hiz_sweep(d, d->nstream, next, p, hz) != 0) return -1;
             }
+            sw.lap("draw: coarse depth");
             HZ_CHECK(hipEventRecord(d->ev_near, d->nstream));
             if(use_hiz || busy)
             {
@@ -1213,8 +1220,10 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
             if(upload_list(d, 1, d->stream, *d->list_scratch) != 0) return -1;
             d->lists->valid = 1;
         }
+        sw.lap("draw: second list");
         if(prof) HZ_CHECK(hipEventRecord(d->ev[9], d->stream));
         if(launch_march(d, d->stream, q, zn, p, listed ? d->lists->d_items[1] : NULL, d->lists->n[1]) != 0) return -1;
+        sw.lap("draw: second march launched");
     }
     if(prof) HZ_CHECK(hipEventRecord(d->ev[2], d->stream));
     /* the kernels that finish the draw run on qstream, so that the next draw's
@@ -1248,6 +1257,7 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
     d->last_plan[4] = p.vcache ? 1 : 0;
     HZ_CHECK(hipEventRecord(d->ev_drawn, d->qstream));
     d->have_times = prof ? 1 : 0;
+    sw.lap("draw: the rest");
     return 0;
 }
 

@@ -321,11 +321,6 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
     s->tanel = malloc((size_t)offscreen_height*sizeof(float));
     if(s->tanel == NULL) goto done;
 
-    /* what horizonator_render_offscreen() needs beyond the draw - host threads, the transfer stream, pinned memory for a
-     * panorama's terrain pixels - is made here, not inside the first call: the reference's CLI makes exactly one
-     * (reference standalone.c:433-460).  A failure is not fatal: the call then makes them itself, or takes the dense path. */
-    (void)hz_hip_host_prepare(s->dev, 1, 1, 0, 0);
-    init_lap(&lap, "host path prepared");
 
     /* reference horizonator-lib.c:203; the count overflows int for 11x11
      * SRTM1 mosaics, which the reference cannot load anyway: saturate */
@@ -370,6 +365,18 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
 
     if(!horizonator_pan_zoom(ctx, -45.f, 45.f)) goto done;                  /* reference :670 */
     init_lap(&lap, "texture, first view");
+    /* what horizonator_render_offscreen() needs beyond the draw - host threads, the copy streams, pinned memory for a
+     * panorama's terrain pixels - is made here, not inside the first call: the reference's CLI makes exactly one
+     * (reference standalone.c:433-460); and the device's share of such a call is run once, for the whole circle from
+     * here, and thrown away (HORIZONATOR_NO_WARMUP=1: not).  A failure is not fatal: the call then does it itself. */
+    if(!s->textured)
+    {
+        hz_view_t warm = s->view;
+        warm.az_deg0 = -180.f; warm.az_deg1 = 180.f;
+        const char* no = getenv("HORIZONATOR_NO_WARMUP");
+        (void)hz_hip_host_prepare(s->dev, 1, 1, 0, 0, (no != NULL && atoi(no) != 0) ? NULL : &warm);
+    }
+    init_lap(&lap, "host path prepared");
     result = true;
 
  done:

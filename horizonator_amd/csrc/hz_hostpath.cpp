@@ -126,9 +126,24 @@ static int make_hoststate(hz_hoststate* h)
     return 0;
 }
 
+/* the NUMA node the context's GPU hangs off (Linux sysfs through its PCI address), -1: unknown */
+static int gpu_numa_node(const hz_dev_t* d)
+{
+    char bdf[64] = "";
+    if(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), d->device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for(char* c = bdf; *c; c++) if(*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[160]; snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE* f = fopen(path, "r"); if(!f) return -1;
+    int node = -1;
+    if(fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 static int ensure_host(hz_dev_t* d)
 {
     if(d->host) return 0;
+    (void)copy_pool(gpu_numa_node(d));      /* (the process's pool is made by its first context: near that context's GPU) */
     hz_hoststate* h = new hz_hoststate();
     memset((void*)h, 0, sizeof(*h));
     d->host = h;
@@ -282,6 +297,72 @@ static uint32_t blob_flags(const void* bgr, const void* ranges, const void* inde
     return ((ranges || z24) ? HZ_BLOB_PACKED : bgr ? HZ_BLOB_RED : 0u) | (index ? HZ_BLOB_INDEX : 0u);
 }
 
+/* the device's share of a panorama into host memory: the draws (sector by sector), the conversions into streams of blobs,
+ * the words that tell the host about them - queued on the context's streams.  0, or -1 with the error text set. */
+static int queue_device_side(hz_dev_t* d, hz_hostjob& jb, const hz_view_t* view, bool draws, size_t ctl_words)
+{
+    const uint32_t flags = jb.flags;
+    const int H = d->H;
+    const bool prof = d->profiling != 0;
+    const int user_col0 = d->col0, user_col1 = d->col1;
+    int rc = 0;
+    hipError_t err = hipSuccess;
+    const char* what = "";
+    #define HZ_TRY(call) do { if(err == hipSuccess && rc == 0) { err = (call); if(err != hipSuccess) what = #call; } } while(0)
+    HZ_TRY(hipMemsetAsync(jb.d_ctl, 0, ctl_words*sizeof(unsigned int), d->rstream));
+    jb.clears = d->env.resolve_clears != 0;
+    for(int s=0; s<jb.nsec && rc == 0 && err == hipSuccess; s++)
+    {
+        if(draws)
+        {
+            d->col0 = jb.col[s]; d->col1 = jb.col[s+1];
+            d->vc.same_draw = s > 0;            /* (the sectors of a call are ONE draw from its viewpoint: hz_draw.cpp, vertex_cache) */
+            const int drawn = hz_draw_impl(d, view);
+            d->vc.same_draw = 0;
+            if(drawn != 0) { rc = -1; break; }
+        }
+        else if(hz_fb_refill(d) != 0) { rc = -1; break; }
+        if(hz_rstream_after_draw(d) != 0) { rc = -1; break; }
+        const int SW = d->col1 - d->col0;
+        if(prof && s == jb.nsec-1) HZ_TRY(hipEventRecord(d->ev[4], d->rstream));
+        hz_hostpack_t hp = { jb.d_hs + jb.off[s], jb.d_ctl + 4*s, (unsigned int)jb.cap[s], (unsigned int)(HZ_STAGE_BYTES/4), flags, jb.d_ctl + jb.pres0[s] };
+        const dim3 grid((unsigned)((SW + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), (unsigned)((H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS));
+        unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];
+        if(err == hipSuccess)
+        {
+            hzk_pack_host(jb.clears, grid, dim3(64*HZ_BLOB_ROWS), d->rstream, d->d_fb, hp, SW, H, d->col0 - jb.out_col0,
+                          d->d_touched[d->fbi], d->seg_stride, jb.clears ? qa : (unsigned int*)NULL, jb.clears ? qb : (unsigned int*)NULL);
+            HZ_TRY(hipGetLastError());
+        }
+        if(err == hipSuccess && jb.clears && hz_fb_mark_consumed(d) != 0) rc = -1;
+        if(prof && s == jb.nsec-1) { HZ_TRY(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
+        /* ... and the host is told: the stream's length, the tiles it holds blobs for */
+        if(err == hipSuccess && rc == 0)
+        {
+            hz_tell_t tl;
+            tl.cursor = jb.d_ctl + 4*s; tl.present = jb.d_ctl + jb.pres0[s];
+            tl.h_info = jb.h_ctl + 4*s; tl.h_present = jb.h_ctl + jb.pres0[s];
+            tl.capacity = (unsigned int)jb.cap[s]; tl.npresent = (unsigned int)jb.npres[s]; tl.epoch = jb.epoch;
+            hzk_tell(d->rstream, tl);
+            HZ_TRY(hipGetLastError());
+        }
+        jb.t_queued[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
+    }
+    HZ_TRY(hipEventRecord(jb.ev_told, d->rstream));
+    #undef HZ_TRY
+    d->col0 = user_col0; d->col1 = user_col1;
+    /* (a reader of the framebuffer after this call - pick, the annotator passes - wants the whole view: the last sector's
+     * framebuffer is not it) */
+    if(jb.nsec > 1) d->fb_consumed = 1;
+    if(err != hipSuccess)
+    {
+        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_begin: %s -> %s", what, hipGetErrorString(err));
+        fprintf(stderr, "hz_hip: %s\n", g_last_error);
+        rc = -1;
+    }
+    return rc;
+}
+
 /* Queues everything the device has to do for one panorama into host memory and starts the sky.  draws: the panorama is
  * drawn here, sector by sector (else: the conversion of the draw already queued, or made again if it was consumed).
  * Returns the job's number, -1 on an error, -2 if this panorama has to take the dense path (no room for the stream). */
@@ -289,6 +370,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
                       unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24)
 {
     hz_hoststate* h = d->host;
+    if(h->next_begin == h->next_end) h->next_begin = h->next_end = 0;      /* (nothing in flight: the first set of memory again, not the other one) */
     hz_hostjob& jb = h->job[h->next_begin % HZ_HOST_JOBS];
     if(jb.active) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_begin: %d panoramas are in flight already: end one first", HZ_HOST_JOBS); return -1; }
     const int H = d->H;
@@ -382,63 +464,7 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
     /* from here on the pool's tasks name the job and the caller's buffers: whatever fails below, hz_hip_host_end() (or
      * the caller of this function, on -1) has to wait for them */
 
-    const bool prof = d->profiling != 0;
-    const int user_col0 = d->col0, user_col1 = d->col1;
-    int rc = 0;
-    hipError_t err = hipSuccess;
-    const char* what = "";
-    #define HZ_TRY(call) do { if(err == hipSuccess && rc == 0) { err = (call); if(err != hipSuccess) what = #call; } } while(0)
-    HZ_TRY(hipMemsetAsync(jb.d_ctl, 0, ctl_words*sizeof(unsigned int), d->rstream));
-    jb.clears = d->env.resolve_clears != 0;
-    for(int s=0; s<jb.nsec && rc == 0 && err == hipSuccess; s++)
-    {
-        if(draws)
-        {
-            d->col0 = jb.col[s]; d->col1 = jb.col[s+1];
-            d->vc.same_draw = s > 0;            /* (the sectors of a call are ONE draw from its viewpoint: hz_draw.cpp, vertex_cache) */
-            const int drawn = hz_draw_impl(d, view);
-            d->vc.same_draw = 0;
-            if(drawn != 0) { rc = -1; break; }
-        }
-        else if(hz_fb_refill(d) != 0) { rc = -1; break; }
-        if(hz_rstream_after_draw(d) != 0) { rc = -1; break; }
-        const int SW = d->col1 - d->col0;
-        if(prof && s == jb.nsec-1) HZ_TRY(hipEventRecord(d->ev[4], d->rstream));
-        hz_hostpack_t hp = { jb.d_hs + jb.off[s], jb.d_ctl + 4*s, (unsigned int)jb.cap[s], (unsigned int)(HZ_STAGE_BYTES/4), flags, jb.d_ctl + jb.pres0[s] };
-        const dim3 grid((unsigned)((SW + HZ_BLOB_COLS-1)/HZ_BLOB_COLS), (unsigned)((H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS));
-        unsigned int* const qa = d->d_big_counters_s[d->fbi], * const qb = d->d_big_counters_s[HZ_NFB + d->fbi];
-        if(err == hipSuccess)
-        {
-            hzk_pack_host(jb.clears, grid, dim3(64*HZ_BLOB_ROWS), d->rstream, d->d_fb, hp, SW, H, d->col0 - jb.out_col0,
-                          d->d_touched[d->fbi], d->seg_stride, jb.clears ? qa : (unsigned int*)NULL, jb.clears ? qb : (unsigned int*)NULL);
-            HZ_TRY(hipGetLastError());
-        }
-        if(err == hipSuccess && jb.clears && hz_fb_mark_consumed(d) != 0) rc = -1;
-        if(prof && s == jb.nsec-1) { HZ_TRY(hipEventRecord(d->ev[5], d->rstream)); d->have_times = 2; }
-        /* ... and the host is told: the stream's length, the tiles it holds blobs for */
-        if(err == hipSuccess && rc == 0)
-        {
-            hz_tell_t tl;
-            tl.cursor = jb.d_ctl + 4*s; tl.present = jb.d_ctl + jb.pres0[s];
-            tl.h_info = jb.h_ctl + 4*s; tl.h_present = jb.h_ctl + jb.pres0[s];
-            tl.capacity = (unsigned int)jb.cap[s]; tl.npresent = (unsigned int)jb.npres[s]; tl.epoch = jb.epoch;
-            hzk_tell(d->rstream, tl);
-            HZ_TRY(hipGetLastError());
-        }
-        jb.t_queued[s] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jb.t_begin).count();
-    }
-    HZ_TRY(hipEventRecord(jb.ev_told, d->rstream));
-    #undef HZ_TRY
-    d->col0 = user_col0; d->col1 = user_col1;
-    /* (a reader of the framebuffer after this call - pick, the annotator passes - wants the whole view: the last sector's
-     * framebuffer is not it) */
-    if(jb.nsec > 1) d->fb_consumed = 1;
-    if(err != hipSuccess)
-    {
-        snprintf(g_last_error, sizeof(g_last_error), "hz_hip_host_begin: %s -> %s", what, hipGetErrorString(err));
-        fprintf(stderr, "hz_hip: %s\n", g_last_error);
-        rc = -1;
-    }
+    int rc = queue_device_side(d, jb, view, draws, ctl_words);
     if(rc != 0)
     {
         (void)hipStreamSynchronize(d->rstream);     /* (k_tell's already queued write this job's control words) */
@@ -657,17 +683,21 @@ static int host_end(hz_dev_t* d)
     return rc;
 }
 
-/* the pool, this context's streams and the memory of one panorama of the given outputs, ahead of the first call (the
- * library's horizonator_init does this: the reference's CLI makes ONE call per process, standalone.c:433-460) */
-extern "C" int hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, int want_index, int want_z24)
+/* The pool, this context's streams and the memory of one panorama of the given outputs, ahead of the first call (the
+ * library's horizonator_init does this: the reference's CLI makes ONE call per process, standalone.c:433-460).
+ * warm_view (may be NULL): the device's share of such a call is run once and thrown away - the first launch of a kernel,
+ * the first use of a stream or of the copy engine, the coarse-depth tables and work lists a draw allocates when it first
+ * wants them cost the first call 15-40 ms otherwise (profiles/r6_host_path.txt). */
+extern "C" int hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, int want_index, int want_z24, const hz_view_t* warm_view)
 {
     HZ_ON_DEVICE(d);
     if(ensure_host(d) != 0) return -1;
-    (void)copy_pool();
-    hz_hostjob& jb = d->host->job[d->host->next_begin % HZ_HOST_JOBS];
-    if(jb.active || d->env.host_dense || d->H > 65535) return 0;
+    hz_hoststate* h = d->host;
+    if(h->next_begin != h->next_end || d->env.host_dense || d->H > 65535) return 0;
+    h->next_begin = h->next_end = 0;
+    hz_hostjob& jb = h->job[0];
     const uint32_t flags = blob_flags(want_bgr ? d : NULL, want_ranges ? d : NULL, want_index ? d : NULL, want_z24 ? d : NULL);
-    if(!flags) return 0;
+    if(!flags || d->col0 != 0 || d->col1 != d->W) return 0;
     /* (the layout with the most sectors the automatic rule may choose: it needs the most room) */
     const double npix = (double)d->W*(double)d->H;
     int nsec = d->env.host_sectors > 0 ? d->env.host_sectors : npix >= 32.0e6 ? 4 : npix >= 12.0e6 ? 2 : 1;
@@ -676,7 +706,24 @@ extern "C" int hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, i
     size_t ctl_words = 0;
     const size_t need = lay_out(jb, d, nsec, flags, &ctl_words);
     for(int s=0; s<jb.nsec; s++) if(jb.cap[s] >= ((size_t)1 << 32)) return 0;
-    return job_memory(d, jb, need, ctl_words) == -1 ? -1 : 0;
+    if(job_memory(d, jb, need, ctl_words) != 0) return 0;      /* (no memory: the call itself will find out, and take the dense path) */
+    if(!warm_view) return 0;
+    jb.view = *warm_view; jb.flags = flags;
+    if(++h->epoch == 0) h->epoch = 1;
+    jb.epoch = h->epoch;
+    jb.t_begin = std::chrono::steady_clock::now();
+    int rc = queue_device_side(d, jb, warm_view, true, ctl_words);
+    (void)hipEventSynchronize(jb.ev_told);
+    /* the copy engine, once on each stream: the first words of the landing */
+    for(int k=0; k<HZ_COPY_STREAMS && rc == 0; k++)
+        if(hipMemcpyAsync(jb.h_land + 1024*k, jb.d_hs + 1024*k, 4096, hipMemcpyDeviceToHost, h->cstream[k]) != hipSuccess) rc = -1;
+    for(int k=0; k<HZ_COPY_STREAMS; k++) (void)hipStreamSynchronize(h->cstream[k]);
+    if(hz_sync_all(d) != hipSuccess) rc = -1;
+    (void)hipGetLastError();
+    d->have_view = 0;                           /* (nothing the caller asked for has been drawn) */
+    d->vc.state = 0;
+    d->adapt.have_view = 0;
+    return rc;
 }
 
 /* ------------------------------------------------------------------------ */

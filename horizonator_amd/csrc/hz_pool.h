@@ -57,7 +57,28 @@ struct hz_copy_pool
     bool stop = false;
     std::atomic<bool> populate_works{true};     /* does this kernel know MADV_POPULATE_WRITE?  Probed once, on a page of our own */
 
-    explicit hz_copy_pool(int n)
+    /* the CPUs of NUMA node `node` (Linux sysfs); false: no such node */
+    static bool cpus_of_node(int node, cpu_set_t* cpus)
+    {
+        char path[96]; snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = fopen(path, "r"); if(!f) return false;
+        char buf[4096]; const bool got = fgets(buf, sizeof(buf), f) != NULL; fclose(f);
+        if(!got) return false;
+        CPU_ZERO(cpus); int n = 0;
+        for(char* tok = strtok(buf, ",\n"); tok; tok = strtok(NULL, ",\n"))
+        {
+            int a, b;
+            if(sscanf(tok, "%d-%d", &a, &b) != 2) { if(sscanf(tok, "%d", &a) != 1) continue; b = a; }
+            for(int c=a; c<=b && c<CPU_SETSIZE; c++) { CPU_SET(c, cpus); n++; }
+        }
+        return n > 0;
+    }
+    /* n threads.  gpu_node: the NUMA node the context's GPU hangs off (-1: unknown).  The threads stay on ONE node - where
+     * they write the caller's pages (first touched by them, if the buffers are fresh), read the landing areas and meet in
+     * this pool's lock: with the threads wherever the scheduler put them on the box's two sockets a call took 3.7 ms,
+     * with the process on either node 3.3-3.4, a series with two in flight 3.7 against 3.1-3.3 (profiles/
+     * r6_host_path.txt).  HZ_COPY_NODE = gpu (default) | here (the node of the thread that makes the pool) | any | a number. */
+    hz_copy_pool(int n, int gpu_node)
     {
         /* (EINVAL on a private anonymous page = the flag is unknown to this kernel; any later failure is about
          * the caller's buffer - a pinned or device mapping, an unmapped range - and only skips that buffer) */
@@ -67,28 +88,22 @@ struct hz_copy_pool
             if(madvise(probe, 4096, MADV_POPULATE_WRITE) != 0) populate_works = false;
             munmap(probe, 4096);
         }
-        /* HZ_COPY_NODE=here (an experiment of round 5): the pool's threads stay on the NUMA node of the thread that made the
-         * pool - the caller's buffers were most likely first touched there */
         cpu_set_t node_cpus; bool pin = false;
         const char* where = getenv("HZ_COPY_NODE");
-        if(where && strcmp(where, "here") == 0)
+        if(!where) where = "gpu";
+        if(strcmp(where, "here") == 0)
         {
             const int cpu = sched_getcpu();
-            for(int node=0; node<16 && !pin; node++)
+            for(int node=0; node<64 && !pin; node++)
             {
-                char path[96]; snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
-                FILE* f = fopen(path, "r"); if(!f) break;
-                char buf[4096]; if(!fgets(buf, sizeof(buf), f)) { fclose(f); continue; } fclose(f);
-                CPU_ZERO(&node_cpus); bool mine = false;
-                for(char* tok = strtok(buf, ",\n"); tok; tok = strtok(NULL, ",\n"))
-                {
-                    int a, b;
-                    if(sscanf(tok, "%d-%d", &a, &b) != 2) { if(sscanf(tok, "%d", &a) != 1) continue; b = a; }
-                    for(int c=a; c<=b; c++) { CPU_SET(c, &node_cpus); if(c == cpu) mine = true; }
-                }
-                pin = mine;
+                if(!cpus_of_node(node, &node_cpus)) break;
+                pin = cpu >= 0 && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &node_cpus);
             }
         }
+        else if(strcmp(where, "gpu") == 0) pin = gpu_node >= 0 && cpus_of_node(gpu_node, &node_cpus);
+        else if(where[0] >= '0' && where[0] <= '9') pin = cpus_of_node(atoi(where), &node_cpus);
+        /* (a node with fewer CPUs than threads - a container's slice of the machine: the threads stay where they are) */
+        if(pin && CPU_COUNT(&node_cpus) < n) pin = false;
         for(int k=0; k<n; k++)
         {
             threads.emplace_back([this] { run(); });
@@ -216,7 +231,8 @@ struct hz_copy_pool
     }
 };
 
-static inline hz_copy_pool* copy_pool()
+/* gpu_node: see the constructor (used when this call makes the pool) */
+static inline hz_copy_pool* copy_pool(int gpu_node = -1)
 {
     /* one pool per process, created on first use, never torn down (its threads
      * sleep on a condition variable) */
@@ -225,16 +241,17 @@ static inline hz_copy_pool* copy_pool()
     std::lock_guard<std::mutex> g(m);
     if(!pool)
     {
-        /* 24: a 16000x4000 panorama into kept buffers takes 5.6 / 4.9 / 4.2 ms with 8 / 12 / 24 threads on the 2 x 64-core
-         * host of an 8-GPU node (round 4, profiles/r4_host_inclusive.txt); at most an eighth of the machine's hardware
-         * threads, so that eight processes, one per GPU, do not get in each other's way.  HZ_COPY_THREADS: the one switch
-         * that belongs to the process, not to a context. */
+        /* an eighth of the machine's hardware threads - eight processes, one per GPU, then do not get in each other's way -,
+         * at most 32: a 16000x4000 panorama into kept buffers took 5.6 / 4.9 / 4.2 ms with 8 / 12 / 24 threads in round 4, and
+         * on the 2 x 64-core host of round 6 (three alternating runs each, threads on the GPU's NUMA node: a call / a series
+         * with two in flight) 3.6 / 3.0 ms with 24, 3.4 / 2.8 with 32; 48 and more lose again (profiles/r6_host_path.txt).
+         * HZ_COPY_THREADS: the one switch that belongs to the process, not to a context. */
         const unsigned hw = std::thread::hardware_concurrency();
-        int n = hw >= 32 ? (int)(hw/8 < 24 ? hw/8 : 24) : 4;
+        int n = hw >= 32 ? (int)(hw/8 < 32 ? hw/8 : 32) : 4;
         const char* e = getenv("HZ_COPY_THREADS");
         if(e && atoi(e) > 0) n = atoi(e);
         if(hw && (unsigned)n > hw) n = (int)hw;
-        pool = new hz_copy_pool(n);
+        pool = new hz_copy_pool(n, gpu_node);
     }
     return pool;
 }

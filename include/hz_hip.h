@@ -169,10 +169,12 @@ int  hz_hip_render_to_host(hz_dev_t* d, const hz_view_t* view, const float* tane
 int  hz_hip_host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel,
                        unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24);
 int  hz_hip_host_end(hz_dev_t* d);
-/* What the first of those calls would otherwise set up - the pool of host threads, the transfer stream, the pinned
+/* What the first of those calls would otherwise set up - the pool of host threads, the copy streams, the pinned
  * memory a panorama with these outputs lands in - ahead of it (horizonator_init does this: the reference's CLI makes
- * ONE render call per process, reference standalone.c:433-460). */
-int  hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, int want_index, int want_z24);
+ * ONE render call per process, reference standalone.c:433-460).  warm_view != NULL: the device's share of such a call
+ * (draws, conversion, the words that tell the host) is run once for that view and thrown away, so that the first real
+ * call finds every kernel loaded and every table and list allocated. */
+int  hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, int want_index, int want_z24, const hz_view_t* warm_view);
 
 /* 24-bit depth of image pixel (x, y), y = 0 top row, from the last draw
  * (reference horizonator-lib.c:1268-1270) */
