@@ -33,6 +33,10 @@ def run(root, env):
             out["render of a series, ms"] = round(d["ms_per_step"], 4)
             if "same_viewpoint" in d:
                 out["the same view again, ms"] = round(d["same_viewpoint"]["ms_per_step"], 4)
+            if "zfar_40km" in d:
+                out["far clip 40 km, ms"] = round(d["zfar_40km"]["ms_per_step"], 4)
+            if "single_panorama_latency_ms" in d:
+                out["one panorama waited for, ms"] = round(d["single_panorama_latency_ms"]["value"], 4)
     return out
 
 
