@@ -328,43 +328,6 @@ extern "C" int hz_hip_download_mosaic(hz_dev_t* d, int16_t* mosaic)
 }
 
 
-extern "C" int hz_hip_ingest_tiles(hz_dev_t* d, const unsigned char* const* tiles,
-                                   int ntx, int nty, int cpd, int oc_x, int oc_y)
-{
-    HZ_ON_DEVICE(d);
-    const int nt = ntx*nty;
-    const size_t tile_bytes = (size_t)(cpd+1)*(cpd+1)*2;
-    unsigned char** h_ptrs = (unsigned char**)calloc(nt, sizeof(*h_ptrs));
-    unsigned char** d_ptrs = NULL;
-    int rc = -1;
-    if(!h_ptrs) return -1;
-    if(hz_sync_all(d) != hipSuccess) { free(h_ptrs); return -1; }      /* draws in flight still read the old mosaic */
-    do {
-        bool ok = true;
-        for(int k=0; k<nt && ok; k++)
-        {
-            if(tiles[k] == NULL) continue;
-            if(hipMalloc(&h_ptrs[k], tile_bytes) != hipSuccess) { ok = false; break; }
-            if(hipMemcpyAsync(h_ptrs[k], tiles[k], tile_bytes, hipMemcpyHostToDevice, d->stream) != hipSuccess) ok = false;
-        }
-        if(!ok) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip_ingest_tiles: tile upload failed"); break; }
-        if(hipMalloc(&d_ptrs, nt*sizeof(*d_ptrs)) != hipSuccess) break;
-        if(hipMemcpyAsync(d_ptrs, h_ptrs, nt*sizeof(*d_ptrs), hipMemcpyHostToDevice, d->stream) != hipSuccess) break;
-        dim3 grid((d->N + 255)/256, d->N);
-        hzk_ingest(grid, dim3(256), d->stream, (const unsigned char* const*)d_ptrs, d->d_mosaic, d->N, ntx, nty, cpd, oc_x, oc_y);
-        if(hipGetLastError() != hipSuccess) break;
-        if(hipStreamSynchronize(d->stream) != hipSuccess) break;
-        d->adapt.have_view = 0;         /* (as hz_hip_upload_mosaic: what was observed, and cached, was the old terrain's) */
-        d->vc.state = 0;
-        rc = 0;
-    } while(0);
-    (void)hipStreamSynchronize(d->stream);
-    for(int k=0; k<nt; k++) if(h_ptrs[k]) (void)hipFree(h_ptrs[k]);
-    if(d_ptrs) (void)hipFree(d_ptrs);
-    free(h_ptrs);
-    return rc;
-}
-
 extern "C" int hz_hip_set_sector(hz_dev_t* d, int col0, int col1)
 {
     if(col0 < 0 || col1 > d->W || col0 >= col1)

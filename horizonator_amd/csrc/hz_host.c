@@ -281,10 +281,15 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
         goto done;
     }
 
-    /* DEM -> HBM.  Default: decode on the host into one row-major int16
-     * mosaic and upload it.  HORIZONATOR_INGEST=device uploads the raw tiles
-     * and decodes them in a kernel. */
+    /* (the pinned memory a panorama's terrain pixels will land in, made now: the tiles travel through it first) */
+    (void)hz_hip_host_prepare(s->dev, 1, 1, 0, 0, NULL);
+    init_lap(&lap, "host path: threads, pinned memory");
+
+    /* DEM -> HBM.  Default (round 6): the tiles' raw bytes go to the device through pinned memory and a kernel decodes
+     * them (hz_ingest.cpp).  HORIZONATOR_INGEST=host: decoded on the host into one row-major int16 mosaic, which is
+     * uploaded (round 1's way; also what happens if the device's way fails). */
     const char* ingest = getenv("HORIZONATOR_INGEST");
+    bool in_hbm = false;
     if(given_mosaic != NULL)
     {
         if(0 != hz_hip_upload_mosaic(s->dev, given_mosaic))
@@ -292,19 +297,17 @@ static bool init_device_side(horizonator_context_t* ctx, hz_state_t* s, int slot
             MSG("Mosaic upload failed: %s", hz_hip_last_error());
             goto done;
         }
+        in_hbm = true;
     }
-    else if(ingest != NULL && strcmp(ingest, "device") == 0)
+    else if(ingest == NULL || strcmp(ingest, "host") != 0)
     {
-        if(0 != hz_hip_ingest_tiles(s->dev, (const unsigned char* const*)s->tiles.tile,
-                                    s->tiles.win.ntiles[0], s->tiles.win.ntiles[1],
-                                    s->tiles.win.cells_per_deg,
-                                    s->tiles.win.origin_cell[0], s->tiles.win.origin_cell[1]))
-        {
-            MSG("Device-side DEM ingest failed: %s", hz_hip_last_error());
-            goto done;
-        }
+        in_hbm = 0 == hz_hip_ingest_tiles(s->dev, (const unsigned char* const*)s->tiles.tile,
+                                          s->tiles.win.ntiles[0], s->tiles.win.ntiles[1],
+                                          s->tiles.win.cells_per_deg,
+                                          s->tiles.win.origin_cell[0], s->tiles.win.origin_cell[1]);
+        if(!in_hbm) MSG("Device-side DEM ingest failed (%s): decoding on the host", hz_hip_last_error());
     }
-    else
+    if(!in_hbm)
     {
         mosaic = malloc((size_t)N*N*sizeof(int16_t));
         if(mosaic == NULL) { MSG("out of memory for a %dx%d mosaic", N, N); goto done; }

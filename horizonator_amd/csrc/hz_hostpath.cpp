@@ -166,6 +166,16 @@ static int ensure_ring(hz_dev_t* d)
 
 static int host_end(hz_dev_t* d);
 
+/* the landing area of the first job as pinned scratch memory for whoever needs some while no panorama is in flight
+ * (hz_ingest.cpp stages the DEM's tiles through it) */
+void hz_hostpath_landing(hz_dev_t* d, unsigned char** pinned, size_t* bytes)
+{
+    *pinned = NULL; *bytes = 0;
+    hz_hoststate* h = d->host;
+    if(!h || h->next_begin != h->next_end || !h->job[0].h_land) return;
+    *pinned = (unsigned char*)h->job[0].h_land; *bytes = h->job[0].land_capacity*sizeof(uint32_t);
+}
+
 void hz_hostpath_destroy(hz_dev_t* d)
 {
     hz_hoststate* h = d->host;
