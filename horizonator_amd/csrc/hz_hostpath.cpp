@@ -426,23 +426,26 @@ static int host_begin(hz_dev_t* d, const hz_view_t* view, const float* tanel, bo
         const uintptr_t huge = (uintptr_t)2 << 20, lo = ((uintptr_t)bufs[k].p + huge-1) & ~(huge-1), hi = ((uintptr_t)bufs[k].p + (size_t)jb.out_w*H*bufs[k].px_bytes) & ~(huge-1);
         if(hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
     }
-    /* How much of the image gets its sky beforehand.  Filling (448 MB in ~1.05 ms with this pool: tools/hostfill_bench.c) and
-     * scattering get in each other's way when they run at the same time - side by side they take 4 ms where one after the
-     * other they take 2.4 (tools/scatter_bench.c, profiles/r5_host_microbenchmarks.txt) - so only as much of the image is
-     * filled beforehand as there is time for until the first sector's blobs arrive: all of it for a call in one sector (the
-     * draw takes longer than the fill), the upper 60 % for 2 sectors, 30 % for more - sky for the most part -, and
-     * nothing when another panorama is in flight (its blobs are arriving now).  Below that row a blob writes the sky
-     * pixels of its own tile (hz_blob_scatter_mode: every byte once), and the tiles without a blob are filled as soon as
-     * their sector's bitmap has arrived.  HZ_HOST_PREFILL=percent overrides. */
+    /* How much of the image gets its sky beforehand.  Filling (448 MB in ~1.05 ms: tools/hostfill_bench.c) and scattering get
+     * in each other's way when they run at the same time - side by side they take 4 ms where one after the other they take
+     * 2.4 (tools/scatter_bench.c, profiles/r5_host_microbenchmarks.txt) - so only as much of the image is filled beforehand as
+     * there is time for until the first sector's blobs arrive; below that row a blob writes the sky pixels of its own tile
+     * (hz_blob_scatter_mode: every byte once), and the tiles without a blob are filled as soon as their sector's bitmap
+     * has arrived.  All of it for a call in one sector (the draw takes longer than the fill), the upper 60 % otherwise -
+     * sky for the most part - and 30 % when another panorama is in flight (its blobs are arriving now).  Round 6 swept
+     * both again, three alternating runs each (profiles/r6_host_path.txt): 30 / 45 / 60 / 75 / 100 % for a call 3.35 / 3.33 /
+     * 3.16 / 3.31 / 3.28 ms, 0 / 30 / 45 / 60 / 100 % for a series 2.73 / 2.56 / 2.64 / 2.75 / 2.58 ms per panorama - the
+     * box's run-to-run spread is as large.  HZ_HOST_PREFILL / HZ_HOST_PREFILL_SERIES = percent override. */
     {
-        int percent = jb.nsec <= 1 ? 100 : jb.nsec == 2 ? 60 : 30;     /* (4 sectors of 16000 x 4000: 3.36 ms with 45 %, 3.25 with 60, 3.15 with 30) */
-        if(another) percent = 0;
-        const char* e = getenv("HZ_HOST_PREFILL");
+        int percent = jb.nsec <= 1 ? 100 : 60;
+        if(another) percent = 30;
+        const char* e = getenv(another ? "HZ_HOST_PREFILL_SERIES" : "HZ_HOST_PREFILL");
         if(e && atoi(e) >= 0 && atoi(e) <= 100) percent = atoi(e);
         sc.y_pre = (int)((long long)H*percent/100) / HZ_BLOB_ROWS * HZ_BLOB_ROWS;
         if(percent >= 100) sc.y_pre = (H + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
     }
-    const int widest = jb.col[1] - jb.col[0];
+    int widest = 1;
+    for(int s=0; s<jb.nsec; s++) if(jb.col[s+1] - jb.col[s] > widest) widest = jb.col[s+1] - jb.col[s];
     sc.band_rows = (int)(((size_t)2 << 20)/((size_t)widest*4) + 1);
     if(sc.band_rows < HZ_BLOB_ROWS) sc.band_rows = HZ_BLOB_ROWS;
     sc.band_rows = (sc.band_rows + HZ_BLOB_ROWS-1)/HZ_BLOB_ROWS*HZ_BLOB_ROWS;
