@@ -466,7 +466,26 @@ mr_zones_t hz_make_zones(const hz_params_t& p, bool near_first)
      * round is what a series at 40 km waits for); the whole panorama at 600 km with 2: 0.829 -> 0.850. */
     const float cells_to_zfar = sqrtf(p.far_dd)/(p.u.deg_per_cell*111194.9f);
     const int z4 = cells_to_zfar <= 0.25f*ppr ? 2 : 4;
-    const int rows[MR_NZONES] = { far_rows, z16, z4, 2, z4, z16, far_rows };
+    int rows[MR_NZONES] = { far_rows, z16, z4, 2, z4, z16, far_rows };
+    /* Small draws (round 6).  The chip runs 4096 marching waves at a time; a whole image over a small mosaic has too few of them
+     * for their lengths to average out - BASELINE's configs[1] (3x3 tiles, 8000 x 2000): 20.6 K waves, 125 us of work per slot,
+     * a kernel of 216 us that ends on the far zones' 32-row waves; configs[0] (2000 x 500): 2 K waves, the kernel as long as
+     * its longest.  Fewer than 32 K waves: the far zones in 16 rows, the next in 8, two rows to a wave next to the viewer -
+     * configs[0] 0.106 -> 0.069 ms per render of a series, 3x3 tiles at 4000 x 1000 0.200 -> 0.188, configs[1] 0.257 -> 0.249
+     * (two alternating sweeps over seven settings: profiles/r6_small_images.txt).  Sectors keep their own rules above. */
+    if(p.SW == p.W)
+    {
+        long waves = 0;
+        for(int k=0; k<MR_NZONES; k++) waves += (z.row0[k+1] - z.row0[k] + rows[k]-1)/rows[k];
+        waves *= (p.N-1 + MR_COLS-1)/MR_COLS;
+        if(waves < 32768) { rows[0] = rows[6] = rows[0] < 16 ? rows[0] : 16; rows[1] = rows[5] = rows[1] < 8 ? rows[1] : 8; rows[2] = rows[4] = 2; }
+    }
+    {
+        /* HZ_ZONE_ROWS=far,z16,z4: an experiment's override */
+        static const char* e = getenv("HZ_ZONE_ROWS");
+        int a = 0, b = 0, c = 0;
+        if(e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { rows[0] = rows[6] = a; rows[1] = rows[5] = b; rows[2] = rows[4] = c; }
+    }
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
      * early and the kernel ends on short ones.  With the early depth test

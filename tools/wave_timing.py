@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import hzutil, horizonator_amd
 LAT, LON = hzutil.VIEW_LAT, hzutil.VIEW_LON
-R, W, H = 4200, 16000, 4000
+R, W, H = [int(x) for x in os.environ.get("HZ_WT_CFG", "4200,16000,4000").split(",")]     # (cfg2: 1800,8000,2000; cfg1: 600,2000,500)
 h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=hzutil.dem_dir_for(LAT, LON, R), render_radius_cells=R)
 ZFAR = float(os.environ.get("HZ_WT_ZFAR", "600000"))
 AZ = [float(x) for x in os.environ.get("HZ_WT_AZ", "-180,180").split(",")]
@@ -42,7 +42,9 @@ if os.environ.get("HZ_WT_SAVE"):                    # the raw counters, for tool
 busy = t > 3.0
 print("waves longer than 3 us: %d, their sum %.1f ms; the others: sum %.1f ms, median %.2f us" % (busy.sum(), t[busy].sum()/1e3, t[~busy].sum()/1e3, np.median(t[~busy]) if (~busy).any() else 0))
 q = np.percentile(t, [50, 90, 99, 99.9, 100])
-print("wave duration us: p50 %.1f p90 %.1f p99 %.1f p99.9 %.1f max %.1f; sum %.1f ms" % (*q, t.sum()/1e3))
+print("wave duration us: p50 %.1f p90 %.1f p99 %.1f p99.9 %.1f max %.1f; sum %.1f ms = %.1f us on each of 4096 slots" % (*q, t.sum()/1e3, t.sum()/4096))
+for y in range(0, gy, max(1, gy//24)):
+    print("   seg %4d: waves' us median %.1f max %.1f sum %.0f" % (y, np.median(t[y]), t[y].max(), t[y].sum()))
 print("totals: flushes %d tris %d big %d mid %d inline items %d hidden by early-Z %d" % (flushes.sum(), tris.sum(), big.sum(), mid.sum(), items.sum(), hidden.sum()))
 j, i = np.unravel_index(np.argsort(t.ravel())[-12:], t.shape)
 for y, x in zip(j[::-1], i[::-1]):
