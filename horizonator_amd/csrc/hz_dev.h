@@ -1,7 +1,8 @@
-/* hz_dev.h - the context (hz_dev) and what the host translation units of the HIP side share: hz_draw.cpp (contexts, streams,
- * the plan of a draw, conversions into device memory, the C-ABI of include/hz_hip.h), hz_hostpath.cpp (results into the
- * caller's host memory) and the diagnostics of libhorizonator_selftest.so.  Host code only - plain C++ over the HIP runtime
- * API; the kernels are reached through hz_launch.h. */
+/* hz_dev.h - the context (hz_dev) and what the host translation units of the HIP side share: hz_context.cpp (contexts,
+ * streams, memory, options), hz_plan.cpp (the plan of a draw: zones, rounds, work lists - host arithmetic only), hz_draw.cpp
+ * (a draw), hz_convert.cpp (conversions into device memory, strips, pick and the annotator passes), hz_hostpath.cpp (results
+ * into the caller's host memory), hz_ingest.cpp (the DEM's tiles) and the diagnostics of libhorizonator_selftest.so.
+ * Host code only - plain C++ over the HIP runtime API; the kernels are reached through hz_launch.h. */
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -10,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <vector>
 
@@ -20,7 +22,7 @@
 /* ------------------------------------------------------------------------ */
 /* errors                                                                    */
 
-extern thread_local char hz_g_last_error[512];    /* per thread: contexts may live on different threads (defined in hz_draw.cpp) */
+extern thread_local char hz_g_last_error[512];    /* per thread: contexts may live on different threads (defined in hz_context.cpp) */
 #define g_last_error hz_g_last_error
 
 #define HZ_CHECK(call)                                                        \
@@ -193,8 +195,34 @@ struct hz_dev
     hz_times_t times;
 };
 
-/* ---- hz_draw.cpp, for the other host translation units ---------------------------------------------------------- */
+/* ---- constants, diagnostics ----------------------------------------------------------------------------------------- */
+/* constants that used to be switches (each was swept: DESIGN.md section 4, docs/history/) */
+#define HZ_NEAR_PX            20.0f     /* the first round takes the strips whose cells are wider than this many pixels */
+#define HZ_TWO_ROUNDS_MIN_PIX 6.0e6     /* two rounds from this many pixels on */
+#define HZ_TILES_MIN_PX       35.0f     /* from this width of a cell at the first round's reach on, that round's large triangles go by screen tile */
+#define HZ_HIZ_MIN_PX         25.0f     /* "zoomed" = a cell at the first round's reach is at least this wide */
+
+
+
+/* HZ_INIT_TIMES=1: what a context's set-up is made of, on stderr (tools/init_times.py) */
+struct hz_stopwatch
+{
+    bool on; timespec t0;
+    explicit hz_stopwatch(const char* var) : on(getenv(var) && atoi(getenv(var)) != 0) { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    void lap(const char* what)
+    {
+        if(!on) return;
+        timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "hz_hip init: %-34s %8.2f ms\n", what, 1e3*(double)(t1.tv_sec - t0.tv_sec) + 1e-6*(double)(t1.tv_nsec - t0.tv_nsec));
+        t0 = t1;
+    }
+};
+
+
+/* ---- hz_context.cpp, hz_plan.cpp, hz_draw.cpp, hz_convert.cpp, for the other host translation units ---------------------------------------------------------- */
 hz_options_t hz_options_from_env(void);
+mr_queue_t   hz_queue_set(const hz_dev_t* d, int k);
+int          hz_tile_bins(hz_dev_t* d, int set);             /* the tile bins of a queue set, made on first use; 1: no memory for them */
 hipError_t   hz_sync_all(hz_dev_t* d);                          /* everything queued on any of the context's streams is done */
 hz_params_t  hz_make_params(const hz_dev_t* d, const hz_view_t* v);
 int          hz_plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_t& p);

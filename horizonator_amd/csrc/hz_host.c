@@ -48,7 +48,7 @@ typedef struct
     float        tanel_az0, tanel_az1;
 } hz_state_t;
 
-/* HZ_INIT_TIMES=1: what horizonator_init() is made of, on stderr (the device side's share: hz_draw.cpp) */
+/* HZ_INIT_TIMES=1: what horizonator_init() is made of, on stderr (the device side's share: hz_context.cpp) */
 static double init_lap(double* since, const char* what)
 {
     struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);

@@ -310,7 +310,7 @@ void k_big(unsigned long long* __restrict__ fb,
      * operation behind each, 660 -> 750 us for the first round's launch beside a marching kernel.) */
     __shared__ uint32_t s_start[256/64][64];
     __shared__ int32_t  s_delta[256/64][64];
-    /* (report: pinned host memory - what this round queued, for the host's choice of the next first round's reach: hz_kernels.hip, adapt) */
+    /* (report: pinned host memory - what this round queued, for the host's choice of the next first round's reach: hz_draw.cpp, adapt) */
     if(report && blockIdx.x == 0 && threadIdx.x == 0) { unsigned int records, items; hz_queue_totals(big_counters, &records, &items); report[0] = records; report[1] = items; }
     const int wv = threadIdx.x >> 6;
     s_start[wv][threadIdx.x & 63] = 0u;

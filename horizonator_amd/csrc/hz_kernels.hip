@@ -1,5 +1,5 @@
-/* hz_kernels.hip - the DEM -> panorama render path as HIP kernels for gfx950,
- * and the C-ABI (include/hz_hip.h) through which the C host drives them.
+/* hz_kernels.hip - the DEM -> panorama render path as HIP kernels for gfx950, and one launcher per kernel (hz_launch.h)
+ * through which the host code (hz_context / hz_draw / hz_convert / hz_hostpath / hz_ingest .cpp, compiled by g++) reaches them.
  *
  * What runs here is what the reference hands to OpenGL:
  *   vertex.glsl:111-162     per-vertex transform            -> hz_transform()
@@ -18,9 +18,9 @@
  * One translation unit: the device code lives in hz_k_common.h (parameters,
  * records, helpers, k_clip), hz_k_hiz.h (coarse depth for zoomed views),
  * hz_k_scatter.h (k_scatter, k_big), hz_k_tile.h (the tile-binned option),
- * hz_k_march.h (k_march, k_mid), hz_k_resolve.h (conversions, strips),
- * hz_k_tex.h (textured resolve); this file holds the context (hz_dev), the
- * streams and the C-ABI.
+ * hz_k_march.h (k_march, k_mid), hz_k_resolve.h (conversions, strips, blobs for host memory),
+ * hz_k_tell.h (what the host is told about those blobs), hz_k_tex.h (textured resolve); this file
+ * holds k_ingest, k_polar_fill, the annotator's kernels and the launchers.
  */
 #include <hip/hip_runtime.h>
 

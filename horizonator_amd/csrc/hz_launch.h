@@ -1,5 +1,5 @@
-/* hz_launch.h - the thin launchers between the host code (hz_draw.cpp, hz_hostpath.cpp: plain C++ over the HIP runtime
- * API, compiled by g++) and the kernels (hz_kernels.hip, compiled by hipcc): one function per kernel, the kernel's own
+/* hz_launch.h - the thin launchers between the host code (hz_context / hz_draw / hz_convert / hz_hostpath / hz_ingest .cpp:
+ * plain C++ over the HIP runtime API, compiled by g++) and the kernels (hz_kernels.hip, compiled by hipcc): one function per kernel, the kernel's own
  * parameters behind grid, block and stream; template parameters of a kernel are leading bools.  Errors are the caller's
  * to collect (hipGetLastError). */
 #pragma once

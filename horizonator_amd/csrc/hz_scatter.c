@@ -4,7 +4,7 @@
  * glReadPixels into the caller's buffers, the clear colour and the cleared depth where nothing was drawn,
  * :185, :1016).  In a panorama most pixels are exactly that - sky: BGR (255,0,0), range -1 - and a sky pixel
  * carries no information.  The device therefore sends only the terrain pixels, as "blobs" (k_pack_host,
- * hz_k_resolve.h; layout below), and the host threads of hz_kernels.hip's pool
+ * hz_k_resolve.h; layout below), and the host threads of hz_pool.h
  *   - fill the caller's buffers with the sky's constants while the draw is still running (hz_sky_fill), and
  *   - put each blob's terrain pixels in their places as its bytes arrive (hz_blob_scatter):
  * the same bytes in the caller's buffers as the dense copy, a third to a fifth of the bytes over PCIe.

@@ -1,4 +1,4 @@
-/* hz_types.h - what the kernels (hz_kernels.hip and its hz_k_*.h) and the host code that launches them (hz_draw.cpp,
+/* hz_types.h - what the kernels (hz_kernels.hip and its hz_k_*.h) and the host code that launches them (hz_draw.cpp, hz_convert.cpp,
  * hz_hostpath.cpp) share: kernel parameters, the records and queues between the kernels of a draw, the constants both
  * sides derive launch grids and buffer sizes from.  Plain data and host+device helpers only; no device code. */
 #pragma once
@@ -146,7 +146,7 @@ struct mr_queue_t
  * (profiles/r4_tile_batches.txt) - but it is two of the seven that gain (summit, valley: 0.3-0.4 ms each) and five
  * that lose 0.1.  So views that are still "zoomed" at 512 cells (a cell there HZ_HIZ_MIN_PX pixels wide: up to 70
  * degrees at 16000 columns) MAY reach that far: they do when the draws of the same view before them say it pays
- * (hz_kernels.hip, adapt: what the second round had to queue), the others and every first draw of a view 384. */
+ * (hz_draw.cpp, adapt: what the second round had to queue), the others and every first draw of a view 384. */
 #define HZ_NEAR_CELLS_WIDE 384
 #define HZ_NEAR_CELLS_MAX  512
 

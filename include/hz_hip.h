@@ -291,7 +291,7 @@ int   hz_hip_wait_for(hz_dev_t* d, void* stream);
  * reach in cells, out[3] only the strips behind the drawn columns were launched, out[4] its vertices came from the
  * vertex cache (hz_options_t::vertex_cache).  out: room for 5 ints. */
 int  hz_hip_last_plan(hz_dev_t* d, int* out);
-/* What the first round's reach of zoomed views goes by (hz_kernels.hip, adapt): the latest second round whose queue
+/* What the first round's reach of zoomed views goes by (hz_draw.cpp, adapt): the latest second round whose queue
  * counters have reached the host - out[0] the reach of that draw's first round in cells, out[1] / out[2] the records and
  * work items its second round queued for k_big, out[3] 1 = the next zoomed draw takes the long reach */
 int  hz_hip_last_queue_counts(hz_dev_t* d, unsigned int* out);
