@@ -121,7 +121,7 @@ extern "C" void hz_hip_destroy(hz_dev_t* d)
                 if(wl.ev_copied[k][t]) (void)hipEventDestroy(wl.ev_copied[k][t]);
             }
         }
-    delete d->list_scratch;
+    delete d->list_scratch; delete d->list_scratch2;
     (void)hipFree(d->d_texels);
     (void)hipFree(d->d_tanel);
     free(d->h_tanel);
@@ -189,6 +189,7 @@ static int create_impl(hz_dev_t* d)
     d->exp = experiments_from_env();
 #endif
     d->list_scratch = new std::vector<uint32_t>();
+    d->list_scratch2 = new std::vector<uint32_t>();
     d->lists = &d->list_cache[0];
     HZ_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     if(d->env.serial) d->rstream = d->stream;

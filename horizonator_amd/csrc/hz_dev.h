@@ -103,6 +103,7 @@ struct hz_dev
     hz_worklists_t* lists;              /* the entry of the current draw (never NULL) */
     unsigned int lists_clock;
     std::vector<uint32_t>* list_scratch;
+    std::vector<uint32_t>* list_scratch2;       /* (the second round's items, built in the same walk as the first's) */
     /* diagnostics (hz_hip_debug_wave_timing): where the next draw's marching waves leave their counters */
     struct { unsigned long long* d_cycles; size_t capacity; unsigned int grid_x, grid_y; } wave_timing;
 
@@ -229,6 +230,8 @@ int          hz_plan_rounds(const hz_dev_t* d, const hz_view_t* view, hz_params_
 mr_zones_t   hz_make_zones(const hz_params_t& p, bool near_first);
 bool         hz_azimuths_of_columns(const hz_params_t& p, double* a0, double* a1);
 void         hz_list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, double a1, std::vector<uint32_t>& out, bool every_strip = false);
+void         hz_list_rounds(const hz_params_t& p, const mr_zones_t& zn, double a0, double a1, bool one_round,
+                            std::vector<uint32_t>* first, std::vector<uint32_t>& second, bool every_strip = false);
 int          hz_draw_impl(hz_dev_t* d, const hz_view_t* view);
 int          hz_fb_refill(hz_dev_t* d);                         /* a reader finds the framebuffer consumed: the draw is repeated */
 int          hz_fb_mark_consumed(hz_dev_t* d);                  /* the conversion just queued on rstream left the framebuffer all ones */

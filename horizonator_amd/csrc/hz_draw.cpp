@@ -384,7 +384,8 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
             p1.pass = 1; p1.early_z = 0;
             if(fresh_lists)
             {
-                hz_list_items(p1, zn, a0, a1, *d->list_scratch);
+                /* (both rounds' lists in one walk over the segments: hz_plan.cpp) */
+                hz_list_rounds(p1, zn, a0, a1, false, d->list_scratch, *d->list_scratch2);
                 if(upload_list(d, 0, d->nstream, *d->list_scratch) != 0) return -1;
             }
             if(prof) HZ_CHECK(hipEventRecord(d->ev[7], d->nstream));
@@ -474,8 +475,8 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
         if(!waited_near) HZ_CHECK(hipStreamWaitEvent(d->stream, d->ev_free[next], 0));
         if(fresh_lists)
         {
-            hz_list_items(p, zn, a0, a1, *d->list_scratch);
-            if(upload_list(d, 1, d->stream, *d->list_scratch) != 0) return -1;
+            if(!two_pass) hz_list_rounds(p, zn, a0, a1, true, NULL, *d->list_scratch2);
+            if(upload_list(d, 1, d->stream, *d->list_scratch2) != 0) return -1;
             d->lists->valid = 1;
         }
         if(prof) HZ_CHECK(hipEventRecord(d->ev[9], d->stream));

@@ -154,6 +154,17 @@ hz_params_t hz_make_params(const hz_dev_t* d, const hz_view_t* v)
 
 /* east extent [lo,hi] of { t*(sin a, cos a) : t >= 0, a in [a0,a1] } intersected with
  * the band n_lo <= n <= n_hi; a1 - a0 <= pi (convex).  false: empty. */
+/* sin and cos of a ray's azimuth: the same two or three angles for every band of rows of a walk - kept */
+static void ray_sincos(double a, double* s, double* c)
+{
+    static thread_local double ka[4] = { 1e300, 1e300, 1e300, 1e300 }, ks[4], kc[4];
+    static thread_local int turn = 0;
+    for(int k=0; k<4; k++) if(ka[k] == a) { *s = ks[k]; *c = kc[k]; return; }
+    const int k = turn++ & 3;
+    ka[k] = a; ks[k] = sin(a); kc[k] = cos(a);
+    *s = ks[k]; *c = kc[k];
+}
+
 static bool wedge_band_extent(double a0, double a1, double n_lo, double n_hi, double* lo, double* hi)
 {
     const double inf = 1e300;
@@ -163,7 +174,8 @@ static bool wedge_band_extent(double a0, double a1, double n_lo, double n_hi, do
     const double rays[2] = { a0, a1 };
     for(int r=0; r<2; r++)
     {
-        const double s = sin(rays[r]), c = cos(rays[r]);
+        double s, c;
+        ray_sincos(rays[r], &s, &c);
         if(fabs(c) < 1e-12)
         {
             if(n_lo <= 0.0 && 0.0 <= n_hi) add(s > 0 ? inf : -inf);
@@ -232,16 +244,24 @@ bool hz_azimuths_of_columns(const hz_params_t& p, double* a0, double* a1)
 /* the (segment, strip column) items of one k_march launch (p.pass says which
  * round's) into `out`, in dispatch order: segments as mr_make_zones numbered
  * them, strip columns west to east */
-void hz_list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, double a1, std::vector<uint32_t>& out, bool every_strip)
+/* ... the items of BOTH rounds of a two-round draw in one walk over the segments (first: the strips next to the viewer, as
+ * k_march's pass 1 decides it; second: all the others), or, one_round, every listed item into `second`.  A viewer that
+ * moves brings new lists with every draw - a call into host memory four sectors' worth - and this walk was 0.4 ms of the
+ * host's time per sector: the rays' sines and cosines once per call, the per-strip test only where it can fail. */
+void hz_list_rounds(const hz_params_t& p, const mr_zones_t& zn, double a0, double a1, bool one_round,
+                    std::vector<uint32_t>* first, std::vector<uint32_t>& second, bool every_strip)
 {
     const int nsx = (p.N-1 + MR_COLS-1)/MR_COLS;
-    out.clear();
-    /* Round 6: the band's east extent above is the test along the patch's own axes; a patch (a strip's cells in a band of
-     * rows: a rectangle in east and north, the viewer outside it) can lie inside that extent and still beside the wedge -
-     * in the corner between a ray and the band's edge.  What separates a rectangle from a convex wedge besides its own axes
-     * are the wedge's two rays: a patch with all four corners on the outer side of one of them is not listed (two cross
-     * products per corner; the wedge in two halves where it is wider than 180 degrees, the patch two cells larger east and
-     * west, one north and south).  The eight sectors of the benchmark panorama: 1.03 of the grid's waves listed in sum. */
+    if(first) first->clear();
+    second.clear();
+    /* Round 6: the band's east extent (strips_behind_columns) is the test along the patch's own axes; a patch (a strip's
+     * cells in a band of rows: a rectangle in east and north, the viewer outside it) can lie inside that extent and still
+     * beside the wedge - in the corner between a ray and the band's edge.  What separates a rectangle from a convex wedge
+     * besides its own axes are the wedge's two rays: a patch with all four corners on the outer side of one of them is not
+     * listed (two cross products per corner; the patch two cells larger east and west, one north and south).  The patches
+     * of a band that pass are neighbours (a convex wedge cuts a convex piece out of the band): the test walks in from both
+     * ends of the extent and stops at the first patch that passes.  A wedge wider than 180 degrees is taken in two halves
+     * and every patch of the extent tested.  The eight sectors of the benchmark panorama: 1.03 of the grid's waves in sum. */
     const double m_per_cell_n = (double)HZ_REARTH_PI * (double)p.u.deg_per_cell / 180.0;
     const double m_per_cell_e = m_per_cell_n * (double)p.u.cos_viewer_lat;
     const int parts = (a1 - a0 > M_PI) ? 2 : 1;
@@ -256,37 +276,46 @@ void hz_list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, double
         const bool near_rows = jbeg < p.near_j1 && jend > p.near_j0;
         const double n_lo = ((double)(jbeg-1) - (double)p.u.viewer_cell_j) * m_per_cell_n;
         const double n_hi = ((double)(jend+1) - (double)p.u.viewer_cell_j) * m_per_cell_n;
+        auto reaches = [&](int sx) -> bool
+        {
+            const double e_lo = ((double)(sx*MR_COLS - 2) - (double)p.u.viewer_cell_i) * m_per_cell_e;
+            const double e_hi = ((double)(sx*MR_COLS + MR_COLS + 2) - (double)p.u.viewer_cell_i) * m_per_cell_e;
+            if(e_lo <= 0.0 && 0.0 <= e_hi && n_lo <= 0.0 && 0.0 <= n_hi) return true;      /* (the patch holds the viewer) */
+            for(int k=0; k<parts; k++)
+            {
+                /* cross(ray, corner) = sin*n - cos*e: negative = clockwise of the ray.  Inside the part: clockwise of its
+                 * first ray (or on it) and counter-clockwise of its second */
+                const double c[4][2] = { { e_lo, n_lo }, { e_hi, n_lo }, { e_lo, n_hi }, { e_hi, n_hi } };
+                bool before_first = true, beyond_second = true;
+                for(int q=0; q<4; q++)
+                {
+                    if(!(ray[k][0]*c[q][1] - ray[k][1]*c[q][0] > 0.0))   before_first = false;
+                    if(!(ray[k+1][0]*c[q][1] - ray[k+1][1]*c[q][0] < 0.0)) beyond_second = false;
+                }
+                if(!before_first && !beyond_second) return true;
+            }
+            return false;
+        };
+        if(!every_strip && parts == 1)
+        {
+            while(x0 <= x1 && !reaches(x0)) x0++;
+            while(x1 > x0 && !reaches(x1)) x1--;
+        }
         for(int sx=x0; sx<=x1; sx++)
         {
-            if(!every_strip)
-            {
-                const double e_lo = ((double)(sx*MR_COLS - 2) - (double)p.u.viewer_cell_i) * m_per_cell_e;
-                const double e_hi = ((double)(sx*MR_COLS + MR_COLS + 2) - (double)p.u.viewer_cell_i) * m_per_cell_e;
-                const bool holds_viewer = e_lo <= 0.0 && 0.0 <= e_hi && n_lo <= 0.0 && 0.0 <= n_hi;
-                bool reaches = holds_viewer;
-                for(int k=0; k<parts && !reaches; k++)
-                {
-                    /* cross(ray, corner) = sin*n - cos*e: negative = clockwise of the ray.  Inside the part: clockwise of its
-                     * first ray (or on it) and counter-clockwise of its second */
-                    const double c[4][2] = { { e_lo, n_lo }, { e_hi, n_lo }, { e_lo, n_hi }, { e_hi, n_hi } };
-                    bool before_first = true, beyond_second = true;
-                    for(int q=0; q<4; q++)
-                    {
-                        if(!(ray[k][0]*c[q][1] - ray[k][1]*c[q][0] > 0.0))   before_first = false;
-                        if(!(ray[k+1][0]*c[q][1] - ray[k+1][1]*c[q][0] < 0.0)) beyond_second = false;
-                    }
-                    reaches = !before_first && !beyond_second;
-                }
-                if(!reaches) continue;
-            }
-            if(p.pass)                          /* (as k_march decides it) */
-            {
-                const bool near = near_rows && sx >= p.near_x0 && sx <= p.near_x1;
-                if((p.pass == 1) != near) continue;
-            }
-            out.push_back(MR_ITEM(seg, sx));
+            if(!every_strip && parts == 2 && !reaches(sx)) continue;
+            const bool near = !one_round && near_rows && sx >= p.near_x0 && sx <= p.near_x1;      /* (as k_march decides it) */
+            if(near) { if(first) first->push_back(MR_ITEM(seg, sx)); }
+            else second.push_back(MR_ITEM(seg, sx));
         }
     }
+}
+
+/* the items of one k_march launch (p.pass: 0 the one round of a one-round draw, 1 / 2 the rounds of a two-round draw) */
+void hz_list_items(const hz_params_t& p, const mr_zones_t& zn, double a0, double a1, std::vector<uint32_t>& out, bool every_strip)
+{
+    if(p.pass == 1) { std::vector<uint32_t> rest; hz_list_rounds(p, zn, a0, a1, false, &out, rest, every_strip); }
+    else hz_list_rounds(p, zn, a0, a1, p.pass == 0, NULL, out, every_strip);
 }
 
 /* the draw's plan: one round or two, and which strips are "next to the viewer" */

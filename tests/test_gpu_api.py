@@ -164,15 +164,21 @@ def test_errors_behave_like_the_reference(tmp_path):
     lib.horizonator_deinit(C.byref(ctx))
 
 
-def test_device_side_ingest_builds_the_same_mosaic(monkeypatch):
+@pytest.mark.parametrize("how", ["device", "host", None])
+def test_either_ingest_builds_the_same_mosaic(monkeypatch, how):
+    """the DEM's tiles decoded by k_ingest (hz_ingest.cpp: the default since round 6) or on the host (HORIZONATOR_INGEST=host,
+    round 1's way): the window of reference dem.c:264-309 either way - a window of 2x2 tiles (through the public dem context)
+    and one of 5x5 (the library's own tile table, staged through pinned memory in several pieces)"""
     import horizonator_amd
-    R = 700
-    d = hzutil.dem_dir_for(LAT, LON, R)
-    monkeypatch.setenv("HORIZONATOR_INGEST", "device")
-    h = horizonator_amd.horizonator(LAT, LON, 64, 16, dir_dems=d, render_radius_cells=R)
-    monkeypatch.delenv("HORIZONATOR_INGEST")
-    assert np.array_equal(h.mosaic(), oracle.Dem(LAT, LON, d, radius_cells=R).mosaic())
-    h.close()
+    for R, W, H in ((700, 64, 16), (2100, 4000, 1000)):
+        d = hzutil.dem_dir_for(LAT, LON, R)
+        if how is None:
+            monkeypatch.delenv("HORIZONATOR_INGEST", raising=False)
+        else:
+            monkeypatch.setenv("HORIZONATOR_INGEST", how)
+        h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+        assert np.array_equal(h.mosaic(), oracle.Dem(LAT, LON, d, radius_cells=R).mosaic()), (how, R)
+        h.close()
 
 
 def test_more_tiles_than_the_reference_can_load():

@@ -144,3 +144,77 @@ def test_options_round_trip(scene):
     assert h.options() == o
     with pytest.raises(TypeError):
         h.set_options(no_such_thing=1)
+
+
+def test_a_context_closed_with_a_panorama_in_flight_finishes_it_first():
+    """render_begin() and then close() - the pool's tasks name the caller's buffers and the job's counters, the
+    copies write its landing area: the context ends the panorama itself before it frees anything"""
+    import horizonator_amd
+    R, W, H = 300, 2048, 512
+    d = hzutil.dem_dir_for(LAT, LON, R)
+    od = oracle.Dem(LAT, LON, d, radius_cells=R)
+    want = oracle.render(od.mosaic(), od.view(LAT, LON, W, H, -180.0, 180.0, zfar=100000.0), W, H)
+    for n in (1, 2):
+        h = horizonator_amd.horizonator(LAT, LON, W, H, dir_dems=d, render_radius_cells=R)
+        if h.options()["host_dense"]:
+            h.close()
+            return
+        h.set_view(-180.0, 180.0, zfar=100000.0)
+        bufs = [(np.zeros((H, W, 3), np.uint8), np.zeros((H, W), np.float32)) for _ in range(n)]
+        for b in bufs:
+            h.render_begin(*b)
+        h.close()                                               # no render_end()
+        for b in bufs:
+            assert np.array_equal(b[0], want["bgr"]) and np.array_equal(b[1], want["ranges"])
+
+
+def test_the_sectors_of_a_call_are_one_draw_for_the_vertex_cache(scene):
+    """a viewer that moves between calls never pays for a fill of the vertex cache (every call is the FIRST draw
+    from its viewpoint, however many sectors it is drawn in); a viewer that stays gets it with the second call"""
+    h, od, W, H = scene
+    if not h.options()["vertex_cache"]:
+        return
+    h.set_options(host_sectors=4)
+    try:
+        img, rng = np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32)
+        for k in range(4):
+            h.set_view(-180.0, 180.0, lat=LAT + 2e-4 * (k + 1), lon=LON, zfar=60000.0)
+            h.render_into(img, rng)
+            assert not h.last_plan()["vertex_cache"], k
+        want = _want(od, W, H, -180.0, 180.0, 60000.0, LAT + 8e-4, LON)
+        assert np.array_equal(img, want["bgr"]) and np.array_equal(rng, want["ranges"])
+        h.render_into(img, rng)                                 # the second call from there: filled, and read from it
+        assert h.last_plan()["vertex_cache"]
+        assert np.array_equal(img, want["bgr"]) and np.array_equal(rng, want["ranges"])
+    finally:
+        h.set_options(host_sectors=0)
+        h.set_view(-180.0, 180.0, lat=LAT, lon=LON)
+
+
+def test_a_long_series_with_two_in_flight(scene):
+    """twelve panoramas, begin k+1 before end k, views changing: whatever was issued from inside another panorama's end (the
+    next one's copies) lands in the right buffers"""
+    h, od, W, H = scene
+    if h.options()["host_dense"]:
+        return
+    views = [(-180.0, 180.0, 40000.0 + 9000.0 * (k % 3), LAT + 1e-3 * (k % 4), LON - 1e-3 * (k % 3)) for k in range(12)]
+    bufs = [(np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32)) for _ in range(2)]
+    got = []
+    def begin(k):
+        az0, az1, zfar, lat, lon = views[k]
+        h.set_view(az0, az1, lat=lat, lon=lon, zfar=zfar)
+        h.render_begin(*bufs[k % 2])
+    begin(0)
+    for k in range(1, len(views) + 1):
+        if k < len(views):
+            begin(k)
+        h.render_end()
+        got.append((bufs[(k - 1) % 2][0].copy(), bufs[(k - 1) % 2][1].copy()))
+    cache = {}
+    for k, v in enumerate(views):
+        if v not in cache:
+            az0, az1, zfar, lat, lon = v
+            cache[v] = _want(od, W, H, az0, az1, zfar, lat, lon)
+        assert np.array_equal(got[k][0], cache[v]["bgr"]) and np.array_equal(got[k][1], cache[v]["ranges"]), k
+    h.set_view(-180.0, 180.0, lat=LAT, lon=LON)
+
