@@ -424,9 +424,13 @@ int hz_draw_impl(hz_dev_t* d, const hz_view_t* view)
                 /* (azimuth sectors, round 4 - with k_big's chunk test against the tables: a half gains 8 %, a quarter 6 (strips back to
                  * back 0.273 -> 0.259, 0.250 -> 0.234 ms), an eighth's widest sector 11 and its narrowest loses 4; beside the 8-row
                  * segments narrow sectors get (mr_make_zones) an eighth loses 5: from a sixth of the image on.  profiles/r4_sector_rules.txt) */
-                /* (whatever the far clip: with the API's 40 km the tables change nothing - 0.602 / 0.607 ms without / with,
-                 * three alternating pairs -, at 80 km they gain 3 %, at 150 km 4 %: round 4) */
-                use_hiz = early_z && (d->env.coarse_depth >= 0 ? d->env.coarse_depth != 0 : (zoomed || (busy && 6*p.SW >= p.W)));
+                /* (the far clip: at 80 km the tables gain 3 %, at 150 km 4 % (round 4); with the API's 40 km - a second round of a few
+                 * thousand waves, all next to the viewer - they changed nothing then (0.602 / 0.607 ms without / with) and cost a
+                 * sweep in the first round's chain now: 0.544 / 0.561 ms with them, 0.520 / 0.533 without (round 6, two alternating
+                 * sweeps, gpurun_out/r6v): not where even the farthest cell is four pixels wide, unless the view is zoomed) */
+                const float cells_to_zfar = view->zfar / (p.u.deg_per_cell * 111194.9f);
+                const bool close_clip = cells_to_zfar <= 0.25f*(p.halfW * p.u.az_ndc_per_rad);
+                use_hiz = early_z && (d->env.coarse_depth >= 0 ? d->env.coarse_depth != 0 : (zoomed || (busy && 6*p.SW >= p.W && !close_clip)));
                 if(use_hiz && hiz_tables(d, next, p, &hz) != 0) { use_hiz = false; hz = hz_hiz_t{}; }
                 /* (The sweep on a stream of its own, so that the next panorama's first round need not queue behind it: tried
                  * in round 4 - with HIP's four hardware queues a fifth stream shares one, nothing changes; with eight

@@ -727,9 +727,13 @@ extern "C" int hz_hip_host_prepare(hz_dev_t* d, int want_bgr, int want_ranges, i
     jb.t_begin = std::chrono::steady_clock::now();
     int rc = queue_device_side(d, jb, warm_view, true, ctl_words);
     (void)hipEventSynchronize(jb.ev_told);
-    /* the copy engine, once on each stream: the first words of the landing */
-    for(int k=0; k<HZ_COPY_STREAMS && rc == 0; k++)
-        if(hipMemcpyAsync(jb.h_land + 1024*k, jb.d_hs + 1024*k, 4096, hipMemcpyDeviceToHost, h->cstream[k]) != hipSuccess) rc = -1;
+    /* the copy engine, once on each stream, with a copy large enough to go the way a sector's stream goes (the runtime moves
+     * a few KB by other means) */
+    {
+        const size_t warm_words = jb.land_capacity < ((size_t)1 << 20) ? jb.land_capacity/HZ_COPY_STREAMS : ((size_t)1 << 19);
+        for(int k=0; k<HZ_COPY_STREAMS && rc == 0 && warm_words; k++)
+            if(hipMemcpyAsync(jb.h_land + warm_words*k, jb.d_hs + warm_words*k, warm_words*sizeof(uint32_t), hipMemcpyDeviceToHost, h->cstream[k]) != hipSuccess) rc = -1;
+    }
     for(int k=0; k<HZ_COPY_STREAMS; k++) (void)hipStreamSynchronize(h->cstream[k]);
     if(hz_sync_all(d) != hipSuccess) rc = -1;
     (void)hipGetLastError();
