@@ -34,9 +34,10 @@ def _default_switches(monkeypatch):
         monkeypatch.delenv(k)
 
 
-def _last_of_a_series(h, W, H, n=8):
+def _last_of_a_series(h, W, H, n=8, coarse=True):
     """n panoramas queued back to back, nobody waits in between; returns the last one's four outputs (host arrays)
-    and what the plan of that last draw was"""
+    and what the plan of that last draw was.  coarse: the draws of such a series keep coarse depth (hz_k_hiz.h) - not with a far
+    clip so close that even the farthest cell is four pixels wide (the API's 40 km at 16000 columns: round 6)"""
     import torch
     dev = torch.device("cuda:0")
     out = {"bgr": torch.empty((H, W, 3), dtype=torch.uint8, device=dev), "ranges": torch.empty((H, W), dtype=torch.float32, device=dev),
@@ -47,9 +48,9 @@ def _last_of_a_series(h, W, H, n=8):
             h.render_device(out["bgr"].data_ptr(), out["ranges"].data_ptr(), out["index"].data_ptr(), out["z24"].data_ptr())
         plan = h.last_plan()
         h.sync()
-        if plan["coarse_depth"]:
+        if plan["coarse_depth"] or not coarse:
             break
-    assert plan["rounds"] == 2 and plan["coarse_depth"], f"the last of {n} renders queued back to back did not keep coarse depth: {plan}"
+    assert plan["rounds"] == 2 and bool(plan["coarse_depth"]) == coarse, f"the last of {n} renders queued back to back: coarse depth expected {coarse}: {plan}"
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
@@ -67,7 +68,7 @@ def test_the_last_panorama_of_a_series_equals_oracle_and_reference(name):
     try:
         h.set_view(c["az_deg0"], c["az_deg1"], znear=c["znear"], zfar=c["zfar"])
         assert {k: np.float32(x) for k, x in v.as_dict().items()} == {k: np.float32(x) for k, x in h.view().items()}
-        got = _last_of_a_series(h, W, H)
+        got = _last_of_a_series(h, W, H, coarse=not name.endswith("zfar40km"))
     finally:
         h.close()
     got["z24"] = got["z24"].view(np.uint32)
