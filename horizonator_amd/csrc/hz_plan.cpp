@@ -63,12 +63,6 @@ mr_zones_t hz_make_zones(const hz_params_t& p, bool near_first)
         waves *= (p.N-1 + MR_COLS-1)/MR_COLS;
         if(waves < 32768) { rows[0] = rows[6] = rows[0] < 16 ? rows[0] : 16; rows[1] = rows[5] = rows[1] < 8 ? rows[1] : 8; rows[2] = rows[4] = 2; }
     }
-    {
-        /* HZ_ZONE_ROWS=far,z16,z4: an experiment's override */
-        static const char* e = getenv("HZ_ZONE_ROWS");
-        int a = 0, b = 0, c = 0;
-        if(e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { rows[0] = rows[6] = a; rows[1] = rows[5] = b; rows[2] = rows[4] = c; }
-    }
     /* segment numbers (= blockIdx.y = dispatch order) are handed out to the
      * zones with the longest segments first: the long far-field waves start
      * early and the kernel ends on short ones.  With the early depth test
