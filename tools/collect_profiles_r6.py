@@ -49,8 +49,8 @@ with open(os.path.join(P, "r6_host_inclusive.txt"), "w") as f:
     f.write("round 6, horizonator_render_offscreen() into host memory (tools/gpu_final_r6.sh on one MI355X box): tools/host_inclusive.py - median of\n"
             "10 calls after 2 warm-ups into kept buffers, 7 into fresh numpy arrays, a series with two panoramas in flight - with each call's own\n"
             "account of its time (HZ_HOST_TIMES=1), then by number of sectors, 8000 x 2000, and the dense path; the first calls of four contexts\n"
-            "(tools/r6/first_call2.py); at the end single calls and a series on a time axis (rocprofv3 --kernel-trace --memory-copy-trace of\n"
-            "tools/r6/host_trace_run.py, tools/r6/trace_tail.py).  Cold draws throughout (HZ_VERTEX_CACHE=0).\n\n")
+            "(tools/first_call.py); at the end single calls and a series on a time axis (rocprofv3 --kernel-trace --memory-copy-trace of\n"
+            "tools/host_trace_run.py, tools/trace_tail.py).  Cold draws throughout (HZ_VERTEX_CACHE=0).\n\n")
     for part in ("host_inclusive.txt", "first_call.txt", "host_call_timeline.txt"):
         if os.path.exists(os.path.join(O, part)):
             f.write(open(os.path.join(O, part)).read() + "\n")

@@ -1,6 +1,6 @@
 """the first call of a context: into untouched pages (np.zeros) against pages touched beforehand (np.ones)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import hzutil, horizonator_amd

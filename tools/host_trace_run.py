@@ -1,6 +1,6 @@
 """what a rocprofv3 --kernel-trace run of the host path looks at: a few single calls, then a series with two in flight"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import hzutil, horizonator_amd

@@ -77,7 +77,7 @@ def classify(instr):
 
 def main():
     key = sys.argv[1] if len(sys.argv) > 1 else "k_march_coarse_depth"
-    mix_path = next(p for p in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (5, 4)) if os.path.exists(p))
+    mix_path = next(p for p in (os.path.join(ROOT, "profiles", "pmc_r%d_instruction_mix_cfg3.json" % r) for r in (6, 5, 4)) if os.path.exists(p))
     mix = json.load(open(mix_path))
     k = max((v for name, v in mix.items() if name.startswith(key + " grid")), key=lambda v: v["SQ_INSTS_VALU"])
     issue = {}
