@@ -241,4 +241,5 @@ int          hz_resolve_impl(hz_dev_t* d, const hz_view_t* view, const float* ta
                              unsigned char* bgr, float* ranges, int32_t* index, uint32_t* z24, int nbands, hipEvent_t* ev_band, int* band_rows);
 /* ---- hz_hostpath.cpp ---------------------------------------------------------------------------------------------- */
 void         hz_hostpath_destroy(hz_dev_t* d);                  /* staging ring, copy streams, the stream of blobs */
+int          hz_gpu_numa_node(const hz_dev_t* d);               /* the NUMA node the context's GPU hangs off (Linux sysfs), -1: unknown */
 void         hz_hostpath_landing(hz_dev_t* d, unsigned char** pinned, size_t* bytes);   /* pinned memory nothing is using now (no panorama in flight), or 0 bytes */

@@ -127,7 +127,7 @@ static int make_hoststate(hz_hoststate* h)
 }
 
 /* the NUMA node the context's GPU hangs off (Linux sysfs through its PCI address), -1: unknown */
-static int gpu_numa_node(const hz_dev_t* d)
+int hz_gpu_numa_node(const hz_dev_t* d)
 {
     char bdf[64] = "";
     if(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), d->device) != hipSuccess) { (void)hipGetLastError(); return -1; }
@@ -143,7 +143,7 @@ static int gpu_numa_node(const hz_dev_t* d)
 static int ensure_host(hz_dev_t* d)
 {
     if(d->host) return 0;
-    (void)copy_pool(gpu_numa_node(d));      /* (the process's pool is made by its first context: near that context's GPU) */
+    (void)copy_pool(hz_gpu_numa_node(d));      /* (the process's pool is made by its first context: near that context's GPU) */
     hz_hoststate* h = new hz_hoststate();
     memset((void*)h, 0, sizeof(*h));
     d->host = h;

@@ -46,7 +46,7 @@ extern "C" int hz_hip_ingest_tiles(hz_dev_t* d, const unsigned char* const* tile
         bool ok = true;
         for(int k=0; k<3 && ok; k++) ok = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
         if(!ok) break;
-        hz_copy_pool* pool = copy_pool();
+        hz_copy_pool* pool = copy_pool(hz_gpu_numa_node(d));
         const size_t total = (size_t)npresent*tile_bytes;
         std::vector<const unsigned char*> src;      /* the present tiles, in the order of d_raw */
         for(int k=0; k<nt; k++) if(tiles[k]) src.push_back(tiles[k]);
