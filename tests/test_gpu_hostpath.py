@@ -218,3 +218,33 @@ def test_a_long_series_with_two_in_flight(scene):
         assert np.array_equal(got[k][0], cache[v]["bgr"]) and np.array_equal(got[k][1], cache[v]["ranges"]), k
     h.set_view(-180.0, 180.0, lat=LAT, lon=LON)
 
+
+@pytest.mark.parametrize("sectors", [0, 3])
+def test_a_panorama_without_any_terrain(scene, sectors):
+    """a viewer 9 km up with a far clip of 3 km: what is that near lies below the frame - no blob is sent, every sector's stream is
+    empty, the caller's buffers are sky all over (reference horizonator-lib.c:185, :1016) - in a single call and with two in flight"""
+    h, od, W, H = scene
+    if h.options()["host_dense"]:
+        return
+    h.set_options(host_sectors=sectors)
+    lib, ctx = h._lib, C.byref(h._ctx)
+    try:
+        v = od.view(LAT, LON, W, H, -180.0, 180.0, zfar=3000.0, viewer_z=9000.0)
+        want = oracle.render(od.mosaic(), v, W, H)
+        assert not (want["index"] >= 0).any(), "the scene of this test is meant to be empty"
+        h.set_view(-180.0, 180.0, zfar=3000.0)
+        z = C.c_float(9000.0)
+        assert lib.horizonator_move(ctx, C.byref(z), LAT, LON)
+        bufs = [(np.full((H, W, 3), 7, np.uint8), np.full((H, W), 7.0, np.float32)) for _ in range(2)]
+        assert lib.horizonator_render_offscreen(ctx, bufs[0][0].ctypes.data, bufs[0][1].ctypes.data)
+        assert np.array_equal(bufs[0][0], want["bgr"]) and np.array_equal(bufs[0][1], want["ranges"])
+        bufs[0][0][:] = 9; bufs[0][1][:] = 9.0
+        for b in bufs:
+            assert lib.horizonator_amd_render_begin(ctx, b[0].ctypes.data, b[1].ctypes.data)
+        assert lib.horizonator_amd_render_end(ctx) and lib.horizonator_amd_render_end(ctx)
+        for b in bufs:
+            assert np.array_equal(b[0], want["bgr"]) and np.array_equal(b[1], want["ranges"])
+    finally:
+        h.set_options(host_sectors=0)
+        assert lib.horizonator_move(ctx, None, LAT, LON)
+        h.set_view(-180.0, 180.0, zfar=40000.0)
