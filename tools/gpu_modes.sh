@@ -18,7 +18,7 @@ ALL=("HZ_SERIAL=1 HZ_TWO_PASS=1" "HZ_TWO_PASS=0" "HZ_TWO_PASS=1 HZ_NEAR_CELLS=8"
 if [ -n "$MODES" ]; then IFS=";" read -ra ALL <<< "$MODES"; fi
 for env in "${ALL[@]}"; do
   echo "== $env"
-  env $env timeout 900 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_bench_multi.py 2>&1 | grep -E "passed|failed|error" | tail -2
+  env $env timeout 900 python -m pytest tests -x -q -rf -m gpu --deselect tests/test_gpu_bench_multi.py 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|error" | tail -4
   [ ${PIPESTATUS[0]} -ne 0 ] && rc=1
 done
 exit $rc
