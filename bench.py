@@ -728,14 +728,24 @@ def main():
         h.set_options(vertex_cache=0)
         h.set_view(-180.0, 180.0, lat=LAT, lon=LON, znear=ZNEAR, zfar=args.zfar)
         ts_fresh = []
-        for k in range(8):          # the reference's Python wrapper: new arrays (untouched pages) on every call
+        for k in range(8):          # what the reference's Python wrapper does: new arrays (untouched pages) for every call
             t0 = time.perf_counter()
-            fresh = h.render(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+            fresh = (np.empty((H, W, 3), np.uint8), np.empty((H, W), np.float32))
+            h.render_into(*fresh)
             ts_fresh.append(time.perf_counter() - t0)
             if k == 7:
                 same = same and bool(np.array_equal(fresh[0], want_img) and np.array_equal(fresh[1], want_rng))
             del fresh
         t_fresh = float(np.median(ts_fresh[2:]))
+        ts_py = []
+        for k in range(8):          # the Python mirror's render(): its arrays are made of the memory of results the caller dropped
+            t0 = time.perf_counter()
+            res = h.render(-180.0, 180.0, znear=ZNEAR, zfar=args.zfar)
+            ts_py.append(time.perf_counter() - t0)
+            if k == 7:
+                same = same and bool(np.array_equal(res[0], want_img) and np.array_equal(res[1], want_rng))
+            del res
+        t_py = float(np.median(ts_py[2:]))
         # a caller that renders a series with two sets of buffers: begin k+1, then end k (include/horizonator_amd.h)
         himg2 = np.zeros((H, W, 3), np.uint8)
         hrng2 = np.zeros((H, W), np.float32)
@@ -767,6 +777,11 @@ def main():
                      "moving_viewer": "the same call with the library's default options from a viewpoint that moves by 1e-4 degrees of "
                                       "latitude between calls (median of 6 after 2)",
                      "ms_with_fresh_arrays_per_call": t_fresh * 1e3,
+                     "ms_python_render": t_py * 1e3,
+                     "python_render": "horizonator_amd.horizonator.render() in a loop that drops its results (the mirror of the reference's "
+                                      "Python API): the arrays it returns are made of the memory of results the caller let go of - pages mapped "
+                                      "already - where ms_with_fresh_arrays_per_call hands np.empty() arrays to every call, as the reference's "
+                                      "wrapper does (horizonator-pywrap.c:234-250)",
                      "ms_per_panorama_two_in_flight": t_series * 1e3,
                      "two_in_flight": "horizonator_amd_render_begin / _end with two sets of buffers: begin k+1, then end k - the device draws one "
                                       "panorama while the other crosses PCIe; median interval between ends over a series of %d" % nser,

@@ -29,6 +29,48 @@ def _enc(s):
     return None if s is None else str(s).encode()
 
 
+class _ResultMemory:
+    """The arrays render() returns, recycled.  The reference's wrapper makes new arrays for every call
+    (horizonator-pywrap.c:234-250, PyArray_SimpleNew): 448 MB of pages the kernel has to map and zero while the call
+    writes them - 2 ms of a 5 ms call for a 16000x4000 panorama, where the render and its transfer take 3.  A caller
+    that loops `image, ranges = h.render(...)` drops the previous results as it goes: their memory, pages mapped and
+    on the NUMA node the library's threads first wrote them from, is what the next call's results are made of.
+    Memory still referenced - by the caller's arrays or any view of them - is never handed out again (its reference
+    count says so); at most two calls' worth of dropped memory is kept.  HZ_PY_RECYCLE=0: plain np.empty()."""
+
+    def __init__(self):
+        import os
+        self._bufs = []                 # uint8 owners, the most recently handed out last
+        import sys
+        self._on = os.environ.get("HZ_PY_RECYCLE", "1") != "0" and hasattr(sys, "getrefcount")
+
+    def take(self, specs):
+        """arrays of the given (shape, dtype) list, contents undefined"""
+        import sys
+        if not self._on:
+            return [np.empty(shape, dt) for shape, dt in specs]
+        out = []
+        for shape, dt in specs:
+            n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
+            b = None
+            for k in range(len(self._bufs)):
+                # (the list's reference and getrefcount's own argument: nobody else holds the owner or a view of it)
+                if self._bufs[k].nbytes == n and sys.getrefcount(self._bufs[k]) == 2:
+                    b = self._bufs.pop(k)
+                    break
+            if b is None:
+                b = np.empty(n, np.uint8)
+            self._bufs.append(b)
+            out.append(b.view(dt).reshape(shape))
+            del b
+        # two calls' worth at most: the oldest go (memory the caller still holds lives on through the caller's arrays)
+        del self._bufs[:max(0, len(self._bufs) - 2 * len(specs))]
+        return out
+
+    def clear(self):
+        self._bufs = []
+
+
 class horizonator:
     """SRTM terrain renderer (reference horizonator.docstring, horizonator-pywrap.c:49-125).
 
@@ -111,6 +153,8 @@ class horizonator:
         if getattr(self, "_ctx", None) is not None:
             self._lib.horizonator_deinit(C.byref(self._ctx))
             self._ctx = None
+        if getattr(self, "_results", None) is not None:
+            self._results.clear()
 
     def __del__(self):
         try:
@@ -144,6 +188,12 @@ class horizonator:
     @property
     def sector(self):
         return getattr(self, "_sector", (0, self.width))
+
+    def _result_memory(self):
+        m = getattr(self, "_results", None)
+        if m is None:
+            m = self._results = _ResultMemory()
+        return m
 
     # -- the reference's render() -------------------------------------------
     def _prepare(self, az_deg0, az_deg1, lat, lon, az_extents_use_pixel_centers,
@@ -188,8 +238,10 @@ class horizonator:
                       float(znear), float(zfar), float(znear_color), float(zfar_color))
         c0, c1 = self.sector
         H, W = self._ctx.offscreen.height, c1 - c0
-        image = np.empty((H, W, 3), np.uint8) if return_image else None
-        ranges = np.empty((H, W), np.float32) if return_range else None
+        specs = ([((H, W, 3), np.uint8)] if return_image else []) + ([((H, W), np.float32)] if return_range else [])
+        got = self._result_memory().take(specs)
+        image = got.pop(0) if return_image else None
+        ranges = got.pop(0) if return_range else None
         ok = self._lib.horizonator_render_offscreen(
             C.byref(self._ctx),
             image.ctypes.data if image is not None else None,
@@ -244,10 +296,8 @@ class horizonator:
                       float(znear), float(zfar), float(znear_color), float(zfar_color))
         c0, c1 = self.sector
         H, W = self._ctx.offscreen.height, c1 - c0
-        image = np.empty((H, W, 3), np.uint8)
-        ranges = np.empty((H, W), np.float32)
-        index = np.empty((H, W), np.int32)
-        z24 = np.empty((H, W), np.uint32)
+        image, ranges, index, z24 = self._result_memory().take(
+            [((H, W, 3), np.uint8), ((H, W), np.float32), ((H, W), np.int32), ((H, W), np.uint32)])
         ok = self._lib.horizonator_amd_render(
             C.byref(self._ctx), image.ctypes.data, ranges.ctypes.data,
             index.ctypes.data, z24.ctypes.data)

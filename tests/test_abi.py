@@ -172,3 +172,40 @@ def test_series_rejects_bad_arguments_without_a_gpu():
     assert call(C.byref(ctx), fake_comm, C.byref(series(words=10)), 0, 1, 0) == -1
     assert call(C.byref(ctx), fake_comm, C.byref(series(d_bins=None)), 0, 1, 0) == -1       # rank 0 gathers: it needs bins
     assert call(C.byref(ctx), fake_comm, C.byref(series()), -1, 1, 0) == -1
+
+
+def test_result_memory_of_the_python_mirror_is_recycled_only_when_dropped(monkeypatch):
+    """render() makes its results of memory the caller has dropped (horizonator_amd._ResultMemory): never of memory an
+    array or a view of one still names, two calls' worth kept at most, HZ_PY_RECYCLE=0 = new arrays every time"""
+    import numpy as np
+    import horizonator_amd
+    specs = [((6, 10, 3), np.uint8), ((6, 10), np.float32)]
+    m = horizonator_amd._ResultMemory()
+    image, ranges = m.take(specs)
+    assert image.shape == (6, 10, 3) and image.dtype == np.uint8 and image.flags.c_contiguous and image.flags.writeable
+    assert ranges.shape == (6, 10) and ranges.dtype == np.float32 and ranges.flags.c_contiguous
+    first = {image.ctypes.data, ranges.ctypes.data}
+    image[:] = 7
+    image2, ranges2 = m.take(specs)                     # the first results are still held: other memory
+    assert not {image2.ctypes.data, ranges2.ctypes.data} & first and (image == 7).all()
+    row = image[2]                                      # a view keeps the memory as well
+    del image, ranges
+    image3, ranges3 = m.take(specs)
+    assert image3.ctypes.data not in first and ranges3.ctypes.data in first
+    assert (row == 7).all()
+    del row, image2, ranges2, image3, ranges3
+    seen = set()
+    for _ in range(8):                                  # `image, ranges = h.render(...)` in a loop: the names hold one set during the next call
+        image, ranges = m.take(specs)
+        seen |= {image.ctypes.data, ranges.ctypes.data}
+    assert len(seen) == 4 and len(m._bufs) <= 4
+    # another size (a sector was set): nothing of the old size is handed out, and it does not pile up
+    small = m.take([((6, 4, 3), np.uint8)])[0]
+    assert small.shape == (6, 4, 3) and len(m._bufs) <= 2
+    monkeypatch.setenv("HZ_PY_RECYCLE", "0")
+    off = horizonator_amd._ResultMemory()
+    a = off.take(specs)[0]
+    p = a.ctypes.data
+    assert a.flags.owndata
+    del a
+    assert off._bufs == []

@@ -48,6 +48,26 @@ def test_render_returns_reference_shapes_and_matches_oracle(scene):
     assert {k: np.float32(x) for k, x in v.items()} == {k: np.float32(x) for k, x in ov.items()}
 
 
+def test_render_recycles_only_the_results_the_caller_dropped(scene):
+    """render() makes its arrays of memory the caller has let go of (horizonator_amd._ResultMemory; the reference's wrapper
+    allocates per call, horizonator-pywrap.c:234-250): results still held stay what they were, whatever is rendered after"""
+    h, od, W, H = scene
+    first = h.render(-180, 180)
+    keep = (first[0].copy(), first[1].copy())
+    other = h.render(-40, 100)                          # `first` is held: not its memory
+    assert not np.shares_memory(other[0], first[0]) and not np.shares_memory(other[1], first[1])
+    assert np.array_equal(first[0], keep[0]) and np.array_equal(first[1], keep[1])
+    where = (first[0].ctypes.data, first[1].ctypes.data)
+    del first
+    again = h.render(-180, 180)                         # ... dropped: the same memory, the same picture
+    assert (again[0].ctypes.data, again[1].ctypes.data) == where
+    assert np.array_equal(again[0], keep[0]) and np.array_equal(again[1], keep[1])
+    ref = oracle.render(od.mosaic(), od.view(LAT, LON, W, H, -40, 100), W, H)
+    assert np.array_equal(other[0], ref["bgr"]) and np.array_equal(other[1], ref["ranges"])
+    full = h.render_full(-180, 180)
+    assert np.array_equal(full[0], keep[0]) and np.array_equal(full[1], keep[1]) and np.array_equal(again[0], keep[0])
+
+
 def test_move_zextents_and_pixel_centre_azimuths(scene):
     h, od, W, H = scene
     lat, lon = LAT + 0.02, LON - 0.015
