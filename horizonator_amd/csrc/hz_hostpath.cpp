@@ -38,6 +38,8 @@
 
 #include <chrono>
 #include <immintrin.h>
+#include <sched.h>
+#include <sys/mman.h>
 
 /* ------------------------------------------------------------------------ */
 /* the state of a context's host path                                        */
@@ -49,6 +51,53 @@
  *   [4*s .. 4*s+3]          sector s: k_pack_host's cursor words / k_tell's info words
  *   [HZ_CTL_PRESENT + ..]   the sectors' tile bitmaps (sector s's: pres0[s], npres[s] words) */
 #define HZ_CTL_PRESENT (4*HZ_HOST_MAX_SECTORS)
+
+/* Pinned host memory by the hundred megabytes.  hipHostMalloc pins page by page of 4 KB: 277 MB - the landing area of a
+ * 16000 x 4000 panorama - take it 45-47 ms, 1.1 GB 180 ms, most of what horizonator_init() costs a warm process.  Anonymous
+ * memory in 2 MB pages (transparent huge pages, where the system grants them on request) that the driver is then asked to
+ * pin - hipHostRegister, which faults the pages in itself - takes 11.5 / 46 ms, and the copy engine moves the same 55 GB/s
+ * into it (tools/pinned_alloc.hip, profiles/r6_pinned_alloc.txt).  hipHostMalloc places its pages on the NUMA node next to
+ * the GPU; here they land where the thread that faults them in runs, so that thread visits that node for the duration.
+ * Whatever fails on the way - no mmap, no registration - ends in hipHostMalloc. */
+struct hz_pinned_t { void* map; size_t map_bytes; bool registered; };
+static void* pinned_alloc(hz_pinned_t* m, size_t bytes, int numa_node)
+{
+    m->map = NULL; m->map_bytes = 0; m->registered = false;
+    const char* how = getenv("HZ_PINNED");              /* "malloc": hipHostMalloc, as before round 6's last day */
+    if(!(how && strcmp(how, "malloc") == 0) && bytes >= ((size_t)8 << 20))
+    {
+        const size_t huge = (size_t)2 << 20;
+        cpu_set_t before, node_cpus;
+        const bool moved = numa_node >= 0 && hz_copy_pool::cpus_of_node(numa_node, &node_cpus) &&
+                           sched_getaffinity(0, sizeof(before), &before) == 0 && sched_setaffinity(0, sizeof(node_cpus), &node_cpus) == 0;
+        void* map = mmap(NULL, bytes + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        void* p = NULL;
+        if(map != MAP_FAILED)
+        {
+            p = (void*)(((uintptr_t)map + huge-1) & ~(uintptr_t)(huge-1));
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+            if(hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                munmap(map, bytes + huge);
+                p = NULL;
+            }
+            else { m->map = map; m->map_bytes = bytes + huge; m->registered = true; }
+        }
+        if(moved) (void)sched_setaffinity(0, sizeof(before), &before);
+        if(p) return p;
+    }
+    void* p = NULL;
+    if(hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    return p;
+}
+static void pinned_free(hz_pinned_t* m, void* p)
+{
+    if(!p) return;
+    if(m->registered) { (void)hipHostUnregister(p); munmap(m->map, m->map_bytes); }
+    else (void)hipHostFree(p);
+    m->map = NULL; m->map_bytes = 0; m->registered = false;
+}
 
 struct hz_hostjob
 {
@@ -75,6 +124,7 @@ struct hz_hostjob
     /* pinned host memory */
     uint32_t*     h_land;               /* where the copy engine puts the streams: the same offsets as in d_hs */
     size_t        land_capacity;        /* words */
+    hz_pinned_t   land_mem;             /* ... and how that memory was had (pinned_alloc) */
     unsigned int* h_ctl;
     hipEvent_t    ev_told;              /* rstream: every k_tell of this job has run */
     /* the transfer as far as the host has driven it (advance()) */
@@ -97,6 +147,7 @@ struct hz_hoststate
     size_t         ncopies;
     /* the dense path: a ring of pinned chunks (made when that path is first taken) and internal output buffers */
     unsigned char* h_stage[HZ_STAGE_SLOTS];     /* slot k of ONE pinned allocation (h_stage[0]) */
+    hz_pinned_t    stage_mem;
     hipEvent_t     ev_stage[HZ_STAGE_SLOTS];
     hipEvent_t     ev_band[HZ_HOST_BANDS];
     unsigned char* d_bgr;
@@ -155,12 +206,15 @@ static int ensure_host(hz_dev_t* d)
 static int ensure_ring(hz_dev_t* d)
 {
     hz_hoststate* h = d->host;
-    if(h->h_stage[0]) return 0;
-    unsigned char* ring = NULL;
-    HZ_CHECK(hipHostMalloc((void**)&ring, (size_t)HZ_STAGE_SLOTS*HZ_STAGE_BYTES, hipHostMallocDefault));
+    if(h->h_stage[0] && h->ev_stage[HZ_STAGE_SLOTS-1]) return 0;
+    if(!h->h_stage[0])
+    {
+        unsigned char* ring = (unsigned char*)pinned_alloc(&h->stage_mem, (size_t)HZ_STAGE_SLOTS*HZ_STAGE_BYTES, hz_gpu_numa_node(d));
+        if(!ring) { snprintf(g_last_error, sizeof(g_last_error), "hz_hip: no pinned memory for the ring of staging chunks"); return -1; }
+        for(int k=0; k<HZ_STAGE_SLOTS; k++) h->h_stage[k] = ring + (size_t)k*HZ_STAGE_BYTES;      /* (the context's from here on: freed with it) */
+    }
     for(int k=0; k<HZ_HOST_BANDS; k++)  if(!h->ev_band[k])  HZ_CHECK(hipEventCreateWithFlags(&h->ev_band[k], hipEventDisableTiming));
     for(int k=0; k<HZ_STAGE_SLOTS; k++) if(!h->ev_stage[k]) HZ_CHECK(hipEventCreateWithFlags(&h->ev_stage[k], hipEventDisableTiming));
-    for(int k=0; k<HZ_STAGE_SLOTS; k++) h->h_stage[k] = ring + (size_t)k*HZ_STAGE_BYTES;
     return 0;
 }
 
@@ -183,7 +237,7 @@ void hz_hostpath_destroy(hz_dev_t* d)
     /* panoramas begun and never ended: the pool's tasks name their buffers and counters, copies write their landing */
     while(h->next_end != h->next_begin) (void)host_end(d);
     for(int k=0; k<HZ_COPY_STREAMS; k++) if(h->cstream[k]) (void)hipStreamSynchronize(h->cstream[k]);
-    if(h->h_stage[0]) (void)hipHostFree(h->h_stage[0]);
+    pinned_free(&h->stage_mem, h->h_stage[0]);
     for(int k=0; k<HZ_STAGE_SLOTS; k++) if(h->ev_stage[k]) (void)hipEventDestroy(h->ev_stage[k]);
     for(int k=0; k<HZ_HOST_BANDS; k++)   if(h->ev_band[k]) (void)hipEventDestroy(h->ev_band[k]);
     for(int k=0; k<HZ_COPY_STREAMS; k++) if(h->cstream[k]) (void)hipStreamDestroy(h->cstream[k]);
@@ -191,7 +245,7 @@ void hz_hostpath_destroy(hz_dev_t* d)
     {
         hz_hostjob& jb = h->job[j];
         (void)hipFree(jb.d_hs); (void)hipFree(jb.d_ctl);
-        if(jb.h_land) (void)hipHostFree(jb.h_land);
+        pinned_free(&jb.land_mem, jb.h_land);
         if(jb.h_ctl)  (void)hipHostFree(jb.h_ctl);
         if(jb.ev_told) (void)hipEventDestroy(jb.ev_told);
         if(jb.ev_copy) for(hipEvent_t e : *jb.ev_copy) (void)hipEventDestroy(e);
@@ -284,9 +338,10 @@ static int job_memory(hz_dev_t* d, hz_hostjob& jb, size_t need, size_t ctl_words
     }
     if(need > jb.land_capacity)
     {
-        if(jb.h_land) (void)hipHostFree(jb.h_land);
+        pinned_free(&jb.land_mem, jb.h_land);
         jb.h_land = NULL; jb.land_capacity = 0;
-        if(hipHostMalloc((void**)&jb.h_land, need*sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        jb.h_land = (uint32_t*)pinned_alloc(&jb.land_mem, need*sizeof(uint32_t), hz_gpu_numa_node(d));
+        if(!jb.h_land) return -2;
         jb.land_capacity = need;
     }
     if(ctl_words > jb.ctl_capacity)
